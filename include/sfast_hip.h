@@ -1,0 +1,222 @@
+/*
+ * sfast_hip.h -- C ABI of libsfast_hip.so, the MI355X (gfx950 / CDNA4) kernel
+ * library behind the stable-fast diffusion-UNet hot path.
+ *
+ * This is the drop-in boundary: every entry point below replaces one operator
+ * family the reference binds through TORCH_LIBRARY / its Python op registry
+ * (paths relative to the reference tree, src/sfast/):
+ *
+ *   sfast_hip_group_norm   <- sfast_triton::group_norm / group_norm_silu
+ *                             (triton/torch_ops.py:108-238, triton/ops/group_norm.py:352-479)
+ *   sfast_hip_layer_norm   <- sfast_triton::layer_norm
+ *                             (triton/torch_ops.py:241-255, triton/ops/layer_norm.py:276-322)
+ *   sfast_hip_gemm         <- sfast::cublas_lowp_linear / _linear_add / _linear_relu /
+ *                             _linear_gelu / _addmm* / _mm / _matmul
+ *                             (csrc/operators/cublas/cublas_gemm.h:12-49),
+ *                             sfast::linear_relu / linear_gelu (csrc/operators/fused_linear.h:11-15),
+ *                             sfast::cutlass_linear_geglu[_unified]
+ *                             (csrc/operators/cutlass/cutlass_dual_linear_kernel.h:6-15)
+ *   sfast_hip_conv2d       <- sfast::cudnn_convolution_bias[_add][_sigmoid|_relu|_tanh]
+ *                             (csrc/operators/cudnn/cudnn_convolution.h:12-78)
+ *   sfast_hip_attention    <- sfast_xformers::memory_efficient_attention
+ *                             (libs/xformers/xformers_attention.py:26-48), q/k/v as [B,S,H,D]
+ *                             strided views (libs/diffusers/xformers_attention.py:37-69)
+ *   sfast_hip_strided_copy <- sfast_triton::contiguous / clone / reshape
+ *                             (triton/torch_ops.py:24-106, triton/ops/copy.py:184-270)
+ *   sfast_hip_timestep_embedding, sfast_hip_cfg_ddim_step
+ *                          <- host-side glue of the denoise loop that the reference leaves to
+ *                             diffusers / trace_scheduler (compilers/diffusion_pipeline_compiler.py:103-107)
+ *
+ * Conventions (all entry points):
+ *   - plain C types only; every pointer except the params struct and `w_segs` is a DEVICE pointer
+ *     owned by the caller; nothing is allocated, freed or synchronised inside -> safe to record
+ *     into a hipGraph; work is enqueued on `stream` (a hipStream_t passed as void*).
+ *   - return SFAST_OK (0) or a negative error; sfast_hip_last_error() gives a thread-local message.
+ *   - scratch memory is caller-provided: ask sfast_hip_<op>_workspace_bytes(params) first
+ *     (0 means the pointer may be NULL).
+ *   - inputs are never written; weights are read from the caller's (live) storage on every call.
+ *   - arithmetic: f16/bf16 (and f32 on the generic kernels) I/O, fp32 accumulation and fp32
+ *     epilogue math everywhere (CDNA4 MFMA accumulates in fp32 only).
+ */
+#ifndef SFAST_HIP_H
+#define SFAST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFAST_HIP_ABI_VERSION 1
+
+typedef void *sfast_stream_t; /* hipStream_t */
+
+enum sfast_status {
+    SFAST_OK = 0,
+    SFAST_ERR_UNSUPPORTED = -1, /* shape / dtype / alignment not handled by any kernel */
+    SFAST_ERR_INVALID = -2,     /* inconsistent parameters */
+    SFAST_ERR_WORKSPACE = -3,   /* workspace too small / NULL */
+    SFAST_ERR_LAUNCH = -4       /* hipLaunchKernel reported an error */
+};
+
+enum sfast_dtype { SFAST_F16 = 0, SFAST_BF16 = 1, SFAST_F32 = 2 };
+
+enum sfast_act {
+    SFAST_ACT_NONE = 0,
+    SFAST_ACT_RELU = 1,
+    SFAST_ACT_GELU = 2,      /* erf form, aten::gelu(approximate='none') */
+    SFAST_ACT_GELU_TANH = 3, /* tanh form */
+    SFAST_ACT_SILU = 4,
+    SFAST_ACT_SIGMOID = 5,
+    SFAST_ACT_TANH = 6
+};
+
+/* ---- library ---------------------------------------------------------------------------- */
+int sfast_hip_abi_version(void);
+/* one-time per-process setup (kernel attributes); idempotent, cheap, call before capturing. */
+int sfast_hip_init(void);
+const char *sfast_hip_last_error(void);
+/* name of the kernel variant chosen by the most recent gemm / conv2d / attention call on this
+ * thread (diagnostics, tests and bench roofline bookkeeping). */
+const char *sfast_hip_last_kernel(void);
+
+/* ---- GroupNorm (+SiLU) ------------------------------------------------------------------ */
+enum sfast_layout { SFAST_NHWC = 0, SFAST_NCHW = 1 };
+
+typedef struct {
+    int32_t dtype;  /* sfast_dtype (f16/bf16/f32) */
+    int32_t layout; /* sfast_layout: NHWC = dense channels_last, NCHW = contiguous */
+    int32_t N, C, HW, G;
+    int32_t C1;  /* NHWC only: channels [0,C1) are read from x (pitch C1), [C1,C) from x2
+                    (pitch C-C1): a virtual channel concat. C1 == C -> x only. */
+    int32_t act; /* SFAST_ACT_NONE or SFAST_ACT_SILU */
+    float eps;
+} sfast_gn_params;
+
+size_t sfast_hip_group_norm_workspace_bytes(const sfast_gn_params *p);
+int sfast_hip_group_norm(const void *x, const void *x2, const void *gamma, const void *beta,
+                         void *y, const sfast_gn_params *p, void *workspace,
+                         size_t workspace_bytes, sfast_stream_t stream);
+
+/* ---- LayerNorm --------------------------------------------------------------------------- */
+typedef struct {
+    int32_t dtype;
+    int32_t M, N; /* x[M,N] contiguous rows, normalised over N */
+    float eps;
+} sfast_ln_params;
+
+int sfast_hip_layer_norm(const void *x, const void *gamma, const void *beta, void *y,
+                         const sfast_ln_params *p, sfast_stream_t stream);
+
+/* ---- GEMM: out[M,N] = epilogue(x[M,K] . W[N,K]^T) ----------------------------------------
+ * epilogue (fp32):  v = acc + bias[n] + rowbias[m / rows_per_batch][n]
+ *                   res_before_act:  out = act(v + alpha*res[m][n])     (cuDNN-style z add)
+ *                   otherwise     :  out = act(v) + alpha*res[m][n]     (cublas_lowp_linear_add)
+ * geglu: W is [2N,K]; rows [0,N) produce h, rows [N,2N) produce g; bias likewise [2N];
+ *        out = h * gelu(g)   (rewritten pattern jit/passes/__init__.py:643-649, halves order
+ *        cutlass_dual_linear_kernel.cu:531-538)
+ * W may be given as n_wseg stacked segments of rows_per_seg rows each (e.g. the live to_q /
+ * to_k / to_v weights of one attention block) -> one launch, no concatenated copy.           */
+#define SFAST_MAX_WSEG 4
+typedef struct {
+    int32_t dtype;
+    int32_t M, N, K;
+    int64_t ldx, ldw, ldo, ldr; /* row strides in elements (x, W, out, residual) */
+    int32_t n_wseg, rows_per_seg;
+    int32_t geglu;
+    int32_t act;
+    int32_t res_before_act;
+    float alpha;
+    int32_t rows_per_batch; /* 0 = no rowbias */
+    int64_t ld_rowbias;
+    int32_t in_act;  /* activation applied to x on load; small-M (M <= 16) path only */
+    int32_t variant; /* 0 = auto; otherwise force a kernel variant (tuning / tests) */
+    int32_t split_k; /* 0 = auto */
+} sfast_gemm_params;
+
+size_t sfast_hip_gemm_workspace_bytes(const sfast_gemm_params *p);
+int sfast_hip_gemm(const void *x, const void *const *w_segs, const void *bias,
+                   const void *rowbias, const void *residual, void *out,
+                   const sfast_gemm_params *p, void *workspace, size_t workspace_bytes,
+                   sfast_stream_t stream);
+
+/* ---- conv2d (cross-correlation, groups = 1) ------------------------------------------------
+ * y = act(conv(x, w) + bias + rowbias[b] + alpha*z)  (res_before_act = 1, cuDNN fused form,
+ *      cudnn_convolution_impl.cc:995-998) or act(...) + alpha*z (res_before_act = 0).
+ * Tensors are described by strides, order (n, h, w, c), so NHWC (channels_last) and NCHW are
+ * both expressible; the MFMA implicit-GEMM path needs dense NHWC activations and K-contiguous
+ * (channels_last) weights, everything else runs on the generic kernel.
+ * upsample2x: the conv reads nearest-neighbour 2x upsampled x without materialising it.
+ * C1 < Cin: input channels [C1,Cin) come from x2 (virtual concat, as in GroupNorm).          */
+typedef struct {
+    int32_t dtype;
+    int32_t B, H, W, Cin, Cout, KH, KW;
+    int32_t stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;
+    int32_t upsample2x;
+    int32_t C1;
+    int64_t xs[4], x2s[4]; /* element strides (n,h,w,c) */
+    int64_t ws[4];         /* weight strides (o,i,kh,kw) */
+    int64_t os[4];         /* output strides (n,h,w,c) */
+    int64_t zs[4];         /* residual strides (n,h,w,c); 0 = broadcast */
+    int32_t act, res_before_act;
+    float alpha;
+    int64_t ld_rowbias; /* rowbias[b][cout] row stride; ignored when rowbias == NULL */
+    int32_t variant, split_k;
+} sfast_conv_params;
+
+size_t sfast_hip_conv2d_workspace_bytes(const sfast_conv_params *p);
+int sfast_hip_conv2d(const void *x, const void *x2, const void *w, const void *bias,
+                     const void *rowbias, const void *z, void *out, const sfast_conv_params *p,
+                     void *workspace, size_t workspace_bytes, sfast_stream_t stream);
+
+/* ---- scaled-dot-product attention: out = softmax(q k^T * scale) v -------------------------
+ * q [B,Sq,H,D], k/v [B,Skv,H,D], out [B,Sq,H,D]; element strides (b, s, h), d stride 1.       */
+typedef struct {
+    int32_t dtype;
+    int32_t B, H, Sq, Skv, D;
+    int64_t qs[3], ks[3], vs[3], os[3];
+    float scale;
+    int32_t variant;
+} sfast_attn_params;
+
+int sfast_hip_attention(const void *q, const void *k, const void *v, void *out,
+                        const sfast_attn_params *p, sfast_stream_t stream);
+
+/* ---- strided copy (rank <= 4) ------------------------------------------------------------- */
+typedef struct {
+    int32_t elem_bytes; /* 1, 2, 4, 8 */
+    int32_t ndim;       /* <= 4 */
+    int64_t shape[4];
+    int64_t src_strides[4], dst_strides[4]; /* in elements */
+} sfast_copy_params;
+
+int sfast_hip_strided_copy(const void *src, void *dst, const sfast_copy_params *p,
+                           sfast_stream_t stream);
+
+/* ---- sinusoidal timestep embedding -> out[B, dim] ------------------------------------------ */
+typedef struct {
+    int32_t dtype; /* output dtype */
+    int32_t B, dim;
+    int32_t flip_sin_to_cos;
+    float downscale_freq_shift;
+    float max_period;
+} sfast_temb_params;
+
+int sfast_hip_timestep_embedding(const float *timesteps /* [B] device */, void *out,
+                                 const sfast_temb_params *p, sfast_stream_t stream);
+
+/* ---- classifier-free-guidance combine + DDIM update (eta = 0) -----------------------------
+ * eps = eps_u + g (eps_c - eps_u); x0 = (x - sqrt(1-a_t) eps) / sqrt(a_t);
+ * x' = sqrt(a_prev) x0 + sqrt(1-a_prev) eps.  eps_uc holds [eps_u ; eps_c] (2*numel).
+ * x' is written to latents_out and, when unet_in != NULL, duplicated into unet_in[0:2*numel]
+ * (the next step's CFG batch). coef = device float[4] {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev),
+ * sqrt(1-a_prev)} so the same graph node serves every step.                                   */
+int sfast_hip_cfg_ddim_step(const void *eps_uc, const void *latents, void *latents_out,
+                            void *unet_in, const float *coef, float guidance, int64_t numel,
+                            int32_t dtype, sfast_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFAST_HIP_H */

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Build libsfast_hip.so (gfx950) in-tree with hipcc.
+
+    python stable-fast_amd/build.py [--force] [--jobs N]
+
+Every csrc/*.hip is compiled to an object (in parallel) and linked into
+stable-fast_amd/sfast/_lib/libsfast_hip.so. hipcc cross-compiles without a GPU.
+Objects are cached by (source + headers + flags) hash so rebuilds are incremental.
+"""
+import argparse
+import concurrent.futures as cf
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+OUT_DIR = os.path.join(HERE, "sfast", "_lib")
+OBJ_DIR = os.path.join(HERE, "build", "obj")
+LIB = os.path.join(OUT_DIR, "libsfast_hip.so")
+
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
+         "-Wno-unused-result", "-I", INCLUDE]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def _digest(paths, extra):
+    h = hashlib.sha256()
+    for p in sorted(paths):
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(extra).encode())
+    return h.hexdigest()[:16]
+
+
+def build(force=False, jobs=None, verbose=True):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(INCLUDE, "sfast_hip.h"))
+    cc = hipcc()
+    tasks = []
+    objs = []
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        tag = _digest([src] + headers, FLAGS)
+        obj = os.path.join(OBJ_DIR, f"{os.path.splitext(s)[0]}.{tag}.o")
+        objs.append(obj)
+        if force or not os.path.exists(obj):
+            tasks.append((src, obj))
+
+    def compile_one(t):
+        src, obj = t
+        cmd = [cc] + FLAGS + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+        return src
+
+    if tasks:
+        with cf.ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 4)) as ex:
+            for done in ex.map(compile_one, tasks):
+                if verbose:
+                    print(f"[sfast build] compiled {os.path.basename(done)}", flush=True)
+    stamp = os.path.join(OBJ_DIR, "link.stamp")
+    link_tag = _digest(objs, ["link"])
+    old = open(stamp).read() if os.path.exists(stamp) else ""
+    if force or tasks or not os.path.exists(LIB) or old != link_tag:
+        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+        with open(stamp, "w") as f:
+            f.write(link_tag)
+        if verbose:
+            print(f"[sfast build] linked {LIB}", flush=True)
+    # drop stale objects
+    keep = set(objs)
+    for f in os.listdir(OBJ_DIR):
+        p = os.path.join(OBJ_DIR, f)
+        if f.endswith(".o") and p not in keep:
+            os.remove(p)
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--jobs", type=int, default=None)
+    a = ap.parse_args()
+    print(build(force=a.force, jobs=a.jobs))

@@ -1,0 +1,297 @@
+// extern "C" entry points of the GEMM and conv families: validation + kernel selection.
+//   sfast_hip_gemm   -> gemv_small_m | MFMA igemm (linear) | naive
+//   sfast_hip_conv2d -> MFMA igemm (implicit im2col) | conv_small_n | conv_small_c | naive
+// No path leaves the GPU and nothing is allocated: unsupported fast-path preconditions select the
+// generic HIP kernel, never an ATen / host fallback.
+#include "igemm.h"
+#include "small.h"
+
+using namespace sfast;
+
+namespace {
+
+bool is_half(int dtype) { return dtype == SFAST_F16 || dtype == SFAST_BF16; }
+
+struct GemmRoute {
+    enum Kind { GEMV, IGEMM, NAIVE } kind;
+};
+
+GemmRoute gemm_route(const void *x, const void *const *w_segs, const void *bias, const void *rowbias,
+                     const void *residual, const void *out, const sfast_gemm_params *p) {
+    GemmRoute r{GemmRoute::NAIVE};
+    if (!is_half(p->dtype)) return r;
+    bool vec_in = p->K % 8 == 0 && p->ldx % 8 == 0 && p->ldw % 8 == 0 && aligned16(x);
+    for (int i = 0; i < p->n_wseg; ++i) vec_in = vec_in && aligned16(w_segs[i]);
+    if (!vec_in) return r;
+    if (p->variant == 100) return r;  // forced naive
+    if ((p->M <= 16 && p->variant == 0) || p->variant == 101) {
+        r.kind = GemmRoute::GEMV;
+        return r;
+    }
+    bool vec_out = p->N % 4 == 0 && p->ldo % 4 == 0 && aligned8(out) && p->in_act == SFAST_ACT_NONE;
+    if (bias) vec_out = vec_out && aligned8(bias);
+    if (rowbias) vec_out = vec_out && aligned8(rowbias) && p->ld_rowbias % 4 == 0 && p->rows_per_batch > 0;
+    if (residual) vec_out = vec_out && aligned8(residual) && p->ldr % 4 == 0;
+    if (p->geglu) vec_out = vec_out && p->n_wseg == 1;
+    if (vec_out) r.kind = GemmRoute::IGEMM;
+    return r;
+}
+
+int validate_gemm(const void *x, const void *const *w_segs, const void *out, const sfast_gemm_params *p) {
+    SFAST_REQUIRE(p && x && w_segs && out, SFAST_ERR_INVALID, "gemm: null argument");
+    SFAST_REQUIRE(p->M > 0 && p->N > 0 && p->K > 0, SFAST_ERR_INVALID, "gemm: bad shape %dx%dx%d", p->M, p->N, p->K);
+    SFAST_REQUIRE(p->n_wseg >= 1 && p->n_wseg <= SFAST_MAX_WSEG, SFAST_ERR_INVALID, "gemm: n_wseg=%d", p->n_wseg);
+    const int wrows = p->geglu ? 2 * p->N : p->N;
+    SFAST_REQUIRE(p->rows_per_seg > 0 && (int64_t)p->rows_per_seg * p->n_wseg >= wrows, SFAST_ERR_INVALID,
+                  "gemm: %d segments of %d rows do not cover %d weight rows", p->n_wseg, p->rows_per_seg, wrows);
+    SFAST_REQUIRE(!p->geglu || p->n_wseg == 1, SFAST_ERR_INVALID, "gemm: geglu needs a single weight segment");
+    for (int i = 0; i < p->n_wseg; ++i) SFAST_REQUIRE(w_segs[i], SFAST_ERR_INVALID, "gemm: null weight segment %d", i);
+    SFAST_REQUIRE(p->ldx >= p->K && p->ldw >= p->K && p->ldo >= p->N, SFAST_ERR_INVALID, "gemm: bad leading dims");
+    return SFAST_OK;
+}
+
+struct ConvGeom {
+    int Ho, Wo;
+    bool x_dense, x2_dense, w_kcontig, out_dense, z_dense, z_bcast;
+    int64_t ldo, ldr;
+};
+
+ConvGeom conv_geom(const sfast_conv_params *p, const void *z) {
+    ConvGeom g{};
+    const int Hin = p->upsample2x ? 2 * p->H : p->H, Win = p->upsample2x ? 2 * p->W : p->W;
+    g.Ho = (Hin + 2 * p->pad_h - p->dil_h * (p->KH - 1) - 1) / p->stride_h + 1;
+    g.Wo = (Win + 2 * p->pad_w - p->dil_w * (p->KW - 1) - 1) / p->stride_w + 1;
+    const int C1 = p->C1, C2 = p->Cin - p->C1;
+    g.x_dense = p->xs[3] == 1 && p->xs[2] == C1 && p->xs[1] == (int64_t)p->W * C1 && p->xs[0] == (int64_t)p->H * p->W * C1;
+    g.x2_dense = C2 == 0 || (p->x2s[3] == 1 && p->x2s[2] == C2 && p->x2s[1] == (int64_t)p->W * C2 &&
+                             p->x2s[0] == (int64_t)p->H * p->W * C2);
+    g.w_kcontig = p->ws[1] == 1 && p->ws[3] == p->Cin && p->ws[2] == (int64_t)p->KW * p->Cin &&
+                  p->ws[0] == (int64_t)p->KH * p->KW * p->Cin;
+    g.ldo = p->os[2];
+    g.out_dense = p->os[3] == 1 && g.ldo >= p->Cout && p->os[1] == (int64_t)g.Wo * g.ldo &&
+                  p->os[0] == (int64_t)g.Ho * g.Wo * g.ldo;
+    g.ldr = 0;
+    g.z_dense = false;
+    g.z_bcast = false;
+    if (z) {
+        g.ldr = p->zs[2];
+        g.z_dense = p->zs[3] == 1 && g.ldr >= p->Cout && p->zs[1] == (int64_t)g.Wo * g.ldr &&
+                    p->zs[0] == (int64_t)g.Ho * g.Wo * g.ldr;
+        g.z_bcast = p->zs[3] == 1 && p->zs[1] == 0 && p->zs[2] == 0;
+    }
+    return g;
+}
+
+enum ConvKind { CONV_IGEMM, CONV_SMALL_N, CONV_SMALL_C, CONV_NAIVE };
+
+ConvKind conv_route(const void *x, const void *x2, const void *w, const void *bias, const void *rowbias,
+                    const void *z, const void *out, const sfast_conv_params *p, const ConvGeom &g,
+                    bool &fold_z_to_rowbias) {
+    fold_z_to_rowbias = false;
+    if (p->variant == 100) return CONV_NAIVE;
+    const int C2 = p->Cin - p->C1;
+    if (is_half(p->dtype)) {
+        const bool in_ok = g.x_dense && g.x2_dense && g.w_kcontig && p->C1 % 8 == 0 && C2 % 8 == 0 && aligned16(x) &&
+                           (C2 == 0 || aligned16(x2)) && aligned16(w);
+        if (in_ok && p->Cout >= 16 && p->Cout % 4 == 0 && g.out_dense && g.ldo % 4 == 0 && aligned8(out) &&
+            (!bias || aligned8(bias)) && (!rowbias || (aligned8(rowbias) && p->ld_rowbias % 4 == 0))) {
+            bool z_ok = true;
+            if (z) {
+                if (g.z_dense && g.ldr % 4 == 0 && aligned8(z)) {
+                    z_ok = true;
+                } else if (g.z_bcast && !rowbias && p->alpha == 1.0f && aligned8(z) && p->zs[0] % 4 == 0 &&
+                           (p->res_before_act || p->act == SFAST_ACT_NONE)) {
+                    fold_z_to_rowbias = true;
+                } else {
+                    z_ok = false;
+                }
+            }
+            if (z_ok) return CONV_IGEMM;
+        }
+        if (in_ok && C2 == 0 && p->Cout <= 8 && p->variant != 102) return CONV_SMALL_N;
+        if ((int64_t)p->KH * p->KW * p->Cin * p->Cout * 4 <= 64 * 1024 && p->Cout % 8 == 0 && p->variant != 101)
+            return CONV_SMALL_C;
+    }
+    return CONV_NAIVE;
+}
+
+int validate_conv(const void *x, const void *x2, const void *w, const void *out, const sfast_conv_params *p) {
+    SFAST_REQUIRE(p && x && w && out, SFAST_ERR_INVALID, "conv2d: null argument");
+    SFAST_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0 && p->Cin > 0 && p->Cout > 0 && p->KH > 0 && p->KW > 0,
+                  SFAST_ERR_INVALID, "conv2d: bad shape");
+    SFAST_REQUIRE(p->stride_h > 0 && p->stride_w > 0 && p->dil_h > 0 && p->dil_w > 0 && p->pad_h >= 0 && p->pad_w >= 0,
+                  SFAST_ERR_INVALID, "conv2d: bad stride/dilation/padding");
+    SFAST_REQUIRE(p->C1 > 0 && p->C1 <= p->Cin, SFAST_ERR_INVALID, "conv2d: bad C1=%d", p->C1);
+    SFAST_REQUIRE(p->C1 == p->Cin || x2, SFAST_ERR_INVALID, "conv2d: concat needs x2");
+    return SFAST_OK;
+}
+
+void fill_small_conv(SmallConvArgs &a, const void *x, const void *x2, const void *w, const void *bias,
+                     const void *rowbias, const void *z, void *out, const sfast_conv_params *p, const ConvGeom &g) {
+    a.x = x;
+    a.x2 = x2;
+    a.w = w;
+    a.bias = bias;
+    a.rowbias = rowbias;
+    a.z = z;
+    a.out = out;
+    a.B = p->B;
+    a.H = p->H;
+    a.W = p->W;
+    a.Cin = p->Cin;
+    a.C1 = p->C1;
+    a.Cout = p->Cout;
+    a.KH = p->KH;
+    a.KW = p->KW;
+    a.Ho = g.Ho;
+    a.Wo = g.Wo;
+    a.stride_h = p->stride_h;
+    a.stride_w = p->stride_w;
+    a.pad_h = p->pad_h;
+    a.pad_w = p->pad_w;
+    a.dil_h = p->dil_h;
+    a.dil_w = p->dil_w;
+    a.ups = p->upsample2x;
+    for (int i = 0; i < 4; ++i) {
+        a.xs[i] = p->xs[i];
+        a.x2s[i] = p->x2s[i];
+        a.ws[i] = p->ws[i];
+        a.os[i] = p->os[i];
+        a.zs[i] = p->zs[i];
+    }
+    a.ld_rowbias = p->ld_rowbias;
+    a.act = p->act;
+    a.res_before_act = p->res_before_act;
+    a.alpha = p->alpha;
+}
+
+}  // namespace
+
+extern "C" size_t sfast_hip_gemm_workspace_bytes(const sfast_gemm_params *p) {
+    if (!p || !is_half(p->dtype) || p->M <= 16 || p->K % 8 != 0) return 0;
+    return igemm_workspace_bytes(p->M, p->N, p->K, p->geglu != 0, p->variant < 100 ? p->variant : 0, p->split_k);
+}
+
+extern "C" int sfast_hip_gemm(const void *x, const void *const *w_segs, const void *bias, const void *rowbias,
+                              const void *residual, void *out, const sfast_gemm_params *p, void *workspace,
+                              size_t workspace_bytes, sfast_stream_t stream) {
+    int rc = validate_gemm(x, w_segs, out, p);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const GemmRoute route = gemm_route(x, w_segs, bias, rowbias, residual, out, p);
+    if (route.kind == GemmRoute::IGEMM) {
+        IgemmArgs a{};
+        a.x = x;
+        a.x2 = nullptr;
+        for (int i = 0; i < SFAST_MAX_WSEG; ++i) a.w[i] = i < p->n_wseg ? w_segs[i] : w_segs[0];
+        a.bias = bias;
+        a.rowbias = rowbias;
+        a.res = residual;
+        a.out = out;
+        a.M = p->M;
+        a.N = p->N;
+        a.K = p->K;
+        a.ldx = p->ldx;
+        a.ldw = p->ldw;
+        a.ldo = p->ldo;
+        a.ldr = p->ldr;
+        a.ld_rowbias = p->ld_rowbias;
+        a.rows_per_seg = p->rows_per_seg;
+        a.rows_per_batch = p->rows_per_batch > 0 ? p->rows_per_batch : 1;
+        a.act = p->act;
+        a.res_before_act = p->res_before_act;
+        a.alpha = p->alpha;
+        return igemm_run(a, p->dtype, 0, p->geglu != 0, p->variant < 100 ? p->variant : 0, p->split_k, workspace, workspace_bytes, st);
+    }
+    SmallGemmArgs a{};
+    a.x = x;
+    for (int i = 0; i < SFAST_MAX_WSEG; ++i) a.w[i] = i < p->n_wseg ? w_segs[i] : w_segs[0];
+    a.bias = bias;
+    a.rowbias = rowbias;
+    a.res = residual;
+    a.out = out;
+    a.M = p->M;
+    a.N = p->N;
+    a.K = p->K;
+    a.ldx = p->ldx;
+    a.ldw = p->ldw;
+    a.ldo = p->ldo;
+    a.ldr = p->ldr;
+    a.ld_rowbias = p->ld_rowbias;
+    a.rows_per_seg = p->rows_per_seg;
+    a.rows_per_batch = p->rows_per_batch > 0 ? p->rows_per_batch : 1;
+    a.geglu = p->geglu;
+    a.act = p->act;
+    a.res_before_act = p->res_before_act;
+    a.in_act = p->in_act;
+    a.alpha = p->alpha;
+    if (route.kind == GemmRoute::GEMV) return small_gemv(a, p->dtype, st);
+    return small_gemm_naive(a, p->dtype, st);
+}
+
+extern "C" size_t sfast_hip_conv2d_workspace_bytes(const sfast_conv_params *p) {
+    if (!p || !is_half(p->dtype) || p->Cout < 16) return 0;
+    ConvGeom g = conv_geom(p, nullptr);
+    const int64_t M = (int64_t)p->B * g.Ho * g.Wo;
+    const int K = p->KH * p->KW * p->Cin;
+    if (M <= 0 || M > INT32_MAX || K % 8 != 0) return 0;
+    return igemm_workspace_bytes((int)M, p->Cout, K, false, p->variant < 100 ? p->variant : 0, p->split_k);
+}
+
+extern "C" int sfast_hip_conv2d(const void *x, const void *x2, const void *w, const void *bias, const void *rowbias,
+                                const void *z, void *out, const sfast_conv_params *p, void *workspace,
+                                size_t workspace_bytes, sfast_stream_t stream) {
+    int rc = validate_conv(x, x2, w, out, p);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const ConvGeom g = conv_geom(p, z);
+    SFAST_REQUIRE(g.Ho > 0 && g.Wo > 0, SFAST_ERR_INVALID, "conv2d: empty output %dx%d", g.Ho, g.Wo);
+    const int64_t M64 = (int64_t)p->B * g.Ho * g.Wo;
+    SFAST_REQUIRE(M64 <= INT32_MAX, SFAST_ERR_UNSUPPORTED, "conv2d: too many output pixels");
+    bool fold = false;
+    const ConvKind kind = conv_route(x, x2, w, bias, rowbias, z, out, p, g, fold);
+    if (kind == CONV_IGEMM) {
+        IgemmArgs a{};
+        a.x = x;
+        a.x2 = x2;
+        for (int i = 0; i < SFAST_MAX_WSEG; ++i) a.w[i] = w;
+        a.bias = bias;
+        a.rowbias = fold ? z : rowbias;
+        a.res = fold ? nullptr : z;
+        a.out = out;
+        a.M = (int)M64;
+        a.N = p->Cout;
+        a.K = p->KH * p->KW * p->Cin;
+        a.ldx = 0;
+        a.ldw = a.K;
+        a.ldo = g.ldo;
+        a.ldr = g.ldr;
+        a.ld_rowbias = fold ? p->zs[0] : p->ld_rowbias;
+        a.rows_per_seg = p->Cout;
+        a.rows_per_batch = g.Ho * g.Wo;
+        a.act = p->act;
+        a.res_before_act = p->res_before_act;
+        a.alpha = p->alpha;
+        a.H = p->H;
+        a.W = p->W;
+        a.C1 = p->C1;
+        a.C2 = p->Cin - p->C1;
+        a.Ho = g.Ho;
+        a.Wo = g.Wo;
+        a.KH = p->KH;
+        a.KW = p->KW;
+        a.stride_h = p->stride_h;
+        a.stride_w = p->stride_w;
+        a.pad_h = p->pad_h;
+        a.pad_w = p->pad_w;
+        a.dil_h = p->dil_h;
+        a.dil_w = p->dil_w;
+        a.ups = p->upsample2x;
+        return igemm_run(a, p->dtype, 1, false, p->variant < 100 ? p->variant : 0, p->split_k, workspace, workspace_bytes, st);
+    }
+    SmallConvArgs a{};
+    fill_small_conv(a, x, x2, w, bias, rowbias, z, out, p, g);
+    if (kind == CONV_SMALL_N) return small_conv_n(a, p->dtype, st);
+    if (kind == CONV_SMALL_C) return small_conv_c(a, p->dtype, st);
+    return small_conv_naive(a, p->dtype, st);
+}

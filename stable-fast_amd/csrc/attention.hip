@@ -1,0 +1,365 @@
+// Flash-style scaled-dot-product attention forward for gfx950 (no mask, no dropout).
+//
+// Replaces the external xformers.ops.memory_efficient_attention the reference binds as
+// sfast_xformers::memory_efficient_attention (src/sfast/libs/xformers/xformers_attention.py:26-48)
+// with q/k/v kept as [B, S, H, D] strided views (src/sfast/libs/diffusers/xformers_attention.py:37-69),
+// so the fused-QKV projection output is consumed in place (no head permute copies).
+//
+// CDNA4 design:
+//   * one workgroup = NW waves = NW*32 query rows of one (batch, head); K/V tiles of 64 keys are
+//     staged once in LDS and shared by the waves.
+//   * "swapped" products so every reduction stays inside a lane:
+//       S^T = K . Q^T   (MFMA A = K rows from LDS, B = Q rows held in registers)
+//     leaves lane (q = lane&31) with the scores of its query row for 16 keys per 32-key block
+//     (the other half-wave holds the other 16) -> row max / row sum are register loops plus ONE
+//     cross-half exchange; the probabilities convert to f16 in place and ARE the B operand of
+//       O^T = V^T . P^T (MFMA A = V^T rows from LDS)
+//     with the k-slot <-> key permutation chosen to match the C/D register layout, so P never
+//     moves between lanes and never touches LDS.
+//   * V is transposed while it is written to LDS (pairs of keys packed into one dword, conflict-free
+//     ds_write_b32); V^T fragments are two 8-byte reads. K rows are padded to an odd number of
+//     16-byte slots -> conflict-free ds_read_b128.
+//   * head dims 40 / 80 (SD1.5) are zero-padded to the MFMA K-step inside LDS/registers only.
+//   * softmax in fp32 with exp2 and a folded scale*log2(e); accumulate fp32; global loads of tile
+//     t+1 are issued before the MFMAs of tile t (register prefetch).
+#include "common.h"
+#include <math.h>
+
+namespace sfast {
+
+struct AttnArgs {
+    const void *q, *k, *v;
+    void *out;
+    int B, H, Sq, Skv, D;
+    int64_t qs[3], ks[3], vs[3], os[3];
+    float scale, scale_log2e;
+};
+
+__device__ __forceinline__ f32x16 amfma32(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 amfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <typename T, int D, int NW>
+__global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
+    using vec8 = typename Elem<T>::vec8;
+    constexpr int NT = NW * 64;
+    constexpr int DP = (D + 15) / 16 * 16;  // QK^T contraction length (zero padded)
+    constexpr int KD = DP / 16;             // MFMA k-steps over d
+    constexpr int DO = (D + 31) / 32 * 32;  // padded output width
+    constexpr int DB = DO / 32;             // 32-row blocks of O^T
+    constexpr int KSTR = DP + 8;            // K tile row stride (halves): odd number of 16-B slots
+    constexpr int VSTR = 68;                // V^T tile row stride (halves): 136 B
+    constexpr int KCH = DP / 8;             // 16-B chunks per K row (incl. zero padding)
+    constexpr int VCH = D / 8;              // 16-B chunks per V row
+    constexpr int KTASK = (64 * KCH + NT - 1) / NT;
+    constexpr int VTASK = (32 * VCH + NT - 1) / NT;
+    static_assert(D % 8 == 0, "head dim must be a multiple of 8");
+
+    __shared__ __attribute__((aligned(16))) char smem[64 * KSTR * 2 + DO * VSTR * 2];
+    char *Ksm = smem;
+    char *Vsm = smem + 64 * KSTR * 2;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+    const int qrow = q0 + l31;
+
+    const T *Qp = (const T *)a.q + (int64_t)b * a.qs[0] + (int64_t)h * a.qs[2];
+    const T *Kp = (const T *)a.k + (int64_t)b * a.ks[0] + (int64_t)h * a.ks[2];
+    const T *Vp = (const T *)a.v + (int64_t)b * a.vs[0] + (int64_t)h * a.vs[2];
+
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    // zero the V^T rows that pad D up to DO (never written by the tile loads)
+    for (int i = tid; i < (DO - D) * (VSTR / 2); i += NT) {
+        reinterpret_cast<uint32_t *>(Vsm + D * VSTR * 2)[i] = 0u;
+    }
+
+    // ---- Q fragments (B operand), kept in registers for the whole kernel -------------------------
+    vec8 qf[KD];
+#pragma unroll
+    for (int kd = 0; kd < KD; ++kd) {
+        const int d0 = kd * 16 + hi * 8;
+        u32x4 raw = zero4;
+        if (d0 < D && qrow < a.Sq) raw = *reinterpret_cast<const u32x4 *>(Qp + (int64_t)qrow * a.qs[1] + d0);
+        qf[kd] = __builtin_bit_cast(vec8, raw);
+    }
+
+    u32x4 kreg[KTASK];
+    u32x4 vreg[VTASK][2];
+
+    auto prefetch = [&](int kt) {
+        const int key0 = kt * 64;
+#pragma unroll
+        for (int i = 0; i < KTASK; ++i) {
+            const int id = tid + i * NT;
+            const int key = id / KCH, ch = id - key * KCH;
+            const bool ok = id < 64 * KCH && (key0 + key) < a.Skv && ch * 8 < D;
+            kreg[i] = ok ? *reinterpret_cast<const u32x4 *>(Kp + (int64_t)(key0 + key) * a.ks[1] + ch * 8) : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < VTASK; ++i) {
+            const int id = tid + i * NT;
+            const int kp = id & 31, ch = id >> 5;
+            const int key = key0 + 2 * kp;
+            const bool in = ch < VCH;
+            vreg[i][0] = (in && key < a.Skv) ? *reinterpret_cast<const u32x4 *>(Vp + (int64_t)key * a.vs[1] + ch * 8) : zero4;
+            vreg[i][1] = (in && key + 1 < a.Skv) ? *reinterpret_cast<const u32x4 *>(Vp + (int64_t)(key + 1) * a.vs[1] + ch * 8) : zero4;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < KTASK; ++i) {
+            const int id = tid + i * NT;
+            const int key = id / KCH, ch = id - key * KCH;
+            if (id < 64 * KCH) *reinterpret_cast<u32x4 *>(Ksm + key * (KSTR * 2) + ch * 16) = kreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VTASK; ++i) {
+            const int id = tid + i * NT;
+            const int kp = id & 31, ch = id >> 5;
+            if (ch < VCH) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t w0 = vreg[i][0][e >> 1], w1 = vreg[i][1][e >> 1];
+                    const uint32_t lo = (e & 1) ? (w0 >> 16) : (w0 & 0xffffu);
+                    const uint32_t hi16 = (e & 1) ? (w1 & 0xffff0000u) : (w1 << 16);
+                    *reinterpret_cast<uint32_t *>(Vsm + (ch * 8 + e) * (VSTR * 2) + kp * 4) = lo | hi16;
+                }
+            }
+        }
+    };
+
+    f32x16 o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (a.Skv + 63) / 64;
+    prefetch(0);
+    stage();
+    __syncthreads();
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const bool more = kt + 1 < ntiles;
+        if (more) prefetch(kt + 1);
+
+        // ---- S^T = K . Q^T  (two 32-key blocks) ----------------------------------------------------
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int kd = 0; kd < KD; ++kd) {
+                const vec8 kf = *reinterpret_cast<const vec8 *>(Ksm + (kb * 32 + l31) * (KSTR * 2) + (kd * 16 + hi * 8) * 2);
+                s[kb] = amfma32(kf, qf[kd], s[kb]);
+            }
+        }
+
+        // ---- online softmax (fp32, base-2) -------------------------------------------------------------
+        const bool tail = (kt + 1) * 64 > a.Skv;
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sv = s[kb][r] * a.scale_log2e;
+                if (tail) {
+                    const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= a.Skv) sv = -INFINITY;
+                }
+                s[kb][r] = sv;
+                mloc = fmaxf(mloc, sv);
+            }
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float rowsum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+                s[kb][r] = p;
+                rowsum += p;
+            }
+        }
+        l_run = l_run * alpha + rowsum;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+
+        // ---- P^T fragments: registers [8*s2, 8*s2+8) of block kb, converted in place -----------------
+        vec8 pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) pf[kb][s2][jj] = Elem<T>::from_f32(s[kb][8 * s2 + jj]);
+
+        // ---- O^T += V^T . P^T ------------------------------------------------------------------------------
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            const char *vrow = Vsm + (db * 32 + l31) * (VSTR * 2);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int base = kb * 32 + 16 * s2 + 4 * hi;
+                    const u32x2 v0 = *reinterpret_cast<const u32x2 *>(vrow + base * 2);
+                    const u32x2 v1 = *reinterpret_cast<const u32x2 *>(vrow + (base + 8) * 2);
+                    const u32x4 vv = {v0[0], v0[1], v1[0], v1[1]};
+                    o[db] = amfma32(__builtin_bit_cast(vec8, vv), pf[kb][s2], o[db]);
+                }
+            }
+        }
+
+        __syncthreads();
+        if (more) stage();
+        __syncthreads();
+    }
+
+    // ---- epilogue: normalise and store 4 consecutive d per lane ----------------------------------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qrow < a.Sq) {
+        T *Op = (T *)a.out + (int64_t)b * a.os[0] + (int64_t)qrow * a.os[1] + (int64_t)h * a.os[2];
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = db * 32 + 8 * g + 4 * hi;
+                if (d < D) {
+                    *reinterpret_cast<u32x2 *>(Op + d) =
+                        pack4<T>(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+                }
+            }
+        }
+    }
+}
+
+// Generic fallback: any head dim / dtype. One wave per (b, h, q); scores staged in LDS (Skv <= 12288).
+template <typename T>
+__global__ void __launch_bounds__(64) attn_naive_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sc[];
+    const int lane = threadIdx.x;
+    const int q = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const T *Qp = (const T *)a.q + (int64_t)b * a.qs[0] + (int64_t)q * a.qs[1] + (int64_t)h * a.qs[2];
+    const T *Kp = (const T *)a.k + (int64_t)b * a.ks[0] + (int64_t)h * a.ks[2];
+    const T *Vp = (const T *)a.v + (int64_t)b * a.vs[0] + (int64_t)h * a.vs[2];
+    float mx = -INFINITY;
+    for (int k = lane; k < a.Skv; k += 64) {
+        const T *kr = Kp + (int64_t)k * a.ks[1];
+        float acc = 0.f;
+        for (int d = 0; d < a.D; ++d) acc = fmaf(Elem<T>::to_f32(Qp[d]), Elem<T>::to_f32(kr[d]), acc);
+        acc *= a.scale;
+        sc[k] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int k = lane; k < a.Skv; k += 64) {
+        const float p = __expf(sc[k] - mx);
+        sc[k] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    const float inv = 1.0f / sum;
+    T *Op = (T *)a.out + (int64_t)b * a.os[0] + (int64_t)q * a.os[1] + (int64_t)h * a.os[2];
+    for (int d = lane; d < a.D; d += 64) {
+        float acc = 0.f;
+        for (int k = 0; k < a.Skv; ++k) acc = fmaf(sc[k], Elem<T>::to_f32(Vp[(int64_t)k * a.vs[1] + d]), acc);
+        Op[d] = Elem<T>::from_f32(acc * inv);
+    }
+}
+
+int attention_init() { return 0; }
+
+template <typename T, int D>
+static int attn_launch_d(const AttnArgs &a, int nw, hipStream_t st) {
+    const dim3 grid(ceil_div(a.Sq, nw * 32), a.H, a.B);
+    if (nw == 2)
+        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2>), grid, dim3(128), 0, st, a);
+    else
+        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4>), grid, dim3(256), 0, st, a);
+    return check_launch("attention");
+}
+
+template <typename T>
+static int attn_launch(const AttnArgs &a, int nw, hipStream_t st) {
+    switch (a.D) {
+    case 40: return attn_launch_d<T, 40>(a, nw, st);
+    case 64: return attn_launch_d<T, 64>(a, nw, st);
+    case 80: return attn_launch_d<T, 80>(a, nw, st);
+    case 128: return attn_launch_d<T, 128>(a, 4, st);
+    case 160: return attn_launch_d<T, 160>(a, 4, st);
+    }
+    set_error("attention: head dim %d has no MFMA instantiation", a.D);
+    return SFAST_ERR_UNSUPPORTED;
+}
+
+}  // namespace sfast
+
+using namespace sfast;
+
+extern "C" int sfast_hip_attention(const void *q, const void *k, const void *v, void *out, const sfast_attn_params *p,
+                                   sfast_stream_t stream) {
+    SFAST_REQUIRE(p && q && k && v && out, SFAST_ERR_INVALID, "attention: null argument");
+    SFAST_REQUIRE(p->B > 0 && p->H > 0 && p->Sq > 0 && p->Skv > 0 && p->D > 0, SFAST_ERR_INVALID, "attention: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    AttnArgs a{};
+    a.q = q;
+    a.k = k;
+    a.v = v;
+    a.out = out;
+    a.B = p->B;
+    a.H = p->H;
+    a.Sq = p->Sq;
+    a.Skv = p->Skv;
+    a.D = p->D;
+    for (int i = 0; i < 3; ++i) {
+        a.qs[i] = p->qs[i];
+        a.ks[i] = p->ks[i];
+        a.vs[i] = p->vs[i];
+        a.os[i] = p->os[i];
+    }
+    a.scale = p->scale;
+    a.scale_log2e = p->scale * 1.44269504088896340736f;
+    const bool half = p->dtype == SFAST_F16 || p->dtype == SFAST_BF16;
+    const bool d_ok = p->D == 40 || p->D == 64 || p->D == 80 || p->D == 128 || p->D == 160;
+    bool vec = half && d_ok && aligned16(q) && aligned16(k) && aligned16(v) && aligned8(out);
+    for (int i = 0; i < 3; ++i)
+        vec = vec && p->qs[i] % 8 == 0 && p->ks[i] % 8 == 0 && p->vs[i] % 8 == 0 && p->os[i] % 4 == 0;
+    if (vec && p->variant != 100) {
+        int nw = 4;
+        const int64_t blocks4 = (int64_t)ceil_div(p->Sq, 128) * p->H * p->B;
+        if (blocks4 < 256) nw = 2;
+        if (p->variant == 2 || p->variant == 4) nw = p->variant;
+        set_kernel_name("attn_fwd[D=%d,BQ=%d]", p->D, nw * 32);
+        if (p->dtype == SFAST_F16) return attn_launch<f16>(a, nw, st);
+        return attn_launch<bf16>(a, nw, st);
+    }
+    SFAST_REQUIRE(p->Skv <= 12288, SFAST_ERR_UNSUPPORTED, "attention: generic path supports Skv <= 12288 (got %d)", p->Skv);
+    set_kernel_name("attn_naive");
+    const dim3 grid(p->Sq, p->H, p->B);
+    const size_t smem = (size_t)p->Skv * sizeof(float);
+    switch (p->dtype) {
+    case SFAST_F16: hipLaunchKernelGGL(attn_naive_kernel<f16>, grid, dim3(64), smem, st, a); break;
+    case SFAST_BF16: hipLaunchKernelGGL(attn_naive_kernel<bf16>, grid, dim3(64), smem, st, a); break;
+    case SFAST_F32: hipLaunchKernelGGL(attn_naive_kernel<float>, grid, dim3(64), smem, st, a); break;
+    default: set_error("attention: bad dtype %d", p->dtype); return SFAST_ERR_UNSUPPORTED;
+    }
+    return check_launch("attn_naive");
+}

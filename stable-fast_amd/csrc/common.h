@@ -1,0 +1,124 @@
+// Shared device/host helpers for the gfx950 kernels of libsfast_hip.so.
+// wave = 64 lanes everywhere; no portability shims.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/sfast_hip.h"
+
+namespace sfast {
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+void set_kernel_name(const char *fmt, ...);
+int check_launch(const char *what);
+
+#define SFAST_REQUIRE(cond, code, ...)  \
+    do {                                \
+        if (!(cond)) {                  \
+            sfast::set_error(__VA_ARGS__); \
+            return (code);              \
+        }                               \
+    } while (0)
+
+// ---- element types ------------------------------------------------------------------------------
+using f16 = _Float16;
+using bf16 = __bf16;
+
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T> struct Elem;
+template <> struct Elem<f16> {
+    using vec8 = f16x8;
+    using vec4 = f16x4;
+    static __device__ __forceinline__ float to_f32(f16 v) { return (float)v; }
+    static __device__ __forceinline__ f16 from_f32(float v) { return (f16)v; }
+};
+template <> struct Elem<bf16> {
+    using vec8 = bf16x8;
+    using vec4 = bf16x4;
+    static __device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+    static __device__ __forceinline__ bf16 from_f32(float v) { return (bf16)v; }
+};
+template <> struct Elem<float> {
+    static __device__ __forceinline__ float to_f32(float v) { return v; }
+    static __device__ __forceinline__ float from_f32(float v) { return v; }
+};
+
+// 16-byte chunk <-> 8 floats
+template <typename T> __device__ __forceinline__ void unpack8(const u32x4 &raw, float (&f)[8]) {
+    typename Elem<T>::vec8 v = __builtin_bit_cast(typename Elem<T>::vec8, raw);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+}
+template <typename T> __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+    typename Elem<T>::vec8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = Elem<T>::from_f32(f[i]);
+    return __builtin_bit_cast(u32x4, v);
+}
+template <typename T> __device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d) {
+    typename Elem<T>::vec4 v;
+    v[0] = Elem<T>::from_f32(a);
+    v[1] = Elem<T>::from_f32(b);
+    v[2] = Elem<T>::from_f32(c);
+    v[3] = Elem<T>::from_f32(d);
+    return __builtin_bit_cast(u32x2, v);
+}
+template <typename T> __device__ __forceinline__ void unpack4(const u32x2 &raw, float (&f)[4]) {
+    typename Elem<T>::vec4 v = __builtin_bit_cast(typename Elem<T>::vec4, raw);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = (float)v[i];
+}
+
+// ---- activations (fp32) -------------------------------------------------------------------------
+__device__ __forceinline__ float act_silu(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float act_gelu_erf(float v) {
+    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float act_gelu_tanh(float v) {
+    const float k0 = 0.79788456080286535588f, k1 = 0.044715f;
+    return 0.5f * v * (1.0f + tanhf(k0 * (v + k1 * v * v * v)));
+}
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+    case SFAST_ACT_RELU: return fmaxf(v, 0.0f);
+    case SFAST_ACT_GELU: return act_gelu_erf(v);
+    case SFAST_ACT_GELU_TANH: return act_gelu_tanh(v);
+    case SFAST_ACT_SILU: return act_silu(v);
+    case SFAST_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+    case SFAST_ACT_TANH: return tanhf(v);
+    default: return v;
+    }
+}
+
+// ---- wave-level reductions (64 lanes) ------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+static inline bool aligned8(const void *p) { return (((uintptr_t)p) & 7) == 0; }
+
+static inline size_t dtype_bytes(int dtype) { return dtype == SFAST_F32 ? 4 : 2; }
+
+}  // namespace sfast

@@ -1,0 +1,157 @@
+// Small HBM-bound helpers of the denoise step: strided copy (sfast_triton::contiguous / clone /
+// reshape, reference src/sfast/triton/ops/copy.py:184-270), sinusoidal timestep embedding and the
+// classifier-free-guidance + DDIM update that closes one denoise iteration inside the hipGraph.
+#include "common.h"
+
+namespace sfast {
+
+struct CopyArgs {
+    const void *src;
+    void *dst;
+    int64_t shape[4], ss[4], ds[4];
+    int64_t total;
+};
+
+template <typename U> __global__ void __launch_bounds__(256) strided_copy_kernel(const CopyArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < a.total; idx += stride) {
+        int64_t t = idx;
+        const int64_t i3 = t % a.shape[3];
+        t /= a.shape[3];
+        const int64_t i2 = t % a.shape[2];
+        t /= a.shape[2];
+        const int64_t i1 = t % a.shape[1];
+        const int64_t i0 = t / a.shape[1];
+        ((U *)a.dst)[i0 * a.ds[0] + i1 * a.ds[1] + i2 * a.ds[2] + i3 * a.ds[3]] =
+            ((const U *)a.src)[i0 * a.ss[0] + i1 * a.ss[1] + i2 * a.ss[2] + i3 * a.ss[3]];
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) temb_kernel(const float *__restrict__ t, T *__restrict__ out, int B, int dim,
+                                                   int flip, float shift, float max_period) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int half = dim / 2;
+    if (idx >= B * half) return;
+    const int b = idx / half, i = idx % half;
+    // diffusers get_timestep_embedding: exponent = -ln(max_period) * i / (half - shift)
+    const float freq = expf(-logf(max_period) * (float)i / ((float)half - shift));
+    const float arg = t[b] * freq;
+    const float s = sinf(arg), c = cosf(arg);
+    T *o = out + (int64_t)b * dim;
+    if (flip) {
+        o[i] = Elem<T>::from_f32(c);
+        o[half + i] = Elem<T>::from_f32(s);
+    } else {
+        o[i] = Elem<T>::from_f32(s);
+        o[half + i] = Elem<T>::from_f32(c);
+    }
+    if ((dim & 1) && i == 0) o[dim - 1] = Elem<T>::from_f32(0.f);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) cfg_ddim_kernel(const T *__restrict__ eps_uc, const T *__restrict__ lat,
+                                                       T *__restrict__ lat_out, T *__restrict__ unet_in,
+                                                       const float *__restrict__ coef, float g, int64_t numel) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= numel) return;
+    const float sa = coef[0], s1a = coef[1], sp = coef[2], s1p = coef[3];
+    const float eu = Elem<T>::to_f32(eps_uc[i]), ec = Elem<T>::to_f32(eps_uc[numel + i]);
+    const float e = eu + g * (ec - eu);
+    const float x = Elem<T>::to_f32(lat[i]);
+    const float x0 = (x - s1a * e) / sa;
+    const T r = Elem<T>::from_f32(sp * x0 + s1p * e);
+    lat_out[i] = r;
+    if (unet_in) {
+        unet_in[i] = r;
+        unet_in[numel + i] = r;
+    }
+}
+
+}  // namespace sfast
+
+using namespace sfast;
+
+extern "C" int sfast_hip_strided_copy(const void *src, void *dst, const sfast_copy_params *p, sfast_stream_t stream) {
+    SFAST_REQUIRE(p && src && dst, SFAST_ERR_INVALID, "strided_copy: null argument");
+    SFAST_REQUIRE(p->ndim >= 1 && p->ndim <= 4, SFAST_ERR_UNSUPPORTED, "strided_copy: ndim=%d", p->ndim);
+    CopyArgs a{};
+    a.src = src;
+    a.dst = dst;
+    a.total = 1;
+    const int pad = 4 - p->ndim;
+    for (int i = 0; i < 4; ++i) {
+        if (i < pad) {
+            a.shape[i] = 1;
+            a.ss[i] = 0;
+            a.ds[i] = 0;
+        } else {
+            a.shape[i] = p->shape[i - pad];
+            a.ss[i] = p->src_strides[i - pad];
+            a.ds[i] = p->dst_strides[i - pad];
+        }
+        SFAST_REQUIRE(a.shape[i] >= 0, SFAST_ERR_INVALID, "strided_copy: negative extent");
+        a.total *= a.shape[i];
+    }
+    if (a.total == 0) return SFAST_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int64_t blocks = ceil_div64(a.total, 256);
+    if (blocks > 65536) blocks = 65536;
+    const dim3 grid((unsigned)blocks);
+    switch (p->elem_bytes) {
+    case 1: hipLaunchKernelGGL(strided_copy_kernel<uint8_t>, grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(strided_copy_kernel<uint16_t>, grid, dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(strided_copy_kernel<uint32_t>, grid, dim3(256), 0, st, a); break;
+    case 8: hipLaunchKernelGGL(strided_copy_kernel<uint64_t>, grid, dim3(256), 0, st, a); break;
+    default: set_error("strided_copy: elem_bytes=%d", p->elem_bytes); return SFAST_ERR_UNSUPPORTED;
+    }
+    return check_launch("strided_copy");
+}
+
+extern "C" int sfast_hip_timestep_embedding(const float *timesteps, void *out, const sfast_temb_params *p,
+                                            sfast_stream_t stream) {
+    SFAST_REQUIRE(p && timesteps && out, SFAST_ERR_INVALID, "timestep_embedding: null argument");
+    SFAST_REQUIRE(p->B > 0 && p->dim >= 2, SFAST_ERR_INVALID, "timestep_embedding: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(ceil_div(p->B * (p->dim / 2), 256));
+    switch (p->dtype) {
+    case SFAST_F16:
+        hipLaunchKernelGGL(temb_kernel<f16>, grid, dim3(256), 0, st, timesteps, (f16 *)out, p->B, p->dim,
+                           p->flip_sin_to_cos, p->downscale_freq_shift, p->max_period);
+        break;
+    case SFAST_BF16:
+        hipLaunchKernelGGL(temb_kernel<bf16>, grid, dim3(256), 0, st, timesteps, (bf16 *)out, p->B, p->dim,
+                           p->flip_sin_to_cos, p->downscale_freq_shift, p->max_period);
+        break;
+    case SFAST_F32:
+        hipLaunchKernelGGL(temb_kernel<float>, grid, dim3(256), 0, st, timesteps, (float *)out, p->B, p->dim,
+                           p->flip_sin_to_cos, p->downscale_freq_shift, p->max_period);
+        break;
+    default: set_error("timestep_embedding: dtype %d", p->dtype); return SFAST_ERR_UNSUPPORTED;
+    }
+    return check_launch("timestep_embedding");
+}
+
+extern "C" int sfast_hip_cfg_ddim_step(const void *eps_uc, const void *latents, void *latents_out, void *unet_in,
+                                       const float *coef, float guidance, int64_t numel, int32_t dtype,
+                                       sfast_stream_t stream) {
+    SFAST_REQUIRE(eps_uc && latents && latents_out && coef && numel > 0, SFAST_ERR_INVALID, "cfg_ddim_step: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)ceil_div64(numel, 256));
+    switch (dtype) {
+    case SFAST_F16:
+        hipLaunchKernelGGL(cfg_ddim_kernel<f16>, grid, dim3(256), 0, st, (const f16 *)eps_uc, (const f16 *)latents,
+                           (f16 *)latents_out, (f16 *)unet_in, coef, guidance, numel);
+        break;
+    case SFAST_BF16:
+        hipLaunchKernelGGL(cfg_ddim_kernel<bf16>, grid, dim3(256), 0, st, (const bf16 *)eps_uc, (const bf16 *)latents,
+                           (bf16 *)latents_out, (bf16 *)unet_in, coef, guidance, numel);
+        break;
+    case SFAST_F32:
+        hipLaunchKernelGGL(cfg_ddim_kernel<float>, grid, dim3(256), 0, st, (const float *)eps_uc, (const float *)latents,
+                           (float *)latents_out, (float *)unet_in, coef, guidance, numel);
+        break;
+    default: set_error("cfg_ddim_step: dtype %d", dtype); return SFAST_ERR_UNSUPPORTED;
+    }
+    return check_launch("cfg_ddim_step");
+}

@@ -1,0 +1,29 @@
+// Argument block + host entry of the MFMA implicit-GEMM kernels (igemm.hip).
+#pragma once
+#include "common.h"
+
+namespace sfast {
+
+struct IgemmArgs {
+    const void *x, *x2;
+    const void *w[SFAST_MAX_WSEG];
+    const void *bias, *rowbias, *res;
+    void *out;
+    float *partial;
+    int M, N, K;
+    int64_t ldx, ldw, ldo, ldr, ld_rowbias;
+    int rows_per_seg, rows_per_batch;
+    int act, res_before_act;
+    float alpha;
+    // conv geometry (MODE 1)
+    int H, W, C1, C2, Ho, Wo, KH, KW, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, ups;
+    int tiles_m, tiles_n, ktiles, ktiles_per_split, splits;
+};
+
+// mode: 0 = linear (x row m at x + m*ldx), 1 = conv (implicit im2col over dense NHWC x / x2).
+// Fills the plan fields of `a` (tiles, split) and launches on `st`.
+int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int split, void *ws, size_t ws_bytes,
+              hipStream_t st);
+size_t igemm_workspace_bytes(int M, int N, int K, bool geglu, int variant, int split);
+
+}  // namespace sfast

@@ -1,0 +1,554 @@
+// MFMA implicit-GEMM for gfx950: every Linear / 1x1 conv / 3x3 conv / Linear+GEGLU of the UNet.
+//
+//   out[m][n] = epilogue( sum_k X[m][k] * W[n][k] )         X: activations, W: weights [N][K]
+//
+// Replaces (reference, src/sfast/csrc/operators/):
+//   cublas/CUDABlas.cc:720-915 gemm_and_bias (+ cublas_gemm.cpp:798-948 linear / linear_add),
+//   cudnn/cudnn_convolution_impl.cc:890-987 fused conv+bias+add+act,
+//   cutlass/cutlass_dual_linear_kernel.cu:238-245 DualGemm GEGLU.
+//
+// CDNA4 design (not a translation of the CUTLASS 128x128x32 / warp 64x32 tiling):
+//   * v_mfma_f32_32x32x16_{f16,bf16}, fp32 accumulate. The WEIGHT fragment is the MFMA A operand
+//     and the ACTIVATION fragment the B operand, i.e. the wave computes D[n][m]. In the 32x32 C/D
+//     layout (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) a lane then owns 4
+//     CONSECUTIVE output columns n for one output row m -> bias / residual / store are 8-byte
+//     vector accesses with no LDS transpose.
+//   * both operands are K-contiguous in memory (activations NHWC, weights [Cout][kh][kw][Cin] =
+//     the channels_last physical layout of the live nn.Parameter), so a fragment is ONE 16-byte
+//     read. K-tile = 64 halves = 128 B per tile row; LDS rows are XOR-swizzled in 16-B chunks
+//     (chunk ^= (row>>1)&7) which makes both the ds_write_b128 staging and the ds_read_b128
+//     fragment reads bank-conflict free for the instruction lane groups of gfx950.
+//   * conv = the same kernel with an implicit im2col gather: a K-chunk k -> (tap, channel),
+//     a tile row m -> (b, ho, wo); out-of-image taps are zero-filled in registers. Nearest-2x
+//     upsample and the channel concat of the up-blocks are folded into the gather, so neither is
+//     ever materialised.
+//   * register-staged double buffering (global_load_dwordx4 of tile t+1 issued before the MFMAs
+//     of tile t, ds_write after), one barrier per K-tile.
+//   * GEGLU: the W tile interleaves 32 hidden rows with 32 gate rows per wave so h and g of the
+//     same output element land in the same lane/register slot -> in-register h * gelu(g); the
+//     [M, 2N] intermediate never exists.
+//   * split-K (fp32 slabs + a reduce/epilogue kernel) for the weight-streaming 16x16 / 8x8 levels
+//     where M <= 512 gives too few tiles for 256 CUs.
+#include "igemm.h"
+
+namespace sfast {
+
+
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// byte offset of 16-B chunk `chunk` (0..7) of tile row `row` (128 B per row), XOR-swizzled
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+// final epilogue for 4 consecutive columns n..n+3 of row m (fp32 in, T out)
+template <typename T>
+__device__ __forceinline__ void epilogue4(const IgemmArgs &a, int m, int n, float (&v)[4]) {
+    if (a.bias) {
+        float b[4];
+        unpack4<T>(*reinterpret_cast<const u32x2 *>((const T *)a.bias + n), b);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += b[i];
+    }
+    if (a.rowbias) {
+        float b[4];
+        const int bi = m / a.rows_per_batch;
+        unpack4<T>(*reinterpret_cast<const u32x2 *>((const T *)a.rowbias + (int64_t)bi * a.ld_rowbias + n), b);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += b[i];
+    }
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.res) {
+        unpack4<T>(*reinterpret_cast<const u32x2 *>((const T *)a.res + (int64_t)m * a.ldr + n), r);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] *= a.alpha;
+    }
+    if (a.res_before_act) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += r[i];
+    }
+    if (a.act != SFAST_ACT_NONE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], a.act);
+    }
+    if (!a.res_before_act) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += r[i];
+    }
+    *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+}
+
+template <typename T>
+__device__ __forceinline__ void epilogue4_geglu(const IgemmArgs &a, int m, int n, float (&h)[4], float (&g)[4]) {
+    if (a.bias) {
+        float bh[4], bg[4];
+        unpack4<T>(*reinterpret_cast<const u32x2 *>((const T *)a.bias + n), bh);
+        unpack4<T>(*reinterpret_cast<const u32x2 *>((const T *)a.bias + a.N + n), bg);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            h[i] += bh[i];
+            g[i] += bg[i];
+        }
+    }
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = h[i] * act_gelu_erf(g[i]);
+    *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+}
+
+// MODE 0: linear (row m -> x + m*ldx). MODE 1: conv (implicit im2col, NHWC).
+template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GEGLU>
+__global__ void __launch_bounds__(WM *WN * 64) igemm_kernel(const IgemmArgs a) {
+    using vec8 = typename Elem<T>::vec8;
+    constexpr int NT = WM * WN * 64;
+    constexpr int FM = BM / (WM * 32);  // 32-row activation fragments per wave
+    constexpr int FN = BN / (WN * 32);  // 32-row weight fragments per wave
+    constexpr int XCH = BM * 8 / NT;    // 16-B chunks staged per thread per K-tile
+    constexpr int WCH = BN * 8 / NT;
+    constexpr int RPP = NT / 8;         // tile rows covered per staging pass
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int BNO = GEGLU ? BN / 2 : BN;  // output columns per tile
+    constexpr int WNB = FN * 32;              // weight rows per wave-n group
+    static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile/wave mismatch");
+    static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "staging mismatch");
+    static_assert(!GEGLU || (FN % 2 == 0), "GEGLU needs paired fragments");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // XCD-aware tile order: hardware places block b on XCD b%8; give each XCD a contiguous run
+    // of logical tiles (n fastest) so tiles sharing an activation row-panel share one L2.
+    int lid;
+    {
+        const int nblk = a.tiles_m * a.tiles_n;
+        const int bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_n = lid % a.tiles_n, tile_m = lid / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BNO;
+    const int kt_begin = blockIdx.y * a.ktiles_per_split;
+    const int kt_end = min(a.ktiles, kt_begin + a.ktiles_per_split);
+
+    const int kc = tid & 7;
+    const int rbase = tid >> 3;
+
+    // ---- per-thread staging metadata -----------------------------------------------------------
+    const T *xrow[XCH];          // MODE 0
+    int xbhw[XCH], xh[XCH], xw[XCH];  // MODE 1
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+        const int m = m0 + rbase + i * RPP;
+        if (MODE == 0) {
+            xrow[i] = (m < a.M) ? (const T *)a.x + (int64_t)m * a.ldx : nullptr;
+        } else {
+            if (m < a.M) {
+                const int hw = a.Ho * a.Wo;
+                const int b = m / hw;
+                const int rem = m - b * hw;
+                const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+                xbhw[i] = b * a.H * a.W;
+                xh[i] = ho * a.stride_h - a.pad_h;
+                xw[i] = wo * a.stride_w - a.pad_w;
+            } else {
+                xbhw[i] = 0;
+                xh[i] = -(1 << 28);
+                xw[i] = -(1 << 28);
+            }
+        }
+    }
+    const T *wrow[WCH];
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+        const int j = rbase + i * RPP;
+        if (GEGLU) {
+            const int grp = j / WNB, within = j % WNB;
+            const int half = within / (WNB / 2), i2 = within % (WNB / 2);
+            const int ncol = n0 + grp * (WNB / 2) + i2;
+            wrow[i] = (ncol < a.N) ? (const T *)a.w[0] + ((int64_t)half * a.N + ncol) * a.ldw : nullptr;
+        } else {
+            const int n = n0 + j;
+            if (n < a.N) {
+                const int seg = n / a.rows_per_seg;
+                const void *base = seg == 0 ? a.w[0] : seg == 1 ? a.w[1] : seg == 2 ? a.w[2] : a.w[3];
+                wrow[i] = (const T *)base + (int64_t)(n - seg * a.rows_per_seg) * a.ldw;
+            } else {
+                wrow[i] = nullptr;
+            }
+        }
+    }
+
+    u32x4 xreg[XCH], wreg[WCH];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    auto load_tile = [&](int kt) {
+        const int k = kt * 64 + kc * 8;
+        const bool kvalid = k < a.K;
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < XCH; ++i) {
+                xreg[i] = (kvalid && xrow[i]) ? *reinterpret_cast<const u32x4 *>(xrow[i] + k) : zero4;
+            }
+        } else {
+            const int cin = a.C1 + a.C2;
+            const int tap = k / cin;
+            const int c = k - tap * cin;
+            const int r = tap / a.KW, s = tap - r * a.KW;
+            const bool first = c < a.C1;
+            const T *base = first ? (const T *)a.x : (const T *)a.x2;
+            const int pitch = first ? a.C1 : a.C2;
+            const int cc = first ? c : c - a.C1;
+            const int dh = r * a.dil_h, dw = s * a.dil_w;
+#pragma unroll
+            for (int i = 0; i < XCH; ++i) {
+                int hi_ = xh[i] + dh, wi_ = xw[i] + dw;
+                bool ok;
+                if (a.ups) {
+                    ok = (unsigned)hi_ < (unsigned)(2 * a.H) && (unsigned)wi_ < (unsigned)(2 * a.W);
+                    hi_ >>= 1;
+                    wi_ >>= 1;
+                } else {
+                    ok = (unsigned)hi_ < (unsigned)a.H && (unsigned)wi_ < (unsigned)a.W;
+                }
+                ok = ok && kvalid;
+                const int64_t off = ((int64_t)(xbhw[i] + hi_ * a.W + wi_)) * pitch + cc;
+                xreg[i] = ok ? *reinterpret_cast<const u32x4 *>(base + off) : zero4;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            wreg[i] = (kvalid && wrow[i]) ? *reinterpret_cast<const u32x4 *>(wrow[i] + k) : zero4;
+        }
+    };
+    auto store_tile = [&](int stage) {
+        char *xs = smem + stage * STAGE;
+        char *ws = xs + BM * 128;
+#pragma unroll
+        for (int i = 0; i < XCH; ++i)
+            *reinterpret_cast<u32x4 *>(xs + lds_off(rbase + i * RPP, kc)) = xreg[i];
+#pragma unroll
+        for (int i = 0; i < WCH; ++i)
+            *reinterpret_cast<u32x4 *>(ws + lds_off(rbase + i * RPP, kc)) = wreg[i];
+    };
+
+    f32x16 acc[FN][FM];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[fn][fm][r] = 0.f;
+
+    auto compute = [&](int stage) {
+        const char *xs = smem + stage * STAGE;
+        const char *ws = xs + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int chunk = ks * 2 + hi;
+            vec8 af[FN], bf[FM];
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+                af[fn] = *reinterpret_cast<const vec8 *>(ws + lds_off(wn * WNB + fn * 32 + l31, chunk));
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm)
+                bf[fm] = *reinterpret_cast<const vec8 *>(xs + lds_off(wm * (FM * 32) + fm * 32 + l31, chunk));
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = mfma32(af[fn], bf[fm], acc[fn][fm]);
+        }
+    };
+
+    // ---- main loop -------------------------------------------------------------------------------
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile(0);
+        __syncthreads();
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const int cur = (kt - kt_begin) & 1;
+            const bool more = kt + 1 < kt_end;
+            if (more) load_tile(kt + 1);
+            compute(cur);
+            if (more) store_tile(cur ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------------
+    const bool partial = a.splits > 1;
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+        const int m = m0 + wm * (FM * 32) + fm * 32 + l31;
+        if (m >= a.M) continue;
+        if (GEGLU) {
+#pragma unroll
+            for (int fh = 0; fh < FN / 2; ++fh) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn * (WNB / 2) + fh * 32 + 8 * g + 4 * hi;
+                    if (n >= a.N) continue;
+                    float h[4], gt[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        h[i] = acc[fh][fm][4 * g + i];
+                        gt[i] = acc[fh + FN / 2][fm][4 * g + i];
+                    }
+                    if (partial) {
+                        float *p = a.partial + ((int64_t)blockIdx.y * a.M + m) * (2 * (int64_t)a.N);
+                        *reinterpret_cast<f32x4 *>(p + n) = f32x4{h[0], h[1], h[2], h[3]};
+                        *reinterpret_cast<f32x4 *>(p + a.N + n) = f32x4{gt[0], gt[1], gt[2], gt[3]};
+                    } else {
+                        epilogue4_geglu<T>(a, m, n, h, gt);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn * WNB + fn * 32 + 8 * g + 4 * hi;
+                    if (n >= a.N) continue;
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = acc[fn][fm][4 * g + i];
+                    if (partial) {
+                        float *p = a.partial + ((int64_t)blockIdx.y * a.M + m) * (int64_t)a.N;
+                        *reinterpret_cast<f32x4 *>(p + n) = f32x4{v[0], v[1], v[2], v[3]};
+                    } else {
+                        epilogue4<T>(a, m, n, v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// split-K reduce + epilogue: one thread per 4 consecutive output columns.
+template <typename T, bool GEGLU>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const IgemmArgs a) {
+    const int64_t n4 = a.N / 4;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)a.M * n4) return;
+    const int m = (int)(idx / n4);
+    const int n = (int)(idx % n4) * 4;
+    const int64_t NP = GEGLU ? 2 * (int64_t)a.N : (int64_t)a.N;
+    float v[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < a.splits; ++z) {
+        const float *p = a.partial + ((int64_t)z * a.M + m) * NP;
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(p + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += t[i];
+        if (GEGLU) {
+            const f32x4 u = *reinterpret_cast<const f32x4 *>(p + a.N + n);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[i] += u[i];
+        }
+    }
+    if (GEGLU)
+        epilogue4_geglu<T>(a, m, n, v, g);
+    else
+        epilogue4<T>(a, m, n, v);
+}
+
+// ---- host side: variants, heuristics, launch -------------------------------------------------------
+struct Variant {
+    int id, BM, BN, WM, WN;
+    float eff;  // relative MFMA efficiency of the tile shape (arithmetic intensity / LDS pressure)
+};
+// BN = weight rows per tile (GEGLU variants produce BN/2 output columns)
+static const Variant kVariants[] = {
+    {1, 128, 128, 2, 2, 1.00f},
+    {2, 128, 160, 4, 1, 1.00f},
+    {3, 64, 64, 2, 2, 0.60f},
+    {4, 64, 160, 2, 1, 0.80f},
+    {5, 256, 128, 4, 2, 1.10f},
+};
+static const Variant kGegluVariants[] = {
+    {1, 128, 128, 2, 2, 1.00f},
+    {3, 64, 128, 2, 2, 0.75f},
+};
+
+template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GEGLU>
+static int launch_one(const IgemmArgs &a, hipStream_t st) {
+    constexpr int smem = 2 * (BM + BN) * 128;
+    auto kern = igemm_kernel<T, BM, BN, WM, WN, MODE, GEGLU>;
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n, a.splits), dim3(WM * WN * 64), smem, st, a);
+    return check_launch("igemm");
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GEGLU>
+static int set_attr_one() {
+    constexpr int smem = 2 * (BM + BN) * 128;
+    auto kern = igemm_kernel<T, BM, BN, WM, WN, MODE, GEGLU>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(igemm %dx%d): %s", BM, BN, hipGetErrorString(e));
+        return SFAST_ERR_LAUNCH;
+    }
+    return 0;
+}
+
+#define SFAST_FOR_VARIANTS(T, MODE, OP)              \
+    OP(T, 128, 128, 2, 2, MODE, false)               \
+    OP(T, 128, 160, 4, 1, MODE, false)               \
+    OP(T, 64, 64, 2, 2, MODE, false)                 \
+    OP(T, 64, 160, 2, 1, MODE, false)                \
+    OP(T, 256, 128, 4, 2, MODE, false)
+
+#define SFAST_FOR_GEGLU_VARIANTS(T, OP) \
+    OP(T, 128, 128, 2, 2, 0, true)      \
+    OP(T, 64, 128, 2, 2, 0, true)
+
+int igemm_init() {
+    int rc = 0;
+#define INIT_OP(T, BM, BN, WM, WN, MODE, G) \
+    if (!rc) rc = set_attr_one<T, BM, BN, WM, WN, MODE, G>();
+    SFAST_FOR_VARIANTS(f16, 0, INIT_OP)
+    SFAST_FOR_VARIANTS(f16, 1, INIT_OP)
+    SFAST_FOR_VARIANTS(bf16, 0, INIT_OP)
+    SFAST_FOR_VARIANTS(bf16, 1, INIT_OP)
+    SFAST_FOR_GEGLU_VARIANTS(f16, INIT_OP)
+    SFAST_FOR_GEGLU_VARIANTS(bf16, INIT_OP)
+#undef INIT_OP
+    return rc;
+}
+
+template <typename T, int MODE>
+static int dispatch_variant(const IgemmArgs &a, const Variant &v, bool geglu, hipStream_t st) {
+#define LAUNCH_OP(TT, BM_, BN_, WM_, WN_, MODE_, G_)                                   \
+    if (v.BM == BM_ && v.BN == BN_ && v.WM == WM_ && v.WN == WN_ && geglu == G_)      \
+        return launch_one<TT, BM_, BN_, WM_, WN_, MODE_, G_>(a, st);
+    if (!geglu) {
+        SFAST_FOR_VARIANTS(T, MODE, LAUNCH_OP)
+    } else {
+        if (MODE == 0) {
+            SFAST_FOR_GEGLU_VARIANTS(T, LAUNCH_OP)
+        }
+    }
+#undef LAUNCH_OP
+    set_error("igemm: no kernel for variant BM=%d BN=%d", v.BM, v.BN);
+    return SFAST_ERR_UNSUPPORTED;
+}
+
+struct IgemmPlan {
+    Variant v;
+    int splits, ktps, tiles_m, tiles_n, ktiles;
+};
+
+// Pick tile shape and split-K factor. Cost model: waves of workgroups over 256 CUs (2 WGs per CU
+// for the <=80 KB tiles) x per-tile work / tile efficiency, plus the split-K slab traffic.
+static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, int force_split) {
+    const Variant *vs = geglu ? kGegluVariants : kVariants;
+    const int nv = geglu ? (int)(sizeof(kGegluVariants) / sizeof(Variant)) : (int)(sizeof(kVariants) / sizeof(Variant));
+    const int ktiles = ceil_div(K, 64);
+    IgemmPlan best{};
+    double best_cost = 1e300;
+    for (int i = 0; i < nv; ++i) {
+        const Variant &v = vs[i];
+        if (force_variant && v.id != force_variant) continue;
+        const int bno = geglu ? v.BN / 2 : v.BN;
+        const int tm = ceil_div(M, v.BM), tn = ceil_div(N, bno);
+        const int tiles = tm * tn;
+        const int lds = 2 * (v.BM + v.BN) * 128;
+        const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;
+        const int slots = 256 * wg_per_cu;
+        int max_split = ktiles / 4;
+        if (max_split < 1) max_split = 1;
+        if (max_split > 32) max_split = 32;
+        for (int s = 1; s <= max_split; s = (s < 4 ? s + 1 : s * 2)) {
+            if (force_split && s != force_split) continue;
+            const int ktps = ceil_div(ktiles, s);
+            const int splits = ceil_div(ktiles, ktps);
+            if (splits != s && !force_split) continue;
+            const double waves = (double)ceil_div(tiles * splits, slots);
+            // time of one WG: ktps K-tiles of BM*BN*64 MACs at tile efficiency; concurrency 1/wg_per_cu share
+            const double tile_work = (double)v.BM * v.BN * 64.0 * ktps / v.eff * wg_per_cu;
+            double cost = waves * tile_work + 40000.0 * 64;  // fixed launch-ish overhead
+            if (splits > 1) {
+                const double np = geglu ? 2.0 * N : (double)N;
+                // slab write+read bytes, expressed in MAC-equivalents (~5 TB/s vs ~1 PF/s tile rate)
+                cost += (double)splits * M * np * 8.0 * 60.0 + 2.0e6;
+            }
+            if (cost < best_cost) {
+                best_cost = cost;
+                best.v = v;
+                best.splits = splits;
+                best.ktps = ktps;
+                best.tiles_m = tm;
+                best.tiles_n = tn;
+                best.ktiles = ktiles;
+            }
+        }
+    }
+    if (best_cost == 1e300) {
+        // forced combination did not exist: fall back to variant 3, no split
+        best.v = vs[nv > 2 ? 2 : nv - 1];
+        const int bno = geglu ? best.v.BN / 2 : best.v.BN;
+        best.splits = 1;
+        best.ktps = ktiles;
+        best.tiles_m = ceil_div(M, best.v.BM);
+        best.tiles_n = ceil_div(N, bno);
+        best.ktiles = ktiles;
+    }
+    return best;
+}
+
+size_t igemm_workspace_bytes(int M, int N, int K, bool geglu, int variant, int split) {
+    IgemmPlan p = igemm_plan(M, N, K, geglu, variant, split);
+    if (p.splits <= 1) return 0;
+    return (size_t)p.splits * M * (geglu ? 2 * (size_t)N : (size_t)N) * sizeof(float);
+}
+
+// entry used by gemm.hip / conv.hip. mode: 0 linear, 1 conv. Fills plan fields of `a`.
+int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int split, void *ws, size_t ws_bytes,
+              hipStream_t st) {
+    IgemmPlan p = igemm_plan(a.M, a.N, a.K, geglu, variant, split);
+    a.tiles_m = p.tiles_m;
+    a.tiles_n = p.tiles_n;
+    a.ktiles = p.ktiles;
+    a.ktiles_per_split = p.ktps;
+    a.splits = p.splits;
+    a.partial = nullptr;
+    if (p.splits > 1) {
+        const size_t need = (size_t)p.splits * a.M * (geglu ? 2 * (size_t)a.N : (size_t)a.N) * sizeof(float);
+        SFAST_REQUIRE(ws && ws_bytes >= need, SFAST_ERR_WORKSPACE, "igemm: workspace %zu < %zu", ws_bytes, need);
+        a.partial = (float *)ws;
+    }
+    set_kernel_name("igemm_%s_%s%s[%dx%d,split=%d]", mode ? "conv" : "lin", dtype == SFAST_F16 ? "f16" : "bf16",
+                    geglu ? "_geglu" : "", p.v.BM, p.v.BN, p.splits);
+    int rc;
+    if (dtype == SFAST_F16)
+        rc = mode ? dispatch_variant<f16, 1>(a, p.v, geglu, st) : dispatch_variant<f16, 0>(a, p.v, geglu, st);
+    else
+        rc = mode ? dispatch_variant<bf16, 1>(a, p.v, geglu, st) : dispatch_variant<bf16, 0>(a, p.v, geglu, st);
+    if (rc) return rc;
+    if (p.splits > 1) {
+        const int64_t total = (int64_t)a.M * (a.N / 4);
+        const dim3 grid((unsigned)ceil_div64(total, 256));
+        if (dtype == SFAST_F16) {
+            if (geglu)
+                hipLaunchKernelGGL((splitk_reduce_kernel<f16, true>), grid, dim3(256), 0, st, a);
+            else
+                hipLaunchKernelGGL((splitk_reduce_kernel<f16, false>), grid, dim3(256), 0, st, a);
+        } else {
+            if (geglu)
+                hipLaunchKernelGGL((splitk_reduce_kernel<bf16, true>), grid, dim3(256), 0, st, a);
+            else
+                hipLaunchKernelGGL((splitk_reduce_kernel<bf16, false>), grid, dim3(256), 0, st, a);
+        }
+        return check_launch("splitk_reduce");
+    }
+    return SFAST_OK;
+}
+
+}  // namespace sfast

@@ -1,0 +1,54 @@
+// Library-level entry points: version, init, thread-local error / kernel-name strings.
+#include "common.h"
+#include <string.h>
+
+namespace sfast {
+
+static thread_local char g_err[512] = "";
+static thread_local char g_kernel[256] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+void set_kernel_name(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return SFAST_ERR_LAUNCH;
+    }
+    return SFAST_OK;
+}
+
+int igemm_init();      // igemm.hip
+int attention_init();  // attention.hip
+
+}  // namespace sfast
+
+extern "C" {
+
+int sfast_hip_abi_version(void) { return SFAST_HIP_ABI_VERSION; }
+
+int sfast_hip_init(void) {
+    static int done = 0;
+    static int rc = 0;
+    if (!done) {
+        rc = sfast::igemm_init();
+        if (rc == 0) rc = sfast::attention_init();
+        done = 1;
+    }
+    return rc;
+}
+
+const char *sfast_hip_last_error(void) { return sfast::g_err; }
+const char *sfast_hip_last_kernel(void) { return sfast::g_kernel; }
+
+}  // extern "C"

@@ -1,0 +1,540 @@
+// GroupNorm(+SiLU) and LayerNorm for gfx950 -- HBM-bound kernels.
+//
+// Replaces the reference's Triton kernels (src/sfast/triton/ops/group_norm.py:111-165 stats,
+// :272-349 apply, src/sfast/triton/ops/layer_norm.py:52-133). Differences by design:
+//   * NHWC fast path: a workgroup streams whole pixel rows (all channels, 16 B per lane, fully
+//     coalesced) instead of one (group, sample) program gathering C/G-wide strips -- the
+//     reference launches only (32, N) programs, far fewer than 256 CUs.
+//   * statistics are shifted sums in fp32 (shift = first element of the group), so the partials
+//     of different workgroups add exactly like Welford merges without carrying means around;
+//     the reduction order is fixed -> bitwise reproducible across graph replays.
+//   * affine + SiLU are computed in fp32 (the reference applies the affine in fp16).
+//   * a virtual channel concat (x | x2) lets the UNet's up-blocks normalise torch.cat([h, skip])
+//     without materialising it.
+#include "common.h"
+#include <type_traits>
+
+namespace sfast {
+
+// =================================================================================================
+// NHWC fast path: C % 8 == 0, C1 % 8 == 0, C/G >= 8, f16 / bf16.
+// thread (tx, ty): tx -> one 8-channel chunk column, ty -> pixel row phase.
+// =================================================================================================
+struct GnGeom {
+    int HW, C, C1, cpg, G;
+    int CX;   // C / 8
+    int TXB;  // chunk columns handled per pass (threads along channels)
+    int TY;   // rows handled concurrently
+};
+
+template <typename T>
+__device__ __forceinline__ const T *gn_src(const T *x, const T *x2, const GnGeom &g, int b, int64_t row,
+                                           int c) {
+    // element pointer for (sample b, pixel row, channel c) under the virtual concat
+    if (c < g.C1) return x + ((int64_t)b * g.HW + row) * g.C1 + c;
+    return x2 + ((int64_t)b * g.HW + row) * (g.C - g.C1) + (c - g.C1);
+}
+
+template <typename T>
+__global__ void gn_nhwc_stats_kernel(const T *__restrict__ x, const T *__restrict__ x2,
+                                     float *__restrict__ partial, GnGeom g, int rows_per_block,
+                                     int nsplit) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int NT = g.TXB * g.TY;
+    float *red = smem;            // [NT][4]
+    float *gsum = smem + NT * 4;  // [G][2]
+    const int tid = threadIdx.x;
+    const int tx = tid % g.TXB, ty = tid / g.TXB;
+    const int b = blockIdx.y, split = blockIdx.x;
+    const int r0 = split * rows_per_block;
+    const int r1 = min(g.HW, r0 + rows_per_block);
+
+    if (tid < g.G) {
+        gsum[tid * 2] = 0.f;
+        gsum[tid * 2 + 1] = 0.f;
+    }
+    for (int cxb = 0; cxb < g.CX; cxb += g.TXB) {
+        const int cx = cxb + tx;
+        float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+        if (cx < g.CX && tid < NT) {
+            const int c = cx * 8;
+            const int g0 = c / g.cpg;
+            const int nb = min(8, (g0 + 1) * g.cpg - c);
+            const float sh0 = (float)*gn_src(x, x2, g, b, 0, g0 * g.cpg);
+            const float sh1 = (nb < 8) ? (float)*gn_src(x, x2, g, b, 0, (g0 + 1) * g.cpg) : 0.f;
+            for (int r = r0 + ty; r < r1; r += g.TY) {
+                const u32x4 raw = *reinterpret_cast<const u32x4 *>(gn_src(x, x2, g, b, r, c));
+                float f[8];
+                unpack8<T>(raw, f);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (i < nb) {
+                        const float d = f[i] - sh0;
+                        s1a += d;
+                        s2a += d * d;
+                    } else {
+                        const float d = f[i] - sh1;
+                        s1b += d;
+                        s2b += d * d;
+                    }
+                }
+            }
+        }
+        if (tid < NT) {
+            red[tid * 4 + 0] = s1a;
+            red[tid * 4 + 1] = s2a;
+            red[tid * 4 + 2] = s1b;
+            red[tid * 4 + 3] = s2b;
+        }
+        __syncthreads();
+        // reduce over ty (fixed order)
+        if (tid < g.TXB) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int j = 0; j < g.TY; ++j) {
+                const float *p = red + (j * g.TXB + tid) * 4;
+                a0 += p[0];
+                a1 += p[1];
+                a2 += p[2];
+                a3 += p[3];
+            }
+            // entry (0, tid) is read by this thread only -> in-place write is race-free
+            red[tid * 4 + 0] = a0;
+            red[tid * 4 + 1] = a1;
+            red[tid * 4 + 2] = a2;
+            red[tid * 4 + 3] = a3;
+        }
+        __syncthreads();
+        // gather chunk columns into groups (thread = group, fixed order)
+        if (tid < g.G) {
+            const int grp = tid;
+            int lo = (grp * g.cpg) / 8, hi = ((grp + 1) * g.cpg - 1) / 8;
+            lo = max(lo, cxb);
+            hi = min(hi, min(g.CX, cxb + g.TXB) - 1);
+            float s1 = 0.f, s2 = 0.f;
+            for (int cxx = lo; cxx <= hi; ++cxx) {
+                const int g0 = (cxx * 8) / g.cpg;
+                const float *p = red + (cxx - cxb) * 4;
+                if (g0 == grp) {
+                    s1 += p[0];
+                    s2 += p[1];
+                } else if (g0 + 1 == grp) {
+                    s1 += p[2];
+                    s2 += p[3];
+                }
+            }
+            gsum[grp * 2] += s1;
+            gsum[grp * 2 + 1] += s2;
+        }
+        __syncthreads();
+    }
+    if (tid < g.G) {
+        float *o = partial + (((int64_t)b * nsplit + split) * g.G + tid) * 2;
+        o[0] = gsum[tid * 2];
+        o[1] = gsum[tid * 2 + 1];
+    }
+}
+
+template <typename T, bool SILU>
+__global__ void gn_nhwc_apply_kernel(const T *__restrict__ x, const T *__restrict__ x2,
+                                     const T *__restrict__ gamma, const T *__restrict__ beta,
+                                     T *__restrict__ y, const float *__restrict__ partial, GnGeom g,
+                                     int rows_per_block, int nsplit, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *mean = smem;               // [G]
+    float *rstd = smem + g.G;         // [G]
+    float *tmp = smem + 2 * g.G;      // [G][8][2]
+    const int NT = g.TXB * g.TY;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    constexpr int RS = 8;
+    // combine the per-split partial sums: (group, lane-of-8) then 8 -> 1, fixed order.
+    if (tid < g.G * RS) {
+        const int grp = tid / RS, j = tid % RS;
+        float s1 = 0.f, s2 = 0.f;
+        for (int s = j; s < nsplit; s += RS) {
+            const float *p = partial + (((int64_t)b * nsplit + s) * g.G + grp) * 2;
+            s1 += p[0];
+            s2 += p[1];
+        }
+        tmp[tid * 2] = s1;
+        tmp[tid * 2 + 1] = s2;
+    }
+    __syncthreads();
+    if (tid < g.G) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < RS; ++j) {
+            s1 += tmp[(tid * RS + j) * 2];
+            s2 += tmp[(tid * RS + j) * 2 + 1];
+        }
+        const float n = (float)g.HW * (float)g.cpg;
+        const float sh = (float)*gn_src(x, x2, g, b, 0, tid * g.cpg);
+        const float m1 = s1 / n;
+        const float var = fmaxf(s2 / n - m1 * m1, 0.f);  // biased variance (group_norm.py:48)
+        mean[tid] = sh + m1;
+        rstd[tid] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+
+    const int tx = tid % g.TXB, ty = tid / g.TXB;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(g.HW, r0 + rows_per_block);
+    if (tid >= NT) return;
+    for (int cxb = 0; cxb < g.CX; cxb += g.TXB) {
+        const int cx = cxb + tx;
+        if (cx >= g.CX) continue;
+        const int c = cx * 8;
+        float a[8], bb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int grp = (c + i) / g.cpg;
+            const float ga = gamma ? (float)gamma[c + i] : 1.f;
+            const float be = beta ? (float)beta[c + i] : 0.f;
+            a[i] = rstd[grp] * ga;
+            bb[i] = be - mean[grp] * a[i];
+        }
+        for (int r = r0 + ty; r < r1; r += g.TY) {
+            const u32x4 raw = *reinterpret_cast<const u32x4 *>(gn_src(x, x2, g, b, r, c));
+            float f[8];
+            unpack8<T>(raw, f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = fmaf(f[i], a[i], bb[i]);
+                if (SILU) v = act_silu(v);
+                f[i] = v;
+            }
+            *reinterpret_cast<u32x4 *>(y + ((int64_t)b * g.HW + r) * g.C + c) = pack8<T>(f);
+        }
+    }
+}
+
+// =================================================================================================
+// Generic path: any C/G, NHWC (with concat) or NCHW, f16 / bf16 / f32. One workgroup per (n, g).
+// =================================================================================================
+template <typename T>
+__device__ __forceinline__ int64_t gn_generic_index(int layout, int n, int64_t i, int HW, int C, int cpg,
+                                                    int grp, int &c_out) {
+    if (layout == SFAST_NHWC) {
+        const int cc = (int)(i % cpg);
+        const int64_t p = i / cpg;
+        c_out = grp * cpg + cc;
+        return p;  // caller resolves the concat source
+    }
+    const int64_t p = i % HW;
+    const int cc = (int)(i / HW);
+    c_out = grp * cpg + cc;
+    return p;
+}
+
+template <typename T>
+__global__ void gn_generic_kernel(const T *__restrict__ x, const T *__restrict__ x2,
+                                  const T *__restrict__ gamma, const T *__restrict__ beta,
+                                  T *__restrict__ y, int layout, int HW, int C, int C1, int cpg, float eps,
+                                  int act) {
+    __shared__ float red[2][256];
+    __shared__ float stat[2];
+    const int tid = threadIdx.x;
+    const int grp = blockIdx.x, n = blockIdx.y;
+    const int64_t total = (int64_t)HW * cpg;
+    auto load = [&](int64_t p, int c) -> float {
+        if (layout == SFAST_NHWC) {
+            if (c < C1) return Elem<T>::to_f32(x[((int64_t)n * HW + p) * C1 + c]);
+            return Elem<T>::to_f32(x2[((int64_t)n * HW + p) * (C - C1) + (c - C1)]);
+        }
+        return Elem<T>::to_f32(x[((int64_t)n * C + c) * HW + p]);
+    };
+    const float sh = load(0, grp * cpg);
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t i = tid; i < total; i += blockDim.x) {
+        int c;
+        const int64_t p = gn_generic_index<T>(layout, n, i, HW, C, cpg, grp, c);
+        const float d = load(p, c) - sh;
+        s1 += d;
+        s2 += d * d;
+    }
+    red[0][tid] = s1;
+    red[1][tid] = s2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            red[0][tid] += red[0][tid + s];
+            red[1][tid] += red[1][tid + s];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float nn = (float)total;
+        const float m1 = red[0][0] / nn;
+        const float var = fmaxf(red[1][0] / nn - m1 * m1, 0.f);
+        stat[0] = sh + m1;
+        stat[1] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    const float mean = stat[0], rstd = stat[1];
+    for (int64_t i = tid; i < total; i += blockDim.x) {
+        int c;
+        const int64_t p = gn_generic_index<T>(layout, n, i, HW, C, cpg, grp, c);
+        const float ga = gamma ? Elem<T>::to_f32(gamma[c]) : 1.f;
+        const float be = beta ? Elem<T>::to_f32(beta[c]) : 0.f;
+        float v = (load(p, c) - mean) * rstd * ga + be;
+        if (act == SFAST_ACT_SILU) v = act_silu(v);
+        const int64_t oi = (layout == SFAST_NHWC) ? ((int64_t)n * HW + p) * C + c
+                                                  : ((int64_t)n * C + c) * HW + p;
+        y[oi] = Elem<T>::from_f32(v);
+    }
+}
+
+// =================================================================================================
+// LayerNorm: one wave per row. Fast path N % 8 == 0 (16-B loads, row cached in registers up to
+// N = 4096); generic path scalar.
+// =================================================================================================
+template <typename T, int MAXCH>
+__global__ void __launch_bounds__(256) ln_rows_kernel(const T *__restrict__ x, const T *__restrict__ gamma,
+                                                      const T *__restrict__ beta, T *__restrict__ y,
+                                                      int M, int N, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= M) return;
+    const int nch = N / 8;
+    const T *xr = x + (int64_t)row * N;
+    u32x4 cache[MAXCH];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) {
+        const int ch = lane + j * 64;
+        if (ch < nch) {
+            cache[j] = *reinterpret_cast<const u32x4 *>(xr + ch * 8);
+            float f[8];
+            unpack8<T>(cache[j], f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += f[i];
+        }
+    }
+    const float mean = wave_sum(s) / (float)N;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) {
+        const int ch = lane + j * 64;
+        if (ch < nch) {
+            float f[8];
+            unpack8<T>(cache[j], f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float d = f[i] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)N + eps);
+    T *yr = y + (int64_t)row * N;
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) {
+        const int ch = lane + j * 64;
+        if (ch < nch) {
+            float f[8], ga[8], be[8];
+            unpack8<T>(cache[j], f);
+            if (gamma) {
+                unpack8<T>(*reinterpret_cast<const u32x4 *>(gamma + ch * 8), ga);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ga[i] = 1.f;
+            }
+            if (beta) {
+                unpack8<T>(*reinterpret_cast<const u32x4 *>(beta + ch * 8), be);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) be[i] = 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = (f[i] - mean) * rstd * ga[i] + be[i];
+            *reinterpret_cast<u32x4 *>(yr + ch * 8) = pack8<T>(f);
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) ln_generic_kernel(const T *__restrict__ x, const T *__restrict__ gamma,
+                                                         const T *__restrict__ beta, T *__restrict__ y,
+                                                         int M, int N, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= M) return;
+    const T *xr = x + (int64_t)row * N;
+    float s = 0.f;
+    for (int i = lane; i < N; i += 64) s += Elem<T>::to_f32(xr[i]);
+    const float mean = wave_sum(s) / (float)N;
+    float q = 0.f;
+    for (int i = lane; i < N; i += 64) {
+        const float d = Elem<T>::to_f32(xr[i]) - mean;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)N + eps);
+    T *yr = y + (int64_t)row * N;
+    for (int i = lane; i < N; i += 64) {
+        const float ga = gamma ? Elem<T>::to_f32(gamma[i]) : 1.f;
+        const float be = beta ? Elem<T>::to_f32(beta[i]) : 0.f;
+        yr[i] = Elem<T>::from_f32((Elem<T>::to_f32(xr[i]) - mean) * rstd * ga + be);
+    }
+}
+
+// ---- host-side planning ----------------------------------------------------------------------
+struct GnPlan {
+    bool fast;
+    GnGeom g;
+    int nsplit, rows_stats, rows_apply, napply;
+};
+
+static GnPlan gn_plan(const sfast_gn_params *p) {
+    GnPlan pl{};
+    const int cpg = p->G > 0 ? p->C / p->G : 0;
+    pl.fast = p->layout == SFAST_NHWC && p->dtype != SFAST_F32 && p->G > 0 && p->C % p->G == 0 &&
+              p->C % 8 == 0 && p->C1 % 8 == 0 && cpg >= 8 && p->G * 8 <= 256 && p->HW > 0;
+    if (!pl.fast) return pl;
+    GnGeom &g = pl.g;
+    g.HW = p->HW;
+    g.C = p->C;
+    g.C1 = p->C1;
+    g.cpg = cpg;
+    g.G = p->G;
+    g.CX = p->C / 8;
+    g.TXB = g.CX < 512 ? g.CX : 512;
+    g.TY = 512 / g.TXB;
+    if (g.TY < 1) g.TY = 1;
+    if (g.TY > p->HW) g.TY = p->HW;
+    const int max_split = ceil_div(p->HW, g.TY);
+    int want = ceil_div(512, p->N);
+    if (want > 128) want = 128;
+    pl.nsplit = want < max_split ? want : max_split;
+    if (pl.nsplit < 1) pl.nsplit = 1;
+    pl.rows_stats = ceil_div(p->HW, pl.nsplit);
+    pl.nsplit = ceil_div(p->HW, pl.rows_stats);
+    int wanta = ceil_div(1024, p->N);
+    int na = wanta < max_split ? wanta : max_split;
+    if (na < 1) na = 1;
+    pl.rows_apply = ceil_div(p->HW, na);
+    pl.napply = ceil_div(p->HW, pl.rows_apply);
+    return pl;
+}
+
+template <typename T>
+static int gn_launch_fast(const void *x, const void *x2, const void *gamma, const void *beta, void *y,
+                          const sfast_gn_params *p, const GnPlan &pl, float *ws, hipStream_t st) {
+    const GnGeom &g = pl.g;
+    const int NT = g.TXB * g.TY;
+    int threads = ((NT + 63) / 64) * 64;
+    if (threads < g.G * 8) threads = ((g.G * 8 + 63) / 64) * 64;  // the partial combine uses G*8 threads
+    const size_t smem_stats = (size_t)(NT * 4 + g.G * 2) * sizeof(float);
+    hipLaunchKernelGGL(gn_nhwc_stats_kernel<T>, dim3(pl.nsplit, p->N), dim3(threads), smem_stats, st,
+                       (const T *)x, (const T *)x2, ws, g, pl.rows_stats, pl.nsplit);
+    const size_t smem_apply = (size_t)(2 * g.G + g.G * 16) * sizeof(float);
+    if (p->act == SFAST_ACT_SILU)
+        hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, true>), dim3(pl.napply, p->N), dim3(threads), smem_apply,
+                           st, (const T *)x, (const T *)x2, (const T *)gamma, (const T *)beta, (T *)y, ws, g,
+                           pl.rows_apply, pl.nsplit, p->eps);
+    else
+        hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, false>), dim3(pl.napply, p->N), dim3(threads), smem_apply,
+                           st, (const T *)x, (const T *)x2, (const T *)gamma, (const T *)beta, (T *)y, ws, g,
+                           pl.rows_apply, pl.nsplit, p->eps);
+    return check_launch("group_norm_nhwc");
+}
+
+template <typename T>
+static int gn_launch_generic(const void *x, const void *x2, const void *gamma, const void *beta, void *y,
+                             const sfast_gn_params *p, hipStream_t st) {
+    hipLaunchKernelGGL(gn_generic_kernel<T>, dim3(p->G, p->N), dim3(256), 0, st, (const T *)x, (const T *)x2,
+                       (const T *)gamma, (const T *)beta, (T *)y, p->layout, p->HW, p->C, p->C1, p->C / p->G,
+                       p->eps, p->act);
+    return check_launch("group_norm_generic");
+}
+
+}  // namespace sfast
+
+using namespace sfast;
+
+extern "C" size_t sfast_hip_group_norm_workspace_bytes(const sfast_gn_params *p) {
+    if (!p) return 0;
+    GnPlan pl = gn_plan(p);
+    if (!pl.fast) return 0;
+    return (size_t)p->N * pl.nsplit * p->G * 2 * sizeof(float);
+}
+
+extern "C" int sfast_hip_group_norm(const void *x, const void *x2, const void *gamma, const void *beta,
+                                    void *y, const sfast_gn_params *p, void *workspace,
+                                    size_t workspace_bytes, sfast_stream_t stream) {
+    SFAST_REQUIRE(p && x && y, SFAST_ERR_INVALID, "group_norm: null argument");
+    SFAST_REQUIRE(p->N > 0 && p->C > 0 && p->HW > 0 && p->G > 0 && p->C % p->G == 0, SFAST_ERR_INVALID,
+                  "group_norm: bad shape N=%d C=%d HW=%d G=%d", p->N, p->C, p->HW, p->G);
+    SFAST_REQUIRE(p->act == SFAST_ACT_NONE || p->act == SFAST_ACT_SILU, SFAST_ERR_UNSUPPORTED,
+                  "group_norm: act %d unsupported", p->act);
+    SFAST_REQUIRE(p->C1 > 0 && p->C1 <= p->C, SFAST_ERR_INVALID, "group_norm: bad C1=%d", p->C1);
+    SFAST_REQUIRE(p->C1 == p->C || (x2 && p->layout == SFAST_NHWC), SFAST_ERR_INVALID,
+                  "group_norm: concat needs x2 and NHWC");
+    hipStream_t st = (hipStream_t)stream;
+    GnPlan pl = gn_plan(p);
+    const bool ptr_ok = aligned16(x) && aligned16(y) && (p->C1 == p->C || aligned16(x2));
+    if (pl.fast && ptr_ok) {
+        const size_t need = sfast_hip_group_norm_workspace_bytes(p);
+        SFAST_REQUIRE(workspace && workspace_bytes >= need, SFAST_ERR_WORKSPACE,
+                      "group_norm: workspace %zu < %zu", workspace_bytes, need);
+        set_kernel_name("gn_nhwc[TXB=%d,TY=%d,split=%d,apply=%d]", pl.g.TXB, pl.g.TY, pl.nsplit, pl.napply);
+        if (p->dtype == SFAST_F16)
+            return gn_launch_fast<f16>(x, x2, gamma, beta, y, p, pl, (float *)workspace, st);
+        return gn_launch_fast<bf16>(x, x2, gamma, beta, y, p, pl, (float *)workspace, st);
+    }
+    set_kernel_name("gn_generic");
+    switch (p->dtype) {
+    case SFAST_F16: return gn_launch_generic<f16>(x, x2, gamma, beta, y, p, st);
+    case SFAST_BF16: return gn_launch_generic<bf16>(x, x2, gamma, beta, y, p, st);
+    case SFAST_F32: return gn_launch_generic<float>(x, x2, gamma, beta, y, p, st);
+    }
+    set_error("group_norm: bad dtype %d", p->dtype);
+    return SFAST_ERR_UNSUPPORTED;
+}
+
+template <typename T>
+static int ln_launch(const void *x, const void *gamma, const void *beta, void *y, const sfast_ln_params *p,
+                     hipStream_t st, bool fast) {
+    const dim3 grid(ceil_div(p->M, 4)), block(256);
+    if constexpr (!std::is_same<T, float>::value) {
+      if (fast) {
+        const int nch = p->N / 8;
+        if (nch <= 64)
+            hipLaunchKernelGGL((ln_rows_kernel<T, 1>), grid, block, 0, st, (const T *)x, (const T *)gamma,
+                               (const T *)beta, (T *)y, p->M, p->N, p->eps);
+        else if (nch <= 128)
+            hipLaunchKernelGGL((ln_rows_kernel<T, 2>), grid, block, 0, st, (const T *)x, (const T *)gamma,
+                               (const T *)beta, (T *)y, p->M, p->N, p->eps);
+        else if (nch <= 256)
+            hipLaunchKernelGGL((ln_rows_kernel<T, 4>), grid, block, 0, st, (const T *)x, (const T *)gamma,
+                               (const T *)beta, (T *)y, p->M, p->N, p->eps);
+        else
+            hipLaunchKernelGGL((ln_rows_kernel<T, 8>), grid, block, 0, st, (const T *)x, (const T *)gamma,
+                               (const T *)beta, (T *)y, p->M, p->N, p->eps);
+        return check_launch("layer_norm");
+      }
+    }
+    {
+        hipLaunchKernelGGL(ln_generic_kernel<T>, grid, block, 0, st, (const T *)x, (const T *)gamma,
+                           (const T *)beta, (T *)y, p->M, p->N, p->eps);
+    }
+    return check_launch("layer_norm");
+}
+
+extern "C" int sfast_hip_layer_norm(const void *x, const void *gamma, const void *beta, void *y,
+                                    const sfast_ln_params *p, sfast_stream_t stream) {
+    SFAST_REQUIRE(p && x && y, SFAST_ERR_INVALID, "layer_norm: null argument");
+    SFAST_REQUIRE(p->M > 0 && p->N > 0, SFAST_ERR_INVALID, "layer_norm: bad shape %d x %d", p->M, p->N);
+    hipStream_t st = (hipStream_t)stream;
+    const bool fast = p->dtype != SFAST_F32 && p->N % 8 == 0 && p->N <= 4096 && aligned16(x) && aligned16(y) &&
+                      (!gamma || aligned16(gamma)) && (!beta || aligned16(beta));
+    set_kernel_name(fast ? "ln_rows" : "ln_generic");
+    switch (p->dtype) {
+    case SFAST_F16: return ln_launch<f16>(x, gamma, beta, y, p, st, fast);
+    case SFAST_BF16: return ln_launch<bf16>(x, gamma, beta, y, p, st, fast);
+    case SFAST_F32: return ln_launch<float>(x, gamma, beta, y, p, st, false);
+    }
+    set_error("layer_norm: bad dtype %d", p->dtype);
+    return SFAST_ERR_UNSUPPORTED;
+}

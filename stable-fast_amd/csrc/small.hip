@@ -1,0 +1,369 @@
+// Non-MFMA kernels of the GEMM / conv families:
+//   * gemv_small_m   : M <= 16 rows (time-embedding MLP, time_emb_proj): pure weight streaming,
+//                      one wave per output column, 16-B loads, fp32 accumulate.
+//   * conv_small_n   : Cout <= 8 (conv_out 320->4): one wave per 4 output pixels, K split over lanes.
+//   * conv_small_c   : Cin <= 8 (conv_in 4->320): weights staged once per workgroup in LDS as fp32,
+//                      thread = (pixel, 8 output channels); reads NCHW or NHWC input through strides.
+//   * naive gemm / conv: correctness catch-all for shapes, strides and dtypes (f32) the fast
+//                      kernels do not take -- still HIP, there is no ATen/CPU fallback in the library.
+#include "small.h"
+
+namespace sfast {
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void small_epilogue(const SmallGemmArgs &a, int m, int n, float v, float g) {
+    // v (and g for geglu) are raw accumulators of output (m, n)
+    if (a.geglu) {
+        if (a.bias) {
+            v += Elem<T>::to_f32(((const T *)a.bias)[n]);
+            g += Elem<T>::to_f32(((const T *)a.bias)[a.N + n]);
+        }
+        v = v * act_gelu_erf(g);
+    } else {
+        if (a.bias) v += Elem<T>::to_f32(((const T *)a.bias)[n]);
+        if (a.rowbias) v += Elem<T>::to_f32(((const T *)a.rowbias)[(int64_t)(m / a.rows_per_batch) * a.ld_rowbias + n]);
+        float r = 0.f;
+        if (a.res) r = a.alpha * Elem<T>::to_f32(((const T *)a.res)[(int64_t)m * a.ldr + n]);
+        if (a.res_before_act) v += r;
+        v = apply_act(v, a.act);
+        if (!a.res_before_act) v += r;
+    }
+    ((T *)a.out)[(int64_t)m * a.ldo + n] = Elem<T>::from_f32(v);
+}
+
+template <typename T>
+__device__ __forceinline__ const T *small_wrow(const SmallGemmArgs &a, int row) {
+    // row in [0, N) (or [0, 2N) for geglu, single segment)
+    const int seg = row / a.rows_per_seg;
+    const void *base = seg == 0 ? a.w[0] : seg == 1 ? a.w[1] : seg == 2 ? a.w[2] : a.w[3];
+    return (const T *)base + (int64_t)(row - seg * a.rows_per_seg) * a.ldw;
+}
+
+// one wave per output column n, MB rows at a time. K % 8 == 0, 16-B aligned rows.
+template <typename T, int MB>
+__global__ void __launch_bounds__(256) gemv_small_m_kernel(const SmallGemmArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= a.N) return;
+    const T *wr = small_wrow<T>(a, n);
+    const T *wg = a.geglu ? small_wrow<T>(a, a.N + n) : nullptr;
+    const int nch = a.K / 8;
+    for (int mb = 0; mb < a.M; mb += MB) {
+        float acc[MB], accg[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            acc[i] = 0.f;
+            accg[i] = 0.f;
+        }
+        for (int ch = lane; ch < nch; ch += 64) {
+            float wf[8], gf[8];
+            unpack8<T>(*reinterpret_cast<const u32x4 *>(wr + ch * 8), wf);
+            if (wg) unpack8<T>(*reinterpret_cast<const u32x4 *>(wg + ch * 8), gf);
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const int m = mb + i;
+                if (m < a.M) {
+                    float xf[8];
+                    unpack8<T>(*reinterpret_cast<const u32x4 *>((const T *)a.x + (int64_t)m * a.ldx + ch * 8), xf);
+                    if (a.in_act != SFAST_ACT_NONE) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) xf[j] = apply_act(xf[j], a.in_act);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[i] = fmaf(xf[j], wf[j], acc[i]);
+                    if (wg) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) accg[i] = fmaf(xf[j], gf[j], accg[i]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const float s = wave_sum(acc[i]);
+            const float sg = wg ? wave_sum(accg[i]) : 0.f;
+            const int m = mb + i;
+            if (lane == 0 && m < a.M) small_epilogue<T>(a, m, n, s, sg);
+        }
+    }
+}
+
+// thread per output element, scalar loads; any K / alignment / dtype
+template <typename T>
+__global__ void __launch_bounds__(256) gemm_naive_kernel(const SmallGemmArgs a) {
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int m = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (n >= a.N || m >= a.M) return;
+    const T *xr = (const T *)a.x + (int64_t)m * a.ldx;
+    const T *wr = small_wrow<T>(a, n);
+    float acc = 0.f, accg = 0.f;
+    for (int k = 0; k < a.K; ++k) {
+        float xv = Elem<T>::to_f32(xr[k]);
+        if (a.in_act != SFAST_ACT_NONE) xv = apply_act(xv, a.in_act);
+        acc = fmaf(xv, Elem<T>::to_f32(wr[k]), acc);
+    }
+    if (a.geglu) {
+        const T *wg = small_wrow<T>(a, a.N + n);
+        for (int k = 0; k < a.K; ++k) accg = fmaf(Elem<T>::to_f32(xr[k]), Elem<T>::to_f32(wg[k]), accg);
+    }
+    small_epilogue<T>(a, m, n, acc, accg);
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void conv_store(const SmallConvArgs &a, int b, int ho, int wo, int co, float v) {
+    if (a.bias) v += Elem<T>::to_f32(((const T *)a.bias)[co]);
+    if (a.rowbias) v += Elem<T>::to_f32(((const T *)a.rowbias)[(int64_t)b * a.ld_rowbias + co]);
+    float r = 0.f;
+    if (a.z) r = a.alpha * Elem<T>::to_f32(((const T *)a.z)[b * a.zs[0] + ho * a.zs[1] + wo * a.zs[2] + co * a.zs[3]]);
+    if (a.res_before_act) v += r;
+    v = apply_act(v, a.act);
+    if (!a.res_before_act) v += r;
+    ((T *)a.out)[b * a.os[0] + ho * a.os[1] + wo * a.os[2] + co * a.os[3]] = Elem<T>::from_f32(v);
+}
+
+template <typename T>
+__device__ __forceinline__ float conv_load_x(const SmallConvArgs &a, int b, int hi, int wi, int c) {
+    // (hi, wi) in the (possibly 2x-upsampled) input frame; returns 0 outside
+    const int HH = a.ups ? 2 * a.H : a.H, WW = a.ups ? 2 * a.W : a.W;
+    if ((unsigned)hi >= (unsigned)HH || (unsigned)wi >= (unsigned)WW) return 0.f;
+    if (a.ups) {
+        hi >>= 1;
+        wi >>= 1;
+    }
+    if (c < a.C1) return Elem<T>::to_f32(((const T *)a.x)[b * a.xs[0] + hi * a.xs[1] + wi * a.xs[2] + c * a.xs[3]]);
+    return Elem<T>::to_f32(((const T *)a.x2)[b * a.x2s[0] + hi * a.x2s[1] + wi * a.x2s[2] + (c - a.C1) * a.x2s[3]]);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) conv_naive_kernel(const SmallConvArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)a.B * a.Ho * a.Wo * a.Cout;
+    if (idx >= total) return;
+    const int co = (int)(idx % a.Cout);
+    int64_t t = idx / a.Cout;
+    const int wo = (int)(t % a.Wo);
+    t /= a.Wo;
+    const int ho = (int)(t % a.Ho);
+    const int b = (int)(t / a.Ho);
+    float acc = 0.f;
+    for (int r = 0; r < a.KH; ++r) {
+        const int hi = ho * a.stride_h - a.pad_h + r * a.dil_h;
+        for (int s = 0; s < a.KW; ++s) {
+            const int wi = wo * a.stride_w - a.pad_w + s * a.dil_w;
+            for (int c = 0; c < a.Cin; ++c) {
+                const float xv = conv_load_x<T>(a, b, hi, wi, c);
+                const float wv = Elem<T>::to_f32(((const T *)a.w)[co * a.ws[0] + c * a.ws[1] + r * a.ws[2] + s * a.ws[3]]);
+                acc = fmaf(xv, wv, acc);
+            }
+        }
+    }
+    conv_store<T>(a, b, ho, wo, co, acc);
+}
+
+// Cout <= 8, dense NHWC x (no concat), weights [Cout][KH][KW][Cin] K-contiguous, Cin % 8 == 0.
+// One wave per PX consecutive output pixels; lanes split K in 16-B chunks.
+template <typename T, int PX>
+__global__ void __launch_bounds__(256) conv_small_n_kernel(const SmallConvArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
+    const int64_t p0 = ((int64_t)blockIdx.x * 4 + wave) * PX;
+    if (p0 >= M) return;
+    int pb[PX], ph[PX], pw[PX];
+    bool pv[PX];
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        const int64_t p = p0 + i;
+        pv[i] = p < M;
+        const int64_t pp = pv[i] ? p : 0;
+        const int hw = a.Ho * a.Wo;
+        pb[i] = (int)(pp / hw);
+        const int rem = (int)(pp % hw);
+        ph[i] = rem / a.Wo;
+        pw[i] = rem % a.Wo;
+    }
+    float acc[PX][8];
+#pragma unroll
+    for (int i = 0; i < PX; ++i)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[i][c] = 0.f;
+    const int cpc = a.Cin / 8;           // chunks per tap
+    const int nch = a.KH * a.KW * cpc;   // chunks in K
+    const int64_t wstride = (int64_t)a.KH * a.KW * a.Cin;
+    for (int j = lane; j < nch; j += 64) {
+        const int tap = j / cpc, cch = j - tap * cpc;
+        const int r = tap / a.KW, s = tap - r * a.KW;
+        float wf[8][8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (c < a.Cout) unpack8<T>(*reinterpret_cast<const u32x4 *>((const T *)a.w + c * wstride + (int64_t)j * 8), wf[c]);
+        }
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            int hi = ph[i] * a.stride_h - a.pad_h + r * a.dil_h;
+            int wi = pw[i] * a.stride_w - a.pad_w + s * a.dil_w;
+            const int HH = a.ups ? 2 * a.H : a.H, WW = a.ups ? 2 * a.W : a.W;
+            bool ok = pv[i] && (unsigned)hi < (unsigned)HH && (unsigned)wi < (unsigned)WW;
+            if (a.ups) {
+                hi >>= 1;
+                wi >>= 1;
+            }
+            if (ok) {
+                float xf[8];
+                unpack8<T>(*reinterpret_cast<const u32x4 *>((const T *)a.x + (((int64_t)pb[i] * a.H + hi) * a.W + wi) * a.Cin + cch * 8), xf);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if (c < a.Cout) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[i][c] = fmaf(xf[e], wf[c][e], acc[i][c]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (c < a.Cout) {
+                const float s = wave_sum(acc[i][c]);
+                if (lane == 0 && pv[i]) conv_store<T>(a, pb[i], ph[i], pw[i], c, s);
+            }
+        }
+    }
+}
+
+// Cin*KH*KW small: weights staged in LDS as fp32 [K][Cout]; thread = (pixel, 8 output channels).
+// x read through strides (NCHW or NHWC), output dense NHWC-style through strides with os[3] == 1.
+template <typename T>
+__global__ void __launch_bounds__(256) conv_small_c_kernel(const SmallConvArgs a, int pix_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];  // [K][Cout]
+    const int K = a.KH * a.KW * a.Cin;
+    for (int i = threadIdx.x; i < K * a.Cout; i += 256) {
+        const int co = i % a.Cout;
+        const int k = i / a.Cout;
+        const int c = k % a.Cin;
+        const int tap = k / a.Cin;
+        const int r = tap / a.KW, s = tap % a.KW;
+        wsm[i] = Elem<T>::to_f32(((const T *)a.w)[co * a.ws[0] + c * a.ws[1] + r * a.ws[2] + s * a.ws[3]]);
+    }
+    __syncthreads();
+    const int cch = a.Cout / 8;
+    const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
+    const int64_t p_begin = (int64_t)blockIdx.x * pix_per_block;
+    const int ntask = pix_per_block * cch;
+    for (int t = threadIdx.x; t < ntask; t += 256) {
+        const int64_t p = p_begin + t / cch;
+        if (p >= M) break;
+        const int co0 = (t % cch) * 8;
+        const int hw = a.Ho * a.Wo;
+        const int b = (int)(p / hw);
+        const int rem = (int)(p % hw);
+        const int ho = rem / a.Wo, wo = rem % a.Wo;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        int k = 0;
+        for (int r = 0; r < a.KH; ++r) {
+            const int hi = ho * a.stride_h - a.pad_h + r * a.dil_h;
+            for (int s = 0; s < a.KW; ++s) {
+                const int wi = wo * a.stride_w - a.pad_w + s * a.dil_w;
+                for (int c = 0; c < a.Cin; ++c, ++k) {
+                    const float xv = conv_load_x<T>(a, b, hi, wi, c);
+                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wsm + k * a.Cout + co0);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4 *>(wsm + k * a.Cout + co0 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[e] = fmaf(xv, w0[e], acc[e]);
+                        acc[4 + e] = fmaf(xv, w1[e], acc[4 + e]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) conv_store<T>(a, b, ho, wo, co0 + e, acc[e]);
+    }
+}
+
+// ---- host launchers -----------------------------------------------------------------------------------
+template <typename T> static int run_gemv(const SmallGemmArgs &a, hipStream_t st) {
+    const dim3 grid(ceil_div(a.N, 4));
+    if (a.M <= 2)
+        hipLaunchKernelGGL((gemv_small_m_kernel<T, 2>), grid, dim3(256), 0, st, a);
+    else if (a.M <= 4)
+        hipLaunchKernelGGL((gemv_small_m_kernel<T, 4>), grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((gemv_small_m_kernel<T, 8>), grid, dim3(256), 0, st, a);
+    return check_launch("gemv_small_m");
+}
+
+int small_gemv(const SmallGemmArgs &a, int dtype, hipStream_t st) {
+    set_kernel_name("gemv_small_m");
+    if (dtype == SFAST_F16) return run_gemv<f16>(a, st);
+    if (dtype == SFAST_BF16) return run_gemv<bf16>(a, st);
+    set_error("gemv_small_m: dtype %d", dtype);
+    return SFAST_ERR_UNSUPPORTED;
+}
+
+int small_gemm_naive(const SmallGemmArgs &a, int dtype, hipStream_t st) {
+    set_kernel_name("gemm_naive");
+    const dim3 grid(ceil_div(a.N, 64), ceil_div(a.M, 4));
+    switch (dtype) {
+    case SFAST_F16: hipLaunchKernelGGL(gemm_naive_kernel<f16>, grid, dim3(256), 0, st, a); break;
+    case SFAST_BF16: hipLaunchKernelGGL(gemm_naive_kernel<bf16>, grid, dim3(256), 0, st, a); break;
+    case SFAST_F32: hipLaunchKernelGGL(gemm_naive_kernel<float>, grid, dim3(256), 0, st, a); break;
+    default: set_error("gemm_naive: dtype %d", dtype); return SFAST_ERR_UNSUPPORTED;
+    }
+    return check_launch("gemm_naive");
+}
+
+int small_conv_naive(const SmallConvArgs &a, int dtype, hipStream_t st) {
+    set_kernel_name("conv_naive");
+    const int64_t total = (int64_t)a.B * a.Ho * a.Wo * a.Cout;
+    const dim3 grid((unsigned)ceil_div64(total, 256));
+    switch (dtype) {
+    case SFAST_F16: hipLaunchKernelGGL(conv_naive_kernel<f16>, grid, dim3(256), 0, st, a); break;
+    case SFAST_BF16: hipLaunchKernelGGL(conv_naive_kernel<bf16>, grid, dim3(256), 0, st, a); break;
+    case SFAST_F32: hipLaunchKernelGGL(conv_naive_kernel<float>, grid, dim3(256), 0, st, a); break;
+    default: set_error("conv_naive: dtype %d", dtype); return SFAST_ERR_UNSUPPORTED;
+    }
+    return check_launch("conv_naive");
+}
+
+int small_conv_n(const SmallConvArgs &a, int dtype, hipStream_t st) {
+    set_kernel_name("conv_small_n");
+    constexpr int PX = 4;
+    const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
+    const dim3 grid((unsigned)ceil_div64(M, 4 * PX));
+    if (dtype == SFAST_F16)
+        hipLaunchKernelGGL((conv_small_n_kernel<f16, PX>), grid, dim3(256), 0, st, a);
+    else if (dtype == SFAST_BF16)
+        hipLaunchKernelGGL((conv_small_n_kernel<bf16, PX>), grid, dim3(256), 0, st, a);
+    else {
+        set_error("conv_small_n: dtype %d", dtype);
+        return SFAST_ERR_UNSUPPORTED;
+    }
+    return check_launch("conv_small_n");
+}
+
+int small_conv_c(const SmallConvArgs &a, int dtype, hipStream_t st) {
+    set_kernel_name("conv_small_c");
+    const int K = a.KH * a.KW * a.Cin;
+    const size_t smem = (size_t)K * a.Cout * sizeof(float);
+    const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
+    int ppb = 32;
+    while (ppb > 4 && ceil_div64(M, ppb) < 256) ppb >>= 1;
+    const dim3 grid((unsigned)ceil_div64(M, ppb));
+    if (dtype == SFAST_F16)
+        hipLaunchKernelGGL(conv_small_c_kernel<f16>, grid, dim3(256), smem, st, a, ppb);
+    else if (dtype == SFAST_BF16)
+        hipLaunchKernelGGL(conv_small_c_kernel<bf16>, grid, dim3(256), smem, st, a, ppb);
+    else {
+        set_error("conv_small_c: dtype %d", dtype);
+        return SFAST_ERR_UNSUPPORTED;
+    }
+    return check_launch("conv_small_c");
+}
+
+}  // namespace sfast
