@@ -1,0 +1,376 @@
+"""ORACLE -- test infrastructure only (imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py; never by the product package).
+
+Plain-PyTorch restatement of diffusers' `UNet2DConditionModel` for the SD1.5 / SD2.1 / SDXL
+family, with diffusers-compatible module names and state-dict keys so real checkpoints drop in.
+
+PARITY UNPINNED for the whole-UNet topology: diffusers is neither vendored in the reference
+(`/root/reference/setup.py:246-249` only pins `diffusers>=0.19.0`) nor installable here, and the
+reference's own integration test prints the image instead of comparing numbers
+(`/root/reference/tests/compilers/test_stable_diffusion_pipeline_compiler.py:435-436`). The
+restatement follows the published diffusers semantics recorded in SURVEY.md Appendix A and is
+pinned by (a) the public parameter counts -- 859,520,964 for SD1.5 and 2,567,463,684 for
+SDXL-base, asserted in `tests/test_oracle.py` -- and (b) per-op equivalence with the ATen ops the
+reference's operator tests compare against (F.group_norm, F.layer_norm, F.conv2d,
+F.scaled_dot_product_attention, chunk/gelu GEGLU; `/root/reference/tests/operators/*.py`).
+
+The per-module arithmetic follows what the reference's fused ops must reproduce:
+  GroupNorm(+SiLU)  /root/reference/src/sfast/triton/torch_ops.py:179-189 (= native_group_norm + silu)
+  LayerNorm         /root/reference/src/sfast/triton/ops/layer_norm.py:52-133
+  GEGLU             /root/reference/src/sfast/jit/passes/__init__.py:643-649 (linear -> chunk -> h*gelu(g))
+  conv+bias(+add)   /root/reference/src/sfast/csrc/operators/cudnn/cudnn_convolution_impl.cc:995-998
+  attention         /root/reference/src/sfast/libs/xformers/xformers_attention.py:26-43, [B,S,H,D] layout
+                    /root/reference/src/sfast/libs/diffusers/xformers_attention.py:66-69
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+SD15_CONFIG = dict(
+    sample_size=64, in_channels=4, out_channels=4,
+    down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+    up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+    block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, cross_attention_dim=768,
+    attention_head_dim=8, transformer_layers_per_block=1, norm_num_groups=32, norm_eps=1e-5,
+    use_linear_projection=False, flip_sin_to_cos=True, freq_shift=0,
+    addition_embed_type=None, addition_time_embed_dim=None, projection_class_embeddings_input_dim=None,
+)
+
+SDXL_CONFIG = dict(
+    sample_size=128, in_channels=4, out_channels=4,
+    down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+    up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+    block_out_channels=(320, 640, 1280), layers_per_block=2, cross_attention_dim=2048,
+    attention_head_dim=(5, 10, 20), transformer_layers_per_block=(1, 2, 10), norm_num_groups=32,
+    norm_eps=1e-5, use_linear_projection=True, flip_sin_to_cos=True, freq_shift=0,
+    addition_embed_type="text_time", addition_time_embed_dim=256,
+    projection_class_embeddings_input_dim=2816,
+)
+
+
+def tiny_config(**over):
+    """A small config with the SD1.5 topology (cross-attn down/up blocks, odd skip widths)."""
+    cfg = dict(SD15_CONFIG)
+    cfg.update(sample_size=16, block_out_channels=(64, 128, 128), layers_per_block=1,
+               down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+               up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+               cross_attention_dim=64, attention_head_dim=2, norm_num_groups=8)
+    cfg.update(over)
+    return cfg
+
+
+def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0.0, max_period=10000.0):
+    half = dim // 2
+    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device)
+    exponent = exponent / (half - freq_shift)
+    emb = t[:, None].float() * torch.exp(exponent)[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+    return emb
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, cin, dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(cin, dim)
+        self.linear_2 = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        return self.linear_2(F.silu(self.linear_1(x)))
+
+
+class ResnetBlock2D(nn.Module):
+    def __init__(self, cin, cout, temb_dim, groups, eps):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(groups, cin, eps=eps)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.time_emb_proj = nn.Linear(temb_dim, cout)
+        self.norm2 = nn.GroupNorm(groups, cout, eps=eps)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+
+    def forward(self, x, temb):
+        h = self.conv1(F.silu(self.norm1(x)))
+        h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
+        h = self.conv2(F.silu(self.norm2(h)))
+        if self.conv_shortcut is not None:
+            x = self.conv_shortcut(x)
+        return x + h
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, heads, ctx_dim=None):
+        super().__init__()
+        ctx_dim = ctx_dim or dim
+        self.heads = heads
+        self.to_q = nn.Linear(dim, dim, bias=False)
+        self.to_k = nn.Linear(ctx_dim, dim, bias=False)
+        self.to_v = nn.Linear(ctx_dim, dim, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(dim, dim), nn.Identity()])
+
+    def forward(self, x, ctx=None):
+        ctx = x if ctx is None else ctx
+        B, S, C = x.shape
+        H = self.heads
+        q = self.to_q(x).view(B, S, H, C // H).transpose(1, 2)
+        k = self.to_k(ctx).view(B, -1, H, C // H).transpose(1, 2)
+        v = self.to_v(ctx).view(B, -1, H, C // H).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v)  # scale = head_dim ** -0.5
+        return self.to_out[0](o.transpose(1, 2).reshape(B, S, C))
+
+
+class GEGLU(nn.Module):
+    def __init__(self, din, dout):
+        super().__init__()
+        self.proj = nn.Linear(din, dout * 2)
+
+    def forward(self, x):
+        h, g = self.proj(x).chunk(2, dim=-1)
+        return h * F.gelu(g)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Identity(), nn.Linear(dim * 4, dim)])
+
+    def forward(self, x):
+        return self.net[2](self.net[0](x))
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, heads, ctx_dim):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn1 = Attention(dim, heads)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn2 = Attention(dim, heads, ctx_dim)
+        self.norm3 = nn.LayerNorm(dim)
+        self.ff = FeedForward(dim)
+
+    def forward(self, x, ctx):
+        x = self.attn1(self.norm1(x)) + x
+        x = self.attn2(self.norm2(x), ctx) + x
+        return self.ff(self.norm3(x)) + x
+
+
+class Transformer2DModel(nn.Module):
+    def __init__(self, dim, heads, ctx_dim, depth, groups, linear_proj):
+        super().__init__()
+        self.linear_proj = linear_proj
+        self.norm = nn.GroupNorm(groups, dim, eps=1e-6)
+        if linear_proj:
+            self.proj_in = nn.Linear(dim, dim)
+            self.proj_out = nn.Linear(dim, dim)
+        else:
+            self.proj_in = nn.Conv2d(dim, dim, 1)
+            self.proj_out = nn.Conv2d(dim, dim, 1)
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(dim, heads, ctx_dim) for _ in range(depth)])
+
+    def forward(self, x, ctx):
+        B, C, H, W = x.shape
+        res = x
+        h = self.norm(x)
+        if self.linear_proj:
+            h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
+            h = self.proj_in(h)
+        else:
+            h = self.proj_in(h).permute(0, 2, 3, 1).reshape(B, H * W, C)
+        for blk in self.transformer_blocks:
+            h = blk(h, ctx)
+        if self.linear_proj:
+            h = self.proj_out(h).reshape(B, H, W, C).permute(0, 3, 1, 2)
+        else:
+            h = self.proj_out(h.reshape(B, H, W, C).permute(0, 3, 1, 2))
+        return h + res
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, stride=2, padding=1)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+class DownBlock(nn.Module):
+    def __init__(self, cin, cout, temb, layers, groups, eps, attn, heads, ctx_dim, depth, linear_proj, down):
+        super().__init__()
+        self.resnets = nn.ModuleList(
+            [ResnetBlock2D(cin if i == 0 else cout, cout, temb, groups, eps) for i in range(layers)])
+        if attn:
+            self.attentions = nn.ModuleList(
+                [Transformer2DModel(cout, heads, ctx_dim, depth, groups, linear_proj) for _ in range(layers)])
+        self.has_attn = attn
+        if down:
+            self.downsamplers = nn.ModuleList([Downsample2D(cout)])
+        self.has_down = down
+
+    def forward(self, h, temb, ctx, skips):
+        for i, r in enumerate(self.resnets):
+            h = r(h, temb)
+            if self.has_attn:
+                h = self.attentions[i](h, ctx)
+            skips.append(h)
+        if self.has_down:
+            h = self.downsamplers[0](h)
+            skips.append(h)
+        return h
+
+
+class MidBlock(nn.Module):
+    def __init__(self, c, temb, groups, eps, heads, ctx_dim, depth, linear_proj):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(c, c, temb, groups, eps) for _ in range(2)])
+        self.attentions = nn.ModuleList([Transformer2DModel(c, heads, ctx_dim, depth, groups, linear_proj)])
+
+    def forward(self, h, temb, ctx):
+        h = self.resnets[0](h, temb)
+        h = self.attentions[0](h, ctx)
+        return self.resnets[1](h, temb)
+
+
+class UpBlock(nn.Module):
+    def __init__(self, cin_list, cout, temb, groups, eps, attn, heads, ctx_dim, depth, linear_proj, up):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(ci, cout, temb, groups, eps) for ci in cin_list])
+        if attn:
+            self.attentions = nn.ModuleList(
+                [Transformer2DModel(cout, heads, ctx_dim, depth, groups, linear_proj) for _ in cin_list])
+        self.has_attn = attn
+        if up:
+            self.upsamplers = nn.ModuleList([Upsample2D(cout)])
+        self.has_up = up
+
+    def forward(self, h, temb, ctx, skips):
+        for i, r in enumerate(self.resnets):
+            h = r(torch.cat([h, skips.pop()], dim=1), temb)
+            if self.has_attn:
+                h = self.attentions[i](h, ctx)
+        if self.has_up:
+            h = self.upsamplers[0](h)
+        return h
+
+
+def _per_block(v, n):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v,) * n
+
+
+class UNet2DConditionModel(nn.Module):
+    """fp32 CPU oracle of the denoising UNet (and, on the GPU box, the eager-fp16 stand-in for
+    'the reference diffusers fp16 UNet')."""
+
+    def __init__(self, **cfg):
+        super().__init__()
+        full = dict(SD15_CONFIG)
+        full.update(cfg)
+        self.config = SimpleNamespace(**full)
+        c = self.config
+        boc = tuple(c.block_out_channels)
+        n = len(boc)
+        heads = _per_block(c.attention_head_dim, n)  # diffusers misnomer: number of heads
+        depth = _per_block(c.transformer_layers_per_block, n)
+        temb = boc[0] * 4
+        g, eps, lp, L = c.norm_num_groups, c.norm_eps, c.use_linear_projection, c.layers_per_block
+        self.conv_in = nn.Conv2d(c.in_channels, boc[0], 3, padding=1)
+        self.time_embedding = TimestepEmbedding(boc[0], temb)
+        if c.addition_embed_type == "text_time":
+            self.add_embedding = TimestepEmbedding(c.projection_class_embeddings_input_dim, temb)
+        self.down_blocks = nn.ModuleList()
+        ch = boc[0]
+        for i, t in enumerate(c.down_block_types):
+            self.down_blocks.append(DownBlock(ch, boc[i], temb, L, g, eps, t == "CrossAttnDownBlock2D", heads[i],
+                                              c.cross_attention_dim, depth[i], lp, i < n - 1))
+            ch = boc[i]
+        self.mid_block = MidBlock(boc[-1], temb, g, eps, heads[-1], c.cross_attention_dim, depth[-1], lp)
+        self.up_blocks = nn.ModuleList()
+        rev = boc[::-1]
+        rheads, rdepth = heads[::-1], depth[::-1]
+        prev = rev[0]
+        for i, t in enumerate(c.up_block_types):
+            out_c = rev[i]
+            in_c = rev[min(i + 1, n - 1)]
+            cins = []
+            for j in range(L + 1):
+                skip_c = in_c if j == L else out_c
+                res_in = prev if j == 0 else out_c
+                cins.append(res_in + skip_c)
+            self.up_blocks.append(UpBlock(cins, out_c, temb, g, eps, t == "CrossAttnUpBlock2D", rheads[i],
+                                          c.cross_attention_dim, rdepth[i], lp, i < n - 1))
+            prev = out_c
+        self.conv_norm_out = nn.GroupNorm(g, boc[0], eps=eps)
+        self.conv_out = nn.Conv2d(boc[0], c.out_channels, 3, padding=1)
+
+    @property
+    def dtype(self):
+        return self.conv_in.weight.dtype
+
+    @property
+    def device(self):
+        return self.conv_in.weight.device
+
+    def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, return_dict=True, **_):
+        c = self.config
+        B = sample.shape[0]
+        t = timestep
+        if not torch.is_tensor(t):
+            t = torch.tensor([t], dtype=torch.float32, device=sample.device)
+        t = t.to(sample.device).reshape(-1).expand(B)
+        t_emb = timestep_embedding(t, c.block_out_channels[0], c.flip_sin_to_cos, c.freq_shift).to(sample.dtype)
+        emb = self.time_embedding(t_emb)
+        if c.addition_embed_type == "text_time":
+            te = added_cond_kwargs["text_embeds"]
+            tid = added_cond_kwargs["time_ids"]
+            tide = timestep_embedding(tid.flatten(), c.addition_time_embed_dim, c.flip_sin_to_cos, c.freq_shift)
+            add = torch.cat([te, tide.reshape(B, -1).to(te.dtype)], dim=-1).to(emb.dtype)
+            emb = emb + self.add_embedding(add)
+        h = self.conv_in(sample)
+        skips = [h]
+        for blk in self.down_blocks:
+            h = blk(h, emb, encoder_hidden_states, skips)
+        h = self.mid_block(h, emb, encoder_hidden_states)
+        for blk in self.up_blocks:
+            h = blk(h, emb, encoder_hidden_states, skips)
+        out = self.conv_out(F.silu(self.conv_norm_out(h)))
+        if not return_dict:
+            return (out,)
+        return SimpleNamespace(sample=out)
+
+
+def param_count(model):
+    return sum(p.numel() for p in model.parameters())
+
+
+def build(config="sd15", seed=0, dtype=torch.float32, device="cpu", **over):
+    """Seeded default-initialised oracle model. Biases / norm affine params are perturbed so that a
+    kernel which drops a bias or a gamma cannot pass parity (default init zeroes / ones them)."""
+    cfg = dict({"sd15": SD15_CONFIG, "sdxl": SDXL_CONFIG, "tiny": tiny_config()}[config]) if isinstance(config, str) else dict(config)
+    cfg.update(over)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        m = UNet2DConditionModel(**cfg)
+        for name, p in m.named_parameters():
+            if p.ndim == 1:
+                if "norm" in name and name.endswith("weight"):
+                    p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(0.05 * torch.randn(p.shape, generator=g))
+            else:
+                fan_in = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g) * (1.0 / math.sqrt(fan_in)))
+    return m.to(device=device, dtype=dtype).eval()

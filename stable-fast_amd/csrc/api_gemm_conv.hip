@@ -65,7 +65,9 @@ ConvGeom conv_geom(const sfast_conv_params *p, const void *z) {
     g.x_dense = p->xs[3] == 1 && p->xs[2] == C1 && p->xs[1] == (int64_t)p->W * C1 && p->xs[0] == (int64_t)p->H * p->W * C1;
     g.x2_dense = C2 == 0 || (p->x2s[3] == 1 && p->x2s[2] == C2 && p->x2s[1] == (int64_t)p->W * C2 &&
                              p->x2s[0] == (int64_t)p->H * p->W * C2);
-    g.w_kcontig = p->ws[1] == 1 && p->ws[3] == p->Cin && p->ws[2] == (int64_t)p->KW * p->Cin &&
+    // size-1 kernel dims have ambiguous strides (NCHW-contiguous 1x1 weights are K-contiguous too)
+    g.w_kcontig = (p->Cin == 1 || p->ws[1] == 1) && (p->KW == 1 || p->ws[3] == p->Cin) &&
+                  (p->KH == 1 || p->ws[2] == (int64_t)p->KW * p->Cin) &&
                   p->ws[0] == (int64_t)p->KH * p->KW * p->Cin;
     g.ldo = p->os[2];
     g.out_dense = p->os[3] == 1 && g.ldo >= p->Cout && p->os[1] == (int64_t)g.Wo * g.ldo &&

@@ -1,0 +1,242 @@
+"""Drop-in `compile()` surface of stable-fast for MI355X.
+
+Same names, arguments and in-place semantics as the reference module
+/root/reference/src/sfast/compilers/diffusion_pipeline_compiler.py
+  CompilationConfig.Default  (:22-78)   the same 11 fields
+  compile(m, config)         (:81-124)  mutates and returns the pipeline (duck-typed on .unet, .vae, ...)
+  compile_unet(m, config)    (:127-151)
+  compile_vae(m, config)     (:154-190)
+
+What changed is what happens behind `unet.forward`: instead of TorchScript trace + pattern passes +
+CUDA graph, the UNet is handed to `sfast.engine.UNet2DEngine`, which runs the forward as a static
+plan of hand-written gfx950 kernels (libsfast_hip.so) captured in a hipGraph. The per-signature
+cache keeps the reference's "dynamic shape by recapture" behaviour (cuda/graphs.py:31,
+jit/trace_helper.py:44): a new (batch, latent size, context length) builds and captures a new plan.
+
+Config flags: `enable_jit` gates the native engine (the reference does "most optimizations" under
+it), `enable_cuda_graph` gates hipGraph capture, `memory_format` converts 4-D parameters exactly as
+before. `enable_xformers`, `enable_triton`, `enable_cnn_optimization`, `enable_fused_linear_geglu`
+and `prefer_lowp_gemm` select individual fusions in the reference; the native engine always runs
+the fused HIP kernels (fp32 accumulate -- CDNA4 MFMA has no fp16-accumulate mode, so the
+"quality degradation" caveat of the last two does not apply), so they are accepted and recorded
+but do not change the executed kernels.
+"""
+import logging
+import threading
+from dataclasses import dataclass
+
+import torch
+
+from ..cuda.graphs import get_per_device_graph_execution_env, make_dynamic_graphed_callable
+from ..utils import gpu_device
+from ..utils.memory_format import apply_memory_format
+
+logger = logging.getLogger()
+
+
+class CompilationConfig:
+
+    @dataclass
+    class Default:
+        """Default compilation config (field meanings as in the reference, see module docstring)."""
+        memory_format: torch.memory_format = (
+            torch.channels_last if gpu_device.device_has_tensor_core() else torch.contiguous_format)
+        enable_jit: bool = True
+        enable_jit_freeze: bool = True
+        preserve_parameters: bool = True
+        enable_cnn_optimization: bool = gpu_device.device_has_tensor_core()
+        enable_fused_linear_geglu: bool = gpu_device.device_has_capability(8, 0)
+        prefer_lowp_gemm: bool = True
+        enable_xformers: bool = False
+        enable_cuda_graph: bool = False
+        enable_triton: bool = False
+        trace_scheduler: bool = False
+
+
+class UNet2DConditionOutput:
+    """Stand-in for diffusers' output dataclass when diffusers is not importable."""
+
+    def __init__(self, sample):
+        self.sample = sample
+
+    def __getitem__(self, i):
+        return (self.sample,)[i]
+
+    def __iter__(self):
+        return iter((self.sample,))
+
+
+def _make_output(sample):
+    try:
+        from diffusers.models.unets.unet_2d_condition import UNet2DConditionOutput as _Out  # type: ignore
+        return _Out(sample=sample)
+    except Exception:
+        return UNet2DConditionOutput(sample)
+
+
+def _device_of(m):
+    if hasattr(m, "device"):
+        d = m.device
+        return d if isinstance(d, torch.device) else torch.device(d)
+    return torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+class _NativeUNetForward:
+    """Replacement for `unet.forward`: per-signature plan cache + hipGraph replay."""
+
+    def __init__(self, module, engine, orig_forward, enable_graph, warmups=3):
+        self.module = module
+        self.engine = engine
+        self.orig_forward = orig_forward
+        self.enable_graph = enable_graph
+        self.warmups = warmups
+        self._cached = {}
+        self._lock = threading.Lock()
+        self._warned = False
+        self.__self__ = module
+        self.__name__ = "forward"
+
+    def _fallback(self, why, *args, **kwargs):
+        if not self._warned:
+            logger.warning("sfast: UNet call not handled by the native engine (%s); running the original forward", why)
+            self._warned = True
+        return self.orig_forward(*args, **kwargs)
+
+    def _prepare(self, key, sample, timestep, ehs, added):
+        eng = self.engine
+        B, H, W, S = key
+        plan = eng.get_plan(B, H, W, S)
+        env = get_per_device_graph_execution_env(eng.device)
+        graph = None
+        # warm-up: runs the whole plan eagerly (also validates every launch before capture)
+        torch.cuda.synchronize(eng.device)
+        with torch.cuda.device(eng.device), torch.cuda.stream(torch.cuda.Stream(device=eng.device)):
+            eng.load_inputs(plan, sample, timestep, ehs, added)
+            for _ in range(self.warmups if self.enable_graph else 1):
+                plan.run(torch.cuda.current_stream(eng.device).cuda_stream)
+        torch.cuda.synchronize(eng.device)
+        if self.enable_graph:
+            graph = torch.cuda.CUDAGraph()
+            with env.lock:
+                with torch.cuda.device(eng.device), torch.cuda.stream(env.stream):
+                    with torch.cuda.graph(graph, pool=env.mempool, stream=env.stream):
+                        plan.run(torch.cuda.current_stream(eng.device).cuda_stream)
+        return plan, graph, env
+
+    def __call__(self, sample, timestep, encoder_hidden_states=None, class_labels=None, timestep_cond=None,
+                 attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
+                 down_block_additional_residuals=None, mid_block_additional_residual=None,
+                 down_intrablock_additional_residuals=None, encoder_attention_mask=None, return_dict=True):
+        extra = dict(class_labels=class_labels, timestep_cond=timestep_cond, attention_mask=attention_mask,
+                     down_block_additional_residuals=down_block_additional_residuals,
+                     mid_block_additional_residual=mid_block_additional_residual,
+                     down_intrablock_additional_residuals=down_intrablock_additional_residuals,
+                     encoder_attention_mask=encoder_attention_mask)
+        bad = [k for k, v in extra.items() if v is not None]
+        if cross_attention_kwargs:
+            bad.append("cross_attention_kwargs")
+        eng = self.engine
+        if (bad or encoder_hidden_states is None or not torch.is_tensor(sample) or sample.device.type != "cuda"
+                or sample.dtype != eng.dtype or sample.ndim != 4):
+            return self._fallback(", ".join(bad) or "input device/dtype", sample, timestep,
+                                  encoder_hidden_states=encoder_hidden_states, class_labels=class_labels,
+                                  timestep_cond=timestep_cond, attention_mask=attention_mask,
+                                  cross_attention_kwargs=cross_attention_kwargs, added_cond_kwargs=added_cond_kwargs,
+                                  down_block_additional_residuals=down_block_additional_residuals,
+                                  mid_block_additional_residual=mid_block_additional_residual,
+                                  encoder_attention_mask=encoder_attention_mask, return_dict=return_dict)
+        B, _, H, W = sample.shape
+        key = (B, H, W, encoder_hidden_states.shape[1])
+        entry = self._cached.get(key)
+        if entry is None:
+            with self._lock:
+                entry = self._cached.get(key)
+                if entry is None:
+                    logger.info("sfast: building native UNet plan for %s (graph=%s)", key, self.enable_graph)
+                    entry = self._prepare(key, sample, timestep, encoder_hidden_states, added_cond_kwargs)
+                    self._cached[key] = entry
+        plan, graph, env = entry
+        with env.lock:
+            eng.load_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs)
+            if graph is not None:
+                graph.replay()
+            else:
+                plan.run(torch.cuda.current_stream(eng.device).cuda_stream)
+            out = plan.static_out.clone()
+        if not return_dict:
+            return (out,)
+        return _make_output(out)
+
+
+def _looks_like_unet2d_condition(m):
+    return all(hasattr(m, a) for a in ("conv_in", "time_embedding", "down_blocks", "mid_block", "up_blocks",
+                                       "conv_norm_out", "conv_out", "config"))
+
+
+def compile(m, config):
+    device = _device_of(m)
+    enable_cuda_graph = config.enable_cuda_graph and device.type == "cuda"
+
+    m.unet = compile_unet(m.unet, config)
+    if hasattr(m, "controlnet"):
+        m.controlnet = compile_unet(m.controlnet, config)
+    if getattr(m, "vae", None) is not None:
+        m.vae = compile_vae(m.vae, config)
+
+    if enable_cuda_graph:
+        for name in ("text_encoder", "text_encoder_2", "image_encoder"):
+            enc = getattr(m, name, None)
+            if enc is not None:
+                enc.forward = _graphed_with_fallback(enc.forward)
+    return m
+
+
+def _graphed_with_fallback(forward):
+    graphed = make_dynamic_graphed_callable(forward)
+    state = {"ok": True}
+
+    def call(*args, **kwargs):
+        if state["ok"]:
+            try:
+                return graphed(*args, **kwargs)
+            except Exception as e:  # capture can fail on data-dependent host code; behave like the eager module
+                logger.warning("sfast: hipGraph capture of %s failed (%s); running eagerly",
+                               getattr(forward, "__qualname__", forward), e)
+                state["ok"] = False
+        return forward(*args, **kwargs)
+
+    call.__self__ = getattr(forward, "__self__", None)
+    call._cached = graphed._cached
+    return call
+
+
+def compile_unet(m, config):
+    device = _device_of(m)
+    enable_cuda_graph = config.enable_cuda_graph and device.type == "cuda"
+
+    if config.memory_format is not None:
+        apply_memory_format(m, memory_format=config.memory_format)
+
+    native = None
+    if config.enable_jit and device.type == "cuda" and _looks_like_unet2d_condition(m):
+        from ..engine import UNet2DEngine, UnsupportedUNet
+        try:
+            native = UNet2DEngine.from_module(m)
+        except UnsupportedUNet as e:
+            logger.warning("sfast: %s is outside the native engine's coverage (%s); keeping the eager forward",
+                           type(m).__name__, e)
+    if native is not None:
+        fwd = _NativeUNetForward(m, native, m.forward, enable_cuda_graph)
+        m.forward = fwd
+        m._sfast_engine = native
+    elif enable_cuda_graph:
+        m.forward = _graphed_with_fallback(m.forward)
+    return m
+
+
+def compile_vae(m, config):
+    # The VAE is outside the UNet hot path: only the memory-format
+    # conversion of the reference (:165-166) is applied; the decoder keeps running on PyTorch-ROCm.
+    if config.memory_format is not None:
+        apply_memory_format(m, memory_format=config.memory_format)
+    return m

@@ -1,0 +1,2 @@
+"""sfast.engine -- static-plan executors for the hot path (UNet forward)."""
+from .unet2d import UNet2DEngine, UNetPlan, UnsupportedUNet  # noqa: F401

@@ -1,0 +1,341 @@
+"""Tensor-level wrappers over the C ABI (include/sfast_hip.h).
+
+Ownership / stream / error conventions mirror the reference operators
+(reference src/sfast/csrc/operators/cutlass/cutlass_dual_linear_kernel.cu:309-316,
+:364-365): outputs are fresh tensors from the torch caching allocator, inputs are borrowed and never
+mutated, work is enqueued on the CURRENT stream of the input's device (so calls are capturable
+into a hipGraph), errors surface as RuntimeError. PyTorch is only the allocator / stream provider
+here -- every byte of arithmetic runs in libsfast_hip.so.
+"""
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import lib as L
+
+_DT = {torch.float16: L.F16, torch.bfloat16: L.BF16, torch.float32: L.F32}
+_ACT = {None: L.ACT_NONE, "none": L.ACT_NONE, "identity": L.ACT_NONE, "relu": L.ACT_RELU,
+        "gelu": L.ACT_GELU, "gelu_tanh": L.ACT_GELU_TANH, "silu": L.ACT_SILU,
+        "sigmoid": L.ACT_SIGMOID, "tanh": L.ACT_TANH}
+
+
+def _dtype(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise L.SfastHipError(f"sfast HIP kernels support f16/bf16/f32, got {t.dtype}")
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and t.device.type != "cuda":
+            raise L.SfastHipError(
+                "sfast HIP operators need tensors on a ROCm device (got %s); there is no CPU path" % t.device)
+
+
+def _act(a):
+    if isinstance(a, int):
+        return a
+    return _ACT[a]
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ws(nbytes, like):
+    if nbytes == 0:
+        return None, 0
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=like.device)
+    return buf, nbytes
+
+
+def _i64x4(vals):
+    return (C.c_int64 * 4)(*[int(v) for v in vals])
+
+
+def _i64x3(vals):
+    return (C.c_int64 * 3)(*[int(v) for v in vals])
+
+
+# --------------------------------------------------------------------------------------------------
+def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, act=None, x2=None):
+    """GroupNorm(+SiLU). x: [N, C, *] (channels_last 4-D is processed natively as NHWC).
+    x2: optional second channels_last tensor, normalised as if torch.cat([x, x2], 1)."""
+    lib = L.init_device()
+    _require_cuda(x, x2, weight, bias)
+    if x.ndim < 2:
+        raise L.SfastHipError("group_norm: input must be at least 2-D")
+    N, C1 = x.shape[0], x.shape[1]
+    # tensors that are both NCHW- and NHWC-contiguous (C == 1 or H*W == 1) have one memory image
+    nhwc = x.ndim == 4 and x.is_contiguous(memory_format=torch.channels_last)
+    if x2 is not None:
+        if not (nhwc and x2.ndim == 4 and x2.is_contiguous(memory_format=torch.channels_last)):
+            raise L.SfastHipError("group_norm: virtual concat needs two channels_last 4-D tensors")
+        if x2.shape[0] != N or x2.shape[2:] != x.shape[2:] or x2.dtype != x.dtype:
+            raise L.SfastHipError("group_norm: x2 shape/dtype mismatch")
+        Ctot = C1 + x2.shape[1]
+    else:
+        Ctot = C1
+    if not nhwc:
+        x = x.contiguous()
+    HW = 1
+    for s in x.shape[2:]:
+        HW *= s
+    if Ctot % num_groups != 0:
+        raise L.SfastHipError(f"group_norm: {Ctot} channels not divisible by {num_groups} groups")
+    if weight is not None:
+        weight = weight.to(x.dtype).contiguous()
+    if bias is not None:
+        bias = bias.to(x.dtype).contiguous()
+    out_shape = (N, Ctot) + tuple(x.shape[2:])
+    if nhwc:
+        y = torch.empty(out_shape, dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    else:
+        y = torch.empty(out_shape, dtype=x.dtype, device=x.device)
+    p = L.GnParams(_dtype(x), L.NHWC if nhwc else L.NCHW, N, Ctot, HW, num_groups, C1, _act(act), float(eps))
+    nb = lib.sfast_hip_group_norm_workspace_bytes(C.byref(p))
+    ws, nb = _ws(nb, x)
+    rc = lib.sfast_hip_group_norm(_ptr(x), _ptr(x2), _ptr(weight), _ptr(bias), _ptr(y), C.byref(p),
+                                  _ptr(ws), nb, _stream(x))
+    L.check(rc, "sfast_hip_group_norm")
+    return y
+
+
+def layer_norm(x, normalized_shape: Sequence[int], weight=None, bias=None, eps=1e-5):
+    lib = L.init_device()
+    _require_cuda(x, weight, bias)
+    n = 1
+    for s in normalized_shape:
+        n *= int(s)
+    if tuple(x.shape[x.ndim - len(normalized_shape):]) != tuple(int(s) for s in normalized_shape):
+        raise L.SfastHipError("layer_norm: normalized_shape does not match the trailing dims")
+    x = x.contiguous()
+    m = x.numel() // n
+    if weight is not None:
+        weight = weight.to(x.dtype).contiguous()
+    if bias is not None:
+        bias = bias.to(x.dtype).contiguous()
+    y = torch.empty_like(x)
+    p = L.LnParams(_dtype(x), m, n, float(eps))
+    rc = lib.sfast_hip_layer_norm(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), C.byref(p), _stream(x))
+    L.check(rc, "sfast_hip_layer_norm")
+    return y
+
+
+def linear(x, weight, bias=None, *, act=None, residual=None, alpha=1.0, res_before_act=False,
+           geglu=False, rowbias=None, rows_per_batch=0, in_act=None, variant=0, split_k=0, out=None):
+    """out[..., N] = epilogue(x[..., K] @ W[N, K]^T). `weight` may be a list of <= 4 equally sized
+    [n_i, K] tensors stacked along N (e.g. live to_q / to_k / to_v weights)."""
+    lib = L.init_device()
+    ws_list = list(weight) if isinstance(weight, (list, tuple)) else [weight]
+    _require_cuda(x, bias, residual, rowbias, *ws_list)
+    K = x.shape[-1]
+    for w in ws_list:
+        if w.ndim != 2 or w.shape[1] != K or w.dtype != x.dtype:
+            raise L.SfastHipError(f"linear: weight {tuple(w.shape)}/{w.dtype} incompatible with input [..., {K}]/{x.dtype}")
+        if w.shape[0] != ws_list[0].shape[0]:
+            raise L.SfastHipError("linear: stacked weight segments must have equal row counts")
+    ws_list = [w if (w.stride(1) == 1 and w.stride(0) >= K) else w.contiguous() for w in ws_list]
+    ldw = ws_list[0].stride(0) if ws_list[0].shape[0] > 1 else K
+    for w in ws_list:
+        if (w.stride(0) if w.shape[0] > 1 else ldw) != ldw:
+            raise L.SfastHipError("linear: stacked weight segments must share a row stride")
+    rows = ws_list[0].shape[0] * len(ws_list)
+    if geglu:
+        if rows % 2:
+            raise L.SfastHipError("linear: geglu needs an even number of weight rows")
+        N = rows // 2
+    else:
+        N = rows
+    lead = x.shape[:-1]
+    x2d = x.reshape(-1, K)
+    if x2d.stride(-1) != 1 or (x2d.shape[0] > 1 and x2d.stride(0) < K):
+        x2d = x2d.contiguous()
+    M = x2d.shape[0]
+    ldx = x2d.stride(0) if M > 1 else K
+    if out is None:
+        out2d = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    else:
+        out2d = out.reshape(M, N)
+        if out2d.data_ptr() != out.data_ptr():
+            raise L.SfastHipError("linear: `out` must be viewable as [M, N]")
+    ldo = out2d.stride(0) if M > 1 else N
+    res2d = None
+    ldr = 0
+    if residual is not None:
+        res2d = residual.expand(*lead, N).reshape(M, N) if residual.shape != (M, N) else residual
+        if res2d.stride(-1) != 1:
+            res2d = res2d.contiguous()
+        ldr = res2d.stride(0) if M > 1 else N
+        if res2d.dtype != x.dtype:
+            res2d = res2d.to(x.dtype)
+    if bias is not None:
+        bias = bias.to(x.dtype).contiguous()
+    ld_rb = 0
+    if rowbias is not None:
+        rowbias = rowbias.to(x.dtype)
+        if rowbias.stride(-1) != 1:
+            rowbias = rowbias.contiguous()
+        ld_rb = rowbias.stride(0) if rowbias.shape[0] > 1 else N
+    p = L.GemmParams()
+    p.dtype, p.M, p.N, p.K = _dtype(x), M, N, K
+    p.ldx, p.ldw, p.ldo, p.ldr = ldx, ldw, ldo, ldr
+    p.n_wseg, p.rows_per_seg = len(ws_list), ws_list[0].shape[0]
+    p.geglu = 1 if geglu else 0
+    p.act, p.res_before_act, p.alpha = _act(act), 1 if res_before_act else 0, float(alpha)
+    p.rows_per_batch, p.ld_rowbias = int(rows_per_batch), ld_rb
+    p.in_act, p.variant, p.split_k = _act(in_act), int(variant), int(split_k)
+    segs = (C.c_void_p * len(ws_list))(*[w.data_ptr() for w in ws_list])
+    nb = lib.sfast_hip_gemm_workspace_bytes(C.byref(p))
+    wsb, nb = _ws(nb, x)
+    rc = lib.sfast_hip_gemm(_ptr(x2d), segs, _ptr(bias), _ptr(rowbias), _ptr(res2d), _ptr(out2d), C.byref(p),
+                            _ptr(wsb), nb, _stream(x))
+    L.check(rc, "sfast_hip_gemm")
+    return out2d.reshape(*lead, N) if out is None else out
+
+
+def _nhwc_strides(t):
+    # logical NCHW tensor -> element strides in (n, h, w, c) order
+    return (t.stride(0), t.stride(2), t.stride(3), t.stride(1))
+
+
+def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dilation=1, act=None,
+           res_before_act=True, x2=None, upsample2x=False, rowbias=None, variant=0, split_k=0,
+           channels_last_out: Optional[bool] = None):
+    """y = act(conv2d(x, w) + bias + rowbias[b] + alpha*z) on logical NCHW tensors of any strides.
+    x2: optional tensor concatenated to x along channels (virtual). upsample2x: nearest 2x first."""
+    lib = L.init_device()
+    _require_cuda(x, weight, bias, z, x2, rowbias)
+    if x.ndim != 4 or weight.ndim != 4:
+        raise L.SfastHipError("conv2d: 4-D input and weight required")
+    pair = lambda v: (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
+    sh, sw = pair(stride)
+    ph, pw = pair(padding)
+    dh, dw = pair(dilation)
+    B, C1, H, W = x.shape
+    Cin = C1 + (x2.shape[1] if x2 is not None else 0)
+    Cout, Cw, KH, KW = weight.shape
+    if Cw != Cin:
+        raise L.SfastHipError(f"conv2d: weight expects {Cw} input channels, got {Cin} (groups != 1 unsupported)")
+    if weight.dtype != x.dtype:
+        raise L.SfastHipError("conv2d: input / weight dtype mismatch")
+    Hin, Win = (2 * H, 2 * W) if upsample2x else (H, W)
+    Ho = (Hin + 2 * ph - dh * (KH - 1) - 1) // sh + 1
+    Wo = (Win + 2 * pw - dw * (KW - 1) - 1) // sw + 1
+    if channels_last_out is None:
+        # cudnn_conv_suggest_memory_format semantics (reference cudnn_convolution_impl.cc:1023-1025)
+        def _is_cl(t):
+            return t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
+        channels_last_out = _is_cl(x) or _is_cl(weight)
+    fmt = torch.channels_last if channels_last_out else torch.contiguous_format
+    y = torch.empty((B, Cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=fmt)
+    zz = None
+    if z is not None:
+        zz = z.to(x.dtype).expand(B, Cout, Ho, Wo)
+    if bias is not None:
+        bias = bias.to(x.dtype).contiguous()
+    ld_rb = 0
+    if rowbias is not None:
+        rowbias = rowbias.to(x.dtype)
+        if rowbias.stride(-1) != 1:
+            rowbias = rowbias.contiguous()
+        ld_rb = rowbias.stride(0) if rowbias.shape[0] > 1 else Cout
+    p = L.ConvParams()
+    p.dtype, p.B, p.H, p.W, p.Cin, p.Cout, p.KH, p.KW = _dtype(x), B, H, W, Cin, Cout, KH, KW
+    p.stride_h, p.stride_w, p.pad_h, p.pad_w, p.dil_h, p.dil_w = sh, sw, ph, pw, dh, dw
+    p.upsample2x, p.C1 = 1 if upsample2x else 0, C1
+    p.xs = _i64x4(_nhwc_strides(x))
+    p.x2s = _i64x4(_nhwc_strides(x2) if x2 is not None else (0, 0, 0, 0))
+    p.ws = _i64x4((weight.stride(0), weight.stride(1), weight.stride(2), weight.stride(3)))
+    p.os = _i64x4(_nhwc_strides(y))
+    p.zs = _i64x4(_nhwc_strides(zz) if zz is not None else (0, 0, 0, 0))
+    p.act, p.res_before_act, p.alpha = _act(act), 1 if res_before_act else 0, float(alpha)
+    p.ld_rowbias, p.variant, p.split_k = ld_rb, int(variant), int(split_k)
+    nb = lib.sfast_hip_conv2d_workspace_bytes(C.byref(p))
+    wsb, nb = _ws(nb, x)
+    rc = lib.sfast_hip_conv2d(_ptr(x), _ptr(x2), _ptr(weight), _ptr(bias), _ptr(rowbias), _ptr(zz), _ptr(y),
+                              C.byref(p), _ptr(wsb), nb, _stream(x))
+    L.check(rc, "sfast_hip_conv2d")
+    return y
+
+
+def attention(q, k, v, scale: Optional[float] = None, variant=0):
+    """softmax(q k^T * scale) v with q [B, Sq, H, D], k/v [B, Skv, H, D] (any b/s/h strides)."""
+    lib = L.init_device()
+    _require_cuda(q, k, v)
+    if q.ndim != 4 or k.ndim != 4 or v.ndim != 4:
+        raise L.SfastHipError("attention: expected [B, S, H, D] tensors")
+    B, Sq, H, D = q.shape
+    Skv = k.shape[1]
+    if k.shape != (B, Skv, H, D) or v.shape != (B, Skv, H, D) or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise L.SfastHipError("attention: q/k/v shape or dtype mismatch")
+    q, k, v = [t if t.stride(-1) == 1 else t.contiguous() for t in (q, k, v)]
+    out = torch.empty((B, Sq, H, D), dtype=q.dtype, device=q.device)
+    p = L.AttnParams()
+    p.dtype, p.B, p.H, p.Sq, p.Skv, p.D = _dtype(q), B, H, Sq, Skv, D
+    p.qs = _i64x3(q.stride()[:3])
+    p.ks = _i64x3(k.stride()[:3])
+    p.vs = _i64x3(v.stride()[:3])
+    p.os = _i64x3(out.stride()[:3])
+    p.scale = float(scale) if scale is not None else float(D) ** -0.5
+    p.variant = int(variant)
+    rc = lib.sfast_hip_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), C.byref(p), _stream(q))
+    L.check(rc, "sfast_hip_attention")
+    return out
+
+
+def strided_copy(src, dst):
+    """dst[...] = src[...] for equal-shape tensors of rank <= 4 and arbitrary strides."""
+    lib = L.init_device()
+    _require_cuda(src, dst)
+    if src.shape != dst.shape or src.dtype != dst.dtype:
+        raise L.SfastHipError("strided_copy: shape/dtype mismatch")
+    if src.ndim > 4:
+        raise L.SfastHipError("strided_copy: rank <= 4 only")
+    if src.numel() == 0:
+        return dst
+    nd = max(src.ndim, 1)
+    shape = list(src.shape) if src.ndim else [1]
+    ss = list(src.stride()) if src.ndim else [1]
+    ds = list(dst.stride()) if dst.ndim else [1]
+    p = L.CopyParams()
+    p.elem_bytes, p.ndim = src.element_size(), nd
+    p.shape = _i64x4(shape + [1] * (4 - nd))
+    p.src_strides = _i64x4(ss + [0] * (4 - nd))
+    p.dst_strides = _i64x4(ds + [0] * (4 - nd))
+    rc = lib.sfast_hip_strided_copy(_ptr(src), _ptr(dst), C.byref(p), _stream(src))
+    L.check(rc, "sfast_hip_strided_copy")
+    return dst
+
+
+def timestep_embedding(timesteps, dim, flip_sin_to_cos=True, downscale_freq_shift=0.0, max_period=10000.0,
+                       dtype=torch.float16):
+    lib = L.init_device()
+    _require_cuda(timesteps)
+    t = timesteps.to(torch.float32).contiguous().reshape(-1)
+    out = torch.empty((t.numel(), dim), dtype=dtype, device=t.device)
+    p = L.TembParams(_DT[dtype], t.numel(), dim, 1 if flip_sin_to_cos else 0, float(downscale_freq_shift),
+                     float(max_period))
+    rc = lib.sfast_hip_timestep_embedding(_ptr(t), _ptr(out), C.byref(p), _stream(t))
+    L.check(rc, "sfast_hip_timestep_embedding")
+    return out
+
+
+def cfg_ddim_step(eps_uc, latents, coef, guidance, latents_out=None, unet_in=None):
+    lib = L.init_device()
+    _require_cuda(eps_uc, latents, coef)
+    numel = latents.numel()
+    if eps_uc.numel() != 2 * numel or not eps_uc.is_contiguous() or not latents.is_contiguous():
+        raise L.SfastHipError("cfg_ddim_step: eps_uc must be contiguous [2, *latents.shape]")
+    if latents_out is None:
+        latents_out = torch.empty_like(latents)
+    rc = lib.sfast_hip_cfg_ddim_step(_ptr(eps_uc), _ptr(latents), _ptr(latents_out), _ptr(unet_in), _ptr(coef),
+                                     float(guidance), numel, _dtype(latents), _stream(latents))
+    L.check(rc, "sfast_hip_cfg_ddim_step")
+    return latents_out

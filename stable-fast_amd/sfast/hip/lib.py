@@ -1,0 +1,172 @@
+"""ctypes binding of libsfast_hip.so -- the C ABI declared in include/sfast_hip.h.
+
+This is the only place Python touches the kernel library. The library is REQUIRED: if it is
+missing or fails to load, `load()` raises -- there is no ATen / CPU fallback behind it (the
+reference's ops fall back to ATen when their CUDA extension can't take a tensor,
+src/sfast/triton/torch_ops.py:116-125; here an unsupported fast-path precondition selects the
+generic HIP kernel inside the library instead).
+"""
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "_lib", "libsfast_hip.so")
+
+ABI_VERSION = 1
+
+# enums (include/sfast_hip.h)
+F16, BF16, F32 = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_SILU, ACT_SIGMOID, ACT_TANH = range(7)
+NHWC, NCHW = 0, 1
+MAX_WSEG = 4
+
+EXPORTS = [
+    "sfast_hip_abi_version", "sfast_hip_init", "sfast_hip_last_error", "sfast_hip_last_kernel",
+    "sfast_hip_group_norm_workspace_bytes", "sfast_hip_group_norm", "sfast_hip_layer_norm",
+    "sfast_hip_gemm_workspace_bytes", "sfast_hip_gemm",
+    "sfast_hip_conv2d_workspace_bytes", "sfast_hip_conv2d",
+    "sfast_hip_attention", "sfast_hip_strided_copy", "sfast_hip_timestep_embedding",
+    "sfast_hip_cfg_ddim_step",
+]
+
+
+class GnParams(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("layout", C.c_int32), ("N", C.c_int32), ("C", C.c_int32),
+                ("HW", C.c_int32), ("G", C.c_int32), ("C1", C.c_int32), ("act", C.c_int32),
+                ("eps", C.c_float)]
+
+
+class LnParams(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("eps", C.c_float)]
+
+
+class GemmParams(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("ldx", C.c_int64), ("ldw", C.c_int64), ("ldo", C.c_int64), ("ldr", C.c_int64),
+                ("n_wseg", C.c_int32), ("rows_per_seg", C.c_int32), ("geglu", C.c_int32),
+                ("act", C.c_int32), ("res_before_act", C.c_int32), ("alpha", C.c_float),
+                ("rows_per_batch", C.c_int32), ("ld_rowbias", C.c_int64), ("in_act", C.c_int32),
+                ("variant", C.c_int32), ("split_k", C.c_int32)]
+
+
+class ConvParams(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("Cin", C.c_int32), ("Cout", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32),
+                ("stride_h", C.c_int32), ("stride_w", C.c_int32), ("pad_h", C.c_int32),
+                ("pad_w", C.c_int32), ("dil_h", C.c_int32), ("dil_w", C.c_int32),
+                ("upsample2x", C.c_int32), ("C1", C.c_int32),
+                ("xs", C.c_int64 * 4), ("x2s", C.c_int64 * 4), ("ws", C.c_int64 * 4),
+                ("os", C.c_int64 * 4), ("zs", C.c_int64 * 4),
+                ("act", C.c_int32), ("res_before_act", C.c_int32), ("alpha", C.c_float),
+                ("ld_rowbias", C.c_int64), ("variant", C.c_int32), ("split_k", C.c_int32)]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("Sq", C.c_int32),
+                ("Skv", C.c_int32), ("D", C.c_int32),
+                ("qs", C.c_int64 * 3), ("ks", C.c_int64 * 3), ("vs", C.c_int64 * 3), ("os", C.c_int64 * 3),
+                ("scale", C.c_float), ("variant", C.c_int32)]
+
+
+class CopyParams(C.Structure):
+    _fields_ = [("elem_bytes", C.c_int32), ("ndim", C.c_int32), ("shape", C.c_int64 * 4),
+                ("src_strides", C.c_int64 * 4), ("dst_strides", C.c_int64 * 4)]
+
+
+class TembParams(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("B", C.c_int32), ("dim", C.c_int32),
+                ("flip_sin_to_cos", C.c_int32), ("downscale_freq_shift", C.c_float),
+                ("max_period", C.c_float)]
+
+
+class SfastHipError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def _declare(lib):
+    vp, sz = C.c_void_p, C.c_size_t
+    lib.sfast_hip_abi_version.restype = C.c_int
+    lib.sfast_hip_init.restype = C.c_int
+    lib.sfast_hip_last_error.restype = C.c_char_p
+    lib.sfast_hip_last_kernel.restype = C.c_char_p
+    lib.sfast_hip_group_norm_workspace_bytes.restype = sz
+    lib.sfast_hip_group_norm_workspace_bytes.argtypes = [C.POINTER(GnParams)]
+    lib.sfast_hip_group_norm.restype = C.c_int
+    lib.sfast_hip_group_norm.argtypes = [vp, vp, vp, vp, vp, C.POINTER(GnParams), vp, sz, vp]
+    lib.sfast_hip_layer_norm.restype = C.c_int
+    lib.sfast_hip_layer_norm.argtypes = [vp, vp, vp, vp, C.POINTER(LnParams), vp]
+    lib.sfast_hip_gemm_workspace_bytes.restype = sz
+    lib.sfast_hip_gemm_workspace_bytes.argtypes = [C.POINTER(GemmParams)]
+    lib.sfast_hip_gemm.restype = C.c_int
+    lib.sfast_hip_gemm.argtypes = [vp, C.POINTER(vp), vp, vp, vp, vp, C.POINTER(GemmParams), vp, sz, vp]
+    lib.sfast_hip_conv2d_workspace_bytes.restype = sz
+    lib.sfast_hip_conv2d_workspace_bytes.argtypes = [C.POINTER(ConvParams)]
+    lib.sfast_hip_conv2d.restype = C.c_int
+    lib.sfast_hip_conv2d.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(ConvParams), vp, sz, vp]
+    lib.sfast_hip_attention.restype = C.c_int
+    lib.sfast_hip_attention.argtypes = [vp, vp, vp, vp, C.POINTER(AttnParams), vp]
+    lib.sfast_hip_strided_copy.restype = C.c_int
+    lib.sfast_hip_strided_copy.argtypes = [vp, vp, C.POINTER(CopyParams), vp]
+    lib.sfast_hip_timestep_embedding.restype = C.c_int
+    lib.sfast_hip_timestep_embedding.argtypes = [vp, vp, C.POINTER(TembParams), vp]
+    lib.sfast_hip_cfg_ddim_step.restype = C.c_int
+    lib.sfast_hip_cfg_ddim_step.argtypes = [vp, vp, vp, vp, vp, C.c_float, C.c_int64, C.c_int32, vp]
+
+
+def load():
+    """Load (once) and return the ctypes library handle. Raises if it is absent or incompatible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise SfastHipError(
+                f"{LIB_PATH} not found: build it with `python stable-fast_amd/build.py` "
+                "(hipcc --offload-arch=gfx950). The HIP kernel library is required; there is no fallback.")
+        # torch must be imported first so that libamdhip64.so.7 resolves to the runtime torch uses
+        # (streams / device pointers are only valid inside that runtime instance).
+        import torch  # noqa: F401
+        lib = C.CDLL(LIB_PATH)
+        missing = [s for s in EXPORTS if not hasattr(lib, s)]
+        if missing:
+            raise SfastHipError(f"libsfast_hip.so lacks symbols: {missing}")
+        _declare(lib)
+        if lib.sfast_hip_abi_version() != ABI_VERSION:
+            raise SfastHipError("libsfast_hip.so ABI version mismatch; rebuild")
+        _lib = lib
+    return _lib
+
+
+_inited = False
+
+
+def init_device():
+    """One-time kernel-attribute setup; needs a visible GPU. Call before any graph capture."""
+    global _inited
+    lib = load()
+    if not _inited:
+        rc = lib.sfast_hip_init()
+        if rc != 0:
+            raise SfastHipError(f"sfast_hip_init failed ({rc}): {last_error()}")
+        _inited = True
+    return lib
+
+
+def last_error():
+    return load().sfast_hip_last_error().decode(errors="replace")
+
+
+def last_kernel():
+    return load().sfast_hip_last_kernel().decode(errors="replace")
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SfastHipError(f"{what} failed ({rc}): {last_error()}")

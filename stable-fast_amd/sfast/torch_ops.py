@@ -1,0 +1,193 @@
+"""`torch.ops.sfast.*` -- the operator names the reference registers in C++
+(/root/reference/src/sfast/csrc/main.cpp:18-24) re-registered on top of libsfast_hip.so.
+
+Schemas follow the reference headers:
+  cutlass_linear_geglu[_unified]   csrc/operators/cutlass/cutlass_dual_linear_kernel.h:6-15
+  cudnn_convolution_bias[_add][_sigmoid|_relu|_tanh]   csrc/operators/cudnn/cudnn_convolution.h:12-78
+  cublas_lowp_*                    csrc/operators/cublas/cublas_gemm.h:12-49
+  linear_relu / linear_gelu        csrc/operators/fused_linear.h:11-15
+
+The implementations are registered for the CUDA (= ROCm) dispatch key only: calling them with CPU
+tensors is a dispatcher error, there is no ATen fallback (the hot path must not silently leave the
+HIP kernels). They are inference ops (no autograd formulas).
+"""
+import torch
+
+from .hip import functional as F
+
+_lib = torch.library.Library("sfast", "DEF")
+
+
+def _def(schema, fn):
+    name = schema.split("(")[0]
+    _lib.define(schema)
+    _lib.impl(name, fn, "CUDA")
+
+
+# ---- Linear + GEGLU ------------------------------------------------------------------------------
+def cutlass_linear_geglu_unified(input, weight, bias=None):
+    return F.linear(input, weight, bias, geglu=True)
+
+
+def cutlass_linear_geglu(input, weight0, bias0, weight1, bias1):
+    n, k = weight0.shape
+    adjacent = (weight0.is_contiguous() and weight1.is_contiguous() and
+                weight1.data_ptr() == weight0.data_ptr() + n * k * weight0.element_size() and
+                weight1.shape == weight0.shape)
+    if adjacent:
+        w = torch.as_strided(weight0, (2 * n, k), (k, 1))
+    else:
+        w = torch.cat([weight0, weight1], dim=0)
+    if (bias0 is None) != (bias1 is None):
+        z = torch.zeros(n, dtype=input.dtype, device=input.device)
+        bias0 = z if bias0 is None else bias0
+        bias1 = z if bias1 is None else bias1
+    b = None if bias0 is None else torch.cat([bias0, bias1], dim=0)
+    return F.linear(input, w, b, geglu=True)
+
+
+_def("cutlass_linear_geglu_unified(Tensor input, Tensor weight, Tensor? bias) -> Tensor", cutlass_linear_geglu_unified)
+_def("cutlass_linear_geglu(Tensor input, Tensor weight0, Tensor? bias0, Tensor weight1, Tensor? bias1) -> Tensor",
+     cutlass_linear_geglu)
+
+
+# ---- conv + bias (+ alpha*z) (+ activation) ----------------------------------------------------------
+def _conv(input, weight, bias, z, alpha, stride, padding, dilation, transposed, output_padding, groups, act):
+    if transposed or groups != 1 or any(int(o) != 0 for o in output_padding):
+        raise RuntimeError("sfast conv ops on ROCm support groups == 1, non-transposed convolutions only")
+    if input.ndim == 3:  # 1-D conv as 2-D, like the reference (cudnn_convolution_impl.cc:1242-1252)
+        y = _conv(input.unsqueeze(2), weight.unsqueeze(2), bias, None if z is None else z.unsqueeze(2), alpha,
+                  [1, stride[0]], [0, padding[0]], [1, dilation[0]], transposed, [0, 0], groups, act)
+        return y.squeeze(2)
+    a = 1.0 if alpha is None else float(alpha)
+    # y = act(conv + alpha*z + bias)   (cudnn_convolution_impl.cc:995-998)
+    return F.conv2d(input, weight, bias, z=z, alpha=a, stride=tuple(stride), padding=tuple(padding),
+                    dilation=tuple(dilation), act=act, res_before_act=True)
+
+
+def _mk_conv_bias(act):
+    def op(input, weight, bias, stride, padding, dilation, transposed, output_padding, groups):
+        return _conv(input, weight, bias, None, None, stride, padding, dilation, transposed, output_padding, groups, act)
+    return op
+
+
+def _mk_conv_bias_add(act):
+    def op(input, weight, bias, z, alpha, stride, padding, dilation, transposed, output_padding, groups):
+        return _conv(input, weight, bias, z, alpha, stride, padding, dilation, transposed, output_padding, groups, act)
+    return op
+
+
+_CONV_ARGS = "int[] stride, int[] padding, int[] dilation, bool transposed, int[] output_padding, int groups"
+for _suffix, _act in (("", None), ("_sigmoid", "sigmoid"), ("_relu", "relu"), ("_tanh", "tanh")):
+    _def(f"cudnn_convolution_bias{_suffix}(Tensor input, Tensor weight, Tensor? bias, {_CONV_ARGS}) -> Tensor",
+         _mk_conv_bias(_act))
+    _def(f"cudnn_convolution_bias_add{_suffix}(Tensor input, Tensor weight, Tensor? bias, Tensor? z, Scalar? alpha, "
+         f"{_CONV_ARGS}) -> Tensor", _mk_conv_bias_add(_act))
+
+
+# ---- low-precision GEMM family ---------------------------------------------------------------------------
+def _as_weight(mat2):
+    """[K, N] matmul operand -> K-contiguous [N, K] weight view (copy only when unavoidable)."""
+    w = mat2.t()
+    return w if (w.stride(1) == 1 and w.stride(0) >= w.shape[1]) else w.contiguous()
+
+
+def cublas_lowp_linear(input, weight, bias=None):
+    return F.linear(input, weight, bias)
+
+
+def cublas_lowp_linear_relu(input, weight, bias=None):
+    return F.linear(input, weight, bias, act="relu")
+
+
+def cublas_lowp_linear_gelu(input, weight, bias=None):
+    return F.linear(input, weight, bias, act="gelu")
+
+
+def cublas_lowp_linear_add(input, weight, bias, other, alpha=1):
+    # D = (x W^T + bias) + alpha * other   (cublas_gemm.cpp:900-948)
+    return F.linear(input, weight, bias, residual=other, alpha=float(alpha))
+
+
+def cublas_lowp_mm(self, mat2):
+    return F.linear(self, _as_weight(mat2))
+
+
+def _addmm(self, mat1, mat2, beta, alpha, act=None, other=None, gamma=1.0):
+    beta, alpha = float(beta), float(alpha)
+    w = _as_weight(mat2)
+    n = w.shape[0]
+    if alpha == 1.0 and beta == 1.0 and self.ndim == 1 and self.shape[0] == n:
+        return F.linear(mat1, w, self, act=act, residual=other, alpha=float(gamma))
+    out = F.linear(mat1, w)
+    out = out * alpha + self * beta
+    if act == "relu":
+        out = torch.relu(out)
+    elif act == "gelu":
+        out = torch.nn.functional.gelu(out)
+    if other is not None:
+        out = out + other * float(gamma)
+    return out
+
+
+def cublas_lowp_addmm(self, mat1, mat2, beta=1, alpha=1):
+    return _addmm(self, mat1, mat2, beta, alpha)
+
+
+def cublas_lowp_addmm_add(self, mat1, mat2, other, beta=1, alpha=1, gamma=1):
+    return _addmm(self, mat1, mat2, beta, alpha, other=other, gamma=gamma)
+
+
+def cublas_lowp_addmm_activation(self, mat1, mat2, beta=1, alpha=1, use_gelu=False):
+    return _addmm(self, mat1, mat2, beta, alpha, act="gelu" if use_gelu else "relu")
+
+
+def cublas_lowp_bmm(self, batch2):
+    if self.ndim != 3 or batch2.ndim != 3 or self.shape[0] != batch2.shape[0]:
+        raise RuntimeError("cublas_lowp_bmm: expected [B, M, K] x [B, K, N]")
+    outs = [F.linear(self[b], _as_weight(batch2[b])) for b in range(self.shape[0])]
+    return torch.stack(outs, dim=0)
+
+
+def cublas_lowp_baddbmm(self, batch1, batch2, beta, alpha):
+    return cublas_lowp_bmm(batch1, batch2) * float(alpha) + self * float(beta)
+
+
+def cublas_lowp_matmul(tensor1, tensor2):
+    if tensor2.ndim == 2:
+        return F.linear(tensor1, _as_weight(tensor2))
+    if tensor1.ndim == 3 and tensor2.ndim == 3:
+        return cublas_lowp_bmm(tensor1, tensor2)
+    lead = torch.broadcast_shapes(tensor1.shape[:-2], tensor2.shape[:-2])
+    a = tensor1.expand(*lead, *tensor1.shape[-2:]).reshape(-1, *tensor1.shape[-2:])
+    b = tensor2.expand(*lead, *tensor2.shape[-2:]).reshape(-1, *tensor2.shape[-2:])
+    return cublas_lowp_bmm(a, b).reshape(*lead, tensor1.shape[-2], tensor2.shape[-1])
+
+
+_def("cublas_lowp_linear(Tensor input, Tensor weight, Tensor? bias=None) -> Tensor", cublas_lowp_linear)
+_def("cublas_lowp_linear_relu(Tensor input, Tensor weight, Tensor? bias=None) -> Tensor", cublas_lowp_linear_relu)
+_def("cublas_lowp_linear_gelu(Tensor input, Tensor weight, Tensor? bias=None) -> Tensor", cublas_lowp_linear_gelu)
+_def("cublas_lowp_linear_add(Tensor input, Tensor weight, Tensor? bias, Tensor other, Scalar alpha=1) -> Tensor",
+     cublas_lowp_linear_add)
+_def("cublas_lowp_mm(Tensor self, Tensor mat2) -> Tensor", cublas_lowp_mm)
+_def("cublas_lowp_addmm(Tensor self, Tensor mat1, Tensor mat2, Scalar beta=1, Scalar alpha=1) -> Tensor", cublas_lowp_addmm)
+_def("cublas_lowp_addmm_add(Tensor self, Tensor mat1, Tensor mat2, Tensor other, Scalar beta=1, Scalar alpha=1, "
+     "Scalar gamma=1) -> Tensor", cublas_lowp_addmm_add)
+_def("cublas_lowp_addmm_activation(Tensor self, Tensor mat1, Tensor mat2, Scalar beta=1, Scalar alpha=1, "
+     "bool use_gelu=False) -> Tensor", cublas_lowp_addmm_activation)
+_def("cublas_lowp_bmm(Tensor self, Tensor batch2) -> Tensor", cublas_lowp_bmm)
+_def("cublas_lowp_baddbmm(Tensor self, Tensor batch1, Tensor batch2, Scalar beta, Scalar alpha) -> Tensor", cublas_lowp_baddbmm)
+_def("cublas_lowp_matmul(Tensor tensor1, Tensor tensor2) -> Tensor", cublas_lowp_matmul)
+
+
+# ---- fused linear (ATen _addmm_activation in the reference) -------------------------------------------------
+def linear_relu(input, weight, bias=None):
+    return F.linear(input, weight, bias, act="relu")
+
+
+def linear_gelu(input, weight, bias=None):
+    return F.linear(input, weight, bias, act="gelu")
+
+
+_def("linear_relu(Tensor input, Tensor weight, Tensor? bias=None) -> Tensor", linear_relu)
+_def("linear_gelu(Tensor input, Tensor weight, Tensor? bias=None) -> Tensor", linear_gelu)

@@ -1,0 +1,186 @@
+"""CPU emulator of the libsfast_hip.so C ABI -- TEST INFRASTRUCTURE ONLY.
+
+Implements every compute entry point of include/sfast_hip.h on raw HOST pointers with the fp32
+oracle (oracle/ops_ref.py). It lets the CPU test-suite execute a `UNet2DEngine` plan end to end --
+pointer arithmetic, strides, buffer reuse, time-embedding offsets, virtual concat / upsample
+bookkeeping -- and compare it with the oracle UNet, without a GPU. The product never imports this
+module: on a GPU box the engine always calls the real library and raises if it is missing.
+
+The workspace-size queries are forwarded to the REAL library (pure host code), so the kernel
+planner (tile / split-K selection) is exercised too.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "stable-fast_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from oracle import ops_ref as R  # noqa: E402
+from oracle.unet_ref import timestep_embedding as temb_ref  # noqa: E402
+from sfast.hip import lib as L  # noqa: E402
+
+_NP = {L.F16: np.float16, L.F32: np.float32}
+_ACT = {0: None, 1: "relu", 2: "gelu", 3: "gelu_tanh", 4: "silu", 5: "sigmoid", 6: "tanh"}
+
+
+def _flat(ptr, numel, dtype):
+    npd = _NP[dtype]
+    nbytes = int(numel) * np.dtype(npd).itemsize
+    buf = (C.c_char * nbytes).from_address(int(ptr))
+    return torch.from_numpy(np.frombuffer(buf, dtype=npd))
+
+
+def _strided(ptr, shape, strides, dtype):
+    shape = [int(s) for s in shape]
+    strides = [int(s) for s in strides]
+    extent = 1 + sum((s - 1) * st for s, st in zip(shape, strides))
+    return torch.as_strided(_flat(ptr, extent, dtype), shape, strides)
+
+
+def _p(ref):
+    return ref._obj
+
+
+class EmuLib:
+    """Duck-typed stand-in for the ctypes library handle."""
+
+    def __init__(self):
+        self.real = L.load()
+        self.calls = []
+        self.err = b""
+
+    # ---- forwarded host-only queries ---------------------------------------------------------
+    def sfast_hip_group_norm_workspace_bytes(self, ref):
+        return self.real.sfast_hip_group_norm_workspace_bytes(ref)
+
+    def sfast_hip_gemm_workspace_bytes(self, ref):
+        return self.real.sfast_hip_gemm_workspace_bytes(ref)
+
+    def sfast_hip_conv2d_workspace_bytes(self, ref):
+        return self.real.sfast_hip_conv2d_workspace_bytes(ref)
+
+    def sfast_hip_last_error(self):
+        return self.err
+
+    def sfast_hip_init(self):
+        return 0
+
+    # ---- compute entry points ------------------------------------------------------------------
+    def sfast_hip_group_norm(self, x, x2, gamma, beta, y, ref, ws, ws_bytes, stream):
+        p = _p(ref)
+        self.calls.append("group_norm")
+        assert ws_bytes >= self.real.sfast_hip_group_norm_workspace_bytes(ref)
+        C1, C2 = p.C1, p.C - p.C1
+        g = _flat(gamma, p.C, p.dtype).float() if gamma else None
+        b = _flat(beta, p.C, p.dtype).float() if beta else None
+        if p.layout == L.NHWC:
+            xa = _flat(x, p.N * p.HW * C1, p.dtype).reshape(p.N, p.HW, C1)
+            if C2:
+                xb = _flat(x2, p.N * p.HW * C2, p.dtype).reshape(p.N, p.HW, C2)
+                xa = torch.cat([xa, xb], dim=2)
+            xin = xa.permute(0, 2, 1)  # [N, C, HW]
+            out = R.group_norm_ref(xin, p.G, g, b, p.eps, p.act == L.ACT_SILU)
+            _flat(y, p.N * p.HW * p.C, p.dtype).reshape(p.N, p.HW, p.C).copy_(out.permute(0, 2, 1))
+        else:
+            xin = _flat(x, p.N * p.C * p.HW, p.dtype).reshape(p.N, p.C, p.HW)
+            out = R.group_norm_ref(xin, p.G, g, b, p.eps, p.act == L.ACT_SILU)
+            _flat(y, p.N * p.C * p.HW, p.dtype).reshape(p.N, p.C, p.HW).copy_(out)
+        return 0
+
+    def sfast_hip_layer_norm(self, x, gamma, beta, y, ref, stream):
+        p = _p(ref)
+        self.calls.append("layer_norm")
+        xin = _flat(x, p.M * p.N, p.dtype).reshape(p.M, p.N)
+        g = _flat(gamma, p.N, p.dtype) if gamma else None
+        b = _flat(beta, p.N, p.dtype) if beta else None
+        _flat(y, p.M * p.N, p.dtype).reshape(p.M, p.N).copy_(R.layer_norm_ref(xin, (p.N,), g, b, p.eps))
+        return 0
+
+    def sfast_hip_gemm(self, x, segs, bias, rowbias, res, out, ref, ws, ws_bytes, stream):
+        p = _p(ref)
+        self.calls.append("gemm")
+        assert ws_bytes >= self.real.sfast_hip_gemm_workspace_bytes(ref)
+        wrows = 2 * p.N if p.geglu else p.N
+        assert p.rows_per_seg * p.n_wseg >= wrows
+        xin = _strided(x, (p.M, p.K), (p.ldx, 1), p.dtype)
+        ws_ = [_strided(segs[i], (p.rows_per_seg, p.K), (p.ldw, 1), p.dtype) for i in range(p.n_wseg)]
+        w = torch.cat(ws_, dim=0)[:wrows]
+        b = _flat(bias, wrows, p.dtype) if bias else None
+        r = _strided(res, (p.M, p.N), (p.ldr, 1), p.dtype).clone() if res else None
+        rb = None
+        if rowbias:
+            nb = (p.M + p.rows_per_batch - 1) // p.rows_per_batch
+            rb = _strided(rowbias, (nb, p.N), (p.ld_rowbias, 1), p.dtype)
+        o = R.linear_ref(xin, w, b, _ACT[p.act], r, p.alpha, bool(p.res_before_act), bool(p.geglu), rb, p.rows_per_batch,
+                         _ACT[p.in_act])
+        _strided(out, (p.M, p.N), (p.ldo, 1), p.dtype).copy_(o)
+        return 0
+
+    def sfast_hip_conv2d(self, x, x2, w, bias, rowbias, z, out, ref, ws, ws_bytes, stream):
+        p = _p(ref)
+        self.calls.append("conv2d")
+        assert ws_bytes >= self.real.sfast_hip_conv2d_workspace_bytes(ref)
+        C1, C2 = p.C1, p.Cin - p.C1
+
+        def nchw(ptr, c, h, w_, s):  # strides given as (n,h,w,c) -> logical NCHW view
+            return _strided(ptr, (p.B, c, h, w_), (s[0], s[3], s[1], s[2]), p.dtype)
+
+        xin = nchw(x, C1, p.H, p.W, p.xs)
+        x2in = nchw(x2, C2, p.H, p.W, p.x2s) if C2 else None
+        wt = _strided(w, (p.Cout, p.Cin, p.KH, p.KW), tuple(p.ws), p.dtype)
+        Hin, Win = (2 * p.H, 2 * p.W) if p.upsample2x else (p.H, p.W)
+        Ho = (Hin + 2 * p.pad_h - p.dil_h * (p.KH - 1) - 1) // p.stride_h + 1
+        Wo = (Win + 2 * p.pad_w - p.dil_w * (p.KW - 1) - 1) // p.stride_w + 1
+        b = _flat(bias, p.Cout, p.dtype) if bias else None
+        rb = _strided(rowbias, (p.B, p.Cout), (p.ld_rowbias, 1), p.dtype) if rowbias else None
+        zz = nchw(z, p.Cout, Ho, Wo, p.zs).clone() if z else None
+        o = R.conv2d_ref(xin, wt, b, zz, p.alpha, (p.stride_h, p.stride_w), (p.pad_h, p.pad_w), (p.dil_h, p.dil_w),
+                         _ACT[p.act], bool(p.res_before_act), x2in, bool(p.upsample2x), rb)
+        nchw(out, p.Cout, Ho, Wo, p.os).copy_(o)
+        return 0
+
+    def sfast_hip_attention(self, q, k, v, out, ref, stream):
+        p = _p(ref)
+        self.calls.append("attention")
+        qv = _strided(q, (p.B, p.Sq, p.H, p.D), tuple(p.qs) + (1,), p.dtype)
+        kv = _strided(k, (p.B, p.Skv, p.H, p.D), tuple(p.ks) + (1,), p.dtype)
+        vv = _strided(v, (p.B, p.Skv, p.H, p.D), tuple(p.vs) + (1,), p.dtype)
+        o = R.attention_ref(qv, kv, vv, p.scale)
+        _strided(out, (p.B, p.Sq, p.H, p.D), tuple(p.os) + (1,), p.dtype).copy_(o)
+        return 0
+
+    def sfast_hip_strided_copy(self, src, dst, ref, stream):
+        p = _p(ref)
+        self.calls.append("strided_copy")
+        dt = {2: L.F16, 4: L.F32}[p.elem_bytes]
+        shape = tuple(p.shape)[:p.ndim]
+        s = _strided(src, shape, tuple(p.src_strides)[:p.ndim], dt)
+        _strided(dst, shape, tuple(p.dst_strides)[:p.ndim], dt).copy_(s)
+        return 0
+
+    def sfast_hip_timestep_embedding(self, t, out, ref, stream):
+        p = _p(ref)
+        self.calls.append("timestep_embedding")
+        tv = _flat(t, p.B, L.F32)
+        e = temb_ref(tv, p.dim, bool(p.flip_sin_to_cos), p.downscale_freq_shift, p.max_period)
+        _flat(out, p.B * p.dim, p.dtype).reshape(p.B, p.dim).copy_(e)
+        return 0
+
+    def sfast_hip_cfg_ddim_step(self, eps_uc, lat, lat_out, unet_in, coef, g, numel, dtype, stream):
+        self.calls.append("cfg_ddim_step")
+        e = _flat(eps_uc, 2 * numel, dtype)
+        x = _flat(lat, numel, dtype)
+        c = _flat(coef, 4, L.F32)
+        r = R.cfg_ddim_ref(e, x, c.tolist(), g).to(x.dtype)
+        _flat(lat_out, numel, dtype).copy_(r)
+        if unet_in:
+            u = _flat(unet_in, 2 * numel, dtype)
+            u[:numel].copy_(r)
+            u[numel:].copy_(r)
+        return 0
