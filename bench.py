@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: SD1.5 512x512 bs=1 fp16 denoise iterations per second.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one denoise iteration exactly as the reference counts "it/s" (BASELINE.md section 1): one
+classifier-free-guidance batch-2 UNet forward + guidance combine + DDIM update, replayed as ONE
+hipGraph. Synthetic latents / text embeddings, seeded random-init weights of the SD1.5 architecture
+(no checkpoints or network here). Inputs are resident in HBM when the timed region starts.
+With N > 1 every rank owns a full replica (weights broadcast once from rank 0 over RCCL/xGMI) and
+runs its own independent loop on its own image: weak scaling, value = N * K / max-over-ranks time.
+
+Rank 0 prints ONE JSON line. Besides the contract keys it carries
+  "roofline"     for the dominant kernel of the step (measured live with HIP events on the launch stream)
+  "cpu_baseline" the fp32 oracle UNet (restatement of diffusers; diffusers itself is not installable
+                 here) timed on the host cores for the same CFG batch-2 forward, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "stable-fast_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="sd15", choices=["sd15", "sdxl"])
+    ap.add_argument("--images", type=int, default=1, help="images per GPU (UNet batch is 2x this: CFG)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-kernels", default=None, help="write the per-op timing table to this JSON file")
+    return ap.parse_args()
+
+
+def per_op_timing(loop, reps=3):
+    """Eager replay of the step with HIP events around every launch (same stream as the launches)."""
+    from sfast.hip import lib as L
+    plan = loop.plan
+    stream = torch.cuda.current_stream()
+    sp = stream.cuda_stream
+    n = len(plan.ops)
+    tot = [0.0] * n
+    names = [None] * n
+    for _ in range(reps):
+        evs = []
+        for i, op in enumerate(plan.ops):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            op.launch(sp)
+            b.record(stream)
+            names[i] = L.last_kernel()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(evs):
+            tot[i] += a.elapsed_time(b) * 1e-3
+    rows = []
+    for i, op in enumerate(plan.ops):
+        rows.append(dict(kind=op.kind, name=op.name, kernel=names[i], seconds=tot[i] / reps, flops=op.flops, bytes=op.bytes))
+    return rows
+
+
+def roofline_from(rows):
+    by_kernel = {}
+    for r in rows:
+        k = by_kernel.setdefault(r["kernel"], dict(seconds=0.0, flops=0.0, bytes=0.0, launches=0, kinds=set()))
+        k["seconds"] += r["seconds"]
+        k["flops"] += r["flops"]
+        k["bytes"] += r["bytes"]
+        k["launches"] += 1
+        k["kinds"].add(r["kind"])
+    dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["seconds"])
+    total = sum(v["seconds"] for v in by_kernel.values())
+    mfma = dom["flops"] > 0 and (dom["flops"] / MFMA_PEAK_TFLOPS / 1e12) > (dom["bytes"] / HBM_PEAK_GBS / 1e9)
+    if mfma:
+        achieved = dom["flops"] / dom["seconds"] / 1e12
+        roof = dict(bound="mfma", achieved=achieved, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / MFMA_PEAK_TFLOPS)
+    else:
+        achieved = dom["bytes"] / dom["seconds"] / 1e9
+        roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS)
+    roof.update(kernel=dom_name, launches_per_step=dom["launches"], avg_launch_us=dom["seconds"] / dom["launches"] * 1e6,
+                share_of_step=dom["seconds"] / total, traffic=None)
+    fam = {}
+    for r in rows:
+        f = fam.setdefault(r["kind"], dict(seconds=0.0, flops=0.0, bytes=0.0, launches=0))
+        f["seconds"] += r["seconds"]
+        f["flops"] += r["flops"]
+        f["bytes"] += r["bytes"]
+        f["launches"] += 1
+    families = {k: dict(ms=v["seconds"] * 1e3, launches=v["launches"],
+                        tflops=(v["flops"] / v["seconds"] / 1e12 if v["flops"] else None),
+                        gbs=v["bytes"] / v["seconds"] / 1e9) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["seconds"])}
+    return roof, families, total
+
+
+def cpu_baseline(cfg_name, images):
+    """fp32 oracle UNet on the host cores, same CFG batch-2 forward. Bounded: 1 warm-up + 2 timed."""
+    sys.path.insert(0, ROOT)
+    from oracle import unet_ref as U
+    torch.manual_seed(0)
+    m = U.build(cfg_name, seed=0)
+    cfg = U.SD15_CONFIG if cfg_name == "sd15" else U.SDXL_CONFIG
+    B = 2 * images
+    hw = cfg["sample_size"]
+    x = torch.randn(B, 4, hw, hw)
+    e = torch.randn(B, 77, cfg["cross_attention_dim"])
+    added = None
+    if cfg_name == "sdxl":
+        added = dict(text_embeds=torch.randn(B, 1280), time_ids=torch.tensor([[1024., 1024, 0, 0, 1024, 1024]] * B))
+    with torch.inference_mode():
+        m(x, 981, e, added_cond_kwargs=added)
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            m(x, 981, e, added_cond_kwargs=added)
+            ts.append(time.perf_counter() - t0)
+    med = sorted(ts)[len(ts) // 2]
+    return dict(value=1.0 / med, unit="it/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"2 timed CFG batch-{B} fp32 UNet forwards of the oracle restatement (oracle/unet_ref.py) after 1 warm-up; "
+                       f"median {med:.2f} s/forward; diffusers itself is not installable here")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from sfast.engine import UNet2DEngine
+    from sfast.engine.denoise import DenoiseLoop
+    from sfast.engine.replicas import broadcast_parameters
+    from sfast.engine.unet_spec import SD15_CONFIG, SDXL_CONFIG, random_params
+
+    cfg = SD15_CONFIG if args.config == "sd15" else SDXL_CONFIG
+    # rank 0 owns the weights; replicas receive them with one bucketed RCCL broadcast over xGMI
+    params = random_params(cfg, seed=0 if rank == 0 else 1000 + rank, dtype=torch.float16, device=dev)
+    t0 = time.perf_counter()
+    bytes_bcast = broadcast_parameters(params, src=0) if world > 1 else 0
+    torch.cuda.synchronize()
+    t_bcast = time.perf_counter() - t0
+
+    engine = UNet2DEngine(cfg, params)
+    hw = cfg["sample_size"]
+    loop = DenoiseLoop(engine, images=args.images, height=hw, width=hw, ctx_len=77, guidance=7.5, num_steps=50,
+                       use_graph=not args.no_graph)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    latents = torch.randn(args.images, 4, hw, hw, generator=g, device=dev).half()
+    ehs = torch.randn(2 * args.images, 77, cfg["cross_attention_dim"], generator=g, device=dev).half()
+    loop.set_inputs(latents, ehs)
+    if args.config == "sdxl":
+        si = loop.plan.static_in
+        si["text_embeds"].copy_(torch.randn(si["text_embeds"].shape, generator=g, device=dev).half())
+        si["time_ids"].copy_(torch.tensor([1024., 1024, 0, 0, 1024, 1024], device=dev).repeat(2 * args.images))
+    loop.capture(warmups=3)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        loop.step(i)
+    sync_all()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        loop.step(i)
+    ev1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+    gpu_ms = ev0.elapsed_time(ev1)
+    finite = bool(torch.isfinite(loop.latents).all())
+
+    if rank == 0:
+        value = world * args.steps / elapsed
+        out = {
+            "metric": "UNet iters/sec SD1.5 512x512 bs=1 fp16" if args.config == "sd15" else "UNet iters/sec SDXL 1024x1024 bs=1 fp16",
+            "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{'SD1.5 512x512' if args.config == 'sd15' else 'SDXL 1024x1024'} bs={args.images} fp16, 50-step DDIM "
+                                   f"schedule, one step = CFG batch-{2 * args.images} UNet forward + guidance combine + DDIM update, "
+                                   f"hipGraph {'off' if args.no_graph else 'on'}, seeded random-init weights, {world} replica(s) "
+                                   f"(one image per GPU, weights broadcast once over RCCL)",
+                       "images_per_gpu": args.images, "unet_batch": 2 * args.images, "latent": [4, hw, hw], "parallelism": f"replicas x{world}"},
+            "gpu_ms_per_step_events": gpu_ms / args.steps, "outputs_finite": finite,
+            "reference_published_other_hw": {"H100": 104.6, "A100": 61.8, "RTX4080": 51.6, "source": "BASELINE.md section 1 (stable-fast README)"},
+            "kernel_launches_per_step": len(loop.plan.ops) + 1,
+            "activation_pool_mb": loop.plan.pool.total_bytes() / 1e6,
+        }
+        if world > 1:
+            out["weight_broadcast"] = {"bytes": bytes_bcast, "seconds": t_bcast}
+        if not args.no_roofline and world == 1:
+            rows = per_op_timing(loop)
+            roof, families, eager_total = roofline_from(rows)
+            out["roofline"] = roof
+            out["kernel_families"] = families
+            out["sum_of_kernel_ms_eager"] = eager_total * 1e3
+            if args.dump_kernels:
+                os.makedirs(os.path.dirname(os.path.abspath(args.dump_kernels)), exist_ok=True)
+                with open(args.dump_kernels, "w") as f:
+                    json.dump(rows, f, indent=1)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.config, args.images)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -141,6 +141,11 @@ int sfast_hip_gemm(const void *x, const void *const *w_segs, const void *bias,
                    const sfast_gemm_params *p, void *workspace, size_t workspace_bytes,
                    sfast_stream_t stream);
 
+/* diagnostic, host-only: the tile / split-K choice the MFMA path would make for an [M,N,K] problem.
+ * out = {BM, BN (weight rows per tile), splits, k_tiles_per_split}. */
+int sfast_hip_igemm_plan(int32_t M, int32_t N, int32_t K, int32_t geglu, int32_t variant, int32_t split_k,
+                         int32_t out[4]);
+
 /* ---- conv2d (cross-correlation, groups = 1) ------------------------------------------------
  * y = act(conv(x, w) + bias + rowbias[b] + alpha*z)  (res_before_act = 1, cuDNN fused form,
  *      cudnn_convolution_impl.cc:995-998) or act(...) + alpha*z (res_before_act = 0).

@@ -169,6 +169,15 @@ void fill_small_conv(SmallConvArgs &a, const void *x, const void *x2, const void
 
 }  // namespace
 
+extern "C" int sfast_hip_igemm_plan(int32_t M, int32_t N, int32_t K, int32_t geglu, int32_t variant, int32_t split_k,
+                                    int32_t out[4]) {
+    if (!out || M <= 0 || N <= 0 || K <= 0) return SFAST_ERR_INVALID;
+    int o[4];
+    igemm_plan_query(M, N, K, geglu != 0, variant < 100 ? variant : 0, split_k, o);
+    for (int i = 0; i < 4; ++i) out[i] = o[i];
+    return SFAST_OK;
+}
+
 extern "C" size_t sfast_hip_gemm_workspace_bytes(const sfast_gemm_params *p) {
     if (!p || !is_half(p->dtype) || p->M <= 16 || p->K % 8 != 0) return 0;
     return igemm_workspace_bytes(p->M, p->N, p->K, p->geglu != 0, p->variant < 100 ? p->variant : 0, p->split_k);

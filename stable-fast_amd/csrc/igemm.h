@@ -24,6 +24,7 @@ struct IgemmArgs {
 // Fills the plan fields of `a` (tiles, split) and launches on `st`.
 int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int split, void *ws, size_t ws_bytes,
               hipStream_t st);
+void igemm_plan_query(int M, int N, int K, bool geglu, int variant, int split, int out[4]);
 size_t igemm_workspace_bytes(int M, int N, int K, bool geglu, int variant, int split);
 
 }  // namespace sfast

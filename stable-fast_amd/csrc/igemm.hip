@@ -445,12 +445,18 @@ struct IgemmPlan {
     int splits, ktps, tiles_m, tiles_n, ktiles;
 };
 
-// Pick tile shape and split-K factor. Cost model: waves of workgroups over 256 CUs (2 WGs per CU
-// for the <=80 KB tiles) x per-tile work / tile efficiency, plus the split-K slab traffic.
+// Pick tile shape and split-K factor with a small analytic model (times in ns):
+//   t = max(waves * t_workgroup, t_memory) + launch + split-K slab traffic
+// where a CU sustains ~1700 MAC/ns on this kernel structure (about 35 % of the 4900 MAC/ns MFMA
+// peak per CU) scaled by the tile shape's efficiency, shared between co-resident workgroups, and
+// operand traffic streams at ~4 TB/s (L2 / Infinity-Cache assisted). The 16x16 / 8x8 UNet levels
+// (M <= 512, K up to 23k) are weight-streaming bound and want as many K-splits as it takes to put
+// a workgroup on every CU; the 64x64 / 32x32 levels never split.
 static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, int force_split) {
     const Variant *vs = geglu ? kGegluVariants : kVariants;
     const int nv = geglu ? (int)(sizeof(kGegluVariants) / sizeof(Variant)) : (int)(sizeof(kVariants) / sizeof(Variant));
     const int ktiles = ceil_div(K, 64);
+    static const int kSplitCand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
     IgemmPlan best{};
     double best_cost = 1e300;
     for (int i = 0; i < nv; ++i) {
@@ -461,24 +467,31 @@ static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, 
         const int tiles = tm * tn;
         const int lds = 2 * (v.BM + v.BN) * 128;
         const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;
-        const int slots = 256 * wg_per_cu;
-        int max_split = ktiles / 4;
-        if (max_split < 1) max_split = 1;
-        if (max_split > 32) max_split = 32;
-        for (int s = 1; s <= max_split; s = (s < 4 ? s + 1 : s * 2)) {
-            if (force_split && s != force_split) continue;
+        const double wrows = geglu ? 2.0 * N : (double)N;
+        // unique operand bytes stream from HBM (~4 TB/s); panel re-reads by other tiles are served
+        // by the XCD L2s / Infinity Cache (~15 TB/s aggregate)
+        const double t_mem = (wrows * K + (double)M * K) * 2.0 / 4000.0 +
+                             ((double)(tm - 1) * wrows * K + (double)(tn - 1) * M * K) * 2.0 / 15000.0;
+        int last_splits = 0;
+        for (int ci = 0; ci < (int)(sizeof(kSplitCand) / sizeof(int)); ++ci) {
+            int s = force_split ? force_split : kSplitCand[ci];
+            if (s > ktiles) s = ktiles;
+            if (s < 1) s = 1;
             const int ktps = ceil_div(ktiles, s);
             const int splits = ceil_div(ktiles, ktps);
-            if (splits != s && !force_split) continue;
-            const double waves = (double)ceil_div(tiles * splits, slots);
-            // time of one WG: ktps K-tiles of BM*BN*64 MACs at tile efficiency; concurrency 1/wg_per_cu share
-            const double tile_work = (double)v.BM * v.BN * 64.0 * ktps / v.eff * wg_per_cu;
-            double cost = waves * tile_work + 40000.0 * 64;  // fixed launch-ish overhead
-            if (splits > 1) {
-                const double np = geglu ? 2.0 * N : (double)N;
-                // slab write+read bytes, expressed in MAC-equivalents (~5 TB/s vs ~1 PF/s tile rate)
-                cost += (double)splits * M * np * 8.0 * 60.0 + 2.0e6;
-            }
+            if (splits == last_splits) continue;
+            last_splits = splits;
+            if (!force_split && splits > 1 && ktps < 4) continue;
+            const int wgs = tiles * splits;
+            const double waves = (double)ceil_div(wgs, 256 * wg_per_cu);
+            int share = ceil_div(wgs, 256);
+            if (share > wg_per_cu) share = wg_per_cu;
+            const double rate = 1700.0 * v.eff / share;  // MAC/ns available to one workgroup
+            const double t_wg = (double)v.BM * v.BN * 64.0 * ktps / rate;
+            double cost = waves * t_wg;
+            if (cost < t_mem) cost = t_mem;
+            cost += 2000.0;
+            if (splits > 1) cost += (double)splits * M * wrows * 8.0 / 3000.0 + 2000.0;
             if (cost < best_cost) {
                 best_cost = cost;
                 best.v = v;
@@ -488,10 +501,11 @@ static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, 
                 best.tiles_n = tn;
                 best.ktiles = ktiles;
             }
+            if (force_split) break;
         }
     }
     if (best_cost == 1e300) {
-        // forced combination did not exist: fall back to variant 3, no split
+        // forced variant id does not exist for this family: smallest tile, no split
         best.v = vs[nv > 2 ? 2 : nv - 1];
         const int bno = geglu ? best.v.BN / 2 : best.v.BN;
         best.splits = 1;
@@ -501,6 +515,14 @@ static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, 
         best.ktiles = ktiles;
     }
     return best;
+}
+
+void igemm_plan_query(int M, int N, int K, bool geglu, int variant, int split, int out[4]) {
+    IgemmPlan p = igemm_plan(M, N, K, geglu, variant, split);
+    out[0] = p.v.BM;
+    out[1] = p.v.BN;
+    out[2] = p.splits;
+    out[3] = p.ktps;
 }
 
 size_t igemm_workspace_bytes(int M, int N, int K, bool geglu, int variant, int split) {

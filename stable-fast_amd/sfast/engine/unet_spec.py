@@ -1,0 +1,146 @@
+"""Parameter inventory of `UNet2DConditionModel` (diffusers state-dict names and shapes) derived from
+a config -- lets the engine be driven from a bare state dict (safetensors header) or from seeded
+random weights (bench / smoke runs; there are no checkpoints or network on the GPU box) without
+instantiating a PyTorch module.
+
+Names follow the public diffusers layout recorded in SURVEY.md Appendix A (the reference itself
+never spells them out: it traces whatever module it is given).
+"""
+import math
+from typing import Dict, Tuple
+
+import torch
+
+SD15_CONFIG = dict(
+    sample_size=64, in_channels=4, out_channels=4,
+    down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+    up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+    block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, cross_attention_dim=768,
+    attention_head_dim=8, transformer_layers_per_block=1, norm_num_groups=32, norm_eps=1e-5,
+    use_linear_projection=False, flip_sin_to_cos=True, freq_shift=0, addition_embed_type=None,
+    addition_time_embed_dim=None, projection_class_embeddings_input_dim=None,
+)
+
+SDXL_CONFIG = dict(
+    sample_size=128, in_channels=4, out_channels=4,
+    down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+    up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+    block_out_channels=(320, 640, 1280), layers_per_block=2, cross_attention_dim=2048,
+    attention_head_dim=(5, 10, 20), transformer_layers_per_block=(1, 2, 10), norm_num_groups=32, norm_eps=1e-5,
+    use_linear_projection=True, flip_sin_to_cos=True, freq_shift=0, addition_embed_type="text_time",
+    addition_time_embed_dim=256, projection_class_embeddings_input_dim=2816,
+)
+
+
+def _per_block(v, n):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v,) * n
+
+
+def unet2d_param_shapes(cfg: dict) -> Dict[str, Tuple[int, ...]]:
+    boc = tuple(cfg["block_out_channels"])
+    n = len(boc)
+    L = cfg.get("layers_per_block", 2)
+    depth = _per_block(cfg.get("transformer_layers_per_block", 1), n)
+    ctx = cfg["cross_attention_dim"]
+    lin = bool(cfg.get("use_linear_projection", False))
+    T = boc[0] * 4
+    out: Dict[str, Tuple[int, ...]] = {}
+
+    def conv(name, cout, cin, k):
+        out[name + ".weight"] = (cout, cin, k, k)
+        out[name + ".bias"] = (cout,)
+
+    def linear(name, cout, cin, bias=True):
+        out[name + ".weight"] = (cout, cin)
+        if bias:
+            out[name + ".bias"] = (cout,)
+
+    def norm(name, c):
+        out[name + ".weight"] = (c,)
+        out[name + ".bias"] = (c,)
+
+    def resnet(name, cin, cout):
+        norm(name + ".norm1", cin)
+        conv(name + ".conv1", cout, cin, 3)
+        linear(name + ".time_emb_proj", cout, T)
+        norm(name + ".norm2", cout)
+        conv(name + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(name + ".conv_shortcut", cout, cin, 1)
+
+    def transformer(name, c, d):
+        norm(name + ".norm", c)
+        for pn in ("proj_in", "proj_out"):
+            if lin:
+                linear(f"{name}.{pn}", c, c)
+            else:
+                conv(f"{name}.{pn}", c, c, 1)
+        for j in range(d):
+            b = f"{name}.transformer_blocks.{j}"
+            for k_, kv in (("attn1", c), ("attn2", ctx)):
+                norm(f"{b}.norm{1 if k_ == 'attn1' else 2}", c)
+                linear(f"{b}.{k_}.to_q", c, c, bias=False)
+                linear(f"{b}.{k_}.to_k", c, kv, bias=False)
+                linear(f"{b}.{k_}.to_v", c, kv, bias=False)
+                linear(f"{b}.{k_}.to_out.0", c, c)
+            norm(f"{b}.norm3", c)
+            linear(f"{b}.ff.net.0.proj", 8 * c, c)
+            linear(f"{b}.ff.net.2", c, 4 * c)
+
+    conv("conv_in", boc[0], cfg.get("in_channels", 4), 3)
+    linear("time_embedding.linear_1", T, boc[0])
+    linear("time_embedding.linear_2", T, T)
+    if cfg.get("addition_embed_type") == "text_time":
+        linear("add_embedding.linear_1", T, cfg["projection_class_embeddings_input_dim"])
+        linear("add_embedding.linear_2", T, T)
+    ch = boc[0]
+    for i, t in enumerate(cfg["down_block_types"]):
+        for j in range(L):
+            resnet(f"down_blocks.{i}.resnets.{j}", ch if j == 0 else boc[i], boc[i])
+            if t == "CrossAttnDownBlock2D":
+                transformer(f"down_blocks.{i}.attentions.{j}", boc[i], depth[i])
+        ch = boc[i]
+        if i < n - 1:
+            conv(f"down_blocks.{i}.downsamplers.0.conv", ch, ch, 3)
+    resnet("mid_block.resnets.0", boc[-1], boc[-1])
+    transformer("mid_block.attentions.0", boc[-1], depth[-1])
+    resnet("mid_block.resnets.1", boc[-1], boc[-1])
+    rev, rdepth = boc[::-1], depth[::-1]
+    prev = rev[0]
+    for i, t in enumerate(cfg["up_block_types"]):
+        co, ci = rev[i], rev[min(i + 1, n - 1)]
+        for j in range(L + 1):
+            skip = ci if j == L else co
+            rin = prev if j == 0 else co
+            resnet(f"up_blocks.{i}.resnets.{j}", rin + skip, co)
+            if t == "CrossAttnUpBlock2D":
+                transformer(f"up_blocks.{i}.attentions.{j}", co, rdepth[i])
+        if i < n - 1:
+            conv(f"up_blocks.{i}.upsamplers.0.conv", co, co, 3)
+        prev = co
+    norm("conv_norm_out", boc[0])
+    conv("conv_out", cfg.get("out_channels", 4), boc[0], 3)
+    return out
+
+
+def random_params(cfg: dict, seed: int = 0, dtype=torch.float16, device="cuda") -> Dict[str, torch.Tensor]:
+    """Seeded synthetic weights with a variance-preserving init (no checkpoint is reachable offline).
+    4-D weights are produced in channels_last (the K-contiguous layout the conv kernels read)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    params = {}
+    for name, shape in unet2d_param_shapes(cfg).items():
+        if len(shape) == 1:
+            if "norm" in name and name.endswith("weight"):
+                t = 1.0 + 0.1 * torch.randn(shape, generator=g, device=device)
+            else:
+                t = 0.05 * torch.randn(shape, generator=g, device=device)
+        else:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            t = torch.randn(shape, generator=g, device=device) * (1.0 / math.sqrt(fan_in))
+        t = t.to(dtype)
+        if t.ndim == 4:
+            t = t.contiguous(memory_format=torch.channels_last)
+        params[name] = t
+    return params

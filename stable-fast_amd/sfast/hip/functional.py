@@ -67,8 +67,8 @@ def _i64x3(vals):
 def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, act=None, x2=None):
     """GroupNorm(+SiLU). x: [N, C, *] (channels_last 4-D is processed natively as NHWC).
     x2: optional second channels_last tensor, normalised as if torch.cat([x, x2], 1)."""
-    lib = L.init_device()
     _require_cuda(x, x2, weight, bias)
+    lib = L.init_device()
     if x.ndim < 2:
         raise L.SfastHipError("group_norm: input must be at least 2-D")
     N, C1 = x.shape[0], x.shape[1]
@@ -108,8 +108,8 @@ def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, act=None, x2=Non
 
 
 def layer_norm(x, normalized_shape: Sequence[int], weight=None, bias=None, eps=1e-5):
-    lib = L.init_device()
     _require_cuda(x, weight, bias)
+    lib = L.init_device()
     n = 1
     for s in normalized_shape:
         n *= int(s)
@@ -132,9 +132,9 @@ def linear(x, weight, bias=None, *, act=None, residual=None, alpha=1.0, res_befo
            geglu=False, rowbias=None, rows_per_batch=0, in_act=None, variant=0, split_k=0, out=None):
     """out[..., N] = epilogue(x[..., K] @ W[N, K]^T). `weight` may be a list of <= 4 equally sized
     [n_i, K] tensors stacked along N (e.g. live to_q / to_k / to_v weights)."""
-    lib = L.init_device()
     ws_list = list(weight) if isinstance(weight, (list, tuple)) else [weight]
     _require_cuda(x, bias, residual, rowbias, *ws_list)
+    lib = L.init_device()
     K = x.shape[-1]
     for w in ws_list:
         if w.ndim != 2 or w.shape[1] != K or w.dtype != x.dtype:
@@ -210,8 +210,8 @@ def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dila
            channels_last_out: Optional[bool] = None):
     """y = act(conv2d(x, w) + bias + rowbias[b] + alpha*z) on logical NCHW tensors of any strides.
     x2: optional tensor concatenated to x along channels (virtual). upsample2x: nearest 2x first."""
-    lib = L.init_device()
     _require_cuda(x, weight, bias, z, x2, rowbias)
+    lib = L.init_device()
     if x.ndim != 4 or weight.ndim != 4:
         raise L.SfastHipError("conv2d: 4-D input and weight required")
     pair = lambda v: (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
@@ -267,8 +267,8 @@ def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dila
 
 def attention(q, k, v, scale: Optional[float] = None, variant=0):
     """softmax(q k^T * scale) v with q [B, Sq, H, D], k/v [B, Skv, H, D] (any b/s/h strides)."""
-    lib = L.init_device()
     _require_cuda(q, k, v)
+    lib = L.init_device()
     if q.ndim != 4 or k.ndim != 4 or v.ndim != 4:
         raise L.SfastHipError("attention: expected [B, S, H, D] tensors")
     B, Sq, H, D = q.shape
@@ -292,8 +292,8 @@ def attention(q, k, v, scale: Optional[float] = None, variant=0):
 
 def strided_copy(src, dst):
     """dst[...] = src[...] for equal-shape tensors of rank <= 4 and arbitrary strides."""
-    lib = L.init_device()
     _require_cuda(src, dst)
+    lib = L.init_device()
     if src.shape != dst.shape or src.dtype != dst.dtype:
         raise L.SfastHipError("strided_copy: shape/dtype mismatch")
     if src.ndim > 4:
@@ -316,8 +316,8 @@ def strided_copy(src, dst):
 
 def timestep_embedding(timesteps, dim, flip_sin_to_cos=True, downscale_freq_shift=0.0, max_period=10000.0,
                        dtype=torch.float16):
-    lib = L.init_device()
     _require_cuda(timesteps)
+    lib = L.init_device()
     t = timesteps.to(torch.float32).contiguous().reshape(-1)
     out = torch.empty((t.numel(), dim), dtype=dtype, device=t.device)
     p = L.TembParams(_DT[dtype], t.numel(), dim, 1 if flip_sin_to_cos else 0, float(downscale_freq_shift),
@@ -328,8 +328,8 @@ def timestep_embedding(timesteps, dim, flip_sin_to_cos=True, downscale_freq_shif
 
 
 def cfg_ddim_step(eps_uc, latents, coef, guidance, latents_out=None, unet_in=None):
-    lib = L.init_device()
     _require_cuda(eps_uc, latents, coef)
+    lib = L.init_device()
     numel = latents.numel()
     if eps_uc.numel() != 2 * numel or not eps_uc.is_contiguous() or not latents.is_contiguous():
         raise L.SfastHipError("cfg_ddim_step: eps_uc must be contiguous [2, *latents.shape]")

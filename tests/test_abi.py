@@ -1,0 +1,111 @@
+"""The C-ABI library builds, loads and exports what include/sfast_hip.h declares -- runs on CPU
+(hipcc cross-compiles gfx950 without a GPU; no kernel is launched here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "sfast_hip.h")
+
+
+def _declared_symbols():
+    src = open(HEADER).read()
+    return sorted(set(re.findall(r"\b(sfast_hip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    from sfast.hip import lib as L
+    lib = L.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in sfast_hip.h but not exported"
+    assert set(L.EXPORTS) == set(declared)
+    assert lib.sfast_hip_abi_version() == L.ABI_VERSION
+
+
+def test_ctypes_structs_match_the_c_header(built_lib):
+    from sfast.hip import lib as L
+    structs = {"sfast_gn_params": L.GnParams, "sfast_ln_params": L.LnParams, "sfast_gemm_params": L.GemmParams,
+               "sfast_conv_params": L.ConvParams, "sfast_attn_params": L.AttnParams, "sfast_copy_params": L.CopyParams,
+               "sfast_temb_params": L.TembParams}
+    body = "".join(f'printf("%zu\\n", sizeof({n}));' for n in structs)
+    probes = [("sfast_gemm_params", "ld_rowbias"), ("sfast_gemm_params", "split_k"), ("sfast_conv_params", "xs"),
+              ("sfast_conv_params", "ld_rowbias"), ("sfast_attn_params", "scale"), ("sfast_copy_params", "dst_strides")]
+    body += "".join(f'printf("%zu\\n", offsetof({s}, {f}));' for s, f in probes)
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "abi.c")
+        with open(src, "w") as f:
+            f.write(f'#include <stdio.h>\n#include <stddef.h>\n#include "{HEADER}"\nint main(){{{body}return 0;}}\n')
+        exe = os.path.join(d, "abi")
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", src, "-o", exe])  # header is plain C
+        out = [int(x) for x in subprocess.check_output([exe]).split()]
+    for (name, st), size in zip(structs.items(), out):
+        assert C.sizeof(st) == size, name
+    for (s, f), off in zip(probes, out[len(structs):]):
+        assert getattr(structs[s], f).offset == off, (s, f)
+
+
+def test_validation_errors_surface_without_a_gpu(built_lib):
+    # argument validation happens before any launch -> checkable on CPU
+    from sfast.hip import lib as L
+    lib = L.load()
+    p = L.GemmParams()
+    p.M, p.N, p.K = 0, 8, 8
+    segs = (C.c_void_p * 1)(1)
+    rc = lib.sfast_hip_gemm(1, segs, None, None, None, 1, C.byref(p), None, 0, None)
+    assert rc == -2 and b"bad shape" in lib.sfast_hip_last_error()
+    g = L.GnParams(L.F16, L.NHWC, 1, 30, 4, 4, 30, L.ACT_NONE, 1e-5)  # 30 channels, 4 groups: not divisible
+    assert lib.sfast_hip_group_norm(1, None, None, None, 1, C.byref(g), None, 0, None) == -2
+
+
+def test_workspace_queries_are_consistent(built_lib):
+    from sfast.hip import lib as L
+    lib = L.load()
+    # 8x8 level conv of SD1.5 at B=2: M=128, K=11520 -> the planner must split K and ask for slabs
+    p = L.ConvParams()
+    p.dtype, p.B, p.H, p.W, p.Cin, p.Cout, p.KH, p.KW = L.F16, 2, 8, 8, 1280, 1280, 3, 3
+    p.stride_h = p.stride_w = p.dil_h = p.dil_w = 1
+    p.pad_h = p.pad_w = 1
+    p.C1 = 1280
+    nb = lib.sfast_hip_conv2d_workspace_bytes(C.byref(p))
+    assert nb > 0 and nb % (128 * 1280 * 4) == 0
+    # a 64x64-level conv has thousands of tiles: no split, no workspace
+    p.H = p.W = 64
+    p.Cin = p.C1 = p.Cout = 320
+    assert lib.sfast_hip_conv2d_workspace_bytes(C.byref(p)) == 0
+    g = L.GnParams(L.F16, L.NHWC, 2, 320, 4096, 32, 320, L.ACT_SILU, 1e-5)
+    assert lib.sfast_hip_group_norm_workspace_bytes(C.byref(g)) > 0
+
+
+def test_missing_library_is_a_loud_error(monkeypatch):
+    from sfast.hip import lib as L
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libsfast_hip.so")
+    try:
+        L.load()
+        raise AssertionError("load() must raise when the kernel library is absent")
+    except L.SfastHipError as e:
+        assert "no fallback" in str(e)
+
+
+def test_ops_reject_cpu_tensors(built_lib):
+    import torch
+    import sfast  # noqa: F401  registers torch.ops.sfast*
+    from sfast.hip import functional as F
+    x = torch.zeros(2, 8, dtype=torch.float16)
+    for call in (lambda: torch.ops.sfast.cublas_lowp_linear(x, x, None),
+                 lambda: torch.ops.sfast_triton.layer_norm(x, [8], None, None, 1e-5),
+                 lambda: torch.ops.sfast.cutlass_linear_geglu_unified(x, x, None)):
+        try:
+            call()
+            raise AssertionError("CPU call must not succeed")
+        except (NotImplementedError, RuntimeError):
+            pass
+    try:
+        F.layer_norm(x, [8])
+        raise AssertionError("functional wrapper must reject CPU tensors")
+    except RuntimeError as e:
+        assert "no CPU path" in str(e)

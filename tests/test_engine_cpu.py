@@ -1,0 +1,139 @@
+"""Host logic of the native engine, checked on CPU by executing the plan against the C-ABI emulator
+(tests/abi_emulator.py): pointer arithmetic, strides, buffer reuse, time-embedding offsets, virtual
+concat / upsample bookkeeping, op counts. No GPU, no kernel launches."""
+import pytest
+import torch
+
+from abi_emulator import EmuLib
+from oracle import unet_ref as U
+from parity import rel_l2
+from sfast.engine import UNet2DEngine, UnsupportedUNet
+
+
+def _pair(cfg, seed):
+    m16 = U.build(cfg, seed=seed, dtype=torch.float16)
+    m32 = U.build(cfg, seed=seed, dtype=torch.float32)
+    m32.load_state_dict({k: v.float() for k, v in m16.state_dict().items()})
+    return m16, m32
+
+
+def test_plan_executes_tiny_sd15_topology(built_lib):
+    cfg = U.tiny_config()
+    m16, m32 = _pair(cfg, 3)
+    emu = EmuLib()
+    eng = UNet2DEngine.from_module(m16, _lib=emu)
+    g = torch.Generator().manual_seed(0)
+    s = torch.randn(2, 4, 16, 16, generator=g).half()
+    e = torch.randn(2, 77, 64, generator=g).half()
+    y = eng.forward(s, 981, e)
+    with torch.no_grad():
+        want = m32(s.float(), 981, e.float()).sample
+    # fp16 storage between ops, exact fp32 math inside each op -> ~1e-3
+    assert rel_l2(y, want) < 3e-3
+    # per-sample timesteps and a second signature (new plan, shared parameters)
+    t = torch.tensor([981.0, 21.0])
+    y2 = eng.forward(s, t, e)
+    with torch.no_grad():
+        want2 = m32(s.float(), t, e.float()).sample
+    assert rel_l2(y2, want2) < 3e-3
+    s3 = torch.randn(1, 4, 32, 16, generator=g).half()
+    y3 = eng.forward(s3, 5, e[:1, :33])
+    with torch.no_grad():
+        want3 = m32(s3.float(), 5, e[:1, :33].float()).sample
+    assert rel_l2(y3, want3) < 3e-3 and len(eng._plans) == 2
+
+
+def test_plan_executes_tiny_sdxl_topology(built_lib):
+    cfg = U.tiny_config(down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                        up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+                        transformer_layers_per_block=(1, 2, 2), attention_head_dim=(1, 2, 4), use_linear_projection=True,
+                        addition_embed_type="text_time", addition_time_embed_dim=32,
+                        projection_class_embeddings_input_dim=64 + 6 * 32, layers_per_block=2)
+    m16, m32 = _pair(cfg, 4)
+    eng = UNet2DEngine.from_module(m16, _lib=EmuLib())
+    g = torch.Generator().manual_seed(1)
+    s = torch.randn(2, 4, 16, 16, generator=g).half()
+    e = torch.randn(2, 20, 64, generator=g).half()
+    added = dict(text_embeds=torch.randn(2, 64, generator=g).half(), time_ids=torch.tensor([[1024., 1024, 0, 0, 1024, 1024]] * 2).half())
+    y = eng.forward(s, 400, e, added)
+    with torch.no_grad():
+        want = m32(s.float(), 400, e.float(), added_cond_kwargs={k: v.float() for k, v in added.items()}).sample
+    assert rel_l2(y, want) < 3e-3
+    with pytest.raises(ValueError):
+        eng.forward(s, 400, e)  # text_time conditioning is mandatory for this config
+
+
+def _shape_params(cfg):
+    with torch.device("meta"):
+        m = U.UNet2DConditionModel(**cfg)
+    params = {}
+    for k, v in m.named_parameters():
+        t = torch.empty(v.shape, dtype=torch.float16)
+        params[k] = t.contiguous(memory_format=torch.channels_last) if t.ndim == 4 else t
+    return m.config, params
+
+
+def test_sd15_plan_op_inventory(built_lib):
+    """The SD1.5 plan matches the per-forward op inventory of SURVEY.md section 3.3 / 8d."""
+    config, params = _shape_params(U.SD15_CONFIG)
+    eng = UNet2DEngine(config, params, _lib=EmuLib())
+    plan = eng.build_plan(2, 64, 64, 77)
+    s = plan.summary()
+    assert s["gn_silu"]["count"] == 45 and s["gn"]["count"] == 16 and s["ln"]["count"] == 48
+    assert s["attn_self"]["count"] == 16 and s["attn_cross"]["count"] == 16 and s["geglu"]["count"] == 16
+    assert s["conv3x3"]["count"] + s["conv_in"]["count"] + s["conv_out"]["count"] == 52
+    assert s["conv1x1"]["count"] == 46
+    assert s["temb"]["count"] == 2 + 22
+    # algorithmic work at B=2 is twice the B=1 figures of SURVEY.md section 8d (804 GFLOP total)
+    total = sum(v["gflop"] for v in s.values())
+    assert abs(total / 2 - 804) / 804 < 0.02, total
+    assert abs(s["attn_self"]["gflop"] / 2 - 122.5) < 1.0 and abs(s["geglu"]["gflop"] / 2 - 102.3) < 1.0
+    assert abs((s["conv3x3"]["gflop"] + s["conv_in"]["gflop"] + s["conv_out"]["gflop"]) / 2 - 400.3) < 2.0
+    # nothing is materialised for concat / upsample: no copy ops at all in the SD1.5 plan
+    assert "misc" in s and s["misc"]["count"] == 1
+    assert plan.ws[1] > 0  # split-K slabs for the 8x8 / 16x16 levels
+
+
+def test_sdxl_plan_builds(built_lib):
+    config, params = _shape_params(U.SDXL_CONFIG)
+    eng = UNet2DEngine(config, params, _lib=EmuLib())
+    plan = eng.build_plan(1, 128, 128, 77)
+    s = plan.summary()
+    assert s["attn_self"]["count"] == 70 and s["geglu"]["count"] == 70
+    total = sum(v["gflop"] for v in s.values())
+    assert abs(total - 6760) / 6760 < 0.03, total
+
+
+def test_unsupported_configs_are_rejected(built_lib):
+    config, params = _shape_params(U.tiny_config())
+    config.class_embed_type = "timestep"
+    with pytest.raises(UnsupportedUNet):
+        UNet2DEngine(config, params, _lib=EmuLib())
+    config, params = _shape_params(U.tiny_config())
+    with pytest.raises(UnsupportedUNet):
+        UNet2DEngine(config, {k: v.float() for k, v in params.items()}, _lib=EmuLib())
+    config, params = _shape_params(U.tiny_config())
+    eng = UNet2DEngine(config, params, _lib=EmuLib())
+    with pytest.raises(UnsupportedUNet):
+        eng.build_plan(1, 18, 16, 77)  # not divisible by 4
+
+
+def test_engine_requires_gpu_without_emulator(built_lib):
+    from sfast.hip.lib import SfastHipError
+    config, params = _shape_params(U.tiny_config())
+    with pytest.raises(SfastHipError):
+        UNet2DEngine(config, params)
+
+
+@pytest.mark.parametrize("name", ["sd15", "sdxl", "tiny"])
+def test_param_inventory_matches_oracle_state_dict(name):
+    """Two independent enumerations of the diffusers naming (product: unet_spec, oracle: unet_ref)."""
+    from sfast.engine import unet_spec as S
+    cfg = {"sd15": U.SD15_CONFIG, "sdxl": U.SDXL_CONFIG, "tiny": U.tiny_config()}[name]
+    with torch.device("meta"):
+        m = U.UNet2DConditionModel(**cfg)
+    want = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    got = S.unet2d_param_shapes(cfg)
+    assert got == want
+    if name == "sd15":
+        assert S.SD15_CONFIG == U.SD15_CONFIG and S.SDXL_CONFIG == U.SDXL_CONFIG

@@ -1,0 +1,115 @@
+"""Host-side pieces that need no GPU: graph-cache keys, tree copies, config surface, batch sharding
+and the weight broadcast of the multi-GPU path (world_size 2 over gloo)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def test_hash_arg_semantics():
+    # /root/reference/src/sfast/cuda/graphs.py:225-241
+    from sfast.cuda.graphs import hash_arg
+    a = torch.zeros(2, 3)
+    assert hash_arg(a) == hash_arg(torch.ones(2, 3))           # tensors hash by type/shape, not value
+    assert hash_arg(a) != hash_arg(torch.zeros(2, 4))
+    assert hash_arg(a) != hash_arg(a.half())
+    assert hash_arg(torch.tensor(3)) != hash_arg(torch.tensor(4))  # CPU scalars hash by value
+    assert hash_arg((1, "x", [a])) == hash_arg((1, "x", [a.clone()]))
+    assert hash_arg({"k": a, "j": 2}) == hash_arg({"j": 2, "k": a})
+    assert hash_arg(object()) == object
+
+
+def test_tree_copy_roundtrip():
+    from sfast.utils.copy import tree_copy, tree_copy_
+    src = {"a": torch.arange(4.0), "b": (torch.ones(2), [torch.zeros(1), 5]), "c": "s"}
+    dst = tree_copy(src)
+    assert dst["a"] is not src["a"] and torch.equal(dst["a"], src["a"]) and dst["b"][1][1] == 5
+    src["a"].add_(1)
+    tree_copy_(dst, src)
+    assert torch.equal(dst["a"], src["a"])
+
+
+def test_compilation_config_surface():
+    from sfast.compilers.diffusion_pipeline_compiler import CompilationConfig, compile, compile_unet, compile_vae  # noqa: F401
+    import sfast.compilers.stable_diffusion_pipeline_compiler as alias
+    c = CompilationConfig.Default()
+    names = ["memory_format", "enable_jit", "enable_jit_freeze", "preserve_parameters", "enable_cnn_optimization",
+             "enable_fused_linear_geglu", "prefer_lowp_gemm", "enable_xformers", "enable_cuda_graph", "enable_triton",
+             "trace_scheduler"]
+    assert [f for f in c.__dataclass_fields__] == names
+    assert c.enable_jit and c.preserve_parameters and not c.enable_cuda_graph
+    assert alias.compile is compile and alias.CompilationConfig is CompilationConfig
+
+
+def test_compile_unet_on_cpu_keeps_eager_forward():
+    # no GPU -> the native engine is not engaged and nothing silently emulates it
+    from oracle import unet_ref as U
+    from sfast.compilers.diffusion_pipeline_compiler import CompilationConfig, compile_unet
+    m = U.build("tiny", seed=0)
+    fwd = m.forward
+    m2 = compile_unet(m, CompilationConfig.Default())
+    assert m2 is m and m.forward == fwd and not hasattr(m, "_sfast_engine")
+    assert m.conv_in.weight.is_contiguous()  # default memory_format on a CPU-only box is contiguous
+
+
+def test_shard_batch():
+    from sfast.engine.replicas import shard_batch
+    assert [shard_batch(64, r, 8) for r in range(8)] == [(8 * r, 8 * r + 8) for r in range(8)]
+    parts = [shard_batch(10, r, 4) for r in range(4)]
+    assert parts == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert shard_batch(1, 0, 1) == (0, 1)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sfast.engine.replicas import broadcast_parameters, gather_latents, shard_batch
+        torch.manual_seed(100 + rank)  # different weights on every rank before the broadcast
+        params = {
+            "conv.weight": torch.randn(8, 4, 3, 3).contiguous(memory_format=torch.channels_last),
+            "lin.weight": torch.randn(16, 8),
+            "lin.bias": torch.randn(16),
+            "norm.weight": torch.randn(8).half(),
+        }
+        ptrs = {k: v.data_ptr() for k, v in params.items()}
+        nbytes = broadcast_parameters(params, src=0, bucket_bytes=256)  # tiny buckets: several collectives
+        assert all(params[k].data_ptr() == ptrs[k] for k in params)  # in place: captured pointers stay valid
+        assert params["conv.weight"].is_contiguous(memory_format=torch.channels_last)
+        torch.manual_seed(100)
+        want = {"conv.weight": torch.randn(8, 4, 3, 3), "lin.weight": torch.randn(16, 8), "lin.bias": torch.randn(16),
+                "norm.weight": torch.randn(8).half()}
+        ok = all(torch.equal(params[k], want[k]) for k in params)
+        lo, hi = shard_batch(6, rank, world)
+        local = torch.full((hi - lo, 2), float(rank))
+        outs = gather_latents(local, dst=0)
+        if rank == 0:
+            ok = ok and len(outs) == world and all(float(o[0, 0]) == r for r, o in enumerate(outs))
+        q.put((rank, ok, nbytes))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_weight_broadcast_and_sharding_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [True, True]
+    assert res[0][2] == res[1][2] > 0

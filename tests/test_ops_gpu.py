@@ -1,0 +1,460 @@
+"""Per-kernel parity on a real MI355X: HIP path (through the C ABI) vs the fp32 oracle on the same
+seeded inputs, plus the committed golden vectors. Shapes: the reference's own test shapes
+ and the SD1.5 / SDXL layer shapes, every forced tile variant and split-K.
+
+Tolerances (stated per family): outputs are rounded to f16/bf16 (rel. 2^-11 / 2^-8), accumulation and
+epilogues are fp32, so |err| <= atol + rtol*|ref| with rtol = 2e-3 (f16) / 1.6e-2 (bf16) covers the
+output rounding plus the f16 rounding of P in attention; the reference's own tolerances are looser
+(GEGLU 2e-2, conv 1e-3 in fp32, GroupNorm 1e-2).
+"""
+import os
+
+import pytest
+import torch
+
+from oracle import ops_ref as R
+from parity import compare
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda"
+
+
+def F():
+    from sfast.hip import functional
+    return functional
+
+
+def last_kernel():
+    from sfast.hip import lib
+    return lib.last_kernel()
+
+
+def tol(dtype, scale=1.0):
+    if dtype == torch.bfloat16:
+        return 2e-2 * scale, 1.6e-2
+    if dtype == torch.float32:
+        return 1e-4 * scale, 1e-4
+    return 3e-3 * scale, 2e-3
+
+
+def rnd(*shape, dtype=torch.float16, seed=0, scale=1.0, shift=0.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale + shift).to(device=DEV, dtype=dtype)
+
+
+# ---- GroupNorm -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("silu", [False, True])
+@pytest.mark.parametrize("cl", [False, True])
+def test_group_norm_reference_selftest_shape(silu, cl):
+    # triton/ops/group_norm.py:485-523: randn(2,320,32,32) fp16, G=32, both layouts
+    x = rnd(2, 320, 32, 32, seed=1)
+    if cl:
+        x = x.contiguous(memory_format=torch.channels_last)
+    w, b = rnd(320, seed=2), rnd(320, seed=3)
+    y = F().group_norm(x, 32, w, b, 1e-5, "silu" if silu else None)
+    assert y.is_contiguous(memory_format=torch.channels_last if cl else torch.contiguous_format)
+    compare(f"gn_ref_shape cl={cl} silu={silu}", y, R.group_norm_ref(x, 32, w, b, 1e-5, silu), *tol(x.dtype), kernel=last_kernel())
+
+
+@pytest.mark.parametrize("shape", [(2, 320, 64, 64), (2, 640, 32, 32), (2, 1280, 8, 8), (1, 2560, 16, 16), (2, 1920, 32, 32),
+                                   (2, 960, 64, 64), (1, 1280, 16, 16), (3, 640, 24, 40)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_group_norm_silu_unet_shapes(shape, dtype):
+    x = rnd(*shape, dtype=dtype, seed=4, scale=2.0, shift=3.0).contiguous(memory_format=torch.channels_last)
+    w, b = rnd(shape[1], dtype=dtype, seed=5, shift=1.0, scale=0.2), rnd(shape[1], dtype=dtype, seed=6, scale=0.2)
+    y = F().group_norm(x, 32, w, b, 1e-5, "silu")
+    assert "gn_nhwc" in last_kernel()
+    compare(f"gn_silu {shape} {dtype}", y, R.group_norm_ref(x, 32, w, b, 1e-5, True), *tol(dtype, 2.0), kernel=last_kernel())
+
+
+@pytest.mark.parametrize("c1,c2,hw", [(640, 320, 64), (1280, 1280, 16), (1280, 640, 32), (320, 320, 64)])
+def test_group_norm_virtual_concat(c1, c2, hw):
+    x1 = rnd(2, c1, hw, hw, seed=7, shift=-1.0).contiguous(memory_format=torch.channels_last)
+    x2 = rnd(2, c2, hw, hw, seed=8, scale=3.0).contiguous(memory_format=torch.channels_last)
+    w, b = rnd(c1 + c2, seed=9, shift=1.0, scale=0.1), rnd(c1 + c2, seed=10)
+    y = F().group_norm(x1, 32, w, b, 1e-5, "silu", x2=x2)
+    want = R.group_norm_ref(torch.cat([x1, x2], 1), 32, w, b, 1e-5, True)
+    compare(f"gn_concat {c1}+{c2}@{hw}", y, want, *tol(x1.dtype, 2.0), kernel=last_kernel())
+
+
+@pytest.mark.parametrize("case", ["cpg6", "f32", "3d", "tiny", "eps1e-6", "noaffine"])
+def test_group_norm_generic_and_edges(case):
+    if case == "cpg6":  # 6 channels per group -> generic kernel
+        x, G = rnd(2, 36, 8, 8, seed=11).contiguous(memory_format=torch.channels_last), 6
+    elif case == "f32":
+        x, G = rnd(2, 64, 16, 16, dtype=torch.float32, seed=12), 8
+    elif case == "3d":
+        x, G = rnd(2, 64, 50, seed=13), 4
+    elif case == "tiny":
+        x, G = rnd(1, 32, 1, 1, seed=14).contiguous(memory_format=torch.channels_last), 4
+    else:
+        x, G = rnd(2, 320, 16, 16, seed=15).contiguous(memory_format=torch.channels_last), 32
+    C = x.shape[1]
+    w, b = (None, None) if case == "noaffine" else (rnd(C, dtype=x.dtype, seed=16), rnd(C, dtype=x.dtype, seed=17))
+    eps = 1e-6 if case == "eps1e-6" else 1e-5
+    y = F().group_norm(x, G, w, b, eps)
+    compare(f"gn_edge {case}", y, R.group_norm_ref(x, G, w, b, eps), *tol(x.dtype, 2.0), kernel=last_kernel())
+
+
+# ---- LayerNorm -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1151, 8192), (8192, 320), (2048, 640), (512, 1280), (128, 1280), (2, 77, 768), (5, 77), (3, 2048)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_layer_norm(shape, dtype):
+    # (1151, 8192) is the reference self-test (triton/ops/layer_norm.py:522)
+    x = rnd(*shape, dtype=dtype, seed=20, scale=2.0, shift=1.0)
+    n = shape[-1]
+    w, b = rnd(n, dtype=dtype, seed=21, shift=1.0, scale=0.2), rnd(n, dtype=dtype, seed=22)
+    y = F().layer_norm(x, (n,), w, b, 1e-5)
+    compare(f"ln {shape} {dtype}", y, R.layer_norm_ref(x, (n,), w, b), *tol(dtype, 2.0), kernel=last_kernel())
+
+
+def test_layer_norm_f32_and_no_affine():
+    x = rnd(33, 320, dtype=torch.float32, seed=23)
+    compare("ln f32", F().layer_norm(x, (320,)), R.layer_norm_ref(x, (320,)), *tol(torch.float32), kernel=last_kernel())
+
+
+# ---- GEMM family -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("inf", [4, 8, 16])
+@pytest.mark.parametrize("outf", [4, 8, 16])
+@pytest.mark.parametrize("N", [4, 16])
+def test_geglu_reference_grid(dtype, bias, inf, outf, N):
+    # /root/reference/tests/operators/test_cutlass_dual_linear.py:42-56 (tolerance 2e-2 there)
+    x = rnd(N, inf, dtype=dtype, seed=30)
+    w = rnd(2 * outf, inf, dtype=dtype, seed=31, scale=0.5)
+    b = rnd(2 * outf, dtype=dtype, seed=32) if bias else None
+    y = F().linear(x, w, b, geglu=True)
+    compare(f"geglu_grid {dtype} b={bias} {inf}->{outf} N={N}", y, R.linear_ref(x, w, b, geglu=True), 2e-2, 2e-2, kernel=last_kernel())
+
+
+@pytest.mark.parametrize("M,K,N", [(8192, 320, 1280), (2048, 640, 2560), (512, 1280, 5120), (128, 1280, 5120), (100, 320, 1280)])
+@pytest.mark.parametrize("variant", [0, 1, 3])
+def test_geglu_unet_shapes(M, K, N, variant):
+    x = rnd(M, K, seed=33)
+    w = rnd(2 * N, K, seed=34, scale=K ** -0.5)
+    b = rnd(2 * N, seed=35, scale=0.1)
+    y = F().linear(x, w, b, geglu=True, variant=variant)
+    assert "geglu" in last_kernel()
+    compare(f"geglu M{M} K{K} N{N} v{variant}", y, R.linear_ref(x, w, b, geglu=True), *tol(x.dtype), kernel=last_kernel())
+
+
+@pytest.mark.parametrize("split", [2, 4])
+def test_geglu_split_k(split):
+    x, w, b = rnd(256, 1280, seed=36), rnd(2 * 640, 1280, seed=37, scale=1280 ** -0.5), rnd(2 * 640, seed=38)
+    y = F().linear(x, w, b, geglu=True, variant=1, split_k=split)
+    assert f"split={split}" in last_kernel()
+    compare(f"geglu split{split}", y, R.linear_ref(x, w, b, geglu=True), *tol(x.dtype), kernel=last_kernel())
+
+
+@pytest.mark.parametrize("M,K,N", [(8192, 320, 320), (8192, 320, 960), (2048, 2560, 640), (512, 1280, 1280), (154, 768, 640),
+                                   (4095, 328, 324), (77, 64, 36), (130, 1280, 1280)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+def test_linear_variants(M, K, N, variant):
+    x = rnd(M, K, seed=40)
+    w = rnd(N, K, seed=41, scale=K ** -0.5)
+    b = rnd(N, seed=42, scale=0.1)
+    y = F().linear(x, w, b, variant=variant)
+    assert "igemm_lin" in last_kernel()
+    compare(f"linear M{M} K{K} N{N} v{variant}", y, R.linear_ref(x, w, b), *tol(x.dtype), kernel=last_kernel())
+
+
+@pytest.mark.parametrize("split", [2, 3, 8])
+@pytest.mark.parametrize("variant", [1, 2, 4])
+def test_linear_split_k(split, variant):
+    x, w, b = rnd(128, 5120, seed=43), rnd(1280, 5120, seed=44, scale=5120 ** -0.5), rnd(1280, seed=45)
+    r = rnd(128, 1280, seed=46)
+    y = F().linear(x, w, b, residual=r, variant=variant, split_k=split)
+    assert f"split={split}" in last_kernel()
+    compare(f"linear split{split} v{variant}", y, R.linear_ref(x, w, b, residual=r), *tol(x.dtype), kernel=last_kernel())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("epi", ["res_after", "res_before_relu", "gelu", "silu", "rowbias", "segs3", "inplace_res", "strided_out"])
+def test_linear_epilogues(dtype, epi):
+    M, K, N = 600, 640, 640
+    x = rnd(M, K, dtype=dtype, seed=50)
+    w = rnd(N, K, dtype=dtype, seed=51, scale=K ** -0.5)
+    b = rnd(N, dtype=dtype, seed=52, scale=0.1)
+    r = rnd(M, N, dtype=dtype, seed=53)
+    kw, ref_kw = {}, {}
+    if epi == "res_after":
+        kw = dict(residual=r, alpha=0.5)
+    elif epi == "res_before_relu":
+        kw = dict(residual=r, alpha=2.0, res_before_act=True, act="relu")
+    elif epi in ("gelu", "silu"):
+        kw = dict(act=epi)
+    elif epi == "rowbias":
+        rb = rnd(3, N, dtype=dtype, seed=54)
+        kw = dict(rowbias=rb, rows_per_batch=200)
+    if epi == "segs3":
+        ws = [rnd(N, K, dtype=dtype, seed=55 + i, scale=K ** -0.5) for i in range(3)]
+        y = F().linear(x, ws, None)
+        want = R.linear_ref(x, torch.cat(ws, 0))
+    elif epi == "inplace_res":
+        buf = r.clone()
+        y = F().linear(x, w, b, residual=buf, out=buf)
+        want = R.linear_ref(x, w, b, residual=r)
+    elif epi == "strided_out":
+        big = torch.zeros(M, 3 * N, dtype=dtype, device=DEV)
+        y = F().linear(x, w, b, out=big[:, N:2 * N])
+        want = R.linear_ref(x, w, b)
+        assert float(big[:, :N].abs().max()) == 0 and float(big[:, 2 * N:].abs().max()) == 0
+    else:
+        y = F().linear(x, w, b, **kw)
+        want = R.linear_ref(x, w, b, **kw)
+    compare(f"linear_epi {epi} {dtype}", y, want, *tol(dtype, 2.0), kernel=last_kernel())
+
+
+@pytest.mark.parametrize("M", [1, 2, 5, 8, 16])
+@pytest.mark.parametrize("case", ["plain", "silu_out", "in_silu", "res", "segs2", "ldo"])
+def test_gemv_small_m(M, case):
+    K, N = 1280, 1280
+    x, w, b = rnd(M, K, seed=60), rnd(N, K, seed=61, scale=K ** -0.5), rnd(N, seed=62, scale=0.1)
+    if case == "plain":
+        y, want = F().linear(x, w, b), R.linear_ref(x, w, b)
+    elif case == "silu_out":
+        y, want = F().linear(x, w, b, act="silu"), R.linear_ref(x, w, b, act="silu")
+    elif case == "in_silu":
+        y, want = F().linear(x, w, b, in_act="silu"), R.linear_ref(x, w, b, in_act="silu")
+    elif case == "res":
+        r = rnd(M, N, seed=63)
+        y = F().linear(x, w, b, residual=r, res_before_act=True, act="silu")
+        want = R.linear_ref(x, w, b, residual=r, res_before_act=True, act="silu")
+    elif case == "segs2":
+        w2 = rnd(N, K, seed=64, scale=K ** -0.5)
+        y, want = F().linear(x, [w, w2], None), R.linear_ref(x, torch.cat([w, w2], 0))
+    else:
+        big = torch.zeros(M, 4 * N, dtype=x.dtype, device=DEV)
+        y = F().linear(x, w, b, out=big[:, 2 * N:3 * N])
+        want = R.linear_ref(x, w, b)
+    assert last_kernel() == "gemv_small_m"
+    compare(f"gemv M{M} {case}", y, want, *tol(x.dtype), kernel=last_kernel())
+
+
+def test_linear_naive_paths():
+    # unaligned K (not a multiple of 8) and fp32 go to the generic kernel
+    x, w, b = rnd(33, 12, seed=65), rnd(20, 12, seed=66), rnd(20, seed=67)
+    compare("naive K12", F().linear(x, w, b, act="gelu"), R.linear_ref(x, w, b, act="gelu"), *tol(x.dtype), kernel=last_kernel())
+    assert last_kernel() == "gemm_naive"
+    x, w = rnd(40, 64, dtype=torch.float32, seed=68), rnd(48, 64, dtype=torch.float32, seed=69)
+    compare("naive f32", F().linear(x, w), R.linear_ref(x, w), 1e-4, 1e-4, kernel=last_kernel())
+
+
+# ---- conv family ------------------------------------------------------------------------------------------
+def cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("act", [None, "sigmoid", "relu", "tanh"])
+def test_conv_reference_test_model(act):
+    # /root/reference/tests/operators/test_cudnn_convolution.py:39-69 (+ the activation variants):
+    # Conv2d(2,2,3) on ones(1,2,256,256) fp32, z = ones(1,1,254,254) broadcast, alpha 0.5, tol 1e-3
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(2, 2, 3).to(DEV)
+    x = torch.ones(1, 2, 256, 256, device=DEV)
+    z = torch.ones(1, 1, 254, 254, device=DEV)
+    with torch.no_grad():
+        y = F().conv2d(x, conv.weight, conv.bias, z=z, alpha=0.5, act=act)
+        want = R.conv2d_ref(x, conv.weight, conv.bias, z, 0.5, act=act)
+    compare(f"conv_ref_model act={act}", y, want, 1e-3, 1e-3, kernel=last_kernel())
+
+
+CONV_CASES = [
+    # name, B, Cin, H, W, Cout, k, stride, pad, extras
+    ("res 320@64", 2, 320, 64, 64, 320, 3, 1, 1, dict(rowbias=True)),
+    ("res2 320@64 +z", 2, 320, 64, 64, 320, 3, 1, 1, dict(z=True)),
+    ("down 320@64 s2", 2, 320, 64, 64, 320, 3, 2, 1, {}),
+    ("640@32", 2, 640, 32, 32, 640, 3, 1, 1, dict(z=True)),
+    ("1280@16", 2, 1280, 16, 16, 1280, 3, 1, 1, dict(rowbias=True)),
+    ("1280@8", 2, 1280, 8, 8, 1280, 3, 1, 1, dict(z=True)),
+    ("up 1280@16 ups", 1, 1280, 16, 16, 1280, 3, 1, 1, dict(ups=True)),
+    ("cat 640+320@64", 1, 640, 64, 64, 320, 3, 1, 1, dict(c2=320)),
+    ("cat1x1 1280+640@32", 2, 1280, 32, 32, 640, 1, 1, 0, dict(c2=640)),
+    ("1x1 320@64", 2, 320, 64, 64, 320, 1, 1, 0, dict(z=True)),
+    ("cin32 odd", 1, 32, 17, 13, 64, 3, 1, 1, {}),
+    ("cin8", 2, 8, 20, 20, 32, 3, 2, 1, dict(z=True)),
+    ("5x5 pad2", 1, 64, 12, 12, 96, 5, 1, 2, {}),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+def test_conv_igemm(case, variant):
+    name, B, Cin, H, W, Cout, k, stride, pad, ex = case
+    x = cl(rnd(B, Cin, H, W, seed=70))
+    c2 = ex.get("c2", 0)
+    x2 = cl(rnd(B, c2, H, W, seed=71)) if c2 else None
+    w = cl(rnd(Cout, Cin + c2, k, k, seed=72, scale=((Cin + c2) * k * k) ** -0.5))
+    b = rnd(Cout, seed=73, scale=0.1)
+    ups = ex.get("ups", False)
+    Hin, Win = (2 * H, 2 * W) if ups else (H, W)
+    Ho, Wo = (Hin + 2 * pad - k) // stride + 1, (Win + 2 * pad - k) // stride + 1
+    z = cl(rnd(B, Cout, Ho, Wo, seed=74)) if ex.get("z") else None
+    rb = rnd(B, Cout, seed=75) if ex.get("rowbias") else None
+    y = F().conv2d(x, w, b, z=z, stride=stride, padding=pad, x2=x2, upsample2x=ups, rowbias=rb, variant=variant)
+    assert "igemm_conv" in last_kernel(), last_kernel()
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    want = R.conv2d_ref(x, w, b, z, 1.0, stride, pad, x2=x2, upsample2x=ups, rowbias=rb)
+    compare(f"conv {name} v{variant}", y, want, *tol(x.dtype, 2.0), kernel=last_kernel())
+
+
+@pytest.mark.parametrize("split", [2, 4, 16])
+def test_conv_split_k(split):
+    x, w, b = cl(rnd(2, 1280, 8, 8, seed=76)), cl(rnd(1280, 1280, 3, 3, seed=77, scale=11520 ** -0.5)), rnd(1280, seed=78)
+    z = cl(rnd(2, 1280, 8, 8, seed=79))
+    y = F().conv2d(x, w, b, z=z, padding=1, split_k=split, variant=4)
+    assert f"split={split}" in last_kernel()
+    compare(f"conv split{split}", y, R.conv2d_ref(x, w, b, z, 1.0, 1, 1), *tol(x.dtype, 2.0), kernel=last_kernel())
+
+
+def test_conv_broadcast_z_folds_to_rowbias():
+    x, w, b = cl(rnd(2, 320, 32, 32, seed=80)), cl(rnd(320, 320, 3, 3, seed=81, scale=2880 ** -0.5)), rnd(320, seed=82)
+    z = rnd(2, 320, 1, 1, seed=83)  # time-embedding broadcast (cudnn_convolution_impl.cc:1045-1053)
+    y = F().conv2d(x, w, b, z=z, padding=1)
+    assert "igemm_conv" in last_kernel()
+    compare("conv z[B,C,1,1]", y, R.conv2d_ref(x, w, b, z, 1.0, 1, 1), *tol(x.dtype, 2.0), kernel=last_kernel())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_conv_in_and_conv_out_kernels(dtype):
+    # conv_in: NCHW [B,4,64,64] sample -> NHWC 320 channels (conv_small_c)
+    x = rnd(2, 4, 64, 64, dtype=dtype, seed=84)
+    w = cl(rnd(320, 4, 3, 3, dtype=dtype, seed=85, scale=1 / 6))
+    b = rnd(320, dtype=dtype, seed=86)
+    y = F().conv2d(x, w, b, padding=1, channels_last_out=True)
+    assert last_kernel() == "conv_small_c"
+    compare(f"conv_in {dtype}", y, R.conv2d_ref(x, w, b, None, 1.0, 1, 1), *tol(dtype, 2.0), kernel=last_kernel())
+    # conv_out: NHWC 320 -> NCHW 4 (conv_small_n)
+    x = cl(rnd(2, 320, 64, 64, dtype=dtype, seed=87))
+    w = cl(rnd(4, 320, 3, 3, dtype=dtype, seed=88, scale=2880 ** -0.5))
+    b = rnd(4, dtype=dtype, seed=89)
+    y = F().conv2d(x, w, b, padding=1, channels_last_out=False)
+    assert last_kernel() == "conv_small_n" and y.is_contiguous()
+    compare(f"conv_out {dtype}", y, R.conv2d_ref(x, w, b, None, 1.0, 1, 1), *tol(dtype, 2.0), kernel=last_kernel())
+
+
+def test_conv_naive_nchw_and_dilation():
+    x, w, b = rnd(2, 6, 15, 15, seed=90), rnd(10, 6, 3, 3, seed=91, scale=0.2), rnd(10, seed=92)
+    y = F().conv2d(x, w, b, padding=2, dilation=2, act="relu")
+    assert last_kernel() == "conv_naive" and y.is_contiguous()
+    compare("conv naive dil2", y, R.conv2d_ref(x, w, b, None, 1.0, 1, 2, 2, act="relu"), *tol(x.dtype, 2.0), kernel=last_kernel())
+
+
+# ---- attention -----------------------------------------------------------------------------------------------
+ATTN_CASES = [
+    # B, H, Sq, Skv, D
+    (1, 8, 4096, 4096, 40), (2, 8, 1024, 1024, 80), (2, 8, 256, 256, 160), (2, 8, 64, 64, 160),
+    (2, 8, 4096, 77, 40), (2, 8, 1024, 77, 80), (2, 8, 256, 77, 160), (2, 8, 64, 77, 160),
+    (1, 10, 4096, 4096, 64), (2, 20, 1024, 77, 64), (1, 4, 70, 130, 64), (1, 2, 100, 100, 128), (2, 3, 33, 1, 40),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES, ids=[str(c) for c in ATTN_CASES])
+@pytest.mark.parametrize("variant", [0, 2, 4])
+def test_attention(case, variant):
+    B, H, Sq, Skv, D = case
+    q, k, v = rnd(B, Sq, H, D, seed=100), rnd(B, Skv, H, D, seed=101), rnd(B, Skv, H, D, seed=102)
+    o = F().attention(q, k, v, variant=variant)
+    assert "attn_fwd" in last_kernel()
+    compare(f"attn {case} v{variant}", o, R.attention_ref(q, k, v), *tol(q.dtype), kernel=last_kernel())
+
+
+def test_attention_bf16_and_scale():
+    q, k, v = (rnd(2, 300, 8, 64, dtype=torch.bfloat16, seed=103 + i) for i in range(3))
+    o = F().attention(q, k, v, scale=0.2)
+    compare("attn bf16 scale", o, R.attention_ref(q, k, v, 0.2), *tol(torch.bfloat16), kernel=last_kernel())
+
+
+def test_attention_on_fused_qkv_views():
+    # q/k/v as strided [B,S,H,D] views of one [B,S,3C] projection buffer (what the engine does)
+    B, S, H, D = 2, 1024, 8, 80
+    C = H * D
+    qkv = rnd(B, S, 3 * C, seed=106)
+    q, k, v = (qkv[:, :, i * C:(i + 1) * C].unflatten(2, (H, D)) for i in range(3))
+    o = F().attention(q, k, v)
+    assert "attn_fwd" in last_kernel()
+    compare("attn fused-qkv views", o, R.attention_ref(q, k, v), *tol(qkv.dtype), kernel=last_kernel())
+
+
+def test_attention_peaked_softmax_rows():
+    # forces large running-max jumps between K tiles (online-softmax rescale path)
+    B, H, S, D = 1, 2, 512, 64
+    q, k, v = rnd(B, S, H, D, seed=107), rnd(B, S, H, D, seed=108), rnd(B, S, H, D, seed=109)
+    k[:, 300] = q[:, 5] * 4.0
+    k[:, 77] = q[:, 200] * 6.0
+    o = F().attention(q, k, v)
+    compare("attn peaked", o, R.attention_ref(q, k, v), *tol(q.dtype), kernel=last_kernel())
+
+
+def test_attention_naive_path():
+    q, k, v = (rnd(2, 50, 3, 24, seed=110 + i) for i in range(3))
+    o = F().attention(q, k, v)
+    assert last_kernel() == "attn_naive"
+    compare("attn naive D24", o, R.attention_ref(q, k, v), *tol(q.dtype), kernel=last_kernel())
+    q, k, v = (rnd(1, 20, 2, 16, dtype=torch.float32, seed=113 + i) for i in range(3))
+    compare("attn naive f32", F().attention(q, k, v), R.attention_ref(q, k, v), 1e-4, 1e-4, kernel=last_kernel())
+
+
+# ---- elementwise ---------------------------------------------------------------------------------------------------
+def test_strided_copy_reference_case():
+    # /root/reference/tests/triton/test_torch_ops.py:11-30: permuted 1x4x256x512, contiguous + channels_last
+    a = rnd(1, 4, 256, 512, seed=120).permute(0, 1, 3, 2)
+    out = torch.ops.sfast_triton.contiguous(a, torch.contiguous_format)
+    assert out.is_contiguous() and torch.equal(out, a.contiguous())
+    out = torch.ops.sfast_triton.contiguous(a, torch.channels_last)
+    assert out.is_contiguous(memory_format=torch.channels_last) and torch.equal(out, a)
+    out = torch.ops.sfast_triton.clone(a, torch.preserve_format)
+    assert torch.equal(out, a)
+    out = torch.ops.sfast_triton.reshape(a, [4, 512 * 256])
+    assert torch.equal(out, a.reshape(4, -1))
+
+
+def test_timestep_embedding():
+    from oracle.unet_ref import timestep_embedding as ref
+    t = torch.tensor([981.0, 1.0, 500.0], device=DEV)
+    for dim, flip, shift in ((320, True, 0.0), (256, True, 0.0), (128, False, 1.0)):
+        e = F().timestep_embedding(t, dim, flip, shift, dtype=torch.float32)
+        compare(f"temb {dim}", e, ref(t, dim, flip, shift), 2e-4, 1e-4)
+        e16 = F().timestep_embedding(t, dim, flip, shift, dtype=torch.float16)
+        compare(f"temb16 {dim}", e16, ref(t, dim, flip, shift), 1e-3, 1e-3)
+
+
+def test_cfg_ddim_step():
+    ts, coefs = R.ddim_schedule(50)
+    lat = rnd(2, 4, 64, 64, seed=121)
+    eps = rnd(2, 2, 4, 64, 64, seed=122)
+    coef = torch.tensor(coefs[3], dtype=torch.float32, device=DEV)
+    unet_in = torch.empty(2, 2, 4, 64, 64, dtype=lat.dtype, device=DEV)
+    out = F().cfg_ddim_step(eps, lat, coef, 7.5, unet_in=unet_in)
+    want = R.cfg_ddim_ref(eps, lat, coefs[3], 7.5)
+    compare("cfg_ddim", out, want, 5e-3, 2e-3)
+    assert torch.equal(unet_in[0], out) and torch.equal(unet_in[1], out)
+
+
+# ---- committed golden vectors ----------------------------------------------------------------------------------------
+def test_golden_ops():
+    g = torch.load(os.path.join(GOLDEN, "ops.pt"))
+    d = lambda t: t.to(DEV)
+    c = g["group_norm_silu"]
+    compare("golden gn_silu nchw", F().group_norm(d(c["x"]), c["groups"], d(c["weight"]), d(c["bias"]), c["eps"], "silu"), c["y"], 3e-3, 2e-3)
+    compare("golden gn_silu nhwc", F().group_norm(cl(d(c["x"])), c["groups"], d(c["weight"]), d(c["bias"]), c["eps"], "silu"), c["y"], 3e-3, 2e-3)
+    c = g["group_norm"]
+    compare("golden gn", F().group_norm(cl(d(c["x"])), c["groups"], d(c["weight"]), d(c["bias"]), c["eps"]), c["y"], 3e-3, 2e-3)
+    c = g["layer_norm"]
+    compare("golden ln", F().layer_norm(d(c["x"]), (320,), d(c["weight"]), d(c["bias"]), c["eps"]), c["y"], 3e-3, 2e-3)
+    c = g["geglu"]
+    compare("golden geglu", torch.ops.sfast.cutlass_linear_geglu_unified(d(c["x"]), d(c["weight"]), d(c["bias"])), c["y"], 3e-3, 2e-3)
+    c = g["linear_add"]
+    compare("golden linear_add", torch.ops.sfast.cublas_lowp_linear_add(d(c["x"]), d(c["weight"]), d(c["bias"]), d(c["other"]), c["alpha"]), c["y"], 3e-3, 2e-3)
+    c = g["conv3x3_bias_add"]
+    y = torch.ops.sfast.cudnn_convolution_bias_add(cl(d(c["x"])), cl(d(c["weight"])), d(c["bias"]), cl(d(c["z"])), c["alpha"], [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
+    compare("golden conv_bias_add", y, c["y"], 3e-3, 2e-3, kernel=last_kernel())
+    c = g["conv3x3_s2_relu"]
+    y = torch.ops.sfast.cudnn_convolution_bias_relu(d(c["x"]), d(c["weight"]), d(c["bias"]), [2, 2], [1, 1], [1, 1], False, [0, 0], 1)
+    compare("golden conv_s2_relu (NCHW)", y, c["y"], 3e-3, 2e-3, kernel=last_kernel())
+    c = g["attention_d40_kv77"]
+    y = torch.ops.sfast_xformers.memory_efficient_attention(d(c["q"]), d(c["k"]), d(c["v"]), None, 0.0, None, None)
+    compare("golden attention", y, c["y"], 3e-3, 2e-3, kernel=last_kernel())

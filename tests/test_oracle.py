@@ -1,0 +1,116 @@
+"""Pins the oracle (oracle/) -- runs on CPU.
+
+The reference's own tests are differential against eager PyTorch ops and keep no stored vectors
+(SURVEY.md section 8c), so the pins are: (1) the public parameter counts of the two UNets whose
+topology is restated, (2) agreement of every per-op oracle with the ATen op the reference's tests
+use as ground truth, (3) stability against the committed golden vectors.
+"""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ops_ref as R
+from oracle import unet_ref as U
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_topology_known_answer_param_counts():
+    # publicly known UNet sizes
+    with torch.device("meta"):
+        sd15 = U.UNet2DConditionModel(**U.SD15_CONFIG)
+        sdxl = U.UNet2DConditionModel(**U.SDXL_CONFIG)
+    assert U.param_count(sd15) == 859_520_964
+    assert U.param_count(sdxl) == 2_567_463_684
+
+
+def test_state_dict_keys_follow_diffusers_naming():
+    with torch.device("meta"):
+        m = U.UNet2DConditionModel(**U.SD15_CONFIG)
+    keys = set(m.state_dict().keys())
+    for k in ("conv_in.weight", "time_embedding.linear_1.weight", "down_blocks.0.resnets.0.time_emb_proj.bias",
+              "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.weight",
+              "down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_out.0.bias",
+              "down_blocks.0.attentions.0.transformer_blocks.0.ff.net.0.proj.weight",
+              "down_blocks.0.attentions.0.transformer_blocks.0.ff.net.2.bias",
+              "down_blocks.0.downsamplers.0.conv.weight", "mid_block.attentions.0.proj_in.weight",
+              "up_blocks.1.upsamplers.0.conv.bias", "up_blocks.3.resnets.2.conv_shortcut.weight",
+              "conv_norm_out.weight", "conv_out.bias"):
+        assert k in keys, k
+    assert "down_blocks.3.attentions.0.norm.weight" not in keys  # DownBlock2D has no attention
+    assert m.state_dict()["up_blocks.0.resnets.0.conv1.weight"].shape == (1280, 2560, 3, 3)
+    assert m.state_dict()["up_blocks.3.resnets.2.conv1.weight"].shape == (320, 640, 3, 3)
+    assert m.state_dict()["down_blocks.1.attentions.0.transformer_blocks.0.attn2.to_k.weight"].shape == (640, 768)
+
+
+def test_group_norm_oracle_matches_independent_restatement():
+    # reference self-test: randn(2,320,32,32), G=32, eps 1e-5 (triton/ops/group_norm.py:485-523)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 320, 16, 16, generator=g) * 3 + 1
+    w, b = torch.randn(320, generator=g), torch.randn(320, generator=g)
+    a = R.group_norm_ref(x, 32, w, b, 1e-5)
+    m = R.group_norm_manual(x, 32, w, b, 1e-5)
+    torch.testing.assert_close(a, m, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(R.group_norm_ref(x, 32, w, b, 1e-5, silu=True), F.silu(m), rtol=1e-4, atol=1e-4)
+
+
+def test_geglu_oracle_is_the_reference_test_model():
+    # tests/operators/test_cutlass_dual_linear.py:37-40: proj -> chunk(2, -1) -> hidden * gelu(gate)
+    g = torch.Generator().manual_seed(1)
+    x, w, b = torch.randn(16, 8, generator=g), torch.randn(32, 8, generator=g), torch.randn(32, generator=g)
+    h, gate = F.linear(x, w, b).chunk(2, dim=-1)
+    torch.testing.assert_close(R.linear_ref(x, w, b, geglu=True), h * F.gelu(gate))
+
+
+def test_conv_oracle_is_the_reference_test_model():
+    # tests/operators/test_cudnn_convolution.py:14-27,50-69: act(conv(x) + alpha*y) with broadcast y
+    conv = torch.nn.Conv2d(2, 2, 3)
+    x = torch.ones(1, 2, 32, 32)
+    y = torch.ones(1, 1, 30, 30)
+    with torch.no_grad():
+        want = conv(x) + 0.5 * y
+        got = R.conv2d_ref(x, conv.weight, conv.bias, y, 0.5)
+        torch.testing.assert_close(got, want)
+        torch.testing.assert_close(R.conv2d_ref(x, conv.weight, conv.bias, y, 0.5, act="tanh"), torch.tanh(want))
+
+
+def test_attention_oracle_matches_sdpa():
+    g = torch.Generator().manual_seed(2)
+    q, k, v = (torch.randn(2, 33, 4, 40, generator=g) for _ in range(3))
+    want = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2)
+    torch.testing.assert_close(R.attention_ref(q, k, v), want, rtol=1e-4, atol=1e-5)
+
+
+def test_ddim_schedule_constants():
+    ts, coefs = R.ddim_schedule(50)
+    assert ts[0] == 981 and ts[1] == 961 and ts[-1] == 1 and len(ts) == 50
+    for sa, s1a, sp, s1p in coefs:
+        assert abs(sa * sa + s1a * s1a - 1) < 1e-6 and abs(sp * sp + s1p * s1p - 1) < 1e-6
+        assert sp >= sa  # alpha_bar grows towards t = 0
+
+
+def test_oracle_reproduces_golden_ops():
+    gold = torch.load(os.path.join(GOLDEN, "ops.pt"))
+    c = gold["group_norm_silu"]
+    torch.testing.assert_close(R.group_norm_ref(c["x"], c["groups"], c["weight"], c["bias"], c["eps"], True), c["y"], rtol=1e-4, atol=1e-4)
+    c = gold["layer_norm"]
+    torch.testing.assert_close(R.layer_norm_ref(c["x"], (320,), c["weight"], c["bias"], c["eps"]), c["y"], rtol=1e-4, atol=1e-4)
+    c = gold["geglu"]
+    torch.testing.assert_close(R.linear_ref(c["x"], c["weight"], c["bias"], geglu=True), c["y"], rtol=1e-4, atol=1e-4)
+    c = gold["conv3x3_bias_add"]
+    torch.testing.assert_close(R.conv2d_ref(c["x"], c["weight"], c["bias"], c["z"], c["alpha"], 1, 1), c["y"], rtol=1e-4, atol=1e-4)
+    c = gold["attention_d40_kv77"]
+    torch.testing.assert_close(R.attention_ref(c["q"], c["k"], c["v"]), c["y"], rtol=1e-4, atol=1e-4)
+
+
+def test_oracle_reproduces_golden_unet():
+    gold = torch.load(os.path.join(GOLDEN, "unet_tiny.pt"))
+    m = U.build(gold["config"], seed=gold["seed"])
+    m.load_state_dict({k: v.half().float() for k, v in m.state_dict().items()})
+    with torch.no_grad():
+        y = m(gold["sample"].float(), gold["timestep"], gold["encoder_hidden_states"].float()).sample
+        yb = m(gold["sample"].float(), torch.tensor(gold["timesteps_b"]), gold["encoder_hidden_states"].float()).sample
+    torch.testing.assert_close(y, gold["y"], rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(yb, gold["y_b"], rtol=1e-3, atol=1e-4)

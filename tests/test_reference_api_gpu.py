@@ -1,0 +1,148 @@
+"""The reference's own GPU tests, re-stated against the drop-in surface (same op names, shapes and
+tolerances): tests/operators/test_cutlass_dual_linear.py, tests/operators/test_cudnn_convolution.py,
+tests/cuda/test_graphs.py, tests/triton/test_torch_ops.py of /root/reference."""
+import gc
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import sfast  # noqa: F401  (registers torch.ops.sfast / sfast_triton / sfast_xformers)
+
+pytestmark = pytest.mark.gpu
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out, bias=True):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2, bias=bias)
+
+    def forward(self, hidden_states, enable_opt=False):
+        if enable_opt:
+            return torch.ops.sfast.cutlass_linear_geglu_unified(hidden_states, self.proj.weight, self.proj.bias)
+        hidden_states, gate = self.proj(hidden_states).chunk(2, dim=-1)
+        return hidden_states * F.gelu(gate)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("in_features", [4, 8, 16])
+@pytest.mark.parametrize("out_features", [4, 8, 16])
+@pytest.mark.parametrize("N", [4, 16])
+def test_geglu(dtype, bias, in_features, out_features, N):
+    with torch.no_grad():
+        m = GEGLU(in_features, out_features, bias=bias).cuda().to(dtype=dtype).eval()
+        x = torch.randn(N, in_features).cuda().to(dtype=dtype)
+        torch.testing.assert_close(m(x, enable_opt=True), m(x), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("in_features", [320, 640])
+@pytest.mark.parametrize("out_features", [1280, 2560])
+@pytest.mark.parametrize("N", [4608 * 25])
+def test_benchmark_geglu_shapes(dtype, bias, in_features, out_features, N):
+    # SVD shapes of the reference's benchmark test (the 18432*25-row case is 4x this one)
+    with torch.no_grad():
+        m = GEGLU(in_features, out_features, bias=bias).cuda().to(dtype=dtype).eval()
+        x = torch.randn(N, in_features).cuda().to(dtype=dtype)
+        torch.testing.assert_close(m(x, enable_opt=True), m(x), rtol=2e-2, atol=2e-2)
+
+
+class ConvBiasAddActivation(nn.Module):
+    def __init__(self, act=None):
+        super().__init__()
+        self.conv = nn.Conv2d(2, 2, 3, bias=True)
+        self.act = act if act is not None else nn.Identity()
+
+    def forward(self, x, y=None, alpha=1.0):
+        x = self.conv(x)
+        if y is not None:
+            x = x.add(y, alpha=alpha)
+        return self.act(x)
+
+
+@pytest.mark.parametrize("name,act", [("", None), ("_sigmoid", nn.Sigmoid()), ("_relu", nn.ReLU()), ("_tanh", nn.Tanh())])
+def test_conv_bias_add_family(name, act):
+    torch.manual_seed(0)
+    model = ConvBiasAddActivation(act).cuda()
+    conv = model.conv
+    x = torch.ones(1, 2, 256, 256).cuda()
+    y = torch.ones(1, 1, 254, 254).cuda()
+    with torch.no_grad():
+        out = model(x, y, 0.5)
+        fused = getattr(torch.ops.sfast, f"cudnn_convolution_bias_add{name}")(
+            x, conv.weight, conv.bias, y, 0.5, conv.stride, conv.padding, conv.dilation, conv.transposed,
+            conv.output_padding, conv.groups)
+        torch.testing.assert_close(fused, out, rtol=1e-3, atol=1e-3)
+        out = model(x)
+        fused = getattr(torch.ops.sfast, f"cudnn_convolution_bias{name}")(
+            x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.transposed, conv.output_padding,
+            conv.groups)
+        torch.testing.assert_close(fused, out, rtol=1e-3, atol=1e-3)
+
+
+def test_lowp_linear_family():
+    x = torch.randn(300, 640, device="cuda", dtype=torch.float16)
+    lin = nn.Linear(640, 1280).cuda().half()
+    other = torch.randn(300, 1280, device="cuda", dtype=torch.float16)
+    with torch.no_grad():
+        tol = dict(rtol=1e-2, atol=1e-2)
+        torch.testing.assert_close(torch.ops.sfast.cublas_lowp_linear(x, lin.weight, lin.bias), lin(x), **tol)
+        torch.testing.assert_close(torch.ops.sfast.cublas_lowp_linear_relu(x, lin.weight, lin.bias), F.relu(lin(x)), **tol)
+        torch.testing.assert_close(torch.ops.sfast.cublas_lowp_linear_gelu(x, lin.weight, lin.bias), F.gelu(lin(x)), **tol)
+        torch.testing.assert_close(torch.ops.sfast.linear_gelu(x, lin.weight, lin.bias), F.gelu(lin(x)), **tol)
+        torch.testing.assert_close(torch.ops.sfast.cublas_lowp_linear_add(x, lin.weight, lin.bias, other, 0.5), lin(x) + 0.5 * other, **tol)
+        torch.testing.assert_close(torch.ops.sfast.cublas_lowp_addmm(lin.bias, x, lin.weight.t()), lin(x), **tol)
+        torch.testing.assert_close(torch.ops.sfast.cublas_lowp_mm(x, lin.weight.t()), x @ lin.weight.t(), **tol)
+        torch.testing.assert_close(torch.ops.sfast.cublas_lowp_matmul(x.view(3, 100, 640), lin.weight.t()), x.view(3, 100, 640) @ lin.weight.t(), **tol)
+        a, b = torch.randn(4, 64, 80, device="cuda", dtype=torch.float16), torch.randn(4, 80, 96, device="cuda", dtype=torch.float16)
+        torch.testing.assert_close(torch.ops.sfast.cublas_lowp_bmm(a, b), torch.bmm(a, b), rtol=2e-2, atol=2e-2)
+
+
+def test_triton_namespace_norms():
+    x = torch.randn(2, 320, 32, 32, device="cuda", dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    gn = nn.GroupNorm(32, 320).cuda().half()
+    with torch.no_grad():
+        torch.testing.assert_close(torch.ops.sfast_triton.group_norm(x, 32, gn.weight, gn.bias, gn.eps), gn(x), rtol=1e-2, atol=1e-2)
+        torch.testing.assert_close(torch.ops.sfast_triton.group_norm_silu(x, 32, gn.weight, gn.bias, gn.eps), F.silu(gn(x)), rtol=1e-2, atol=1e-2)
+        t = torch.randn(1151, 1280, device="cuda", dtype=torch.float16)
+        ln = nn.LayerNorm(1280).cuda().half()
+        torch.testing.assert_close(torch.ops.sfast_triton.layer_norm(t, [1280], ln.weight, ln.bias, ln.eps), ln(t), rtol=1e-2, atol=1e-2)
+
+
+def test_simple_make_graphed_callable():
+    from sfast.cuda.graphs import get_per_device_graph_execution_env, simple_make_graphed_callable
+    device = torch.device("cuda")
+
+    def add(x, y):
+        return x + y
+
+    x = torch.randn(3, device=device)
+    y = torch.randn(3, device=device)
+    graphed_add = simple_make_graphed_callable(add, example_inputs=(x, y))
+    assert torch.allclose(graphed_add(x, y), add(x, y))
+    x2, y2 = torch.randn(3, device=device), torch.randn(3, device=device)
+    assert torch.allclose(graphed_add(x2, y2), add(x2, y2))
+    env = get_per_device_graph_execution_env(device.index)
+    tmp_graph = torch.cuda.CUDAGraph()
+    with torch.cuda.device(env.device), torch.cuda.stream(env.stream):
+        with torch.cuda.graph(tmp_graph, pool=env.mempool, stream=env.stream):
+            x = torch.randn(3, device=device)
+    del graphed_add, tmp_graph
+    gc.collect()
+    graphed_add = simple_make_graphed_callable(add, example_kwarg_inputs={"x": x, "y": y})
+    assert torch.allclose(graphed_add(x=x, y=y), add(x, y))
+
+
+def test_make_dynamic_graphed_callable_caches_per_signature():
+    from sfast.cuda.graphs import make_dynamic_graphed_callable
+    lin = nn.Linear(64, 64).cuda().half()
+    g = make_dynamic_graphed_callable(lin)
+    a, b = torch.randn(8, 64, device="cuda", dtype=torch.float16), torch.randn(4, 64, device="cuda", dtype=torch.float16)
+    with torch.no_grad():
+        torch.testing.assert_close(g(a), lin(a))
+        torch.testing.assert_close(g(a * 2), lin(a * 2))
+        torch.testing.assert_close(g(b), lin(b))
+    assert len(g._cached) == 2 and g.__self__ is lin

@@ -1,0 +1,33 @@
+#!/bin/bash
+# One GPU session: per-family parity tests (separate processes so a fault in one family cannot hide the
+# others), whole-UNet tests, smoke, bench, rocprofv3 kernel trace. Everything lands in gpurun_out/.
+# usage: tools/gpu_session.sh [quick|full]
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+MODE=${1:-full}
+export TMPDIR=/tmp
+PYT="python -m pytest -q --no-header --tb=short -p no:cacheprovider --timeout=300 --maxfail=40 -m gpu"
+run() { # name, timeout, command...
+  local name=$1 to=$2; shift 2
+  echo "=== $name ===" | tee -a gpurun_out/session.log
+  timeout $to "$@" > gpurun_out/$name.log 2>&1
+  echo "exit=$? $(tail -n 1 gpurun_out/$name.log)" | tee -a gpurun_out/session.log
+}
+rm -f gpurun_out/parity.jsonl gpurun_out/session.log
+rocminfo 2>/dev/null | grep -E "gfx|Compute Unit" | head -4 >> gpurun_out/session.log
+nproc >> gpurun_out/session.log
+run t_norm   600 $PYT tests/test_ops_gpu.py -k "group_norm or layer_norm"
+run t_gemm   900 $PYT tests/test_ops_gpu.py -k "geglu or linear or gemv"
+run t_conv   900 $PYT tests/test_ops_gpu.py -k "conv"
+run t_attn   900 $PYT tests/test_ops_gpu.py -k "attention"
+run t_misc   600 $PYT tests/test_ops_gpu.py -k "copy or timestep or cfg or golden"
+run t_refapi 900 $PYT tests/test_reference_api_gpu.py
+run t_unet  1200 $PYT tests/test_unet_gpu.py
+run smoke    600 python __graft_entry__.py smoke
+run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json
+if [ "$MODE" = "full" ]; then
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -o bench -- python $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline > $OLDPWD/gpurun_out/rocprof.log 2>&1 )
+  echo "rocprof exit=$?" >> gpurun_out/session.log
+  find gpurun_out/prof -name "*stats*" | head >> gpurun_out/session.log
+fi
+cat gpurun_out/session.log
