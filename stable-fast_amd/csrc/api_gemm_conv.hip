@@ -179,7 +179,7 @@ extern "C" int sfast_hip_igemm_plan(int32_t M, int32_t N, int32_t K, int32_t geg
 }
 
 extern "C" size_t sfast_hip_gemm_workspace_bytes(const sfast_gemm_params *p) {
-    if (!p || !is_half(p->dtype) || p->M <= 16 || p->K % 8 != 0) return 0;
+    if (!p || !is_half(p->dtype) || (p->M <= 16 && p->variant == 0) || p->variant >= 100 || p->K % 8 != 0) return 0;
     return igemm_workspace_bytes(p->M, p->N, p->K, p->geglu != 0, p->variant < 100 ? p->variant : 0, p->split_k);
 }
 

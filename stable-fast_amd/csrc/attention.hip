@@ -84,14 +84,23 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
     for (int kd = 0; kd < KD; ++kd) {
         const int d0 = kd * 16 + hi * 8;
-        u32x4 raw = zero4;
-        if (d0 < D && qrow < a.Sq) raw = *reinterpret_cast<const u32x4 *>(Qp + (int64_t)qrow * a.qs[1] + d0);
-        qf[kd] = __builtin_bit_cast(vec8, raw);
+        typedef const u32x4 __attribute__((address_space(1))) * gq_ptr;
+        const bool okq = d0 < D && qrow < a.Sq;
+        const gq_ptr qq = okq ? (gq_ptr)(const void *)(Qp + (int64_t)qrow * a.qs[1] + d0) : (gq_ptr)(const void *)g_zero16;
+        qf[kd] = __builtin_bit_cast(vec8, *qq);
     }
 
     u32x4 kreg[KTASK];
     u32x4 vreg[VTASK][2];
 
+    // unconditional loads (see igemm.hip): out-of-range chunks read a 16-byte zero block through a
+    // global-address-space pointer select, so no load sits behind an exec-masked branch or a
+    // flat_load and the prefetch stays in flight across the MFMAs of the current tile.
+    typedef const u32x4 __attribute__((address_space(1))) * gvec_ptr;
+    auto ldg16 = [&](const T *p, bool ok) -> u32x4 {
+        const gvec_ptr q = ok ? (gvec_ptr)(const void *)p : (gvec_ptr)(const void *)g_zero16;
+        return *q;
+    };
     auto prefetch = [&](int kt) {
         const int key0 = kt * 64;
 #pragma unroll
@@ -99,7 +108,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
             const int id = tid + i * NT;
             const int key = id / KCH, ch = id - key * KCH;
             const bool ok = id < 64 * KCH && (key0 + key) < a.Skv && ch * 8 < D;
-            kreg[i] = ok ? *reinterpret_cast<const u32x4 *>(Kp + (int64_t)(key0 + key) * a.ks[1] + ch * 8) : zero4;
+            kreg[i] = ldg16(Kp + (int64_t)(key0 + key) * a.ks[1] + ch * 8, ok);
         }
 #pragma unroll
         for (int i = 0; i < VTASK; ++i) {
@@ -107,8 +116,8 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
             const int kp = id & 31, ch = id >> 5;
             const int key = key0 + 2 * kp;
             const bool in = ch < VCH;
-            vreg[i][0] = (in && key < a.Skv) ? *reinterpret_cast<const u32x4 *>(Vp + (int64_t)key * a.vs[1] + ch * 8) : zero4;
-            vreg[i][1] = (in && key + 1 < a.Skv) ? *reinterpret_cast<const u32x4 *>(Vp + (int64_t)(key + 1) * a.vs[1] + ch * 8) : zero4;
+            vreg[i][0] = ldg16(Vp + (int64_t)key * a.vs[1] + ch * 8, in && key < a.Skv);
+            vreg[i][1] = ldg16(Vp + (int64_t)(key + 1) * a.vs[1] + ch * 8, in && key + 1 < a.Skv);
         }
     };
     auto stage = [&]() {

@@ -81,6 +81,10 @@ template <typename T> __device__ __forceinline__ void unpack4(const u32x2 &raw, 
     for (int i = 0; i < 4; ++i) f[i] = (float)v[i];
 }
 
+// 16 bytes of zeros in device memory: staging loads of out-of-range chunks are redirected here so
+// they stay unconditional (no exec-masked branch, no select on the loaded registers).
+static __device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
+
 // ---- activations (fp32) -------------------------------------------------------------------------
 __device__ __forceinline__ float act_silu(float v) { return v / (1.0f + __expf(-v)); }
 __device__ __forceinline__ float act_gelu_erf(float v) {

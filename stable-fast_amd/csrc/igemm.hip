@@ -189,18 +189,33 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_kernel(const IgemmArgs a) {
     u32x4 xreg[XCH], wreg[WCH];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
+    // All staging loads are UNCONDITIONAL: an invalid chunk (image border tap, row >= M, k >= K) reads a
+    // known-valid address and is zeroed with a select afterwards. A predicated load
+    // (`ok ? *p : 0`) makes hipcc wrap every load in its own exec-masked branch with a full
+    // s_waitcnt at the join -- eight serialised memory round trips per K-tile.
+    // The zero fill itself comes from memory too (a 16-byte device-resident zero block), so nothing
+    // consumes the loaded registers before store_tile: the loads stay in flight across the MFMAs.
+    // Both candidates are cast to the GLOBAL address space: a generic pointer select would lower to
+    // flat_load, which also ticks lgkmcnt and would make every ds_read wait drain the prefetch.
+    auto ldg16 = [&](const T *p, const T *, bool ok) -> u32x4 {
+        typedef const u32x4 __attribute__((address_space(1))) * gvec_ptr;
+        const gvec_ptr q = ok ? (gvec_ptr)(const void *)p : (gvec_ptr)(const void *)g_zero16;
+        return *q;
+    };
     auto load_tile = [&](int kt) {
         const int k = kt * 64 + kc * 8;
         const bool kvalid = k < a.K;
+        const int ks = kvalid ? k : 0;
         if (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < XCH; ++i) {
-                xreg[i] = (kvalid && xrow[i]) ? *reinterpret_cast<const u32x4 *>(xrow[i] + k) : zero4;
+                const bool ok = kvalid && xrow[i] != nullptr;
+                xreg[i] = ldg16(xrow[i] + ks, (const T *)a.x, ok);
             }
         } else {
             const int cin = a.C1 + a.C2;
-            const int tap = k / cin;
-            const int c = k - tap * cin;
+            const int tap = ks / cin;
+            const int c = ks - tap * cin;
             const int r = tap / a.KW, s = tap - r * a.KW;
             const bool first = c < a.C1;
             const T *base = first ? (const T *)a.x : (const T *)a.x2;
@@ -220,12 +235,13 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_kernel(const IgemmArgs a) {
                 }
                 ok = ok && kvalid;
                 const int64_t off = ((int64_t)(xbhw[i] + hi_ * a.W + wi_)) * pitch + cc;
-                xreg[i] = ok ? *reinterpret_cast<const u32x4 *>(base + off) : zero4;
+                xreg[i] = ldg16(base + off, base, ok);
             }
         }
 #pragma unroll
         for (int i = 0; i < WCH; ++i) {
-            wreg[i] = (kvalid && wrow[i]) ? *reinterpret_cast<const u32x4 *>(wrow[i] + k) : zero4;
+            const bool ok = kvalid && wrow[i] != nullptr;
+            wreg[i] = ldg16(wrow[i] + ks, (const T *)a.w[0], ok);
         }
     };
     auto store_tile = [&](int stage) {

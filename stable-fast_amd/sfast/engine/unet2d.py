@@ -75,10 +75,11 @@ class _Pool:
 
 
 class OpRecord:
-    __slots__ = ("kind", "name", "flops", "bytes", "kernel", "launch")
+    __slots__ = ("kind", "name", "flops", "bytes", "kernel", "launch", "tune")
 
-    def __init__(self, kind, name, flops, nbytes, kernel, launch):
+    def __init__(self, kind, name, flops, nbytes, kernel, launch, tune=None):
         self.kind, self.name, self.flops, self.bytes, self.kernel, self.launch = kind, name, flops, nbytes, kernel, launch
+        self.tune = tune  # (params struct, launch_with(stream, ws_ptr, ws_bytes)) for tools/tune_igemm.py
 
 
 class UNetPlan:
@@ -208,8 +209,8 @@ class UNet2DEngine:
     # ------------------------------------------------------------------------------------------
     # plan construction helpers
     # ------------------------------------------------------------------------------------------
-    def _add(self, plan, kind, name, flops, nbytes, launch):
-        plan.ops.append(OpRecord(kind, name, flops, nbytes, None, launch))
+    def _add(self, plan, kind, name, flops, nbytes, launch, tune=None):
+        plan.ops.append(OpRecord(kind, name, flops, nbytes, None, launch, tune))
 
     def _need_ws(self, plan, nbytes):
         if nbytes > plan.ws[1]:
@@ -264,10 +265,14 @@ class UNet2DEngine:
         def launch(stream, p=p, segs=segs):
             L.check(lib.sfast_hip_gemm(xp, segs, bp, None, rp, op, C.byref(p), ws[0].data_ptr() if ws[0] is not None else None, ws[1], stream), name)
 
+        def launch_with(stream, ws_ptr, ws_bytes, p=p, segs=segs):
+            return lib.sfast_hip_gemm(xp, segs, bp, None, rp, op, C.byref(p), ws_ptr, ws_bytes, stream)
+
         wrows = (2 * N if geglu else N)
         flops = 2.0 * M * wrows * K
         nbytes = (M * K + wrows * K + wrows + M * N + (M * N if residual is not None else 0)) * self.esize
-        self._add(plan, kind or ("geglu" if geglu else ("gemv" if M <= 16 else "linear")), name, flops, nbytes, launch)
+        self._add(plan, kind or ("geglu" if geglu else ("gemv" if M <= 16 else "linear")), name, flops, nbytes, launch,
+                  tune=(p, launch_with))
 
     def _op_conv(self, plan, name, x, x2, w, bias, out, B, H, W, C1, C2, Cout, k, stride, pad, *, ups=False, rowbias=None,
                  ld_rowbias=0, rowbias_offset=0, z=None, xs=None, os_=None, kind=None):
@@ -303,10 +308,13 @@ class UNet2DEngine:
         def launch(stream, p=p):
             L.check(lib.sfast_hip_conv2d(xp, x2p, wp, bp, rbp, zp, op, C.byref(p), ws[0].data_ptr() if ws[0] is not None else None, ws[1], stream), name)
 
+        def launch_with(stream, ws_ptr, ws_bytes, p=p):
+            return lib.sfast_hip_conv2d(xp, x2p, wp, bp, rbp, zp, op, C.byref(p), ws_ptr, ws_bytes, stream)
+
         M = B * Ho * Wo
         flops = 2.0 * M * Cout * Cin * k * k
         nbytes = (B * H * W * Cin + Cout * Cin * k * k + Cout + M * Cout + (M * Cout if z is not None else 0)) * self.esize
-        self._add(plan, kind or ("conv3x3" if k == 3 else "conv1x1"), name, flops, nbytes, launch)
+        self._add(plan, kind or ("conv3x3" if k == 3 else "conv1x1"), name, flops, nbytes, launch, tune=(p, launch_with))
         return Ho, Wo
 
     def _op_attn(self, plan, name, q, k, v, out, B, Hh, Sq, Skv, D, qs, ks, vs, os_, q_off=0, k_off=0, v_off=0):

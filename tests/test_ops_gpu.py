@@ -12,6 +12,7 @@ import os
 import pytest
 import torch
 
+import sfast  # noqa: F401  (registers torch.ops.sfast / sfast_triton / sfast_xformers)
 from oracle import ops_ref as R
 from parity import compare
 
@@ -301,7 +302,7 @@ def test_conv_igemm(case, variant):
     compare(f"conv {name} v{variant}", y, want, *tol(x.dtype, 2.0), kernel=last_kernel())
 
 
-@pytest.mark.parametrize("split", [2, 4, 16])
+@pytest.mark.parametrize("split", [2, 4, 12])
 def test_conv_split_k(split):
     x, w, b = cl(rnd(2, 1280, 8, 8, seed=76)), cl(rnd(1280, 1280, 3, 3, seed=77, scale=11520 ** -0.5)), rnd(1280, seed=78)
     z = cl(rnd(2, 1280, 8, 8, seed=79))

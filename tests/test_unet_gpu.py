@@ -171,7 +171,8 @@ def test_compile_drop_in_surface():
     assert len(pipe.unet.forward._cached) == 2 and rel_l2(o2, w2) < 1e-2
     # unsupported call forms fall back to the original forward instead of computing something else
     o3 = pipe.unet(lat2, 500, encoder_hidden_states=ehs[:, :40], cross_attention_kwargs={"scale": 0.5}, return_dict=False)[0]
-    assert rel_l2(o3, w2) < 1e-6
+    assert pipe.unet.forward._warned  # took the eager path (two eager fp16 runs differ by conv algorithm noise)
+    assert rel_l2(o3, w2) < 1e-2 and len(pipe.unet.forward._cached) == 2
 
 
 def test_live_weight_update_without_recapture():

@@ -11,7 +11,7 @@ run() { # name, timeout, command...
   local name=$1 to=$2; shift 2
   echo "=== $name ===" | tee -a gpurun_out/session.log
   timeout $to "$@" > gpurun_out/$name.log 2>&1
-  echo "exit=$? $(tail -n 1 gpurun_out/$name.log)" | tee -a gpurun_out/session.log
+  echo "exit=$? $(tail -n 1 gpurun_out/$name.log | cut -c1-200)" | tee -a gpurun_out/session.log
 }
 rm -f gpurun_out/parity.jsonl gpurun_out/session.log
 rocminfo 2>/dev/null | grep -E "gfx|Compute Unit" | head -4 >> gpurun_out/session.log
@@ -25,9 +25,12 @@ run t_refapi 900 $PYT tests/test_reference_api_gpu.py
 run t_unet  1200 $PYT tests/test_unet_gpu.py
 run smoke    600 python __graft_entry__.py smoke
 run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json
+if [ "$MODE" = "full" ] || [ "$MODE" = "tune" ]; then
+  run tune 900 bash -c "python tools/tune_igemm.py > gpurun_out/tune.json 2> gpurun_out/tune.txt"
+fi
 if [ "$MODE" = "full" ]; then
   ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -o bench -- python $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline > $OLDPWD/gpurun_out/rocprof.log 2>&1 )
   echo "rocprof exit=$?" >> gpurun_out/session.log
   find gpurun_out/prof -name "*stats*" | head >> gpurun_out/session.log
 fi
-cat gpurun_out/session.log
+cut -c1-300 gpurun_out/session.log
