@@ -404,13 +404,16 @@ static GnPlan gn_plan(const sfast_gn_params *p) {
     if (g.TY < 1) g.TY = 1;
     if (g.TY > p->HW) g.TY = p->HW;
     const int max_split = ceil_div(p->HW, g.TY);
-    int want = ceil_div(512, p->N);
-    if (want > 128) want = 128;
+    // ~one workgroup per CU in each pass. The split count is capped at 32 because every apply
+    // workgroup re-reads all G x nsplit partial sums in its prologue (8 KB at 32 splits): with
+    // 128 splits and 684 apply workgroups that prologue traffic exceeded the tensor itself.
+    int want = ceil_div(256, p->N);
+    if (want > 32) want = 32;
     pl.nsplit = want < max_split ? want : max_split;
     if (pl.nsplit < 1) pl.nsplit = 1;
     pl.rows_stats = ceil_div(p->HW, pl.nsplit);
     pl.nsplit = ceil_div(p->HW, pl.rows_stats);
-    int wanta = ceil_div(1024, p->N);
+    int wanta = ceil_div(256, p->N);
     int na = wanta < max_split ? wanta : max_split;
     if (na < 1) na = 1;
     pl.rows_apply = ceil_div(p->HW, na);
