@@ -142,9 +142,10 @@ int sfast_hip_gemm(const void *x, const void *const *w_segs, const void *bias,
                    sfast_stream_t stream);
 
 /* diagnostic, host-only: the tile / split-K choice the MFMA path would make for an [M,N,K] problem.
- * out = {BM, BN (weight rows per tile), splits, k_tiles_per_split}. */
+ * out = {BM, BN (weight rows per tile), splits, k_tiles_per_split, variant id}; variant ids 1..5 are the
+ * register-staged pipe, 11..15 the LDS-DMA ring with the same tile shapes. */
 int sfast_hip_igemm_plan(int32_t M, int32_t N, int32_t K, int32_t geglu, int32_t variant, int32_t split_k,
-                         int32_t out[4]);
+                         int32_t out[5]);
 
 /* ---- conv2d (cross-correlation, groups = 1) ------------------------------------------------
  * y = act(conv(x, w) + bias + rowbias[b] + alpha*z)  (res_before_act = 1, cuDNN fused form,

@@ -170,17 +170,17 @@ void fill_small_conv(SmallConvArgs &a, const void *x, const void *x2, const void
 }  // namespace
 
 extern "C" int sfast_hip_igemm_plan(int32_t M, int32_t N, int32_t K, int32_t geglu, int32_t variant, int32_t split_k,
-                                    int32_t out[4]) {
+                                    int32_t out[5]) {
     if (!out || M <= 0 || N <= 0 || K <= 0) return SFAST_ERR_INVALID;
-    int o[4];
-    igemm_plan_query(M, N, K, geglu != 0, variant < 100 ? variant : 0, split_k, o);
-    for (int i = 0; i < 4; ++i) out[i] = o[i];
+    int o[5];
+    igemm_plan_query(M, N, K, geglu != 0, variant < 100 ? variant : 0, split_k, true, o);
+    for (int i = 0; i < 5; ++i) out[i] = o[i];
     return SFAST_OK;
 }
 
 extern "C" size_t sfast_hip_gemm_workspace_bytes(const sfast_gemm_params *p) {
     if (!p || !is_half(p->dtype) || (p->M <= 16 && p->variant == 0) || p->variant >= 100 || p->K % 8 != 0) return 0;
-    return igemm_workspace_bytes(p->M, p->N, p->K, p->geglu != 0, p->variant < 100 ? p->variant : 0, p->split_k);
+    return igemm_workspace_bytes(p->M, p->N, p->K, p->geglu != 0, p->variant < 100 ? p->variant : 0, p->split_k, true);
 }
 
 extern "C" int sfast_hip_gemm(const void *x, const void *const *w_segs, const void *bias, const void *rowbias,
@@ -246,7 +246,9 @@ extern "C" size_t sfast_hip_conv2d_workspace_bytes(const sfast_conv_params *p) {
     const int64_t M = (int64_t)p->B * g.Ho * g.Wo;
     const int K = p->KH * p->KW * p->Cin;
     if (M <= 0 || M > INT32_MAX || K % 8 != 0) return 0;
-    return igemm_workspace_bytes((int)M, p->Cout, K, false, p->variant < 100 ? p->variant : 0, p->split_k);
+    const int C2 = p->Cin - p->C1;
+    const bool glds_ok = !p->upsample2x && p->C1 % 64 == 0 && C2 % 64 == 0 && p->KH * p->KW <= 32;
+    return igemm_workspace_bytes((int)M, p->Cout, K, false, p->variant < 100 ? p->variant : 0, p->split_k, glds_ok);
 }
 
 extern "C" int sfast_hip_conv2d(const void *x, const void *x2, const void *w, const void *bias, const void *rowbias,

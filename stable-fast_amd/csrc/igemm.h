@@ -1,4 +1,4 @@
-// Argument block + host entry of the MFMA implicit-GEMM kernels (igemm.hip).
+// Argument block + host entry of the MFMA implicit-GEMM kernels (igemm.hip, igemm_glds.hip).
 #pragma once
 #include "common.h"
 
@@ -24,7 +24,9 @@ struct IgemmArgs {
 // Fills the plan fields of `a` (tiles, split) and launches on `st`.
 int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int split, void *ws, size_t ws_bytes,
               hipStream_t st);
-void igemm_plan_query(int M, int N, int K, bool geglu, int variant, int split, int out[4]);
-size_t igemm_workspace_bytes(int M, int N, int K, bool geglu, int variant, int split);
+// glds_ok: whether the LDS-DMA pipe may be chosen for this problem (see igemm_glds_eligible)
+void igemm_plan_query(int M, int N, int K, bool geglu, int variant, int split, bool glds_ok, int out[5]);
+size_t igemm_workspace_bytes(int M, int N, int K, bool geglu, int variant, int split, bool glds_ok);
+bool igemm_glds_eligible(const IgemmArgs &a, int mode);
 
 }  // namespace sfast

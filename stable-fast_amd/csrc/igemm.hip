@@ -30,76 +30,10 @@
 //   * split-K (fp32 slabs + a reduce/epilogue kernel) for the weight-streaming 16x16 / 8x8 levels
 //     where M <= 512 gives too few tiles for 256 CUs.
 #include "igemm.h"
+#include "igemm_device.h"
 
 namespace sfast {
 
-
-__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
-// byte offset of 16-B chunk `chunk` (0..7) of tile row `row` (128 B per row), XOR-swizzled
-__device__ __forceinline__ int lds_off(int row, int chunk) {
-    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-}
-
-// final epilogue for 4 consecutive columns n..n+3 of row m (fp32 in, T out)
-template <typename T>
-__device__ __forceinline__ void epilogue4(const IgemmArgs &a, int m, int n, float (&v)[4]) {
-    if (a.bias) {
-        float b[4];
-        unpack4<T>(*reinterpret_cast<const u32x2 *>((const T *)a.bias + n), b);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] += b[i];
-    }
-    if (a.rowbias) {
-        float b[4];
-        const int bi = m / a.rows_per_batch;
-        unpack4<T>(*reinterpret_cast<const u32x2 *>((const T *)a.rowbias + (int64_t)bi * a.ld_rowbias + n), b);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] += b[i];
-    }
-    float r[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.res) {
-        unpack4<T>(*reinterpret_cast<const u32x2 *>((const T *)a.res + (int64_t)m * a.ldr + n), r);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] *= a.alpha;
-    }
-    if (a.res_before_act) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] += r[i];
-    }
-    if (a.act != SFAST_ACT_NONE) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], a.act);
-    }
-    if (!a.res_before_act) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] += r[i];
-    }
-    *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
-}
-
-template <typename T>
-__device__ __forceinline__ void epilogue4_geglu(const IgemmArgs &a, int m, int n, float (&h)[4], float (&g)[4]) {
-    if (a.bias) {
-        float bh[4], bg[4];
-        unpack4<T>(*reinterpret_cast<const u32x2 *>((const T *)a.bias + n), bh);
-        unpack4<T>(*reinterpret_cast<const u32x2 *>((const T *)a.bias + a.N + n), bg);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            h[i] += bh[i];
-            g[i] += bg[i];
-        }
-    }
-    float v[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = h[i] * act_gelu_erf(g[i]);
-    *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
-}
 
 // MODE 0: linear (row m -> x + m*ldx). MODE 1: conv (implicit im2col, NHWC).
 template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GEGLU>
@@ -298,54 +232,8 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_kernel(const IgemmArgs a) {
         }
     }
 
-    // ---- epilogue ----------------------------------------------------------------------------------
-    const bool partial = a.splits > 1;
-#pragma unroll
-    for (int fm = 0; fm < FM; ++fm) {
-        const int m = m0 + wm * (FM * 32) + fm * 32 + l31;
-        if (m >= a.M) continue;
-        if (GEGLU) {
-#pragma unroll
-            for (int fh = 0; fh < FN / 2; ++fh) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = n0 + wn * (WNB / 2) + fh * 32 + 8 * g + 4 * hi;
-                    if (n >= a.N) continue;
-                    float h[4], gt[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        h[i] = acc[fh][fm][4 * g + i];
-                        gt[i] = acc[fh + FN / 2][fm][4 * g + i];
-                    }
-                    if (partial) {
-                        float *p = a.partial + ((int64_t)blockIdx.y * a.M + m) * (2 * (int64_t)a.N);
-                        *reinterpret_cast<f32x4 *>(p + n) = f32x4{h[0], h[1], h[2], h[3]};
-                        *reinterpret_cast<f32x4 *>(p + a.N + n) = f32x4{gt[0], gt[1], gt[2], gt[3]};
-                    } else {
-                        epilogue4_geglu<T>(a, m, n, h, gt);
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int fn = 0; fn < FN; ++fn) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = n0 + wn * WNB + fn * 32 + 8 * g + 4 * hi;
-                    if (n >= a.N) continue;
-                    float v[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = acc[fn][fm][4 * g + i];
-                    if (partial) {
-                        float *p = a.partial + ((int64_t)blockIdx.y * a.M + m) * (int64_t)a.N;
-                        *reinterpret_cast<f32x4 *>(p + n) = f32x4{v[0], v[1], v[2], v[3]};
-                    } else {
-                        epilogue4<T>(a, m, n, v);
-                    }
-                }
-            }
-        }
-    }
+    // ---- epilogue: batched operand loads, fp32 math, 8-byte stores (igemm_device.h) -------------------------
+    epilogue_tile<T, FN, FM, GEGLU>(a, acc, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi, blockIdx.y);
 }
 
 // split-K reduce + epilogue: one thread per 4 consecutive output columns.
@@ -376,22 +264,29 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const IgemmArgs a) {
 }
 
 // ---- host side: variants, heuristics, launch -------------------------------------------------------
+// Two main-loop structures share the tile shapes: pipe 0 = register-staged double buffer (this
+// file), pipe 1 = LDS-DMA ring (igemm_glds.hip). Variant ids 1..5 select pipe 0, 11..15 pipe 1.
 struct Variant {
-    int id, BM, BN, WM, WN;
-    float eff;  // relative MFMA efficiency of the tile shape (arithmetic intensity / LDS pressure)
+    int id, BM, BN, WM, WN, pipe;
+    float eff;  // relative efficiency of the tile shape (arithmetic intensity / LDS pressure)
 };
 // BN = weight rows per tile (GEGLU variants produce BN/2 output columns)
 static const Variant kVariants[] = {
-    {1, 128, 128, 2, 2, 1.00f},
-    {2, 128, 160, 4, 1, 1.00f},
-    {3, 64, 64, 2, 2, 0.60f},
-    {4, 64, 160, 2, 1, 0.80f},
-    {5, 256, 128, 4, 2, 1.10f},
+    {1, 128, 128, 2, 2, 0, 1.00f},  {2, 128, 160, 4, 1, 0, 1.00f},  {3, 64, 64, 2, 2, 0, 0.60f},
+    {4, 64, 160, 2, 1, 0, 0.80f},   {5, 256, 128, 4, 2, 0, 1.10f},  {11, 128, 128, 2, 2, 1, 1.00f},
+    {12, 128, 160, 4, 1, 1, 1.00f}, {13, 64, 64, 2, 2, 1, 0.60f},   {14, 64, 160, 2, 1, 1, 0.80f},
+    {15, 256, 128, 4, 2, 1, 1.10f},
 };
 static const Variant kGegluVariants[] = {
-    {1, 128, 128, 2, 2, 1.00f},
-    {3, 64, 128, 2, 2, 0.75f},
+    {1, 128, 128, 2, 2, 0, 1.00f},
+    {3, 64, 128, 2, 2, 0, 0.75f},
+    {11, 128, 128, 2, 2, 1, 1.00f},
+    {13, 64, 128, 2, 2, 1, 0.75f},
 };
+
+int igemm_glds_init();                                                                               // igemm_glds.hip
+int igemm_glds_stages(int BM, int BN, bool geglu);                                                   // igemm_glds.hip
+int igemm_glds_launch(const IgemmArgs &a, int dtype, int mode, bool geglu, int BM, int BN, hipStream_t st);  // igemm_glds.hip
 
 template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GEGLU>
 static int launch_one(const IgemmArgs &a, hipStream_t st) {
@@ -425,6 +320,8 @@ static int set_attr_one() {
     OP(T, 128, 128, 2, 2, 0, true)      \
     OP(T, 64, 128, 2, 2, 0, true)
 
+static int g_pipe_pref = -1;  // -1 auto, 0 force register pipe, 1 force LDS-DMA pipe (SFAST_IGEMM_PIPE)
+
 int igemm_init() {
     int rc = 0;
 #define INIT_OP(T, BM, BN, WM, WN, MODE, G) \
@@ -436,6 +333,10 @@ int igemm_init() {
     SFAST_FOR_GEGLU_VARIANTS(f16, INIT_OP)
     SFAST_FOR_GEGLU_VARIANTS(bf16, INIT_OP)
 #undef INIT_OP
+    if (!rc) rc = igemm_glds_init();
+    const char *e = getenv("SFAST_IGEMM_PIPE");
+    if (e && e[0] == 'r') g_pipe_pref = 0;
+    if (e && e[0] == 'g') g_pipe_pref = 1;
     return rc;
 }
 
@@ -461,14 +362,14 @@ struct IgemmPlan {
     int splits, ktps, tiles_m, tiles_n, ktiles;
 };
 
-// Pick tile shape and split-K factor with a small analytic model (times in ns):
-//   t = max(waves * t_workgroup, t_memory) + launch + split-K slab traffic
-// where a CU sustains ~1700 MAC/ns on this kernel structure (about 35 % of the 4900 MAC/ns MFMA
-// peak per CU) scaled by the tile shape's efficiency, shared between co-resident workgroups, and
-// operand traffic streams at ~4 TB/s (L2 / Infinity-Cache assisted). The 16x16 / 8x8 UNet levels
-// (M <= 512, K up to 23k) are weight-streaming bound and want as many K-splits as it takes to put
-// a workgroup on every CU; the 64x64 / 32x32 levels never split.
-static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, int force_split) {
+// Pick main-loop structure, tile shape and split-K factor with a small analytic model (ns):
+//   t = max(waves * t_workgroup, t_memory) + per-workgroup prologue/epilogue + split-K slab traffic
+// calibrated on MI355X sweeps (profiles/r01_tune_*.json): a CU sustains ~560 MAC/ns with one resident
+// workgroup of the register pipe and ~650 MAC/ns with two; the LDS-DMA pipe keeps NS-1 tiles in flight
+// and is modelled by its own rate. The 16x16 / 8x8 UNet levels (M <= 512, K up to 23k) are
+// weight-streaming bound and want as many K-splits as it takes to put ~2 workgroups on every CU;
+// measured optima cluster at 480..640 workgroups.
+static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, int force_split, bool glds_ok) {
     const Variant *vs = geglu ? kGegluVariants : kVariants;
     const int nv = geglu ? (int)(sizeof(kGegluVariants) / sizeof(Variant)) : (int)(sizeof(kVariants) / sizeof(Variant));
     const int ktiles = ceil_div(K, 64);
@@ -477,11 +378,18 @@ static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, 
     double best_cost = 1e300;
     for (int i = 0; i < nv; ++i) {
         const Variant &v = vs[i];
-        if (force_variant && v.id != force_variant) continue;
+        if (force_variant) {
+            if (v.id != force_variant) continue;
+        } else {
+            if (v.pipe == 1 && (!glds_ok || g_pipe_pref == 0)) continue;
+            if (v.pipe == 0 && glds_ok && g_pipe_pref == 1) continue;
+        }
+        if (v.pipe == 1 && !glds_ok) continue;
         const int bno = geglu ? v.BN / 2 : v.BN;
         const int tm = ceil_div(M, v.BM), tn = ceil_div(N, bno);
         const int tiles = tm * tn;
-        const int lds = 2 * (v.BM + v.BN) * 128;
+        const int stages = v.pipe ? igemm_glds_stages(v.BM, v.BN, geglu) : 2;
+        const int lds = stages * (v.BM + v.BN) * 128;
         const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;
         const double wrows = geglu ? 2.0 * N : (double)N;
         // unique operand bytes stream from HBM (~4 TB/s); panel re-reads by other tiles are served
@@ -502,8 +410,13 @@ static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, 
             const double waves = (double)ceil_div(wgs, 256 * wg_per_cu);
             int share = ceil_div(wgs, 256);
             if (share > wg_per_cu) share = wg_per_cu;
-            const double rate = 1700.0 * v.eff / share;  // MAC/ns available to one workgroup
-            const double t_wg = (double)v.BM * v.BN * 64.0 * ktps / rate;
+            // MAC/ns available to one workgroup
+            double rate;
+            if (v.pipe == 0)
+                rate = (share == 1 ? 560.0 : 325.0) * v.eff;
+            else
+                rate = (share == 1 ? 900.0 : 500.0) * v.eff;
+            const double t_wg = (double)v.BM * v.BN * 64.0 * ktps / rate + (v.pipe ? 2500.0 : 4000.0);
             double cost = waves * t_wg;
             if (cost < t_mem) cost = t_mem;
             cost += 2000.0;
@@ -521,8 +434,8 @@ static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, 
         }
     }
     if (best_cost == 1e300) {
-        // forced variant id does not exist for this family: smallest tile, no split
-        best.v = vs[nv > 2 ? 2 : nv - 1];
+        // forced variant id unknown / not applicable: smallest register-pipe tile, no split
+        best.v = vs[geglu ? 1 : 2];
         const int bno = geglu ? best.v.BN / 2 : best.v.BN;
         best.splits = 1;
         best.ktps = ktiles;
@@ -533,24 +446,32 @@ static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, 
     return best;
 }
 
-void igemm_plan_query(int M, int N, int K, bool geglu, int variant, int split, int out[4]) {
-    IgemmPlan p = igemm_plan(M, N, K, geglu, variant, split);
+void igemm_plan_query(int M, int N, int K, bool geglu, int variant, int split, bool glds_ok, int out[5]) {
+    IgemmPlan p = igemm_plan(M, N, K, geglu, variant, split, glds_ok);
     out[0] = p.v.BM;
     out[1] = p.v.BN;
     out[2] = p.splits;
     out[3] = p.ktps;
+    out[4] = p.v.id;
 }
 
-size_t igemm_workspace_bytes(int M, int N, int K, bool geglu, int variant, int split) {
-    IgemmPlan p = igemm_plan(M, N, K, geglu, variant, split);
+size_t igemm_workspace_bytes(int M, int N, int K, bool geglu, int variant, int split, bool glds_ok) {
+    IgemmPlan p = igemm_plan(M, N, K, geglu, variant, split, glds_ok);
     if (p.splits <= 1) return 0;
     return (size_t)p.splits * M * (geglu ? 2 * (size_t)N : (size_t)N) * sizeof(float);
 }
 
-// entry used by gemm.hip / conv.hip. mode: 0 linear, 1 conv. Fills plan fields of `a`.
+// The LDS-DMA pipe takes every linear problem; conv problems need uniform taps per K-tile.
+bool igemm_glds_eligible(const IgemmArgs &a, int mode) {
+    if (mode == 0) return true;
+    return !a.ups && a.C1 % 64 == 0 && a.C2 % 64 == 0 && a.KH * a.KW <= 32;
+}
+
+// entry used by api_gemm_conv.hip. mode: 0 linear, 1 conv. Fills plan fields of `a`.
 int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int split, void *ws, size_t ws_bytes,
               hipStream_t st) {
-    IgemmPlan p = igemm_plan(a.M, a.N, a.K, geglu, variant, split);
+    const bool glds_ok = igemm_glds_eligible(a, mode);
+    IgemmPlan p = igemm_plan(a.M, a.N, a.K, geglu, variant, split, glds_ok);
     a.tiles_m = p.tiles_m;
     a.tiles_n = p.tiles_n;
     a.ktiles = p.ktiles;
@@ -562,10 +483,12 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
         SFAST_REQUIRE(ws && ws_bytes >= need, SFAST_ERR_WORKSPACE, "igemm: workspace %zu < %zu", ws_bytes, need);
         a.partial = (float *)ws;
     }
-    set_kernel_name("igemm_%s_%s%s[%dx%d,split=%d]", mode ? "conv" : "lin", dtype == SFAST_F16 ? "f16" : "bf16",
-                    geglu ? "_geglu" : "", p.v.BM, p.v.BN, p.splits);
+    set_kernel_name("igemm_%s_%s%s[%dx%d,split=%d,%s]", mode ? "conv" : "lin", dtype == SFAST_F16 ? "f16" : "bf16",
+                    geglu ? "_geglu" : "", p.v.BM, p.v.BN, p.splits, p.v.pipe ? "dma" : "reg");
     int rc;
-    if (dtype == SFAST_F16)
+    if (p.v.pipe == 1)
+        rc = igemm_glds_launch(a, dtype, mode, geglu, p.v.BM, p.v.BN, st);
+    else if (dtype == SFAST_F16)
         rc = mode ? dispatch_variant<f16, 1>(a, p.v, geglu, st) : dispatch_variant<f16, 0>(a, p.v, geglu, st);
     else
         rc = mode ? dispatch_variant<bf16, 1>(a, p.v, geglu, st) : dispatch_variant<bf16, 0>(a, p.v, geglu, st);

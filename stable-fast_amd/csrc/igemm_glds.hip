@@ -1,0 +1,324 @@
+// Deep-pipelined MFMA implicit-GEMM: direct global->LDS staging (LDS-DMA) over an NS-stage ring.
+//
+// Why a second main-loop structure: PMC on MI355X showed the register-staged kernel (igemm.hip) at
+// ~20 % MFMA busy with 0 LDS bank conflicts -- each K-tile costs one full memory round trip because
+// only ONE tile can be in flight (its data sits in VGPRs until the ds_write), and the short-K GEMMs of
+// the transformer blocks (K = 320..1280, 5..20 K-tiles) never leave the latency-bound regime.
+// Here the tile bytes travel HBM/L2 -> LDS without touching registers
+// (`global_load_lds_dwordx4`, 1 KiB per wave-instruction), so NS-1 K-tiles are in flight at any time
+// at zero VGPR cost, the ds_write pass disappears, and for K <= (NS-1)*64 the whole operand is
+// requested up front: one memory latency per workgroup instead of one per K-tile.
+//
+//   * LDS image identical to igemm.hip (128-B rows, chunk ^= (row>>1)&7) so the fragment reads stay
+//     conflict-free. LDS-DMA writes lane-linearly (wave-uniform base + lane*16), therefore the
+//     swizzle is applied on the SOURCE side: the lane that fills physical chunk p of row r fetches
+//     logical chunk p ^ ((r>>1)&7).
+//   * zero fill (image border taps, rows >= M, k >= K) = the lane's source address is redirected to
+//     a 16-byte zero block in device memory; the DMA stays unconditional.
+//   * ordering is hand-placed: counted `s_waitcnt vmcnt(L*tiles_in_flight)` (never 0 in steady
+//     state), ONE raw `s_barrier` per K-tile, refill of the stage freed by the previous iteration
+//     right after the barrier.
+//   * conv addressing is hoisted: per tile row a pixel index and a 9-bit (KH*KW <= 32) tap-validity
+//     mask are computed once; per K-tile the tap / channel decode is wave-uniform scalar state
+//     advanced incrementally (needs Cin % 64 == 0 and C1 % 64 == 0: true for every UNet layer but
+//     conv_in). Problems outside that envelope (upsample-fused convs, odd channel counts) keep using
+//     the register-staged kernel.
+#include "igemm_device.h"
+
+namespace sfast {
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+typedef const u32x4 __attribute__((address_space(1))) * glds_src_t;
+typedef __attribute__((address_space(3))) void *glds_dst_t;
+
+template <typename T, int BM, int BN, int WM, int WN, int NS, int MODE, bool GEGLU>
+__global__ void __launch_bounds__(WM *WN * 64) igemm_glds_kernel(const IgemmArgs a) {
+    using vec8 = typename Elem<T>::vec8;
+    constexpr int NT = WM * WN * 64;
+    constexpr int FM = BM / (WM * 32);
+    constexpr int FN = BN / (WN * 32);
+    constexpr int XCH = BM * 8 / NT;
+    constexpr int WCH = BN * 8 / NT;
+    constexpr int RPP = NT / 8;
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int BNO = GEGLU ? BN / 2 : BN;
+    constexpr int WNB = FN * 32;
+    constexpr int L = XCH + WCH;  // LDS-DMA instructions per thread per K-tile
+    static_assert(RPP % 16 == 0, "swizzle phase must not depend on the staging pass");
+    static_assert(L * (NS - 2) <= 63, "vmcnt field");
+    static_assert(NS >= 3 && NS <= 5, "ring depth");
+    static_assert(!GEGLU || (FN % 2 == 0), "GEGLU needs paired fragments");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    int lid;
+    {
+        const int nblk = a.tiles_m * a.tiles_n;
+        const int bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_n = lid % a.tiles_n, tile_m = lid / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BNO;
+    const int kt_begin = blockIdx.y * a.ktiles_per_split;
+    const int kt_end = min(a.ktiles, kt_begin + a.ktiles_per_split);
+
+    // staging role of this thread: tile row (tid>>3) + i*RPP, PHYSICAL chunk tid&7, which must hold
+    // LOGICAL chunk kc (source-side swizzle; RPP % 16 == 0 keeps it independent of i)
+    const int rbase = tid >> 3;
+    const int kc = (tid & 7) ^ ((rbase >> 1) & 7);
+
+    // ---- activation-row metadata -------------------------------------------------------------------
+    const T *xrow[XCH];  // MODE 0: row pointer or nullptr
+    int xpix[XCH];       // MODE 1: pixel index of tap (0,0) (may be negative), in input pixels
+    unsigned xmask[XCH];  // MODE 1: bit (r*KW+s) set when that tap is inside the image
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+        const int m = m0 + rbase + i * RPP;
+        if (MODE == 0) {
+            xrow[i] = (m < a.M) ? (const T *)a.x + (int64_t)m * a.ldx : nullptr;
+        } else {
+            unsigned mask = 0;
+            int pix = 0;
+            if (m < a.M) {
+                const int hw = a.Ho * a.Wo;
+                const int b = m / hw;
+                const int rem = m - b * hw;
+                const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+                const int h0 = ho * a.stride_h - a.pad_h, w0 = wo * a.stride_w - a.pad_w;
+                pix = (b * a.H + h0) * a.W + w0;
+                for (int r = 0; r < a.KH; ++r)
+                    for (int s = 0; s < a.KW; ++s) {
+                        const int hh = h0 + r * a.dil_h, ww = w0 + s * a.dil_w;
+                        if ((unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W) mask |= 1u << (r * a.KW + s);
+                    }
+            }
+            xpix[i] = pix;
+            xmask[i] = mask;
+        }
+    }
+    const T *wrow[WCH];
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+        const int j = rbase + i * RPP;
+        if (GEGLU) {
+            const int grp = j / WNB, within = j % WNB;
+            const int half = within / (WNB / 2), i2 = within % (WNB / 2);
+            const int ncol = n0 + grp * (WNB / 2) + i2;
+            wrow[i] = (ncol < a.N) ? (const T *)a.w[0] + ((int64_t)half * a.N + ncol) * a.ldw : nullptr;
+        } else {
+            const int n = n0 + j;
+            if (n < a.N) {
+                const int seg = n / a.rows_per_seg;
+                const void *base = seg == 0 ? a.w[0] : seg == 1 ? a.w[1] : seg == 2 ? a.w[2] : a.w[3];
+                wrow[i] = (const T *)base + (int64_t)(n - seg * a.rows_per_seg) * a.ldw;
+            } else {
+                wrow[i] = nullptr;
+            }
+        }
+    }
+
+    // ---- wave-uniform conv tap state of the NEXT tile to be issued ---------------------------------------
+    const int cin = a.C1 + a.C2;
+    int t_tap = 0, t_r = 0, t_s = 0, t_c = 0;
+    if (MODE == 1) {
+        const int k0 = kt_begin * 64;
+        t_tap = k0 / cin;
+        t_c = k0 - t_tap * cin;
+        t_r = t_tap / a.KW;
+        t_s = t_tap - t_r * a.KW;
+    }
+
+    auto issue = [&](int kt, int stage) {
+        char *sx = smem + stage * STAGE + wave * 1024;
+        char *sw = sx + BM * 128;
+        const int k = kt * 64 + kc * 8;
+        if (MODE == 0) {
+            const bool kvalid = k < a.K;
+#pragma unroll
+            for (int i = 0; i < XCH; ++i) {
+                const bool ok = kvalid && xrow[i] != nullptr;
+                const glds_src_t src = ok ? (glds_src_t)(const void *)(xrow[i] + k) : (glds_src_t)(const void *)g_zero16;
+                __builtin_amdgcn_global_load_lds(src, (glds_dst_t)(sx + i * (RPP * 128)), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < WCH; ++i) {
+                const bool ok = kvalid && wrow[i] != nullptr;
+                const glds_src_t src = ok ? (glds_src_t)(const void *)(wrow[i] + k) : (glds_src_t)(const void *)g_zero16;
+                __builtin_amdgcn_global_load_lds(src, (glds_dst_t)(sw + i * (RPP * 128)), 16, 0, 0);
+            }
+        } else {
+            // uniform: which tap / source tensor / channel window this K-tile covers
+            const bool first = t_c < a.C1;
+            const T *base = first ? (const T *)a.x : (const T *)a.x2;
+            const int pitch = first ? a.C1 : a.C2;
+            const int cc = (first ? t_c : t_c - a.C1) + kc * 8;
+            const int dpix = t_r * a.dil_h * a.W + t_s * a.dil_w;
+#pragma unroll
+            for (int i = 0; i < XCH; ++i) {
+                const bool ok = (xmask[i] >> t_tap) & 1u;
+                const int64_t off = (int64_t)(xpix[i] + dpix) * pitch + cc;
+                const glds_src_t src = ok ? (glds_src_t)(const void *)(base + off) : (glds_src_t)(const void *)g_zero16;
+                __builtin_amdgcn_global_load_lds(src, (glds_dst_t)(sx + i * (RPP * 128)), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < WCH; ++i) {
+                const bool ok = wrow[i] != nullptr;
+                const glds_src_t src = ok ? (glds_src_t)(const void *)(wrow[i] + k) : (glds_src_t)(const void *)g_zero16;
+                __builtin_amdgcn_global_load_lds(src, (glds_dst_t)(sw + i * (RPP * 128)), 16, 0, 0);
+            }
+            // advance the uniform tap state by one K-tile (Cin % 64 == 0: at most one wrap)
+            t_c += 64;
+            if (t_c >= cin) {
+                t_c -= cin;
+                ++t_tap;
+                if (++t_s == a.KW) {
+                    t_s = 0;
+                    ++t_r;
+                }
+            }
+        }
+    };
+
+    f32x16 acc[FN][FM];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[fn][fm][r] = 0.f;
+
+    auto compute = [&](int stage) {
+        const char *xs = smem + stage * STAGE;
+        const char *ws = xs + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int chunk = ks * 2 + hi;
+            vec8 af[FN], bf[FM];
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+                af[fn] = *reinterpret_cast<const vec8 *>(ws + lds_off(wn * WNB + fn * 32 + l31, chunk));
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm)
+                bf[fm] = *reinterpret_cast<const vec8 *>(xs + lds_off(wm * (FM * 32) + fm * 32 + l31, chunk));
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = mfma32(af[fn], bf[fm], acc[fn][fm]);
+        }
+    };
+
+    // ---- NS-stage ring: tiles kt+1 .. kt+NS-2 stay in flight while tile kt is multiplied ------------------
+    int issued = kt_begin, istage = 0;
+    for (int s = 0; s < NS - 1 && issued < kt_end; ++s) {
+        issue(issued, istage);
+        ++issued;
+        istage = (istage + 1 == NS) ? 0 : istage + 1;
+    }
+    int cstage = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int inflight = issued - kt - 1;  // tiles younger than kt that may stay outstanding
+        if (inflight >= NS - 2) {
+            wait_vmcnt<L *(NS - 2)>();
+        } else if (NS > 3 && inflight == NS - 3) {
+            wait_vmcnt<L *(NS > 3 ? NS - 3 : 0)>();
+        } else if (NS > 4 && inflight == NS - 4) {
+            wait_vmcnt<L *(NS > 4 ? NS - 4 : 0)>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        if (issued < kt_end) {
+            issue(issued, istage);
+            ++issued;
+            istage = (istage + 1 == NS) ? 0 : istage + 1;
+        }
+        compute(cstage);
+        cstage = (cstage + 1 == NS) ? 0 : cstage + 1;
+    }
+
+    // ---- epilogue: batched operand loads, fp32 math, 8-byte stores (igemm_device.h) -------------------------
+    epilogue_tile<T, FN, FM, GEGLU>(a, acc, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi, blockIdx.y);
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+// glds variants are addressed as variant ids 11..15 (same tile shapes as ids 1..5 of igemm.hip)
+#define SFAST_FOR_GLDS_VARIANTS(T, MODE, OP) \
+    OP(T, 128, 128, 2, 2, 4, MODE, false)    \
+    OP(T, 128, 160, 4, 1, 4, MODE, false)    \
+    OP(T, 64, 64, 2, 2, 5, MODE, false)      \
+    OP(T, 64, 160, 2, 1, 4, MODE, false)     \
+    OP(T, 256, 128, 4, 2, 3, MODE, false)
+
+#define SFAST_FOR_GLDS_GEGLU_VARIANTS(T, OP) \
+    OP(T, 128, 128, 2, 2, 4, 0, true)        \
+    OP(T, 64, 128, 2, 2, 5, 0, true)
+
+template <typename T, int BM, int BN, int WM, int WN, int NS, int MODE, bool GEGLU>
+static int glds_set_attr() {
+    constexpr int smem = NS * (BM + BN) * 128;
+    auto kern = igemm_glds_kernel<T, BM, BN, WM, WN, NS, MODE, GEGLU>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(igemm_glds %dx%dx%d): %s", BM, BN, NS, hipGetErrorString(e));
+        return SFAST_ERR_LAUNCH;
+    }
+    return 0;
+}
+
+int igemm_glds_init() {
+    int rc = 0;
+#define INIT_OP(T, BM, BN, WM, WN, NS, MODE, G) \
+    if (!rc) rc = glds_set_attr<T, BM, BN, WM, WN, NS, MODE, G>();
+    SFAST_FOR_GLDS_VARIANTS(f16, 0, INIT_OP)
+    SFAST_FOR_GLDS_VARIANTS(f16, 1, INIT_OP)
+    SFAST_FOR_GLDS_VARIANTS(bf16, 0, INIT_OP)
+    SFAST_FOR_GLDS_VARIANTS(bf16, 1, INIT_OP)
+    SFAST_FOR_GLDS_GEGLU_VARIANTS(f16, INIT_OP)
+    SFAST_FOR_GLDS_GEGLU_VARIANTS(bf16, INIT_OP)
+#undef INIT_OP
+    return rc;
+}
+
+int igemm_glds_stages(int BM, int BN, bool geglu) {
+    if (geglu) return BM == 128 ? 4 : 5;
+    if (BM == 128) return 4;
+    if (BM == 64 && BN == 64) return 5;
+    if (BM == 64) return 4;
+    return 3;
+}
+
+template <typename T, int MODE>
+static int glds_dispatch(const IgemmArgs &a, int BM_, int BN_, bool geglu, hipStream_t st) {
+#define LAUNCH_OP(TT, BM, BN, WM, WN, NS, MODE_, G_)                                                         \
+    if (BM_ == BM && BN_ == BN && geglu == G_) {                                                             \
+        auto kern = igemm_glds_kernel<TT, BM, BN, WM, WN, NS, MODE_, G_>;                                    \
+        hipLaunchKernelGGL(kern, dim3(a.tiles_m *a.tiles_n, a.splits), dim3(WM *WN * 64), NS *(BM + BN) * 128, st, a); \
+        return check_launch("igemm_glds");                                                                   \
+    }
+    if (!geglu) {
+        SFAST_FOR_GLDS_VARIANTS(T, MODE, LAUNCH_OP)
+    } else {
+        if (MODE == 0) {
+            SFAST_FOR_GLDS_GEGLU_VARIANTS(T, LAUNCH_OP)
+        }
+    }
+#undef LAUNCH_OP
+    set_error("igemm_glds: no kernel for tile %dx%d", BM_, BN_);
+    return SFAST_ERR_UNSUPPORTED;
+}
+
+int igemm_glds_launch(const IgemmArgs &a, int dtype, int mode, bool geglu, int BM, int BN, hipStream_t st) {
+    if (dtype == SFAST_F16) return mode ? glds_dispatch<f16, 1>(a, BM, BN, geglu, st) : glds_dispatch<f16, 0>(a, BM, BN, geglu, st);
+    return mode ? glds_dispatch<bf16, 1>(a, BM, BN, geglu, st) : glds_dispatch<bf16, 0>(a, BM, BN, geglu, st);
+}
+
+}  // namespace sfast

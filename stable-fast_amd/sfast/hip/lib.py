@@ -115,7 +115,7 @@ def _declare(lib):
     lib.sfast_hip_timestep_embedding.restype = C.c_int
     lib.sfast_hip_timestep_embedding.argtypes = [vp, vp, C.POINTER(TembParams), vp]
     lib.sfast_hip_igemm_plan.restype = C.c_int
-    lib.sfast_hip_igemm_plan.argtypes = [C.c_int32] * 6 + [C.POINTER(C.c_int32 * 4)]
+    lib.sfast_hip_igemm_plan.argtypes = [C.c_int32] * 6 + [C.POINTER(C.c_int32 * 5)]
     lib.sfast_hip_cfg_ddim_step.restype = C.c_int
     lib.sfast_hip_cfg_ddim_step.argtypes = [vp, vp, vp, vp, vp, C.c_float, C.c_int64, C.c_int32, vp]
 

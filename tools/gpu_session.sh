@@ -25,12 +25,15 @@ run t_refapi 900 $PYT tests/test_reference_api_gpu.py
 run t_unet  1200 $PYT tests/test_unet_gpu.py
 run smoke    600 python __graft_entry__.py smoke
 run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json
+run bench_regpipe 600 env SFAST_IGEMM_PIPE=reg python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
 if [ "$MODE" = "full" ] || [ "$MODE" = "tune" ]; then
   run tune 900 bash -c "python tools/tune_igemm.py > gpurun_out/tune.json 2> gpurun_out/tune.txt"
 fi
 if [ "$MODE" = "full" ]; then
   ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -o bench -- python $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline > $OLDPWD/gpurun_out/rocprof.log 2>&1 )
   echo "rocprof exit=$?" >> gpurun_out/session.log
+  for db in $(find gpurun_out/prof -name "*.db"); do python tools/rocpd_summary.py $db --csv gpurun_out/kernel_stats.csv --top 60 > gpurun_out/kernel_stats.txt; done
+  rm -rf gpurun_out/prof
   find gpurun_out/prof -name "*stats*" | head >> gpurun_out/session.log
 fi
 cut -c1-300 gpurun_out/session.log

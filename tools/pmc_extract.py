@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Reduce a rocprofv3 --pmc rocpd database to a small JSON: per (kernel, grid) mean counter values."""
+import collections
+import json
+import re
+import sqlite3
+import sys
+
+
+def short(n):
+    n = re.sub(r"\(.*$", "", n).replace("void ", "").replace("sfast::", "")
+    return n[:90]
+
+
+def main(db, out):
+    con = sqlite3.connect(db)
+    cur = con.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info('counters_collection')")]
+    sel = "select dispatch_id, kernel_name, counter_name, value, grid_size_x, grid_size_y, workgroup_size_x from counters_collection"
+    d = collections.OrderedDict()
+    for did, kn, cn, val, gx, gy, wx in cur.execute(sel):
+        if "sfast" not in kn:
+            continue
+        key = (short(kn), gx // max(wx, 1), gy)
+        e = d.setdefault(key, {})
+        per = e.setdefault(did, {})
+        per[cn] = per.get(cn, 0) + val
+    res = []
+    for (kn, gx, gy), per in d.items():
+        agg = collections.defaultdict(float)
+        for did, cs in per.items():
+            for c, v in cs.items():
+                agg[c] += v
+        n = len(per)
+        res.append(dict(kernel=kn, grid_x=gx, grid_y=gy, dispatches=n, counters={c: v / n for c, v in agg.items()}))
+    # kernel durations from the trace in the same db
+    dur = collections.defaultdict(list)
+    for name, gx, gy, wx, du in cur.execute("select name, grid_x, grid_y, workgroup_x, duration from kernels"):
+        if "sfast" in name:
+            dur[(short(name), gx // max(wx, 1), gy)].append(du)
+    for r in res:
+        ds = dur.get((r["kernel"], r["grid_x"], r["grid_y"]), [])
+        r["avg_us"] = sum(ds) / len(ds) / 1e3 if ds else None
+    json.dump(dict(columns=cols, rows=res), open(out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

@@ -75,19 +75,21 @@ def main():
         rec = dict(key=list(key), name=op.name, kind=op.kind, flops=op.flops, count=1, results=[])
         seen[key] = rec
         out.append(rec)
-        o = (C.c_int32 * 4)()
+        o = (C.c_int32 * 5)()
         lib.sfast_hip_igemm_plan(M, N, K, geglu, 0, 0, C.byref(o))
         rec["auto"] = list(o)
         p.variant, p.split_k = 0, 0
         rec["auto_us"] = time_launch(lambda: launch_with(sp, ws.data_ptr(), ws.numel()))
-        variants = [1, 3] if geglu else [1, 2, 3, 4, 5]
+        variants = [1, 3, 11, 13] if geglu else [1, 2, 3, 5, 11, 12, 13, 15]
         ktiles = (K + 63) // 64
         for v in variants:
             for s in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
                 if s > 1 and (ktiles // s) < 2:
                     continue
                 lib.sfast_hip_igemm_plan(M, N, K, geglu, v, s, C.byref(o))
-                bm, bn, splits, ktps = list(o)
+                bm, bn, splits, ktps, vid = list(o)
+                if vid != v:
+                    continue
                 if splits != s:
                     continue
                 bno = bn // 2 if geglu else bn
@@ -98,6 +100,8 @@ def main():
                 rc = launch_with(sp, ws.data_ptr(), ws.numel())
                 if rc != 0:
                     continue
+                if (v >= 10) != ("dma" in L.last_kernel()):
+                    continue  # the library substituted another pipe (problem not eligible)
                 us = time_launch(lambda: launch_with(sp, ws.data_ptr(), ws.numel()))
                 rec["results"].append(dict(variant=v, bm=bm, bn=bn, split=s, us=us, tflops=op.flops / us / 1e6))
         p.variant, p.split_k = 0, 0
