@@ -381,6 +381,7 @@ static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, 
         if (force_variant) {
             if (v.id != force_variant) continue;
         } else {
+            if (v.BM == 64 && v.BN == 160) continue;  // never the measured optimum on MI355X sweeps
             if (v.pipe == 1 && (!glds_ok || g_pipe_pref == 0)) continue;
             if (v.pipe == 0 && glds_ok && g_pipe_pref == 1) continue;
         }
@@ -415,7 +416,7 @@ static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, 
             if (v.pipe == 0)
                 rate = (share == 1 ? 560.0 : 325.0) * v.eff;
             else
-                rate = (share == 1 ? 900.0 : 500.0) * v.eff;
+                rate = (share == 1 ? 700.0 : 380.0) * v.eff;
             const double t_wg = (double)v.BM * v.BN * 64.0 * ktps / rate + (v.pipe ? 2500.0 : 4000.0);
             double cost = waves * t_wg;
             if (cost < t_mem) cost = t_mem;

@@ -1,0 +1,166 @@
+"""Measured kernel-variant selection for the MFMA implicit-GEMM ops of a plan.
+
+The reference picks its convolution algorithm by benchmarking the candidates once per problem and
+caching the winner (cuDNN `cudnnFind...Ex` behind `benchmark_cache`,
+/root/reference/src/sfast/csrc/operators/cudnn/cudnn_convolution_impl.cc:344-370, :492-541). This is the
+same idea for libsfast_hip.so: every distinct (problem shape, epilogue form) of a plan is timed on the
+device over the library's tile shapes x main-loop structures x split-K factors, and the fastest
+(variant, split_k) is written into the op's params struct before the plan is captured. Results are
+cached per process (and optionally in a JSON file, `SFAST_TUNE_CACHE=path`), so later plans and
+replicas pay nothing. `SFAST_AUTOTUNE=0` disables it; the library's analytic planner is used then.
+"""
+import ctypes as C
+import json
+import os
+import threading
+
+import torch
+
+from ..hip import lib as L
+
+_cache = {}
+_cache_lock = threading.Lock()
+_loaded_files = set()
+
+SPLITS = (1, 2, 3, 4, 6, 8, 12, 16, 24)
+VARIANTS = (1, 2, 3, 5, 11, 12, 13, 15)
+GEGLU_VARIANTS = (1, 3, 11, 13)
+MAX_SLAB_BYTES = 192 << 20
+
+
+def enabled():
+    return os.environ.get("SFAST_AUTOTUNE", "1") not in ("0", "false", "off", "")
+
+
+def _load_file(path):
+    if not path or path in _loaded_files or not os.path.exists(path):
+        return
+    try:
+        with open(path) as f:
+            for k, v in json.load(f).items():
+                _cache.setdefault(k, tuple(v))
+    except (OSError, ValueError):
+        pass
+    _loaded_files.add(path)
+
+
+def _save_file(path):
+    if not path:
+        return
+    try:
+        with open(path, "w") as f:
+            json.dump({k: list(v) for k, v in sorted(_cache.items())}, f, indent=0)
+    except OSError:
+        pass
+
+
+def problem_key(p, dtype_tag, device_name):
+    if isinstance(p, L.GemmParams):
+        epi = (int(p.geglu), int(p.act), int(p.n_wseg))
+        return f"{device_name}|{dtype_tag}|gemm|{p.M}x{p.N}x{p.K}|{epi}"
+    Hin = 2 * p.H if p.upsample2x else p.H
+    Win = 2 * p.W if p.upsample2x else p.W
+    Ho = (Hin + 2 * p.pad_h - p.dil_h * (p.KH - 1) - 1) // p.stride_h + 1
+    Wo = (Win + 2 * p.pad_w - p.dil_w * (p.KW - 1) - 1) // p.stride_w + 1
+    geo = (p.KH, p.KW, p.stride_h, int(p.upsample2x), int(p.C1 != p.Cin))
+    return f"{device_name}|{dtype_tag}|conv|{p.B * Ho * Wo}x{p.Cout}x{p.KH * p.KW * p.Cin}|{geo}"
+
+
+def _mnk(p):
+    if isinstance(p, L.GemmParams):
+        return p.M, p.N, p.K, bool(p.geglu)
+    Hin = 2 * p.H if p.upsample2x else p.H
+    Win = 2 * p.W if p.upsample2x else p.W
+    Ho = (Hin + 2 * p.pad_h - p.dil_h * (p.KH - 1) - 1) // p.stride_h + 1
+    Wo = (Win + 2 * p.pad_w - p.dil_w * (p.KW - 1) - 1) // p.stride_w + 1
+    return p.B * Ho * Wo, p.Cout, p.KH * p.KW * p.Cin, False
+
+
+def _time(fn, stream, inner=4, groups=3):
+    fn()
+    best = None
+    for _ in range(groups):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for _ in range(inner):
+            fn()
+        b.record(stream)
+        b.synchronize()
+        t = a.elapsed_time(b) / inner
+        best = t if best is None or t < best else best
+    return best
+
+
+def tune_plan(plan, device, dtype_tag="f16", verbose=False):
+    """Choose (variant, split_k) for every tunable op of `plan` in place. Returns #problems measured."""
+    lib = L.load()
+    cache_path = os.environ.get("SFAST_TUNE_CACHE")
+    with _cache_lock:
+        _load_file(cache_path)
+    devname = getattr(torch.cuda.get_device_properties(device), "gcnArchName", "gpu").split(":")[0]
+    todo = {}
+    for op in plan.ops:
+        if op.tune is None:
+            continue
+        p, _ = op.tune
+        M, N, K, geglu = _mnk(p)
+        if M <= 16 or (not isinstance(p, L.GemmParams) and (p.Cout < 16 or p.Cin % 8)):
+            continue
+        key = problem_key(p, dtype_tag, devname)
+        hit = _cache.get(key)
+        if hit is not None:
+            p.variant, p.split_k = int(hit[0]), int(hit[1])
+        else:
+            todo.setdefault(key, []).append(op)
+    if not todo:
+        return 0
+    ws = torch.empty(MAX_SLAB_BYTES, dtype=torch.uint8, device=device)
+    for t in plan.pool.all:
+        t.zero_()
+    stream = torch.cuda.current_stream(device)
+    sp = stream.cuda_stream
+    o = (C.c_int32 * 5)()
+    measured = 0
+    for key, ops in todo.items():
+        p, launch_with = ops[0].tune
+        M, N, K, geglu = _mnk(p)
+        ktiles = (K + 63) // 64
+        wrows = 2 * N if geglu else N
+        best = None
+        for v in (GEGLU_VARIANTS if geglu else VARIANTS):
+            for s in SPLITS:
+                if s > 1 and ktiles // s < 2:
+                    continue
+                if s > 1 and s * M * wrows * 4 > MAX_SLAB_BYTES:
+                    continue
+                lib.sfast_hip_igemm_plan(M, N, K, int(geglu), v, s, C.byref(o))
+                bm, bn, splits, _, vid = list(o)
+                if splits != s or vid != v:
+                    continue
+                bno = bn // 2 if geglu else bn
+                wgs = -(-M // bm) * -(-N // bno) * s
+                if wgs > 8192 or (s > 1 and wgs > 2048):
+                    continue
+                p.variant, p.split_k = v, s
+                if launch_with(sp, ws.data_ptr(), ws.numel()) != 0:
+                    continue
+                if (v >= 10) != ("dma" in L.last_kernel()):
+                    continue  # pipe not applicable to this problem: the library substituted another
+                t = _time(lambda: launch_with(sp, ws.data_ptr(), ws.numel()), stream)
+                if best is None or t < best[0]:
+                    best = (t, v, s)
+        if best is None:
+            choice = (0, 0)
+        else:
+            choice = (best[1], best[2])
+        measured += 1
+        with _cache_lock:
+            _cache[key] = choice
+        for op in ops:
+            op.tune[0].variant, op.tune[0].split_k = choice
+        if verbose:
+            print(f"[sfast autotune] {key}: variant {choice[0]} split {choice[1]}" + (f" {best[0] * 1e3:.1f} us" if best else ""))
+    torch.cuda.synchronize(device)
+    with _cache_lock:
+        _save_file(cache_path)
+    return measured

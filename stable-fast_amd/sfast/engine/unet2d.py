@@ -597,6 +597,15 @@ class UNet2DEngine:
         self._op_conv(plan, "conv_out", nout, None, P["conv_out.weight"], P["conv_out.bias"], out, B, H, W, ch, 0, self.out_ch, 3, 1, 1,
                       os_=(self.out_ch * H * W, W, 1, H * W), kind="conv_out")
         pool.put(nout)
+        # measured tile / pipe / split-K selection per distinct GEMM / conv problem (cuDNN-benchmark style)
+        from . import autotune
+        if not self._emulated and autotune.enabled():
+            autotune.tune_plan(plan, dev, "f16" if self.dtype == torch.float16 else "bf16")
+            for op in plan.ops:
+                if op.tune is not None:
+                    p = op.tune[0]
+                    q = lib.sfast_hip_gemm_workspace_bytes if isinstance(p, L.GemmParams) else lib.sfast_hip_conv2d_workspace_bytes
+                    self._need_ws(plan, q(C.byref(p)))
         if plan.ws[1]:
             plan.ws[0] = torch.empty(plan.ws[1], dtype=torch.uint8, device=dev)
         return plan

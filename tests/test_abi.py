@@ -72,10 +72,18 @@ def test_workspace_queries_are_consistent(built_lib):
     p.C1 = 1280
     nb = lib.sfast_hip_conv2d_workspace_bytes(C.byref(p))
     assert nb > 0 and nb % (128 * 1280 * 4) == 0
-    # a 64x64-level conv has thousands of tiles: no split, no workspace
+    # the workspace query and the plan query agree: bytes = splits * M * N * 4 (0 when unsplit)
     p.H = p.W = 64
     p.Cin = p.C1 = p.Cout = 320
+    o = (C.c_int32 * 5)()
+    assert lib.sfast_hip_igemm_plan(2 * 64 * 64, 320, 9 * 320, 0, 0, 0, C.byref(o)) == 0
+    splits = o[2]
+    want = 0 if splits == 1 else splits * (2 * 64 * 64) * 320 * 4
+    assert lib.sfast_hip_conv2d_workspace_bytes(C.byref(p)) == want
+    # forcing the register pipe without split needs none
+    p.variant, p.split_k = 1, 1
     assert lib.sfast_hip_conv2d_workspace_bytes(C.byref(p)) == 0
+    p.variant, p.split_k = 0, 0
     g = L.GnParams(L.F16, L.NHWC, 2, 320, 4096, 32, 320, L.ACT_SILU, 1e-5)
     assert lib.sfast_hip_group_norm_workspace_bytes(C.byref(g)) > 0
 

@@ -10,6 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "stable-fast_amd"))
 
+os.environ.setdefault("SFAST_AUTOTUNE", "0")
 import torch  # noqa: E402
 
 from sfast.engine import UNet2DEngine  # noqa: E402
