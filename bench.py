@@ -83,8 +83,14 @@ def roofline_from(rows):
         k["bytes"] += r["bytes"]
         k["launches"] += 1
         k["kinds"].add(r["kind"])
-    dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["seconds"])
     total = sum(v["seconds"] for v in by_kernel.values())
+    # dominant = the kernel variant with the largest time share inside the dominant op family of the step
+    fam_time = {}
+    for r in rows:
+        fam_time[r["kind"]] = fam_time.get(r["kind"], 0.0) + r["seconds"]
+    dom_family = max(fam_time.items(), key=lambda kv: kv[1])[0]
+    in_family = {r["kernel"] for r in rows if r["kind"] == dom_family}
+    dom_name, dom = max(((k, v) for k, v in by_kernel.items() if k in in_family), key=lambda kv: kv[1]["seconds"])
     mfma = dom["flops"] > 0 and (dom["flops"] / MFMA_PEAK_TFLOPS / 1e12) > (dom["bytes"] / HBM_PEAK_GBS / 1e9)
     if mfma:
         achieved = dom["flops"] / dom["seconds"] / 1e12
@@ -92,8 +98,10 @@ def roofline_from(rows):
     else:
         achieved = dom["bytes"] / dom["seconds"] / 1e9
         roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS)
-    roof.update(kernel=dom_name, launches_per_step=dom["launches"], avg_launch_us=dom["seconds"] / dom["launches"] * 1e6,
-                share_of_step=dom["seconds"] / total, traffic=None)
+    roof.update(kernel=dom_name, family=dom_family, family_share_of_step=fam_time[dom_family] / total,
+                launches_per_step=dom["launches"], avg_launch_us=dom["seconds"] / dom["launches"] * 1e6,
+                share_of_step=dom["seconds"] / total, algorithmic_gflop_per_launch=dom["flops"] / dom["launches"] / 1e9,
+                algorithmic_mbytes_per_launch=dom["bytes"] / dom["launches"] / 1e6, traffic=None)
     fam = {}
     for r in rows:
         f = fam.setdefault(r["kind"], dict(seconds=0.0, flops=0.0, bytes=0.0, launches=0))

@@ -42,25 +42,30 @@ __device__ __forceinline__ f32x16 amfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+template <int D> struct AttnGeom {
+    static constexpr int DP = (D + 15) / 16 * 16;  // QK^T contraction length (zero padded)
+    static constexpr int DO = (D + 31) / 32 * 32;  // padded output width
+    static constexpr int KSTR = DP + 8;            // K tile row stride (halves): odd number of 16-B slots
+    static constexpr int VSTR = 68;                // V^T tile row stride (halves): 136 B
+    static constexpr int STAGE = 64 * KSTR * 2 + DO * VSTR * 2;
+    static constexpr int LDS = 2 * STAGE;          // double-buffered K / V^T tiles
+};
+
 template <typename T, int D, int NW>
 __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
     using vec8 = typename Elem<T>::vec8;
+    using G = AttnGeom<D>;
     constexpr int NT = NW * 64;
-    constexpr int DP = (D + 15) / 16 * 16;  // QK^T contraction length (zero padded)
-    constexpr int KD = DP / 16;             // MFMA k-steps over d
-    constexpr int DO = (D + 31) / 32 * 32;  // padded output width
-    constexpr int DB = DO / 32;             // 32-row blocks of O^T
-    constexpr int KSTR = DP + 8;            // K tile row stride (halves): odd number of 16-B slots
-    constexpr int VSTR = 68;                // V^T tile row stride (halves): 136 B
-    constexpr int KCH = DP / 8;             // 16-B chunks per K row (incl. zero padding)
-    constexpr int VCH = D / 8;              // 16-B chunks per V row
+    constexpr int DP = G::DP, DO = G::DO, KSTR = G::KSTR, VSTR = G::VSTR, STAGE = G::STAGE;
+    constexpr int KD = DP / 16;   // MFMA k-steps over d
+    constexpr int DB = DO / 32;   // 32-row blocks of O^T
+    constexpr int KCH = DP / 8;   // 16-B chunks per K row (incl. zero padding)
+    constexpr int VCH = D / 8;    // 16-B chunks per V row
     constexpr int KTASK = (64 * KCH + NT - 1) / NT;
     constexpr int VTASK = (32 * VCH + NT - 1) / NT;
     static_assert(D % 8 == 0, "head dim must be a multiple of 8");
 
-    __shared__ __attribute__((aligned(16))) char smem[64 * KSTR * 2 + DO * VSTR * 2];
-    char *Ksm = smem;
-    char *Vsm = smem + 64 * KSTR * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -72,35 +77,30 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
     const T *Kp = (const T *)a.k + (int64_t)b * a.ks[0] + (int64_t)h * a.ks[2];
     const T *Vp = (const T *)a.v + (int64_t)b * a.vs[0] + (int64_t)h * a.vs[2];
 
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-
-    // zero the V^T rows that pad D up to DO (never written by the tile loads)
-    for (int i = tid; i < (DO - D) * (VSTR / 2); i += NT) {
-        reinterpret_cast<uint32_t *>(Vsm + D * VSTR * 2)[i] = 0u;
+    // zero the V^T rows that pad D up to DO in both stages (never written by the tile loads)
+    for (int i = tid; i < 2 * (DO - D) * (VSTR / 2); i += NT) {
+        const int st = i / ((DO - D) * (VSTR / 2) > 0 ? (DO - D) * (VSTR / 2) : 1);
+        const int j = i - st * ((DO - D) * (VSTR / 2));
+        reinterpret_cast<uint32_t *>(smem + st * STAGE + 64 * KSTR * 2 + D * VSTR * 2)[j] = 0u;
     }
 
     // ---- Q fragments (B operand), kept in registers for the whole kernel -------------------------
+    typedef const u32x4 __attribute__((address_space(1))) * gvec_ptr;
+    auto ldg16 = [&](const T *p, bool ok) -> u32x4 {
+        // unconditional load; out-of-range chunks read the device zero block (see igemm.hip)
+        const gvec_ptr q = ok ? (gvec_ptr)(const void *)p : (gvec_ptr)(const void *)g_zero16;
+        return *q;
+    };
     vec8 qf[KD];
 #pragma unroll
     for (int kd = 0; kd < KD; ++kd) {
         const int d0 = kd * 16 + hi * 8;
-        typedef const u32x4 __attribute__((address_space(1))) * gq_ptr;
-        const bool okq = d0 < D && qrow < a.Sq;
-        const gq_ptr qq = okq ? (gq_ptr)(const void *)(Qp + (int64_t)qrow * a.qs[1] + d0) : (gq_ptr)(const void *)g_zero16;
-        qf[kd] = __builtin_bit_cast(vec8, *qq);
+        qf[kd] = __builtin_bit_cast(vec8, ldg16(Qp + (int64_t)qrow * a.qs[1] + d0, d0 < D && qrow < a.Sq));
     }
 
     u32x4 kreg[KTASK];
     u32x4 vreg[VTASK][2];
 
-    // unconditional loads (see igemm.hip): out-of-range chunks read a 16-byte zero block through a
-    // global-address-space pointer select, so no load sits behind an exec-masked branch or a
-    // flat_load and the prefetch stays in flight across the MFMAs of the current tile.
-    typedef const u32x4 __attribute__((address_space(1))) * gvec_ptr;
-    auto ldg16 = [&](const T *p, bool ok) -> u32x4 {
-        const gvec_ptr q = ok ? (gvec_ptr)(const void *)p : (gvec_ptr)(const void *)g_zero16;
-        return *q;
-    };
     auto prefetch = [&](int kt) {
         const int key0 = kt * 64;
 #pragma unroll
@@ -120,7 +120,9 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
             vreg[i][1] = ldg16(Vp + (int64_t)(key + 1) * a.vs[1] + ch * 8, in && key + 1 < a.Skv);
         }
     };
-    auto stage = [&]() {
+    auto stage = [&](int st) {
+        char *Ksm = smem + st * STAGE;
+        char *Vsm = Ksm + 64 * KSTR * 2;
 #pragma unroll
         for (int i = 0; i < KTASK; ++i) {
             const int id = tid + i * NT;
@@ -148,15 +150,20 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
     for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    // running max is tracked on the RAW scores; the softmax scale (> 0) is folded into the exp2 argument
     float m_run = -INFINITY, l_run = 0.f;
+    const float c = a.scale_log2e;
 
     const int ntiles = (a.Skv + 63) / 64;
     prefetch(0);
-    stage();
+    stage(0);
     __syncthreads();
 
     for (int kt = 0; kt < ntiles; ++kt) {
         const bool more = kt + 1 < ntiles;
+        const int cur = kt & 1;
+        const char *Ksm = smem + cur * STAGE;
+        const char *Vsm = Ksm + 64 * KSTR * 2;
         if (more) prefetch(kt + 1);
 
         // ---- S^T = K . Q^T  (two 32-key blocks) ----------------------------------------------------
@@ -173,40 +180,44 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
         }
 
         // ---- online softmax (fp32, base-2) -------------------------------------------------------------
-        const bool tail = (kt + 1) * 64 > a.Skv;
+        if ((kt + 1) * 64 > a.Skv) {  // tail tile: mask keys >= Skv
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= a.Skv) s[kb][r] = -INFINITY;
+                }
+        }
         float mloc = -INFINITY;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float sv = s[kb][r] * a.scale_log2e;
-                if (tail) {
-                    const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key >= a.Skv) sv = -INFINITY;
-                }
-                s[kb][r] = sv;
-                mloc = fmaxf(mloc, sv);
-            }
-        }
+            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[kb][r]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        // exact lazy rescale: O and l only need rescaling when some row's running max actually grows
+        if (__any(mloc > m_run)) {
+            const float m_new = fmaxf(m_run, mloc);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
+        const float mc = m_run * c;
         float rowsum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, -mc));
                 s[kb][r] = p;
                 rowsum += p;
             }
         }
-        l_run = l_run * alpha + rowsum;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        l_run += rowsum;
 
         // ---- P^T fragments: registers [8*s2, 8*s2+8) of block kb, converted in place -----------------
         vec8 pf[2][2];
@@ -234,8 +245,8 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
             }
         }
 
-        __syncthreads();
-        if (more) stage();
+        // stage tile kt+1 into the OTHER buffer (last read in iteration kt-1, before the previous barrier)
+        if (more) stage(cur ^ 1);
         __syncthreads();
     }
 
@@ -294,15 +305,40 @@ __global__ void __launch_bounds__(64) attn_naive_kernel(const AttnArgs a) {
     }
 }
 
-int attention_init() { return 0; }
+template <typename T, int D, int NW> static int attn_set_attr() {
+    auto kern = attn_fwd_kernel<T, D, NW>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       AttnGeom<D>::LDS);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(attn D=%d): %s", D, hipGetErrorString(e));
+        return SFAST_ERR_LAUNCH;
+    }
+    return 0;
+}
+
+template <typename T> static int attn_init_t() {
+    int rc = 0;
+#define A_INIT(D)                                  \
+    if (!rc) rc = attn_set_attr<T, D, 2>();        \
+    if (!rc) rc = attn_set_attr<T, D, 4>();
+    A_INIT(40) A_INIT(64) A_INIT(80) A_INIT(128) A_INIT(160)
+#undef A_INIT
+    return rc;
+}
+
+int attention_init() {
+    int rc = attn_init_t<f16>();
+    if (!rc) rc = attn_init_t<bf16>();
+    return rc;
+}
 
 template <typename T, int D>
 static int attn_launch_d(const AttnArgs &a, int nw, hipStream_t st) {
     const dim3 grid(ceil_div(a.Sq, nw * 32), a.H, a.B);
     if (nw == 2)
-        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2>), grid, dim3(128), 0, st, a);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2>), grid, dim3(128), AttnGeom<D>::LDS, st, a);
     else
-        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4>), grid, dim3(256), AttnGeom<D>::LDS, st, a);
     return check_launch("attention");
 }
 
@@ -351,7 +387,7 @@ extern "C" int sfast_hip_attention(const void *q, const void *k, const void *v, 
     bool vec = half && d_ok && aligned16(q) && aligned16(k) && aligned16(v) && aligned8(out);
     for (int i = 0; i < 3; ++i)
         vec = vec && p->qs[i] % 8 == 0 && p->ks[i] % 8 == 0 && p->vs[i] % 8 == 0 && p->os[i] % 4 == 0;
-    if (vec && p->variant != 100) {
+    if (vec && p->variant != 100 && p->scale > 0.f) {
         int nw = 4;
         const int64_t blocks4 = (int64_t)ceil_div(p->Sq, 128) * p->H * p->B;
         if (blocks4 < 256) nw = 2;

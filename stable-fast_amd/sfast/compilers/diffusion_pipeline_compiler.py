@@ -120,7 +120,7 @@ class _NativeUNetForward:
             with env.lock:
                 with torch.cuda.device(eng.device), torch.cuda.stream(env.stream):
                     with torch.cuda.graph(graph, pool=env.mempool, stream=env.stream):
-                        plan.run(torch.cuda.current_stream(eng.device).cuda_stream)
+                        plan.run_forked(torch.cuda.current_stream(eng.device))
         return plan, graph, env
 
     def __call__(self, sample, timestep, encoder_hidden_states=None, class_labels=None, timestep_cond=None,

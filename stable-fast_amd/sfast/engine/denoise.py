@@ -60,8 +60,11 @@ class DenoiseLoop:
         si["sample"][self.images:].copy_(latents)
         si["encoder_hidden_states"].copy_(ehs_uncond_cond)
 
-    def _launch_all(self, stream):
-        self.plan.run(stream)
+    def _launch_all(self, stream, forked=False):
+        if forked:
+            self.plan.run_forked(torch.cuda.current_stream(self.engine.device))
+        else:
+            self.plan.run(stream)
         rc = self.lib.sfast_hip_cfg_ddim_step(self.plan.static_out.data_ptr(), self.latents.data_ptr(), self.latents.data_ptr(),
                                              self.plan.static_in["sample"].data_ptr(), self.coef.data_ptr(),
                                              C.c_float(self.guidance), self.latents.numel(), self.engine.dt, stream)
@@ -83,7 +86,7 @@ class DenoiseLoop:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.stream(side):
                 with torch.cuda.graph(self.graph, stream=side):
-                    self._launch_all(torch.cuda.current_stream(dev).cuda_stream)
+                    self._launch_all(torch.cuda.current_stream(dev).cuda_stream, forked=True)
             torch.cuda.synchronize(dev)
         self.latents.copy_(keep_lat)
         self.plan.static_in["sample"].copy_(keep_in)

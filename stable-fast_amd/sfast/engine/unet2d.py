@@ -74,12 +74,17 @@ class _Pool:
         return sum(t.numel() * t.element_size() for t in self.all)
 
 
-class OpRecord:
-    __slots__ = ("kind", "name", "flops", "bytes", "kernel", "launch", "tune")
+LANE_MAIN, LANE_TEMB, LANE_KV = 0, 1, 2
 
-    def __init__(self, kind, name, flops, nbytes, kernel, launch, tune=None):
+
+class OpRecord:
+    __slots__ = ("kind", "name", "flops", "bytes", "kernel", "launch", "tune", "lane", "needs")
+
+    def __init__(self, kind, name, flops, nbytes, kernel, launch, tune=None, lane=LANE_MAIN, needs=None):
         self.kind, self.name, self.flops, self.bytes, self.kernel, self.launch = kind, name, flops, nbytes, kernel, launch
         self.tune = tune  # (params struct, launch_with(stream, ws_ptr, ws_bytes)) for tools/tune_igemm.py
+        self.lane = lane  # ops that depend only on (timestep | text context) form side lanes of the graph
+        self.needs = needs  # LANE_TEMB / LANE_KV: first consumer of a side lane's results joins it
 
 
 class UNetPlan:
@@ -89,7 +94,9 @@ class UNetPlan:
         self.engine = engine
         self.B, self.H, self.W, self.S_ctx = B, H, W, S_ctx
         self.ops = []
-        self.ws = [None, 0]  # shared workspace [tensor, nbytes]; ops run serially on one stream
+        self.ws = [None, 0]  # shared workspace [tensor, nbytes]; main-lane ops run serially on one stream
+        self.ws_side = [None, 0]  # workspace of the side lanes (they may overlap main-lane kernels)
+        self.side_stream = None
         self.graph = None
         self.static_in = {}
         self.static_out = None
@@ -97,8 +104,40 @@ class UNetPlan:
         self.keep = []  # ctypes objects / tensors that must outlive the launches
 
     def run(self, stream_ptr):
+        """Serial execution in program order on one stream (eager mode, tuning, per-op timing)."""
         for op in self.ops:
             op.launch(stream_ptr)
+
+    def run_forked(self, main):
+        """Execution for hipGraph capture: the time-embedding chain (depends only on t) and the cross-attention
+        K/V projections (depend only on the text context) run on a side stream and become parallel branches of the
+        captured graph; the main chain joins them at their first consumer. `main` is a torch.cuda.Stream."""
+        side = self.side_stream
+        if side is None or not any(op.lane != LANE_MAIN for op in self.ops):
+            return self.run(main.cuda_stream)
+        side.wait_stream(main)
+        events = {}
+        with torch.cuda.stream(side):
+            sp = side.cuda_stream
+            for lane in (LANE_TEMB, LANE_KV):
+                for op in self.ops:
+                    if op.lane == lane:
+                        op.launch(sp)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                events[lane] = ev
+        mp = main.cuda_stream
+        joined = set()
+        for op in self.ops:
+            if op.lane != LANE_MAIN:
+                continue
+            if op.needs is not None and op.needs not in joined:
+                for lane in (LANE_TEMB, LANE_KV):  # joining KV implies the earlier temb work too
+                    if lane <= op.needs and lane not in joined:
+                        main.wait_event(events[lane])
+                        joined.add(lane)
+            op.launch(mp)
+        main.wait_stream(side)
 
     def summary(self):
         agg = defaultdict(lambda: [0, 0.0, 0.0])
@@ -209,12 +248,13 @@ class UNet2DEngine:
     # ------------------------------------------------------------------------------------------
     # plan construction helpers
     # ------------------------------------------------------------------------------------------
-    def _add(self, plan, kind, name, flops, nbytes, launch, tune=None):
-        plan.ops.append(OpRecord(kind, name, flops, nbytes, None, launch, tune))
+    def _add(self, plan, kind, name, flops, nbytes, launch, tune=None, lane=LANE_MAIN, needs=None):
+        plan.ops.append(OpRecord(kind, name, flops, nbytes, None, launch, tune, lane, needs))
 
-    def _need_ws(self, plan, nbytes):
-        if nbytes > plan.ws[1]:
-            plan.ws[1] = int(nbytes)
+    def _need_ws(self, plan, nbytes, lane=LANE_MAIN):
+        holder = plan.ws if lane == LANE_MAIN else plan.ws_side
+        if nbytes > holder[1]:
+            holder[1] = int(nbytes)
 
     def _op_gn(self, plan, name, x, x2, C1, Ctot, N, HW, y, eps, silu, prefix):
         lib = self.lib
@@ -243,7 +283,7 @@ class UNet2DEngine:
         self._add(plan, "ln", name, 0.0, (2.0 * M * N + 2 * N) * self.esize, launch)
 
     def _op_gemm(self, plan, name, x, weights, bias, out, M, N, K, ldx, ldo, *, residual=None, ldr=0, act=L.ACT_NONE,
-                 geglu=False, res_before_act=False, out_offset=0, kind=None):
+                 geglu=False, res_before_act=False, out_offset=0, kind=None, lane=LANE_MAIN):
         lib = self.lib
         p = L.GemmParams()
         p.dtype, p.M, p.N, p.K = self.dt, M, N, K
@@ -253,13 +293,13 @@ class UNet2DEngine:
         p.n_wseg, p.rows_per_seg = len(weights), w0.shape[0]
         p.geglu, p.act, p.res_before_act, p.alpha = int(geglu), act, int(res_before_act), 1.0
         p.rows_per_batch, p.ld_rowbias, p.in_act, p.variant, p.split_k = 0, 0, 0, 0, 0
-        self._need_ws(plan, lib.sfast_hip_gemm_workspace_bytes(C.byref(p)))
+        self._need_ws(plan, lib.sfast_hip_gemm_workspace_bytes(C.byref(p)), lane)
         segs = (C.c_void_p * len(weights))(*[w.data_ptr() for w in weights])
         xp = x.data_ptr()
         bp = bias.data_ptr() if bias is not None else None
         rp = residual.data_ptr() if residual is not None else None
         op = out.data_ptr() + out_offset * self.esize
-        ws = plan.ws
+        ws = plan.ws if lane == LANE_MAIN else plan.ws_side
         plan.keep += [p, segs]
 
         def launch(stream, p=p, segs=segs):
@@ -272,7 +312,7 @@ class UNet2DEngine:
         flops = 2.0 * M * wrows * K
         nbytes = (M * K + wrows * K + wrows + M * N + (M * N if residual is not None else 0)) * self.esize
         self._add(plan, kind or ("geglu" if geglu else ("gemv" if M <= 16 else "linear")), name, flops, nbytes, launch,
-                  tune=(p, launch_with))
+                  tune=(p, launch_with), lane=lane)
 
     def _op_conv(self, plan, name, x, x2, w, bias, out, B, H, W, C1, C2, Cout, k, stride, pad, *, ups=False, rowbias=None,
                  ld_rowbias=0, rowbias_offset=0, z=None, xs=None, os_=None, kind=None):
@@ -314,7 +354,8 @@ class UNet2DEngine:
         M = B * Ho * Wo
         flops = 2.0 * M * Cout * Cin * k * k
         nbytes = (B * H * W * Cin + Cout * Cin * k * k + Cout + M * Cout + (M * Cout if z is not None else 0)) * self.esize
-        self._add(plan, kind or ("conv3x3" if k == 3 else "conv1x1"), name, flops, nbytes, launch, tune=(p, launch_with))
+        self._add(plan, kind or ("conv3x3" if k == 3 else "conv1x1"), name, flops, nbytes, launch, tune=(p, launch_with),
+                  needs=LANE_TEMB if rowbias is not None else None)
         return Ho, Wo
 
     def _op_attn(self, plan, name, q, k, v, out, B, Hh, Sq, Skv, D, qs, ks, vs, os_, q_off=0, k_off=0, v_off=0):
@@ -338,7 +379,8 @@ class UNet2DEngine:
 
         flops = 4.0 * B * Hh * Sq * Skv * D
         nbytes = (2.0 * B * Sq * Hh * D + 2.0 * B * Skv * Hh * D) * self.esize
-        self._add(plan, "attn_self" if Sq == Skv and q is k else "attn_cross", name, flops, nbytes, launch)
+        cross = not (Sq == Skv and q is k)
+        self._add(plan, "attn_cross" if cross else "attn_self", name, flops, nbytes, launch, needs=LANE_KV if cross else None)
 
     # ------------------------------------------------------------------------------------------
     # network pieces
@@ -408,14 +450,16 @@ class UNet2DEngine:
             self._op_ln(plan, bp + ".norm2", t, n, M, Cc, bp + ".norm2")
             q = pool.get(M * Cc)
             self._op_gemm(plan, bp + ".attn2.to_q", n, [P[bp + ".attn2.to_q.weight"]], None, q, M, Cc, Cc, Cc, Cc)
-            kv = pool.get(B * S_ctx * 2 * Cc)
+            # K/V of the text context depend on nothing inside the UNet: dedicated buffer (never recycled) so the
+            # projection can be hoisted onto the side lane of the graph
+            kv = torch.empty(B * S_ctx * 2 * Cc, dtype=self.dtype, device=self.device)
+            plan.keep.append(kv)
             self._op_gemm(plan, bp + ".attn2.to_kv", ctx, [P[bp + ".attn2.to_k.weight"], P[bp + ".attn2.to_v.weight"]], None, kv,
-                          B * S_ctx, 2 * Cc, self.ctx_dim, self.ctx_dim, 2 * Cc)
+                          B * S_ctx, 2 * Cc, self.ctx_dim, self.ctx_dim, 2 * Cc, lane=LANE_KV)
             skv = (S_ctx * 2 * Cc, 2 * Cc, D)
             self._op_attn(plan, bp + ".attn2", q, kv, kv, a, B, heads, S, S_ctx, D, (S * Cc, Cc, D), skv, skv, (S * Cc, Cc, D),
                           k_off=0, v_off=Cc)
             pool.put(q)
-            pool.put(kv)
             self._op_gemm(plan, bp + ".attn2.to_out", a, [P[bp + ".attn2.to_out.0.weight"]], P[bp + ".attn2.to_out.0.bias"], t,
                           M, Cc, Cc, Cc, Cc, residual=t, ldr=Cc)
             pool.put(a)
@@ -472,10 +516,11 @@ class UNet2DEngine:
         plan.keep.append(tp)
         tb_ptr, te_ptr = tbuf.data_ptr(), t_emb.data_ptr()
         self._add(plan, "misc", "timestep_embedding", 0.0, B * c0 * 2.0,
-                  lambda s, tp=tp: L.check(lib.sfast_hip_timestep_embedding(tb_ptr, te_ptr, C.byref(tp), s), "timestep_embedding"))
+                  lambda s, tp=tp: L.check(lib.sfast_hip_timestep_embedding(tb_ptr, te_ptr, C.byref(tp), s), "timestep_embedding"),
+                  lane=LANE_TEMB)
         e1 = pool.get(B * T)
         self._op_gemm(plan, "time_embedding.linear_1", t_emb, [P["time_embedding.linear_1.weight"]], P["time_embedding.linear_1.bias"],
-                      e1, B, T, c0, c0, T, act=L.ACT_SILU, kind="temb")
+                      e1, B, T, c0, c0, T, act=L.ACT_SILU, kind="temb", lane=LANE_TEMB)
         act_emb = pool.get(B * T)
         if self.add_type == "text_time":
             Din = P["add_embedding.linear_1.weight"].shape[1]
@@ -489,7 +534,8 @@ class UNet2DEngine:
             plan.keep.append(tp2)
             ti_ptr, tide_ptr = time_ids.data_ptr(), tide.data_ptr()
             self._add(plan, "misc", "add_time_ids_embedding", 0.0, B * 6 * td * 2.0,
-                      lambda s, tp2=tp2: L.check(lib.sfast_hip_timestep_embedding(ti_ptr, tide_ptr, C.byref(tp2), s), "time_ids"))
+                      lambda s, tp2=tp2: L.check(lib.sfast_hip_timestep_embedding(ti_ptr, tide_ptr, C.byref(tp2), s), "time_ids"),
+                      lane=LANE_TEMB)
             add_in = pool.get(B * Din)
             ntext = Din - 6 * td
 
@@ -501,22 +547,23 @@ class UNet2DEngine:
                 cp.dst_strides = (C.c_int64 * 4)(dst_ld, 1, 0, 0)
                 plan.keep.append(cp)
                 self._add(plan, "misc", name, 0.0, rows * cols * 4.0,
-                          lambda s, cp=cp: L.check(lib.sfast_hip_strided_copy(src_ptr, dst_ptr, C.byref(cp), s), name))
+                          lambda s, cp=cp: L.check(lib.sfast_hip_strided_copy(src_ptr, dst_ptr, C.byref(cp), s), name),
+                          lane=LANE_TEMB)
 
             copy2d("add_in.text", text_embeds.data_ptr(), B, ntext, ntext, add_in.data_ptr(), Din)
             copy2d("add_in.time", tide.data_ptr(), B, 6 * td, 6 * td, add_in.data_ptr() + ntext * 2, Din)
             a1 = pool.get(B * T)
             self._op_gemm(plan, "add_embedding.linear_1", add_in, [P["add_embedding.linear_1.weight"]], P["add_embedding.linear_1.bias"],
-                          a1, B, T, Din, Din, T, act=L.ACT_SILU, kind="temb")
+                          a1, B, T, Din, Din, T, act=L.ACT_SILU, kind="temb", lane=LANE_TEMB)
             aug = pool.get(B * T)
             self._op_gemm(plan, "add_embedding.linear_2", a1, [P["add_embedding.linear_2.weight"]], P["add_embedding.linear_2.bias"],
-                          aug, B, T, T, T, T, kind="temb")
+                          aug, B, T, T, T, T, kind="temb", lane=LANE_TEMB)
             self._op_gemm(plan, "time_embedding.linear_2", e1, [P["time_embedding.linear_2.weight"]], P["time_embedding.linear_2.bias"],
-                          act_emb, B, T, T, T, T, act=L.ACT_SILU, residual=aug, ldr=T, res_before_act=True, kind="temb")
+                          act_emb, B, T, T, T, T, act=L.ACT_SILU, residual=aug, ldr=T, res_before_act=True, kind="temb", lane=LANE_TEMB)
         else:
             # act_emb = silu(emb): the embedding is only ever consumed through SiLU (ResnetBlock2D)
             self._op_gemm(plan, "time_embedding.linear_2", e1, [P["time_embedding.linear_2.weight"]], P["time_embedding.linear_2.bias"],
-                          act_emb, B, T, T, T, T, act=L.ACT_SILU, kind="temb")
+                          act_emb, B, T, T, T, T, act=L.ACT_SILU, kind="temb", lane=LANE_TEMB)
         # every resnet's time_emb_proj depends only on t: hoisted to the top of the graph
         rnames = self._resnet_names()
         offs, tot = {}, 0
@@ -527,7 +574,7 @@ class UNet2DEngine:
         for rn in rnames:
             w = P[rn + ".time_emb_proj.weight"]
             self._op_gemm(plan, rn + ".time_emb_proj", act_emb, [w], P[rn + ".time_emb_proj.bias"], temb_all, B, w.shape[0], T, T, tot,
-                          out_offset=offs[rn], kind="temb")
+                          out_offset=offs[rn], kind="temb", lane=LANE_TEMB)
 
         # ---- conv_in (reads the NCHW sample through strides, writes NHWC) -----------------------
         h = pool.get(B * H * W * c0)
@@ -605,9 +652,13 @@ class UNet2DEngine:
                 if op.tune is not None:
                     p = op.tune[0]
                     q = lib.sfast_hip_gemm_workspace_bytes if isinstance(p, L.GemmParams) else lib.sfast_hip_conv2d_workspace_bytes
-                    self._need_ws(plan, q(C.byref(p)))
+                    self._need_ws(plan, q(C.byref(p)), op.lane)
         if plan.ws[1]:
             plan.ws[0] = torch.empty(plan.ws[1], dtype=torch.uint8, device=dev)
+        if plan.ws_side[1]:
+            plan.ws_side[0] = torch.empty(plan.ws_side[1], dtype=torch.uint8, device=dev)
+        if not self._emulated:
+            plan.side_stream = torch.cuda.Stream(device=dev)
         return plan
 
     # ------------------------------------------------------------------------------------------

@@ -112,6 +112,20 @@ def test_sd15_unet_parity_and_graph(sd15):
     torch.cuda.synchronize()
     assert torch.equal(r1, r2) and torch.equal(r1, y)
 
+    # forked capture (time-embedding chain and text K/V projections as parallel graph branches) computes the same
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g2, stream=s):
+            plan.run_forked(torch.cuda.current_stream())
+    torch.cuda.current_stream().wait_stream(s)
+    plan.static_out.zero_()
+    g2.replay()
+    r3 = plan.static_out.clone()
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(r3, y) and torch.equal(plan.static_out, y)
+    assert sum(op.lane != 0 for op in plan.ops) == 24 + 1 + 16  # temb MLP + 22 projections + sinusoid, 16 text K/V GEMMs
+
     # batch independence: every op is per-sample, so B=1 must reproduce row 0 of the B=2 run
     y1 = eng.forward(sample[:1], 981, ehs[:1])
     e_b = rel_l2(y1, y[:1])
