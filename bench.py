@@ -151,7 +151,8 @@ def main():
         raise SystemExit("bench.py needs a ROCm GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ  # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -184,7 +185,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -199,7 +200,7 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -221,7 +222,7 @@ def main():
                        "images_per_gpu": args.images, "unet_batch": 2 * args.images, "latent": [4, hw, hw], "parallelism": f"replicas x{world}"},
             "gpu_ms_per_step_events": gpu_ms / args.steps, "outputs_finite": finite,
             "reference_published_other_hw": {"H100": 104.6, "A100": 61.8, "RTX4080": 51.6, "source": "BASELINE.md section 1 (stable-fast README)"},
-            "kernel_launches_per_step": len(loop.plan.ops) + 1,
+            "kernel_launches_per_step": len(loop.plan.ops) + 1, "graph_side_lanes": bool(getattr(loop, "graph_forked", False)),
             "activation_pool_mb": loop.plan.pool.total_bytes() / 1e6,
         }
         if world > 1:
@@ -239,7 +240,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.config, args.images)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -116,11 +116,11 @@ class _NativeUNetForward:
                 plan.run(torch.cuda.current_stream(eng.device).cuda_stream)
         torch.cuda.synchronize(eng.device)
         if self.enable_graph:
-            graph = torch.cuda.CUDAGraph()
+            from ..engine import capture_plan_graph
             with env.lock:
-                with torch.cuda.device(eng.device), torch.cuda.stream(env.stream):
-                    with torch.cuda.graph(graph, pool=env.mempool, stream=env.stream):
-                        plan.run_forked(torch.cuda.current_stream(eng.device))
+                with torch.cuda.device(eng.device):
+                    graph, _ = capture_plan_graph(plan, env.stream, pool=env.mempool)
+                torch.cuda.synchronize(eng.device)
         return plan, graph, env
 
     def __call__(self, sample, timestep, encoder_hidden_states=None, class_labels=None, timestep_cond=None,

@@ -1,2 +1,2 @@
 """sfast.engine -- static-plan executors for the hot path (UNet forward)."""
-from .unet2d import UNet2DEngine, UNetPlan, UnsupportedUNet  # noqa: F401
+from .unet2d import UNet2DEngine, UNetPlan, UnsupportedUNet, capture_plan_graph  # noqa: F401

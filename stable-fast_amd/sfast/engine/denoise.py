@@ -50,7 +50,7 @@ class DenoiseLoop:
         self.latents = torch.zeros((images, engine.in_ch, height, width), dtype=dt, device=dev)
         self.use_graph = use_graph
         self.graph = None
-        self._stream = None
+        self.graph_forked = False
 
     def set_inputs(self, latents, ehs_uncond_cond):
         """latents [images,4,H,W]; ehs_uncond_cond [2*images, ctx, dim] ordered [uncond..., cond...]."""
@@ -60,15 +60,15 @@ class DenoiseLoop:
         si["sample"][self.images:].copy_(latents)
         si["encoder_hidden_states"].copy_(ehs_uncond_cond)
 
-    def _launch_all(self, stream, forked=False):
-        if forked:
-            self.plan.run_forked(torch.cuda.current_stream(self.engine.device))
-        else:
-            self.plan.run(stream)
+    def _tail(self, stream):
         rc = self.lib.sfast_hip_cfg_ddim_step(self.plan.static_out.data_ptr(), self.latents.data_ptr(), self.latents.data_ptr(),
                                              self.plan.static_in["sample"].data_ptr(), self.coef.data_ptr(),
                                              C.c_float(self.guidance), self.latents.numel(), self.engine.dt, stream)
         L.check(rc, "sfast_hip_cfg_ddim_step")
+
+    def _launch_all(self, stream):
+        self.plan.run(stream)
+        self._tail(stream)
 
     def capture(self, warmups=3):
         dev = self.engine.device
@@ -83,10 +83,8 @@ class DenoiseLoop:
                 self._launch_all(side.cuda_stream)
         torch.cuda.synchronize(dev)
         if self.use_graph:
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.stream(side):
-                with torch.cuda.graph(self.graph, stream=side):
-                    self._launch_all(torch.cuda.current_stream(dev).cuda_stream, forked=True)
+            from .unet2d import capture_plan_graph
+            self.graph, self.graph_forked = capture_plan_graph(self.plan, side, tail=self._tail)
             torch.cuda.synchronize(dev)
         self.latents.copy_(keep_lat)
         self.plan.static_in["sample"].copy_(keep_in)

@@ -39,13 +39,14 @@ def _buckets(params: Dict[str, torch.Tensor], bucket_bytes: int) -> List[List[st
     return out
 
 
-def broadcast_parameters(params: Dict[str, torch.Tensor], src: int = 0, bucket_bytes: int = 1 << 30, group=None) -> int:
+def broadcast_parameters(params: Dict[str, torch.Tensor], src: int = 0, bucket_bytes: int = 1 << 30, group=None,
+                         force: bool = False) -> int:
     """Broadcast rank `src`'s parameter values into every rank's (already allocated, same-shaped)
     parameter storage, in place. Parameters are packed into large flat buckets (default 1 GiB --
     sized for xGMI point-to-point links and 288 GB of HBM: SD1.5's 1.72 GB goes in two collectives)
     so the transfer is bandwidth- not latency-bound. In-place `copy_` keeps the pointers that captured
     hipGraphs hold valid. Returns the number of bytes broadcast."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return 0
     rank = dist.get_rank(group)
     total = 0

@@ -149,6 +149,54 @@ class UNetPlan:
         return {k: {"count": v[0], "gflop": v[1] / 1e9, "mbytes": v[2] / 1e6} for k, v in agg.items()}
 
 
+def capture_plan_graph(plan, stream, pool=None, tail=None, calibrate=True):
+    """Capture `plan` (+ an optional `tail(stream_ptr)` launch) into a hipGraph on `stream`.
+
+    Two graph shapes are possible: a single chain, or the chain with the time-embedding / text-K/V side lanes
+    forked into parallel branches (`UNetPlan.run_forked`). Which one replays faster depends on how much idle
+    capacity the main chain leaves, so both are captured and the faster one (median of a few replays) is kept --
+    the same measure-then-commit policy as the kernel autotuner."""
+    dev = plan.engine.device
+
+    def cap(forked):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(stream):
+            kw = {"pool": pool} if pool is not None else {}
+            with torch.cuda.graph(g, stream=stream, **kw):
+                cur = torch.cuda.current_stream(dev)
+                if forked:
+                    plan.run_forked(cur)
+                else:
+                    plan.run(cur.cuda_stream)
+                if tail is not None:
+                    tail(cur.cuda_stream)
+        return g
+
+    has_side = plan.side_stream is not None and any(op.lane != LANE_MAIN for op in plan.ops)
+    graphs = [(False, cap(False))]
+    if has_side:
+        graphs.append((True, cap(True)))
+    if len(graphs) == 1 or not calibrate:
+        return graphs[-1][1], graphs[-1][0]
+    best = None
+    with torch.cuda.stream(stream):
+        for forked, g in graphs:
+            g.replay()
+            g.replay()
+            ts = []
+            for _ in range(5):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                g.replay()
+                b.record(stream)
+                b.synchronize()
+                ts.append(a.elapsed_time(b))
+            t = sorted(ts)[2]
+            if best is None or t < best[0]:
+                best = (t, forked, g)
+    return best[2], best[1]
+
+
 class UNet2DEngine:
     """Executor for SD1.5 / SD2.x / SDXL-family `UNet2DConditionModel` parameter sets."""
 

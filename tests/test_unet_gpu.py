@@ -213,3 +213,23 @@ def test_live_weight_update_without_recapture():
     assert len(unet.forward._cached) == 1
     assert rel_l2(y0, want) > 1e-2  # the update really changed the function
     assert rel_l2(y1, want) < 4e-3
+
+
+def test_rccl_weight_broadcast_single_rank():
+    """The RCCL leg of the replica path (bucketed in-place broadcast) on the one GPU this box has."""
+    import torch.distributed as dist
+    from sfast.engine.replicas import broadcast_parameters
+    from sfast.engine.unet_spec import random_params
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        params = random_params(U.tiny_config(), seed=3, device=DEV)
+        ref = {k: v.clone() for k, v in params.items()}
+        ptrs = {k: v.data_ptr() for k, v in params.items()}
+        n = broadcast_parameters(params, src=0, bucket_bytes=1 << 20, force=True)
+        torch.cuda.synchronize()
+        assert n == sum(v.numel() * v.element_size() for v in params.values())
+        assert all(torch.equal(params[k], ref[k]) and params[k].data_ptr() == ptrs[k] for k in params)
+    finally:
+        dist.destroy_process_group()
