@@ -80,6 +80,9 @@ const char *sfast_hip_last_error(void);
 /* name of the kernel variant chosen by the most recent gemm / conv2d / attention call on this
  * thread (diagnostics, tests and bench roofline bookkeeping). */
 const char *sfast_hip_last_kernel(void);
+/* profiling ablations of the LDS-DMA GEMM pipe (bit0: skip the MFMA phase, bit1: skip in-loop refills);
+ * results are garbage while set. Returns the previous flags; 0 (default) = production behaviour. */
+int sfast_hip_set_debug(int flags);
 
 /* ---- GroupNorm (+SiLU) ------------------------------------------------------------------ */
 enum sfast_layout { SFAST_NHWC = 0, SFAST_NCHW = 1 };

@@ -237,11 +237,11 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_glds_kernel(const IgemmArgs
         }
         __builtin_amdgcn_s_barrier();
         if (issued < kt_end) {
-            issue(issued, istage);
+            if (!(a.dbg & 2)) issue(issued, istage);
             ++issued;
             istage = (istage + 1 == NS) ? 0 : istage + 1;
         }
-        compute(cstage);
+        if (!(a.dbg & 1)) compute(cstage);
         cstage = (cstage + 1 == NS) ? 0 : cstage + 1;
     }
 
@@ -288,6 +288,8 @@ int igemm_glds_init() {
     return rc;
 }
 
+int g_igemm_dbg = 0;  // set through sfast_hip_set_debug (profiling ablations only)
+
 int igemm_glds_stages(int BM, int BN, bool geglu) {
     if (geglu) return BM == 128 ? 4 : 5;
     if (BM == 128) return 4;
@@ -316,7 +318,9 @@ static int glds_dispatch(const IgemmArgs &a, int BM_, int BN_, bool geglu, hipSt
     return SFAST_ERR_UNSUPPORTED;
 }
 
-int igemm_glds_launch(const IgemmArgs &a, int dtype, int mode, bool geglu, int BM, int BN, hipStream_t st) {
+int igemm_glds_launch(const IgemmArgs &a_in, int dtype, int mode, bool geglu, int BM, int BN, hipStream_t st) {
+    IgemmArgs a = a_in;
+    a.dbg = g_igemm_dbg;
     if (dtype == SFAST_F16) return mode ? glds_dispatch<f16, 1>(a, BM, BN, geglu, st) : glds_dispatch<f16, 0>(a, BM, BN, geglu, st);
     return mode ? glds_dispatch<bf16, 1>(a, BM, BN, geglu, st) : glds_dispatch<bf16, 0>(a, BM, BN, geglu, st);
 }

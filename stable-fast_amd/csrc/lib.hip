@@ -28,6 +28,7 @@ int check_launch(const char *what) {
     return SFAST_OK;
 }
 
+extern int g_igemm_dbg;  // igemm_glds.hip
 int igemm_init();      // igemm.hip
 int attention_init();  // attention.hip
 
@@ -46,6 +47,12 @@ int sfast_hip_init(void) {
         done = 1;
     }
     return rc;
+}
+
+int sfast_hip_set_debug(int flags) {
+    const int prev = sfast::g_igemm_dbg;
+    sfast::g_igemm_dbg = flags;
+    return prev;
 }
 
 const char *sfast_hip_last_error(void) { return sfast::g_err; }
