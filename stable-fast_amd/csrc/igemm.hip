@@ -189,6 +189,12 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_kernel(const IgemmArgs a) {
             *reinterpret_cast<u32x4 *>(ws + lds_off(rbase + i * RPP, kc)) = wreg[i];
     };
 
+    // epilogue operands (bias / row-bias / residual) are requested now and consumed after the K loop when the
+    // tile shape leaves registers for them (the 5-fragment tiles would drop to one wave per SIMD)
+    constexpr bool EPI_EARLY = GEGLU || FN * FM <= 4;
+    EpiOperands<(EPI_EARLY ? (GEGLU ? FN / 2 : FN) : 1), (EPI_EARLY ? FM : 1)> epi;
+    if constexpr (EPI_EARLY) epilogue_prefetch<T, FN, FM, GEGLU>(a, epi, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi);
+
     f32x16 acc[FN][FM];
 #pragma unroll
     for (int fn = 0; fn < FN; ++fn)
@@ -233,7 +239,10 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_kernel(const IgemmArgs a) {
     }
 
     // ---- epilogue: batched operand loads, fp32 math, 8-byte stores (igemm_device.h) -------------------------
-    epilogue_tile<T, FN, FM, GEGLU>(a, acc, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi, blockIdx.y);
+    if constexpr (!EPI_EARLY)
+        epilogue_late<T, FN, FM>(a, acc, m0 + wm * (FM * 32), n0 + wn * WNB, l31, hi, blockIdx.y);
+    else
+        epilogue_finish<T, FN, FM, GEGLU>(a, acc, epi, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi, blockIdx.y);
 }
 
 // split-K reduce + epilogue: one thread per 4 consecutive output columns.
@@ -267,26 +276,24 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const IgemmArgs a) {
 // Two main-loop structures share the tile shapes: pipe 0 = register-staged double buffer (this
 // file), pipe 1 = LDS-DMA ring (igemm_glds.hip). Variant ids 1..5 select pipe 0, 11..15 pipe 1.
 struct Variant {
-    int id, BM, BN, WM, WN, pipe;
+    int id, BM, BN, WM, WN, pipe, ns;  // ns = LDS ring depth (2 for the register pipe's double buffer)
     float eff;  // relative efficiency of the tile shape (arithmetic intensity / LDS pressure)
 };
 // BN = weight rows per tile (GEGLU variants produce BN/2 output columns)
 static const Variant kVariants[] = {
-    {1, 128, 128, 2, 2, 0, 1.00f},  {2, 128, 160, 4, 1, 0, 1.00f},  {3, 64, 64, 2, 2, 0, 0.60f},
-    {4, 64, 160, 2, 1, 0, 0.80f},   {5, 256, 128, 4, 2, 0, 1.10f},  {11, 128, 128, 2, 2, 1, 1.00f},
-    {12, 128, 160, 4, 1, 1, 1.00f}, {13, 64, 64, 2, 2, 1, 0.60f},   {14, 64, 160, 2, 1, 1, 0.80f},
-    {15, 256, 128, 4, 2, 1, 1.10f},
+    {1, 128, 128, 2, 2, 0, 2, 1.00f},  {2, 128, 160, 4, 1, 0, 2, 1.00f},  {3, 64, 64, 2, 2, 0, 2, 0.60f},
+    {4, 64, 160, 2, 1, 0, 2, 0.80f},   {5, 256, 128, 4, 2, 0, 2, 1.10f},  {11, 128, 128, 2, 2, 1, 4, 1.00f},
+    {12, 128, 160, 4, 1, 1, 4, 1.00f}, {13, 64, 64, 2, 2, 1, 5, 0.60f},   {14, 64, 160, 2, 1, 1, 4, 0.80f},
+    {15, 256, 128, 4, 2, 1, 3, 1.10f}, {16, 128, 128, 2, 2, 1, 2, 1.00f}, {17, 128, 160, 4, 1, 1, 2, 1.00f},
+    {18, 64, 64, 2, 2, 1, 3, 0.60f},
 };
 static const Variant kGegluVariants[] = {
-    {1, 128, 128, 2, 2, 0, 1.00f},
-    {3, 64, 128, 2, 2, 0, 0.75f},
-    {11, 128, 128, 2, 2, 1, 1.00f},
-    {13, 64, 128, 2, 2, 1, 0.75f},
+    {1, 128, 128, 2, 2, 0, 2, 1.00f},  {3, 64, 128, 2, 2, 0, 2, 0.75f},  {11, 128, 128, 2, 2, 1, 4, 1.00f},
+    {13, 64, 128, 2, 2, 1, 5, 0.75f},  {16, 128, 128, 2, 2, 1, 2, 1.00f}, {18, 64, 128, 2, 2, 1, 3, 0.75f},
 };
 
 int igemm_glds_init();                                                                               // igemm_glds.hip
-int igemm_glds_stages(int BM, int BN, bool geglu);                                                   // igemm_glds.hip
-int igemm_glds_launch(const IgemmArgs &a, int dtype, int mode, bool geglu, int BM, int BN, hipStream_t st);  // igemm_glds.hip
+int igemm_glds_launch(const IgemmArgs &a, int dtype, int mode, bool geglu, int BM, int BN, int NS, hipStream_t st);  // igemm_glds.hip
 
 template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GEGLU>
 static int launch_one(const IgemmArgs &a, hipStream_t st) {
@@ -382,6 +389,7 @@ static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, 
             if (v.id != force_variant) continue;
         } else {
             if (v.BM == 64 && v.BN == 160) continue;  // never the measured optimum on MI355X sweeps
+            if (v.id >= 16) continue;                  // shallow rings are autotuner candidates only
             if (v.pipe == 1 && (!glds_ok || g_pipe_pref == 0)) continue;
             if (v.pipe == 0 && glds_ok && g_pipe_pref == 1) continue;
         }
@@ -389,8 +397,7 @@ static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, 
         const int bno = geglu ? v.BN / 2 : v.BN;
         const int tm = ceil_div(M, v.BM), tn = ceil_div(N, bno);
         const int tiles = tm * tn;
-        const int stages = v.pipe ? igemm_glds_stages(v.BM, v.BN, geglu) : 2;
-        const int lds = stages * (v.BM + v.BN) * 128;
+        const int lds = v.ns * (v.BM + v.BN) * 128;
         const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;
         const double wrows = geglu ? 2.0 * N : (double)N;
         // unique operand bytes stream from HBM (~4 TB/s); panel re-reads by other tiles are served
@@ -484,11 +491,13 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
         SFAST_REQUIRE(ws && ws_bytes >= need, SFAST_ERR_WORKSPACE, "igemm: workspace %zu < %zu", ws_bytes, need);
         a.partial = (float *)ws;
     }
+    char pipe[8];
+    snprintf(pipe, sizeof(pipe), p.v.pipe ? "dma%d" : "reg", p.v.ns);
     set_kernel_name("igemm_%s_%s%s[%dx%d,split=%d,%s]", mode ? "conv" : "lin", dtype == SFAST_F16 ? "f16" : "bf16",
-                    geglu ? "_geglu" : "", p.v.BM, p.v.BN, p.splits, p.v.pipe ? "dma" : "reg");
+                    geglu ? "_geglu" : "", p.v.BM, p.v.BN, p.splits, pipe);
     int rc;
     if (p.v.pipe == 1)
-        rc = igemm_glds_launch(a, dtype, mode, geglu, p.v.BM, p.v.BN, st);
+        rc = igemm_glds_launch(a, dtype, mode, geglu, p.v.BM, p.v.BN, p.v.ns, st);
     else if (dtype == SFAST_F16)
         rc = mode ? dispatch_variant<f16, 1>(a, p.v, geglu, st) : dispatch_variant<f16, 0>(a, p.v, geglu, st);
     else

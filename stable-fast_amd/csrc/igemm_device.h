@@ -74,20 +74,61 @@ __device__ __forceinline__ void epilogue4_geglu(const IgemmArgs &a, int m, int n
 
 
 // ---- whole-tile epilogue ---------------------------------------------------------------------------------
-// acc[fn][fm] holds D[n][m] fragments (32x32 C/D layout). For each 32-row activation fragment the
-// epilogue runs in two phases so the memory system sees ONE batch of loads instead of a chain of
-// load -> wait -> store groups: (1) every bias / row-bias / residual vector of the fragment column is
-// requested unconditionally (absent operands and out-of-range groups are redirected to the device zero
-// block, so there is no branch between the loads and no select on their results); (2) fp32 epilogue
-// math and the 8-byte stores. In-place residuals (out == res) stay correct: a group's residual is read
-// in phase 1 and only that group's lanes write it in phase 2.
+// acc[fn][fm] holds D[n][m] fragments (32x32 C/D layout). Every bias / row-bias / residual vector of the
+// tile is requested unconditionally in ONE batch (absent operands and out-of-range groups are redirected
+// to the device zero block: no branch between the loads, no select on their results), then fp32 epilogue
+// math and 8-byte stores. In-place residuals (out == res) stay correct: a group's residual is read by the
+// same lane that later writes it, and no other workgroup touches it.
+// The operand vectors are fetched by epilogue_prefetch() BEFORE the K loop (their latency hides under the
+// whole main loop instead of being paid once more at the end of every workgroup -- the short-K GEMMs of
+// the transformer blocks are chains of exposed memory round trips otherwise) and consumed by
+// epilogue_finish(). Split-K launches skip both (the reduce kernel applies the epilogue).
+template <int FH, int FM> struct EpiOperands {
+    u32x2 vb[FH][4];       // bias (GEGLU: bias of the h half)
+    u32x2 vb2[FM][FH][4];  // row-bias (GEGLU: bias of the g half, index [0])
+    u32x2 vr[FM][FH][4];   // residual
+};
+
 template <typename T, int FN, int FM, bool GEGLU>
-__device__ __forceinline__ void epilogue_tile(const IgemmArgs &a, f32x16 (&acc)[FN][FM], int mbase, int nbase, int l31, int hi,
-                                              int split_idx) {
+__device__ __forceinline__ void epilogue_prefetch(const IgemmArgs &a, EpiOperands<(GEGLU ? FN / 2 : FN), FM> &e, int mbase, int nbase,
+                                                  int l31, int hi) {
     typedef const u32x2 __attribute__((address_space(1))) * g2_ptr;
     const g2_ptr zero = (g2_ptr)(const void *)g_zero16;
+    constexpr int FH = GEGLU ? FN / 2 : FN;
+    if (a.splits > 1) return;
+#pragma unroll
+    for (int fh = 0; fh < FH; ++fh)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = nbase + fh * 32 + 8 * g + 4 * hi;
+            const bool nok = n < a.N;
+            e.vb[fh][g] = *((nok && a.bias) ? (g2_ptr)(const void *)((const T *)a.bias + n) : zero);
+            if (GEGLU) e.vb2[0][fh][g] = *((nok && a.bias) ? (g2_ptr)(const void *)((const T *)a.bias + a.N + n) : zero);
+        }
+    if (GEGLU) return;
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+        const int m = mbase + fm * 32 + l31;
+        const bool mok = m < a.M;
+        const int bi = a.rowbias ? m / a.rows_per_batch : 0;
+#pragma unroll
+        for (int fh = 0; fh < FH; ++fh)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nbase + fh * 32 + 8 * g + 4 * hi;
+                const bool ok = mok && n < a.N;
+                e.vb2[fm][fh][g] = *((ok && a.rowbias) ? (g2_ptr)(const void *)((const T *)a.rowbias + (int64_t)bi * a.ld_rowbias + n) : zero);
+                e.vr[fm][fh][g] = *((ok && a.res) ? (g2_ptr)(const void *)((const T *)a.res + (int64_t)m * a.ldr + n) : zero);
+            }
+    }
+}
+
+template <typename T, int FN, int FM, bool GEGLU>
+__device__ __forceinline__ void epilogue_finish(const IgemmArgs &a, f32x16 (&acc)[FN][FM], const EpiOperands<(GEGLU ? FN / 2 : FN), FM> &e,
+                                                int mbase, int nbase, int l31, int hi, int split_idx) {
     const bool partial = a.splits > 1;
     constexpr int FH = GEGLU ? FN / 2 : FN;  // output fragments along n
+    constexpr int o = GEGLU ? FN / 2 : 0;
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
         const int m = mbase + fm * 32 + l31;
@@ -105,45 +146,21 @@ __device__ __forceinline__ void epilogue_tile(const IgemmArgs &a, f32x16 (&acc)[
                     *reinterpret_cast<f32x4 *>(p + n) =
                         f32x4{acc[fh][fm][4 * g], acc[fh][fm][4 * g + 1], acc[fh][fm][4 * g + 2], acc[fh][fm][4 * g + 3]};
                     if (GEGLU) {
-                        constexpr int o = GEGLU ? FN / 2 : 0;
                         *reinterpret_cast<f32x4 *>(p + a.N + n) = f32x4{acc[fh + o][fm][4 * g], acc[fh + o][fm][4 * g + 1],
                                                                          acc[fh + o][fm][4 * g + 2], acc[fh + o][fm][4 * g + 3]};
                     }
                 }
             continue;
         }
-        // ---- phase 1: batched operand loads ----------------------------------------------------------
-        u32x2 vb[FH][4], vb2[FH][4], vr[FH][4];
-        const int bi = a.rowbias ? m / a.rows_per_batch : 0;
-#pragma unroll
-        for (int fh = 0; fh < FH; ++fh)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = nbase + fh * 32 + 8 * g + 4 * hi;
-                const bool ok = mok && n < a.N;
-                const g2_ptr pb = (ok && a.bias) ? (g2_ptr)(const void *)((const T *)a.bias + n) : zero;
-                vb[fh][g] = *pb;
-                if (GEGLU) {
-                    const g2_ptr pg = (ok && a.bias) ? (g2_ptr)(const void *)((const T *)a.bias + a.N + n) : zero;
-                    vb2[fh][g] = *pg;
-                } else {
-                    const g2_ptr prb = (ok && a.rowbias) ? (g2_ptr)(const void *)((const T *)a.rowbias + (int64_t)bi * a.ld_rowbias + n) : zero;
-                    vb2[fh][g] = *prb;
-                    const g2_ptr pr = (ok && a.res) ? (g2_ptr)(const void *)((const T *)a.res + (int64_t)m * a.ldr + n) : zero;
-                    vr[fh][g] = *pr;
-                }
-            }
-        // ---- phase 2: fp32 math + stores -----------------------------------------------------------------
 #pragma unroll
         for (int fh = 0; fh < FH; ++fh)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = nbase + fh * 32 + 8 * g + 4 * hi;
                 float v[4], b0[4], b1[4];
-                unpack4<T>(vb[fh][g], b0);
-                unpack4<T>(vb2[fh][g], b1);
+                unpack4<T>(e.vb[fh][g], b0);
+                unpack4<T>(e.vb2[GEGLU ? 0 : fm][fh][g], b1);
                 if (GEGLU) {
-                    constexpr int o = GEGLU ? FN / 2 : 0;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float h = acc[fh][fm][4 * g + i] + b0[i];
@@ -152,7 +169,7 @@ __device__ __forceinline__ void epilogue_tile(const IgemmArgs &a, f32x16 (&acc)[
                     }
                 } else {
                     float r[4];
-                    unpack4<T>(vr[fh][g], r);
+                    unpack4<T>(e.vr[fm][fh][g], r);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float t = acc[fh][fm][4 * g + i] + b0[i] + b1[i];
@@ -165,6 +182,71 @@ __device__ __forceinline__ void epilogue_tile(const IgemmArgs &a, f32x16 (&acc)[
                 }
                 if (mok && n < a.N) *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
             }
+    }
+}
+
+// Late form for the 5-fragment tiles: operands are fetched fragment by fragment right before use (one batch of
+// 12 vectors per 32x32 fragment), which keeps the epilogue inside the register budget of two waves per SIMD.
+template <typename T, int FN, int FM>
+__device__ __forceinline__ void epilogue_late(const IgemmArgs &a, f32x16 (&acc)[FN][FM], int mbase, int nbase, int l31, int hi,
+                                              int split_idx) {
+    typedef const u32x2 __attribute__((address_space(1))) * g2_ptr;
+    const g2_ptr zero = (g2_ptr)(const void *)g_zero16;
+    if (a.splits > 1) {
+        EpiOperands<FN, FM> *none = nullptr;
+        (void)none;
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const int m = mbase + fm * 32 + l31;
+            if (m >= a.M) continue;
+            float *p = a.partial + ((int64_t)split_idx * a.M + m) * (int64_t)a.N;
+#pragma unroll
+            for (int fh = 0; fh < FN; ++fh)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = nbase + fh * 32 + 8 * g + 4 * hi;
+                    if (n >= a.N) continue;
+                    *reinterpret_cast<f32x4 *>(p + n) =
+                        f32x4{acc[fh][fm][4 * g], acc[fh][fm][4 * g + 1], acc[fh][fm][4 * g + 2], acc[fh][fm][4 * g + 3]};
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+        const int m = mbase + fm * 32 + l31;
+        const bool mok = m < a.M;
+        const int bi = a.rowbias ? m / a.rows_per_batch : 0;
+#pragma unroll
+        for (int fh = 0; fh < FN; ++fh) {
+            u32x2 vb[4], vb2[4], vr[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nbase + fh * 32 + 8 * g + 4 * hi;
+                const bool ok = mok && n < a.N;
+                vb[g] = *((ok && a.bias) ? (g2_ptr)(const void *)((const T *)a.bias + n) : zero);
+                vb2[g] = *((ok && a.rowbias) ? (g2_ptr)(const void *)((const T *)a.rowbias + (int64_t)bi * a.ld_rowbias + n) : zero);
+                vr[g] = *((ok && a.res) ? (g2_ptr)(const void *)((const T *)a.res + (int64_t)m * a.ldr + n) : zero);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nbase + fh * 32 + 8 * g + 4 * hi;
+                float v[4], b0[4], b1[4], r[4];
+                unpack4<T>(vb[g], b0);
+                unpack4<T>(vb2[g], b1);
+                unpack4<T>(vr[g], r);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float t = acc[fh][fm][4 * g + i] + b0[i] + b1[i];
+                    const float rr = r[i] * a.alpha;
+                    if (a.res_before_act) t += rr;
+                    if (a.act != SFAST_ACT_NONE) t = apply_act(t, a.act);
+                    if (!a.res_before_act) t += rr;
+                    v[i] = t;
+                }
+                if (mok && n < a.N) *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+            }
+        }
     }
 }
 

@@ -48,8 +48,8 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_glds_kernel(const IgemmArgs
     constexpr int WNB = FN * 32;
     constexpr int L = XCH + WCH;  // LDS-DMA instructions per thread per K-tile
     static_assert(RPP % 16 == 0, "swizzle phase must not depend on the staging pass");
-    static_assert(L * (NS - 2) <= 63, "vmcnt field");
-    static_assert(NS >= 3 && NS <= 5, "ring depth");
+    static_assert(L * (NS > 2 ? NS - 2 : 0) <= 63, "vmcnt field");
+    static_assert(NS >= 2 && NS <= 5, "ring depth");
     static_assert(!GEGLU || (FN % 2 == 0), "GEGLU needs paired fragments");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -188,6 +188,12 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_glds_kernel(const IgemmArgs
         }
     };
 
+    // epilogue operands (bias / row-bias / residual) are requested now and consumed after the K loop when the
+    // tile shape leaves registers for them (the 5-fragment tiles would drop to one wave per SIMD)
+    constexpr bool EPI_EARLY = GEGLU || FN * FM <= 4;
+    EpiOperands<(EPI_EARLY ? (GEGLU ? FN / 2 : FN) : 1), (EPI_EARLY ? FM : 1)> epi;
+    if constexpr (EPI_EARLY) epilogue_prefetch<T, FN, FM, GEGLU>(a, epi, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi);
+
     f32x16 acc[FN][FM];
 #pragma unroll
     for (int fn = 0; fn < FN; ++fn)
@@ -226,8 +232,8 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_glds_kernel(const IgemmArgs
     int cstage = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int inflight = issued - kt - 1;  // tiles younger than kt that may stay outstanding
-        if (inflight >= NS - 2) {
-            wait_vmcnt<L *(NS - 2)>();
+        if (NS > 2 && inflight >= NS - 2) {
+            wait_vmcnt<L *(NS > 2 ? NS - 2 : 0)>();
         } else if (NS > 3 && inflight == NS - 3) {
             wait_vmcnt<L *(NS > 3 ? NS - 3 : 0)>();
         } else if (NS > 4 && inflight == NS - 4) {
@@ -246,7 +252,10 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_glds_kernel(const IgemmArgs
     }
 
     // ---- epilogue: batched operand loads, fp32 math, 8-byte stores (igemm_device.h) -------------------------
-    epilogue_tile<T, FN, FM, GEGLU>(a, acc, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi, blockIdx.y);
+    if constexpr (!EPI_EARLY)
+        epilogue_late<T, FN, FM>(a, acc, m0 + wm * (FM * 32), n0 + wn * WNB, l31, hi, blockIdx.y);
+    else
+        epilogue_finish<T, FN, FM, GEGLU>(a, acc, epi, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi, blockIdx.y);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
@@ -256,11 +265,16 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_glds_kernel(const IgemmArgs
     OP(T, 128, 160, 4, 1, 4, MODE, false)    \
     OP(T, 64, 64, 2, 2, 5, MODE, false)      \
     OP(T, 64, 160, 2, 1, 4, MODE, false)     \
-    OP(T, 256, 128, 4, 2, 3, MODE, false)
+    OP(T, 256, 128, 4, 2, 3, MODE, false)    \
+    OP(T, 128, 128, 2, 2, 2, MODE, false)    \
+    OP(T, 128, 160, 4, 1, 2, MODE, false)    \
+    OP(T, 64, 64, 2, 2, 3, MODE, false)
 
 #define SFAST_FOR_GLDS_GEGLU_VARIANTS(T, OP) \
     OP(T, 128, 128, 2, 2, 4, 0, true)        \
-    OP(T, 64, 128, 2, 2, 5, 0, true)
+    OP(T, 64, 128, 2, 2, 5, 0, true)         \
+    OP(T, 128, 128, 2, 2, 2, 0, true)        \
+    OP(T, 64, 128, 2, 2, 3, 0, true)
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, int MODE, bool GEGLU>
 static int glds_set_attr() {
@@ -290,18 +304,10 @@ int igemm_glds_init() {
 
 int g_igemm_dbg = 0;  // set through sfast_hip_set_debug (profiling ablations only)
 
-int igemm_glds_stages(int BM, int BN, bool geglu) {
-    if (geglu) return BM == 128 ? 4 : 5;
-    if (BM == 128) return 4;
-    if (BM == 64 && BN == 64) return 5;
-    if (BM == 64) return 4;
-    return 3;
-}
-
 template <typename T, int MODE>
-static int glds_dispatch(const IgemmArgs &a, int BM_, int BN_, bool geglu, hipStream_t st) {
+static int glds_dispatch(const IgemmArgs &a, int BM_, int BN_, int NS_, bool geglu, hipStream_t st) {
 #define LAUNCH_OP(TT, BM, BN, WM, WN, NS, MODE_, G_)                                                         \
-    if (BM_ == BM && BN_ == BN && geglu == G_) {                                                             \
+    if (BM_ == BM && BN_ == BN && NS_ == NS && geglu == G_) {                                                             \
         auto kern = igemm_glds_kernel<TT, BM, BN, WM, WN, NS, MODE_, G_>;                                    \
         hipLaunchKernelGGL(kern, dim3(a.tiles_m *a.tiles_n, a.splits), dim3(WM *WN * 64), NS *(BM + BN) * 128, st, a); \
         return check_launch("igemm_glds");                                                                   \
@@ -314,15 +320,15 @@ static int glds_dispatch(const IgemmArgs &a, int BM_, int BN_, bool geglu, hipSt
         }
     }
 #undef LAUNCH_OP
-    set_error("igemm_glds: no kernel for tile %dx%d", BM_, BN_);
+    set_error("igemm_glds: no kernel for tile %dx%d ring %d", BM_, BN_, NS_);
     return SFAST_ERR_UNSUPPORTED;
 }
 
-int igemm_glds_launch(const IgemmArgs &a_in, int dtype, int mode, bool geglu, int BM, int BN, hipStream_t st) {
+int igemm_glds_launch(const IgemmArgs &a_in, int dtype, int mode, bool geglu, int BM, int BN, int NS, hipStream_t st) {
     IgemmArgs a = a_in;
     a.dbg = g_igemm_dbg;
-    if (dtype == SFAST_F16) return mode ? glds_dispatch<f16, 1>(a, BM, BN, geglu, st) : glds_dispatch<f16, 0>(a, BM, BN, geglu, st);
-    return mode ? glds_dispatch<bf16, 1>(a, BM, BN, geglu, st) : glds_dispatch<bf16, 0>(a, BM, BN, geglu, st);
+    if (dtype == SFAST_F16) return mode ? glds_dispatch<f16, 1>(a, BM, BN, NS, geglu, st) : glds_dispatch<f16, 0>(a, BM, BN, NS, geglu, st);
+    return mode ? glds_dispatch<bf16, 1>(a, BM, BN, NS, geglu, st) : glds_dispatch<bf16, 0>(a, BM, BN, NS, geglu, st);
 }
 
 }  // namespace sfast

@@ -132,7 +132,7 @@ def test_geglu_reference_grid(dtype, bias, inf, outf, N):
 
 
 @pytest.mark.parametrize("M,K,N", [(8192, 320, 1280), (2048, 640, 2560), (512, 1280, 5120), (128, 1280, 5120), (100, 320, 1280)])
-@pytest.mark.parametrize("variant", [0, 1, 3, 11, 13])
+@pytest.mark.parametrize("variant", [0, 1, 3, 11, 13, 16, 18])
 def test_geglu_unet_shapes(M, K, N, variant):
     x = rnd(M, K, seed=33)
     w = rnd(2 * N, K, seed=34, scale=K ** -0.5)
@@ -155,7 +155,7 @@ def test_geglu_split_k(split):
 
 @pytest.mark.parametrize("M,K,N", [(8192, 320, 320), (8192, 320, 960), (2048, 2560, 640), (512, 1280, 1280), (154, 768, 640),
                                    (4095, 328, 324), (77, 64, 36), (130, 1280, 1280)])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18])
 def test_linear_variants(M, K, N, variant):
     x = rnd(M, K, seed=40)
     w = rnd(N, K, seed=41, scale=K ** -0.5)
@@ -300,7 +300,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18])
 def test_conv_igemm(case, variant):
     name, B, Cin, H, W, Cout, k, stride, pad, ex = case
     x = cl(rnd(B, Cin, H, W, seed=70))

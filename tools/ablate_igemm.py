@@ -13,11 +13,11 @@ from sfast.engine.unet_spec import SD15_CONFIG, random_params  # noqa: E402
 from sfast.hip import lib as L  # noqa: E402
 
 PROBES = [
-    ("down_blocks.0.resnets.0.conv2", [(12, 2), (11, 1), (15, 2), (13, 2), (2, 2)]),
+    ("down_blocks.0.resnets.0.conv2", [(12, 2), (17, 2), (17, 4), (16, 2), (15, 2), (2, 2), (2, 4)]),
     ("up_blocks.3.resnets.0.conv1", [(12, 4), (15, 4)]),
-    ("down_blocks.0.attentions.0.transformer_blocks.0.ff.out", [(13, 1), (11, 1), (3, 1)]),
-    ("down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_out", [(13, 1), (3, 1)]),
-    ("down_blocks.0.attentions.0.transformer_blocks.0.ff.geglu", [(11, 1), (13, 1), (1, 1), (3, 1)]),
+    ("down_blocks.0.attentions.0.transformer_blocks.0.ff.out", [(13, 1), (18, 1), (16, 1), (3, 1)]),
+    ("down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_out", [(13, 1), (18, 1), (3, 1)]),
+    ("down_blocks.0.attentions.0.transformer_blocks.0.ff.geglu", [(11, 1), (16, 1), (18, 1), (1, 1), (3, 1)]),
     ("down_blocks.2.resnets.1.conv2", [(15, 12), (11, 6)]),
 ]
 
