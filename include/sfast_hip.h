@@ -83,6 +83,10 @@ const char *sfast_hip_last_kernel(void);
 /* profiling ablations of the LDS-DMA GEMM pipe (bit0: skip the MFMA phase, bit1: skip in-loop refills);
  * results are garbage while set. Returns the previous flags; 0 (default) = production behaviour. */
 int sfast_hip_set_debug(int flags);
+/* profiling: while `buf` is non-NULL every MFMA GEMM workgroup writes 8 uint64 (100 MHz wall-clock stamps of
+ * its phases + HW_ID) at buf[(blockIdx.y*gridDim.x+blockIdx.x)*8]; the caller sizes buf for the launch
+ * (sfast_hip_igemm_plan gives the grid). NULL (default) = production behaviour. */
+int sfast_hip_set_trace(void *buf);
 
 /* ---- GroupNorm (+SiLU) ------------------------------------------------------------------ */
 enum sfast_layout { SFAST_NHWC = 0, SFAST_NCHW = 1 };

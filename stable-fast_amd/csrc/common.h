@@ -86,13 +86,36 @@ template <typename T> __device__ __forceinline__ void unpack4(const u32x2 &raw, 
 static __device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
 
 // ---- activations (fp32) -------------------------------------------------------------------------
-__device__ __forceinline__ float act_silu(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float act_relu(float v) { return fmaxf(v, 0.0f); }
+__device__ __forceinline__ float act_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+__device__ __forceinline__ float act_silu(float v) { return v * act_sigmoid(v); }
+// Normal CDF through erfc (Abramowitz & Stegun 7.1.26, |abs err| <= 1.5e-7 -- below fp32 erff's own last-ulp
+// noise once multiplied by v and rounded to f16/bf16): 2 transcendentals + 8 FMAs instead of libm erff's
+// ~50-instruction two-branch polynomial. The GEGLU epilogue evaluates this 10M times per SD1.5 FF layer; with erff
+// it was VALU-bound for ~40 % of the kernel (per-workgroup phase trace, profiles/r01_igemm_phase_trace.log).
+// Negative arguments use erfc directly, so there is no 1 + erf(x) cancellation in the tail.
 __device__ __forceinline__ float act_gelu_erf(float v) {
-    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    const float z = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float half_erfc = 0.5f * p * t * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);  // 0.5*erfc(|z|)
+    return v * (v >= 0.0f ? 1.0f - half_erfc : half_erfc);
+}
+// tanh from one exp + one rcp; |x| < 0.1 uses the odd series (the rational form cancels there)
+__device__ __forceinline__ float act_tanh(float v) {
+    const float x = fabsf(v);
+    const float e = __builtin_amdgcn_exp2f(x * -2.88539008177792681472f);  // exp(-2|x|)
+    const float big = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+    const float x2 = x * x;
+    const float small = x * fmaf(x2, fmaf(x2, 0.13333333f, -0.33333333f), 1.0f);
+    return copysignf(x < 0.1f ? small : big, v);
 }
 __device__ __forceinline__ float act_gelu_tanh(float v) {
     const float k0 = 0.79788456080286535588f, k1 = 0.044715f;
-    return 0.5f * v * (1.0f + tanhf(k0 * (v + k1 * v * v * v)));
+    return 0.5f * v * (1.0f + act_tanh(k0 * (v + k1 * v * v * v)));
 }
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
@@ -100,8 +123,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     case SFAST_ACT_GELU: return act_gelu_erf(v);
     case SFAST_ACT_GELU_TANH: return act_gelu_tanh(v);
     case SFAST_ACT_SILU: return act_silu(v);
-    case SFAST_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
-    case SFAST_ACT_TANH: return tanhf(v);
+    case SFAST_ACT_SIGMOID: return act_sigmoid(v);
+    case SFAST_ACT_TANH: return act_tanh(v);
     default: return v;
     }
 }

@@ -37,7 +37,7 @@ namespace sfast {
 
 // MODE 0: linear (row m -> x + m*ldx). MODE 1: conv (implicit im2col, NHWC).
 template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GEGLU>
-__global__ void __launch_bounds__(WM *WN * 64) igemm_kernel(const IgemmArgs a) {
+__global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, 2 * (BM + BN) * 128)) igemm_kernel(const IgemmArgs a) {
     using vec8 = typename Elem<T>::vec8;
     constexpr int NT = WM * WN * 64;
     constexpr int FM = BM / (WM * 32);  // 32-row activation fragments per wave
@@ -54,6 +54,7 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_kernel(const IgemmArgs a) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    trace_mark(a, 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -78,6 +79,7 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_kernel(const IgemmArgs a) {
     // ---- per-thread staging metadata -----------------------------------------------------------
     const T *xrow[XCH];          // MODE 0
     int xbhw[XCH], xh[XCH], xw[XCH];  // MODE 1
+    const PixelDecoder decode(a);
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
         const int m = m0 + rbase + i * RPP;
@@ -85,10 +87,8 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_kernel(const IgemmArgs a) {
             xrow[i] = (m < a.M) ? (const T *)a.x + (int64_t)m * a.ldx : nullptr;
         } else {
             if (m < a.M) {
-                const int hw = a.Ho * a.Wo;
-                const int b = m / hw;
-                const int rem = m - b * hw;
-                const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+                int b, ho, wo;
+                decode(m, b, ho, wo);
                 xbhw[i] = b * a.H * a.W;
                 xh[i] = ho * a.stride_h - a.pad_h;
                 xw[i] = wo * a.stride_w - a.pad_w;
@@ -111,7 +111,8 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_kernel(const IgemmArgs a) {
         } else {
             const int n = n0 + j;
             if (n < a.N) {
-                const int seg = n / a.rows_per_seg;
+                const int rs = a.rows_per_seg;
+                const int seg = (n >= rs) + (n - rs >= rs) + (n - rs - rs >= rs);
                 const void *base = seg == 0 ? a.w[0] : seg == 1 ? a.w[1] : seg == 2 ? a.w[2] : a.w[3];
                 wrow[i] = (const T *)base + (int64_t)(n - seg * a.rows_per_seg) * a.ldw;
             } else {
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_kernel(const IgemmArgs a) {
         if (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < XCH; ++i) {
-                const bool ok = kvalid && xrow[i] != nullptr;
+                const bool ok = kvalid & (xrow[i] != nullptr);
                 xreg[i] = ldg16(xrow[i] + ks, (const T *)a.x, ok);
             }
         } else {
@@ -174,7 +175,7 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_kernel(const IgemmArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < WCH; ++i) {
-            const bool ok = kvalid && wrow[i] != nullptr;
+            const bool ok = kvalid & (wrow[i] != nullptr);
             wreg[i] = ldg16(wrow[i] + ks, (const T *)a.w[0], ok);
         }
     };
@@ -203,31 +204,41 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_kernel(const IgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[fn][fm][r] = 0.f;
 
+    // fragment reads run one 16-wide K step AHEAD of the MFMAs that consume them (two register sets): at one wave per
+    // SIMD nothing else hides the ds_read latency
     auto compute = [&](int stage) {
         const char *xs = smem + stage * STAGE;
         const char *ws = xs + BM * 128;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        vec8 af[2][FN], bf[2][FM];
+        auto read_frags = [&](int ks, int set) {
             const int chunk = ks * 2 + hi;
-            vec8 af[FN], bf[FM];
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
-                af[fn] = *reinterpret_cast<const vec8 *>(ws + lds_off(wn * WNB + fn * 32 + l31, chunk));
+                af[set][fn] = *reinterpret_cast<const vec8 *>(ws + lds_off(wn * WNB + fn * 32 + l31, chunk));
 #pragma unroll
             for (int fm = 0; fm < FM; ++fm)
-                bf[fm] = *reinterpret_cast<const vec8 *>(xs + lds_off(wm * (FM * 32) + fm * 32 + l31, chunk));
+                bf[set][fm] = *reinterpret_cast<const vec8 *>(xs + lds_off(wm * (FM * 32) + fm * 32 + l31, chunk));
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) read_frags(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs (the scheduler sinks them otherwise)
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
-                for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = mfma32(af[fn], bf[fm], acc[fn][fm]);
+                for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = mfma32(af[ks & 1][fn], bf[ks & 1][fm], acc[fn][fm]);
         }
     };
 
     // ---- main loop -------------------------------------------------------------------------------
+    trace_mark(a, 1);
     if (kt_begin < kt_end) {
         load_tile(kt_begin);
+        trace_mark(a, 2);
         store_tile(0);
         __syncthreads();
+        trace_mark(a, 3);
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             const int cur = (kt - kt_begin) & 1;
             const bool more = kt + 1 < kt_end;
@@ -239,10 +250,12 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_kernel(const IgemmArgs a) {
     }
 
     // ---- epilogue: batched operand loads, fp32 math, 8-byte stores (igemm_device.h) -------------------------
+    trace_mark(a, 4);
     if constexpr (!EPI_EARLY)
         epilogue_late<T, FN, FM>(a, acc, m0 + wm * (FM * 32), n0 + wn * WNB, l31, hi, blockIdx.y);
     else
         epilogue_finish<T, FN, FM, GEGLU>(a, acc, epi, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi, blockIdx.y);
+    trace_finish(a);
 }
 
 // split-K reduce + epilogue: one thread per 4 consecutive output columns.
@@ -292,6 +305,7 @@ static const Variant kGegluVariants[] = {
     {13, 64, 128, 2, 2, 1, 5, 0.75f},  {16, 128, 128, 2, 2, 1, 2, 1.00f}, {18, 64, 128, 2, 2, 1, 3, 0.75f},
 };
 
+extern unsigned long long *g_igemm_trace;  // igemm_glds.hip
 int igemm_glds_init();                                                                               // igemm_glds.hip
 int igemm_glds_launch(const IgemmArgs &a, int dtype, int mode, bool geglu, int BM, int BN, int NS, hipStream_t st);  // igemm_glds.hip
 
@@ -486,6 +500,7 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
     a.ktiles_per_split = p.ktps;
     a.splits = p.splits;
     a.partial = nullptr;
+    a.trace = g_igemm_trace;
     if (p.splits > 1) {
         const size_t need = (size_t)p.splits * a.M * (geglu ? 2 * (size_t)a.N : (size_t)a.N) * sizeof(float);
         SFAST_REQUIRE(ws && ws_bytes >= need, SFAST_ERR_WORKSPACE, "igemm: workspace %zu < %zu", ws_bytes, need);

@@ -5,6 +5,28 @@
 
 namespace sfast {
 
+// Profiling only (sfast_hip_set_trace): thread 0 of every workgroup stamps the 100 MHz wall clock into
+// slot `slot` of its 8-slot record. One uniform scalar branch when tracing is off.
+__device__ __forceinline__ void trace_mark(const IgemmArgs &a, int slot) {
+    if (a.trace != nullptr) {
+        if (threadIdx.x == 0)
+            a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + slot] = wall_clock64();
+    }
+}
+__device__ __forceinline__ void trace_finish(const IgemmArgs &a) {
+    if (a.trace != nullptr) {
+        trace_mark(a, 5);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        trace_mark(a, 6);
+        if (threadIdx.x == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+            const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+            a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = ((unsigned long long)xcc << 32) | hw;
+        }
+    }
+}
+
+
 __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
@@ -17,7 +39,72 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-// final epilogue for 4 consecutive columns n..n+3 of row m (fp32 in, T out)
+// Waves per SIMD the kernel is compiled for (second __launch_bounds__ argument): what the workgroup's LDS footprint
+// lets a CU hold, capped at 3 -- the register allocator then stays inside 512 / that many registers instead of
+// trading occupancy for scheduling freedom in the epilogue.
+constexpr int igemm_min_waves(int threads, int lds_bytes) {
+    const int w = (163840 / lds_bytes) * (threads / 256);
+    return w < 1 ? 1 : (w > 3 ? 3 : w);
+}
+
+// floor(n / d) for 0 <= n <= 2^22 and d >= 1 with a precomputed rd = rcp((float)d): float(n) is exact and the
+// quotient estimate is off by at most one (n/d * 2^-22.4 < 1), fixed by one compare each way. ~8 VALU ops instead of
+// the ~40 of the integer sequence; the per-row pixel decode at the top of a conv workgroup is pure latency at one
+// workgroup per CU (measured 4 us of a 30 us conv, profiles/r01_igemm_phase_trace.log).
+__device__ __forceinline__ int fdiv22(int n, int d, float rd) {
+    int q = (int)((float)n * rd);
+    const int r = n - q * d;
+    q += (r >= d) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
+struct PixelDecoder {
+    int hw, wo;
+    float r_hw, r_wo;
+    bool fast;
+    __device__ __forceinline__ PixelDecoder(const IgemmArgs &a)
+        : hw(a.Ho * a.Wo), wo(a.Wo), r_hw(__builtin_amdgcn_rcpf((float)(a.Ho * a.Wo))), r_wo(__builtin_amdgcn_rcpf((float)a.Wo)),
+          fast(a.M <= (1 << 22)) {}
+    __device__ __forceinline__ void operator()(int m, int &b, int &ho, int &wo_) const {
+        if (fast) {
+            b = fdiv22(m, hw, r_hw);
+            const int rem = m - b * hw;
+            ho = fdiv22(rem, wo, r_wo);
+            wo_ = rem - ho * wo;
+        } else {
+            b = m / hw;
+            const int rem = m - b * hw;
+            ho = rem / wo;
+            wo_ = rem - ho * wo;
+        }
+    }
+};
+// row -> batch index for the per-batch row bias (time-embedding projection): same trick
+struct BatchOfRow {
+    int d;
+    float rd;
+    bool fast;
+    __device__ __forceinline__ BatchOfRow(const IgemmArgs &a)
+        : d(a.rows_per_batch > 0 ? a.rows_per_batch : 1), rd(__builtin_amdgcn_rcpf((float)(a.rows_per_batch > 0 ? a.rows_per_batch : 1))),
+          fast(a.M <= (1 << 22)) {}
+    __device__ __forceinline__ int operator()(int m) const { return fast ? fdiv22(m, d, rd) : m / d; }
+};
+
+// Activations of the MFMA GEMM epilogue run as one ROLLED 16-element loop per 32x32 fragment (uniform dynamic index
+// into the fragment's registers). A per-element `switch (a.act)` inlined 64x made every kernel ~100 KB of code --
+// more than the 64 KB instruction cache, with the executed path scattered across it -- and the UNet path itself
+// only ever runs the no-activation form here (SiLU is fused into GroupNorm, GELU into the GEGLU kernel).
+template <int FN, int FM, int FH> __device__ __forceinline__ void apply_act_tile(f32x16 (&acc)[FN][FM], int act) {
+#pragma unroll
+    for (int fh = 0; fh < FH; ++fh)
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+#pragma unroll 1
+            for (int r = 0; r < 16; ++r) acc[fh][fm][r] = apply_act(acc[fh][fm][r], act);
+        }
+}
+
+// final epilogue for 4 consecutive columns n..n+3 of row m (fp32 in, T out) -- split-K reduce kernel
 template <typename T>
 __device__ __forceinline__ void epilogue4(const IgemmArgs &a, int m, int n, float (&v)[4]) {
     if (a.bias) {
@@ -44,8 +131,20 @@ __device__ __forceinline__ void epilogue4(const IgemmArgs &a, int m, int n, floa
         for (int i = 0; i < 4; ++i) v[i] += r[i];
     }
     if (a.act != SFAST_ACT_NONE) {
+        switch (a.act) {
+        case SFAST_ACT_SILU:
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], a.act);
+            for (int i = 0; i < 4; ++i) v[i] = act_silu(v[i]);
+            break;
+        case SFAST_ACT_GELU:
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = act_gelu_erf(v[i]);
+            break;
+        default:
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], a.act);
+            break;
+        }
     }
     if (!a.res_before_act) {
 #pragma unroll
@@ -106,11 +205,12 @@ __device__ __forceinline__ void epilogue_prefetch(const IgemmArgs &a, EpiOperand
             if (GEGLU) e.vb2[0][fh][g] = *((nok && a.bias) ? (g2_ptr)(const void *)((const T *)a.bias + a.N + n) : zero);
         }
     if (GEGLU) return;
+    const BatchOfRow batch_of(a);
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
         const int m = mbase + fm * 32 + l31;
         const bool mok = m < a.M;
-        const int bi = a.rowbias ? m / a.rows_per_batch : 0;
+        const int bi = a.rowbias ? batch_of(m) : 0;
 #pragma unroll
         for (int fh = 0; fh < FH; ++fh)
 #pragma unroll
@@ -123,131 +223,179 @@ __device__ __forceinline__ void epilogue_prefetch(const IgemmArgs &a, EpiOperand
     }
 }
 
+// fp32 slab store of one workgroup's partial tile (split-K); the reduce kernel applies the epilogue
+template <int FN, int FM, bool GEGLU>
+__device__ __forceinline__ void store_partial(const IgemmArgs &a, f32x16 (&acc)[FN][FM], int mbase, int nbase, int l31, int hi, int split_idx) {
+    constexpr int FH = GEGLU ? FN / 2 : FN;
+    constexpr int o = GEGLU ? FN / 2 : 0;
+    const int64_t np = GEGLU ? 2 * (int64_t)a.N : (int64_t)a.N;
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+        const int m = mbase + fm * 32 + l31;
+        if (m >= a.M) continue;
+        float *p = a.partial + ((int64_t)split_idx * a.M + m) * np;
+#pragma unroll
+        for (int fh = 0; fh < FH; ++fh)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nbase + fh * 32 + 8 * g + 4 * hi;
+                if (n >= a.N) continue;
+                *reinterpret_cast<f32x4 *>(p + n) = f32x4{acc[fh][fm][4 * g], acc[fh][fm][4 * g + 1], acc[fh][fm][4 * g + 2], acc[fh][fm][4 * g + 3]};
+                if (GEGLU) {
+                    *reinterpret_cast<f32x4 *>(p + a.N + n) =
+                        f32x4{acc[fh + o][fm][4 * g], acc[fh + o][fm][4 * g + 1], acc[fh + o][fm][4 * g + 2], acc[fh + o][fm][4 * g + 3]};
+                }
+            }
+    }
+}
+
+// Pass 1 over one 32x32 fragment: acc += bias + row-bias (+ residual when it belongs before the activation, or when
+// there is no activation and the order is moot). Without an activation the fragment is finished and stored here.
+template <typename T>
+__device__ __forceinline__ void fragment_pass1(const IgemmArgs &a, f32x16 &acc, const u32x2 (&vb)[4], const u32x2 (&vb2)[4],
+                                               const u32x2 (&vr)[4], bool mok, int m, int nfrag, int hi) {
+    const bool res_now = a.res_before_act || a.act == SFAST_ACT_NONE;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float b0[4], b1[4], r[4];
+        unpack4<T>(vb[g], b0);
+        unpack4<T>(vb2[g], b1);
+        unpack4<T>(vr[g], r);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * g + i] = acc[4 * g + i] + b0[i] + b1[i] + (res_now ? r[i] * a.alpha : -0.0f);
+    }
+    if (a.act == SFAST_ACT_NONE) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = nfrag + 8 * g + 4 * hi;
+            if (mok && n < a.N)
+                *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = pack4<T>(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        }
+    }
+}
+// Pass 2 (only with an activation): add the residual that belongs after it, store.
+template <typename T>
+__device__ __forceinline__ void fragment_pass2(const IgemmArgs &a, const f32x16 &acc, const u32x2 (&vr)[4], bool mok, int m, int nfrag, int hi) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float r[4];
+        unpack4<T>(vr[g], r);
+        const int n = nfrag + 8 * g + 4 * hi;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[4 * g + i] + (a.res_before_act ? -0.0f : r[i] * a.alpha);
+        if (mok && n < a.N) *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// Activation tail (only when a.act != NONE): one switch over the tile, then the residual that belongs AFTER the
+// activation is fetched again, one fragment ahead, and the tile is stored. Re-fetching instead of keeping the
+// prefetched residual live across the switch keeps the register peak of this rare path out of the kernel's budget.
+template <typename T, int FN, int FM>
+__device__ __forceinline__ void epilogue_act_tail(const IgemmArgs &a, f32x16 (&acc)[FN][FM], int mbase, int nbase, int l31, int hi) {
+    typedef const u32x2 __attribute__((address_space(1))) * g2_ptr;
+    const g2_ptr zero = (g2_ptr)(const void *)g_zero16;
+    apply_act_tile<FN, FM, FN>(acc, a.act);
+    const bool post = a.res != nullptr && !a.res_before_act;
+    u32x2 vr[2][4];
+    auto fetch = [&](int f, int buf) {
+        const int fm = f / FN, fh = f % FN;
+        const int m = mbase + fm * 32 + l31;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = nbase + fh * 32 + 8 * g + 4 * hi;
+            const bool ok = post && m < a.M && n < a.N;
+            vr[buf][g] = *(ok ? (g2_ptr)(const void *)((const T *)a.res + (int64_t)m * a.ldr + n) : zero);
+        }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int f = 0; f < FN * FM; ++f) {
+        const int fm = f / FN, fh = f % FN;
+        if (f + 1 < FN * FM) fetch(f + 1, (f + 1) & 1);
+        const int m = mbase + fm * 32 + l31;
+        fragment_pass2<T>(a, acc[fh][fm], vr[f & 1], m < a.M, m, nbase + fh * 32, hi);
+    }
+}
+
 template <typename T, int FN, int FM, bool GEGLU>
 __device__ __forceinline__ void epilogue_finish(const IgemmArgs &a, f32x16 (&acc)[FN][FM], const EpiOperands<(GEGLU ? FN / 2 : FN), FM> &e,
                                                 int mbase, int nbase, int l31, int hi, int split_idx) {
-    const bool partial = a.splits > 1;
+    if (a.splits > 1) {
+        store_partial<FN, FM, GEGLU>(a, acc, mbase, nbase, l31, hi, split_idx);
+        return;
+    }
     constexpr int FH = GEGLU ? FN / 2 : FN;  // output fragments along n
     constexpr int o = GEGLU ? FN / 2 : 0;
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
         const int m = mbase + fm * 32 + l31;
         const bool mok = m < a.M;
-        if (partial) {
-            if (!mok) continue;
-            const int64_t np = GEGLU ? 2 * (int64_t)a.N : (int64_t)a.N;
-            float *p = a.partial + ((int64_t)split_idx * a.M + m) * np;
 #pragma unroll
-            for (int fh = 0; fh < FH; ++fh)
+        for (int fh = 0; fh < FH; ++fh) {
+            if (GEGLU) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int n = nbase + fh * 32 + 8 * g + 4 * hi;
-                    if (n >= a.N) continue;
-                    *reinterpret_cast<f32x4 *>(p + n) =
-                        f32x4{acc[fh][fm][4 * g], acc[fh][fm][4 * g + 1], acc[fh][fm][4 * g + 2], acc[fh][fm][4 * g + 3]};
-                    if (GEGLU) {
-                        *reinterpret_cast<f32x4 *>(p + a.N + n) = f32x4{acc[fh + o][fm][4 * g], acc[fh + o][fm][4 * g + 1],
-                                                                         acc[fh + o][fm][4 * g + 2], acc[fh + o][fm][4 * g + 3]};
-                    }
-                }
-            continue;
-        }
-#pragma unroll
-        for (int fh = 0; fh < FH; ++fh)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = nbase + fh * 32 + 8 * g + 4 * hi;
-                float v[4], b0[4], b1[4];
-                unpack4<T>(e.vb[fh][g], b0);
-                unpack4<T>(e.vb2[GEGLU ? 0 : fm][fh][g], b1);
-                if (GEGLU) {
+                    float v[4], b0[4], b1[4];
+                    unpack4<T>(e.vb[fh][g], b0);
+                    unpack4<T>(e.vb2[0][fh][g], b1);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float h = acc[fh][fm][4 * g + i] + b0[i];
                         const float gt = acc[fh + o][fm][4 * g + i] + b1[i];
                         v[i] = h * act_gelu_erf(gt);
                     }
-                } else {
-                    float r[4];
-                    unpack4<T>(e.vr[fm][fh][g], r);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float t = acc[fh][fm][4 * g + i] + b0[i] + b1[i];
-                        const float rr = r[i] * a.alpha;
-                        if (a.res_before_act) t += rr;
-                        if (a.act != SFAST_ACT_NONE) t = apply_act(t, a.act);
-                        if (!a.res_before_act) t += rr;
-                        v[i] = t;
-                    }
+                    if (mok && n < a.N) *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
                 }
-                if (mok && n < a.N) *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+            } else {
+                fragment_pass1<T>(a, acc[fh][fm], e.vb[fh], e.vb2[fm][fh], e.vr[fm][fh], mok, m, nbase + fh * 32, hi);
             }
+        }
+    }
+    if constexpr (!GEGLU) {
+        if (a.act != SFAST_ACT_NONE) epilogue_act_tail<T, FN, FM>(a, acc, mbase, nbase, l31, hi);
     }
 }
 
-// Late form for the 5-fragment tiles: operands are fetched fragment by fragment right before use (one batch of
-// 12 vectors per 32x32 fragment), which keeps the epilogue inside the register budget of two waves per SIMD.
+// Late form for the 5-fragment tiles at two workgroups per CU: operands are fetched fragment by fragment, one
+// fragment AHEAD of the one being finished (12 vectors each), which keeps the epilogue inside the register budget
+// of two waves per SIMD while still overlapping every operand round trip but the first with math and stores.
+// (Program order = load(f+1), store(f): legal for in-place residuals because fragments never overlap.)
 template <typename T, int FN, int FM>
 __device__ __forceinline__ void epilogue_late(const IgemmArgs &a, f32x16 (&acc)[FN][FM], int mbase, int nbase, int l31, int hi,
                                               int split_idx) {
     typedef const u32x2 __attribute__((address_space(1))) * g2_ptr;
     const g2_ptr zero = (g2_ptr)(const void *)g_zero16;
     if (a.splits > 1) {
-        EpiOperands<FN, FM> *none = nullptr;
-        (void)none;
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm) {
-            const int m = mbase + fm * 32 + l31;
-            if (m >= a.M) continue;
-            float *p = a.partial + ((int64_t)split_idx * a.M + m) * (int64_t)a.N;
-#pragma unroll
-            for (int fh = 0; fh < FN; ++fh)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = nbase + fh * 32 + 8 * g + 4 * hi;
-                    if (n >= a.N) continue;
-                    *reinterpret_cast<f32x4 *>(p + n) =
-                        f32x4{acc[fh][fm][4 * g], acc[fh][fm][4 * g + 1], acc[fh][fm][4 * g + 2], acc[fh][fm][4 * g + 3]};
-                }
-        }
+        store_partial<FN, FM, false>(a, acc, mbase, nbase, l31, hi, split_idx);
         return;
     }
-#pragma unroll
-    for (int fm = 0; fm < FM; ++fm) {
+    const BatchOfRow batch_of(a);
+    u32x2 vb[2][4], vb2[2][4], vr[2][4];
+    auto fetch = [&](int f, int buf) {
+        const int fm = f / FN, fh = f % FN;
         const int m = mbase + fm * 32 + l31;
         const bool mok = m < a.M;
-        const int bi = a.rowbias ? m / a.rows_per_batch : 0;
+        const int bi = a.rowbias ? batch_of(m) : 0;
 #pragma unroll
-        for (int fh = 0; fh < FN; ++fh) {
-            u32x2 vb[4], vb2[4], vr[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = nbase + fh * 32 + 8 * g + 4 * hi;
-                const bool ok = mok && n < a.N;
-                vb[g] = *((ok && a.bias) ? (g2_ptr)(const void *)((const T *)a.bias + n) : zero);
-                vb2[g] = *((ok && a.rowbias) ? (g2_ptr)(const void *)((const T *)a.rowbias + (int64_t)bi * a.ld_rowbias + n) : zero);
-                vr[g] = *((ok && a.res) ? (g2_ptr)(const void *)((const T *)a.res + (int64_t)m * a.ldr + n) : zero);
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = nbase + fh * 32 + 8 * g + 4 * hi;
-                float v[4], b0[4], b1[4], r[4];
-                unpack4<T>(vb[g], b0);
-                unpack4<T>(vb2[g], b1);
-                unpack4<T>(vr[g], r);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float t = acc[fh][fm][4 * g + i] + b0[i] + b1[i];
-                    const float rr = r[i] * a.alpha;
-                    if (a.res_before_act) t += rr;
-                    if (a.act != SFAST_ACT_NONE) t = apply_act(t, a.act);
-                    if (!a.res_before_act) t += rr;
-                    v[i] = t;
-                }
-                if (mok && n < a.N) *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
-            }
+        for (int g = 0; g < 4; ++g) {
+            const int n = nbase + fh * 32 + 8 * g + 4 * hi;
+            const bool ok = mok && n < a.N;
+            vb[buf][g] = *((ok && a.bias) ? (g2_ptr)(const void *)((const T *)a.bias + n) : zero);
+            vb2[buf][g] = *((ok && a.rowbias) ? (g2_ptr)(const void *)((const T *)a.rowbias + (int64_t)bi * a.ld_rowbias + n) : zero);
+            vr[buf][g] = *((ok && a.res) ? (g2_ptr)(const void *)((const T *)a.res + (int64_t)m * a.ldr + n) : zero);
         }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int f = 0; f < FN * FM; ++f) {
+        const int fm = f / FN, fh = f % FN;
+        if (f + 1 < FN * FM) fetch(f + 1, (f + 1) & 1);
+        const int m = mbase + fm * 32 + l31;
+        fragment_pass1<T>(a, acc[fh][fm], vb[f & 1], vb2[f & 1], vr[f & 1], m < a.M, m, nbase + fh * 32, hi);
     }
+    if (a.act != SFAST_ACT_NONE) epilogue_act_tail<T, FN, FM>(a, acc, mbase, nbase, l31, hi);
 }
 
 }  // namespace sfast

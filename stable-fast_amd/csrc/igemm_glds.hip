@@ -35,7 +35,7 @@ typedef const u32x4 __attribute__((address_space(1))) * glds_src_t;
 typedef __attribute__((address_space(3))) void *glds_dst_t;
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, int MODE, bool GEGLU>
-__global__ void __launch_bounds__(WM *WN * 64) igemm_glds_kernel(const IgemmArgs a) {
+__global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, NS *(BM + BN) * 128)) igemm_glds_kernel(const IgemmArgs a) {
     using vec8 = typename Elem<T>::vec8;
     constexpr int NT = WM * WN * 64;
     constexpr int FM = BM / (WM * 32);
@@ -54,6 +54,7 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_glds_kernel(const IgemmArgs
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    trace_mark(a, 0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
@@ -80,6 +81,7 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_glds_kernel(const IgemmArgs
     const T *xrow[XCH];  // MODE 0: row pointer or nullptr
     int xpix[XCH];       // MODE 1: pixel index of tap (0,0) (may be negative), in input pixels
     unsigned xmask[XCH];  // MODE 1: bit (r*KW+s) set when that tap is inside the image
+    const PixelDecoder decode(a);
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
         const int m = m0 + rbase + i * RPP;
@@ -89,17 +91,14 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_glds_kernel(const IgemmArgs
             unsigned mask = 0;
             int pix = 0;
             if (m < a.M) {
-                const int hw = a.Ho * a.Wo;
-                const int b = m / hw;
-                const int rem = m - b * hw;
-                const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+                int b, ho, wo;
+                decode(m, b, ho, wo);
                 const int h0 = ho * a.stride_h - a.pad_h, w0 = wo * a.stride_w - a.pad_w;
                 pix = (b * a.H + h0) * a.W + w0;
-                for (int r = 0; r < a.KH; ++r)
-                    for (int s = 0; s < a.KW; ++s) {
-                        const int hh = h0 + r * a.dil_h, ww = w0 + s * a.dil_w;
-                        if ((unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W) mask |= 1u << (r * a.KW + s);
-                    }
+                // validity is separable: KW column bits, replicated into every valid tap row
+                unsigned cols = 0;
+                for (int s = 0; s < a.KW; ++s) cols |= ((unsigned)(w0 + s * a.dil_w) < (unsigned)a.W ? 1u : 0u) << s;
+                for (int r = 0; r < a.KH; ++r) mask |= ((unsigned)(h0 + r * a.dil_h) < (unsigned)a.H ? cols : 0u) << (r * a.KW);
             }
             xpix[i] = pix;
             xmask[i] = mask;
@@ -117,7 +116,8 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_glds_kernel(const IgemmArgs
         } else {
             const int n = n0 + j;
             if (n < a.N) {
-                const int seg = n / a.rows_per_seg;
+                const int rs = a.rows_per_seg;
+                const int seg = (n >= rs) + (n - rs >= rs) + (n - rs - rs >= rs);
                 const void *base = seg == 0 ? a.w[0] : seg == 1 ? a.w[1] : seg == 2 ? a.w[2] : a.w[3];
                 wrow[i] = (const T *)base + (int64_t)(n - seg * a.rows_per_seg) * a.ldw;
             } else {
@@ -145,13 +145,13 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_glds_kernel(const IgemmArgs
             const bool kvalid = k < a.K;
 #pragma unroll
             for (int i = 0; i < XCH; ++i) {
-                const bool ok = kvalid && xrow[i] != nullptr;
+                const bool ok = kvalid & (xrow[i] != nullptr);
                 const glds_src_t src = ok ? (glds_src_t)(const void *)(xrow[i] + k) : (glds_src_t)(const void *)g_zero16;
                 __builtin_amdgcn_global_load_lds(src, (glds_dst_t)(sx + i * (RPP * 128)), 16, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < WCH; ++i) {
-                const bool ok = kvalid && wrow[i] != nullptr;
+                const bool ok = kvalid & (wrow[i] != nullptr);
                 const glds_src_t src = ok ? (glds_src_t)(const void *)(wrow[i] + k) : (glds_src_t)(const void *)g_zero16;
                 __builtin_amdgcn_global_load_lds(src, (glds_dst_t)(sw + i * (RPP * 128)), 16, 0, 0);
             }
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_glds_kernel(const IgemmArgs
 
     // epilogue operands (bias / row-bias / residual) are requested now and consumed after the K loop when the
     // tile shape leaves registers for them (the 5-fragment tiles would drop to one wave per SIMD)
-    constexpr bool EPI_EARLY = GEGLU || FN * FM <= 4;
+    constexpr bool EPI_EARLY = GEGLU || FN * FM <= 4 || NS >= 3;  // ring depth >= 3: one workgroup per CU anyway
     EpiOperands<(EPI_EARLY ? (GEGLU ? FN / 2 : FN) : 1), (EPI_EARLY ? FM : 1)> epi;
     if constexpr (EPI_EARLY) epilogue_prefetch<T, FN, FM, GEGLU>(a, epi, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi);
 
@@ -202,33 +202,42 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_glds_kernel(const IgemmArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[fn][fm][r] = 0.f;
 
+    // fragment reads run one 16-wide K step AHEAD of the MFMAs that consume them (two register sets): at one wave per
+    // SIMD nothing else hides the ds_read latency
     auto compute = [&](int stage) {
         const char *xs = smem + stage * STAGE;
         const char *ws = xs + BM * 128;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        vec8 af[2][FN], bf[2][FM];
+        auto read_frags = [&](int ks, int set) {
             const int chunk = ks * 2 + hi;
-            vec8 af[FN], bf[FM];
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
-                af[fn] = *reinterpret_cast<const vec8 *>(ws + lds_off(wn * WNB + fn * 32 + l31, chunk));
+                af[set][fn] = *reinterpret_cast<const vec8 *>(ws + lds_off(wn * WNB + fn * 32 + l31, chunk));
 #pragma unroll
             for (int fm = 0; fm < FM; ++fm)
-                bf[fm] = *reinterpret_cast<const vec8 *>(xs + lds_off(wm * (FM * 32) + fm * 32 + l31, chunk));
+                bf[set][fm] = *reinterpret_cast<const vec8 *>(xs + lds_off(wm * (FM * 32) + fm * 32 + l31, chunk));
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) read_frags(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs (the scheduler sinks them otherwise)
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
-                for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = mfma32(af[fn], bf[fm], acc[fn][fm]);
+                for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = mfma32(af[ks & 1][fn], bf[ks & 1][fm], acc[fn][fm]);
         }
     };
 
     // ---- NS-stage ring: tiles kt+1 .. kt+NS-2 stay in flight while tile kt is multiplied ------------------
+    trace_mark(a, 1);
     int issued = kt_begin, istage = 0;
     for (int s = 0; s < NS - 1 && issued < kt_end; ++s) {
         issue(issued, istage);
         ++issued;
         istage = (istage + 1 == NS) ? 0 : istage + 1;
     }
+    trace_mark(a, 2);
     int cstage = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int inflight = issued - kt - 1;  // tiles younger than kt that may stay outstanding
@@ -242,6 +251,7 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_glds_kernel(const IgemmArgs
             wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
+        if (kt == kt_begin) trace_mark(a, 3);
         if (issued < kt_end) {
             if (!(a.dbg & 2)) issue(issued, istage);
             ++issued;
@@ -252,10 +262,12 @@ __global__ void __launch_bounds__(WM *WN * 64) igemm_glds_kernel(const IgemmArgs
     }
 
     // ---- epilogue: batched operand loads, fp32 math, 8-byte stores (igemm_device.h) -------------------------
+    trace_mark(a, 4);
     if constexpr (!EPI_EARLY)
         epilogue_late<T, FN, FM>(a, acc, m0 + wm * (FM * 32), n0 + wn * WNB, l31, hi, blockIdx.y);
     else
         epilogue_finish<T, FN, FM, GEGLU>(a, acc, epi, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi, blockIdx.y);
+    trace_finish(a);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
@@ -303,6 +315,7 @@ int igemm_glds_init() {
 }
 
 int g_igemm_dbg = 0;  // set through sfast_hip_set_debug (profiling ablations only)
+unsigned long long *g_igemm_trace = nullptr;  // set through sfast_hip_set_trace (profiling only)
 
 template <typename T, int MODE>
 static int glds_dispatch(const IgemmArgs &a, int BM_, int BN_, int NS_, bool geglu, hipStream_t st) {
@@ -327,6 +340,7 @@ static int glds_dispatch(const IgemmArgs &a, int BM_, int BN_, int NS_, bool geg
 int igemm_glds_launch(const IgemmArgs &a_in, int dtype, int mode, bool geglu, int BM, int BN, int NS, hipStream_t st) {
     IgemmArgs a = a_in;
     a.dbg = g_igemm_dbg;
+    a.trace = g_igemm_trace;
     if (dtype == SFAST_F16) return mode ? glds_dispatch<f16, 1>(a, BM, BN, NS, geglu, st) : glds_dispatch<f16, 0>(a, BM, BN, NS, geglu, st);
     return mode ? glds_dispatch<bf16, 1>(a, BM, BN, NS, geglu, st) : glds_dispatch<bf16, 0>(a, BM, BN, NS, geglu, st);
 }

@@ -29,6 +29,7 @@ int check_launch(const char *what) {
 }
 
 extern int g_igemm_dbg;  // igemm_glds.hip
+extern unsigned long long *g_igemm_trace;  // igemm_glds.hip
 int igemm_init();      // igemm.hip
 int attention_init();  // attention.hip
 
@@ -53,6 +54,11 @@ int sfast_hip_set_debug(int flags) {
     const int prev = sfast::g_igemm_dbg;
     sfast::g_igemm_dbg = flags;
     return prev;
+}
+
+int sfast_hip_set_trace(void *buf) {
+    sfast::g_igemm_trace = (unsigned long long *)buf;
+    return 0;
 }
 
 const char *sfast_hip_last_error(void) { return sfast::g_err; }

@@ -16,6 +16,15 @@ run() { # name, timeout, command...
 rm -f gpurun_out/parity.jsonl gpurun_out/session.log
 rocminfo 2>/dev/null | grep -E "gfx|Compute Unit" | head -4 >> gpurun_out/session.log
 nproc >> gpurun_out/session.log
+if [ "$MODE" = "micro" ]; then
+  run t_gemm   900 $PYT tests/test_ops_gpu.py -k "geglu or linear or gemv"
+  run t_conv   900 $PYT tests/test_ops_gpu.py -k "conv"
+  run t_refapi 900 $PYT tests/test_reference_api_gpu.py
+  run trace 600 python tools/trace_igemm.py
+  run bench2 600 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-roofline
+  cut -c1-300 gpurun_out/session.log
+  exit 0
+fi
 run t_norm   600 $PYT tests/test_ops_gpu.py -k "group_norm or layer_norm"
 run t_gemm   900 $PYT tests/test_ops_gpu.py -k "geglu or linear or gemv"
 run t_conv   900 $PYT tests/test_ops_gpu.py -k "conv"

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Per-workgroup phase timeline of the MFMA GEMM kernels (sfast_hip_set_trace): where a workgroup's time goes.
+
+Slots (100 MHz wall clock): 0 entry, 1 metadata done, 2 prologue loads issued, 3 first K-tile usable,
+4 K loop done, 5 epilogue issued, 6 stores drained, 7 HW_ID | XCC_ID << 32.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "stable-fast_amd"))
+os.environ.setdefault("SFAST_AUTOTUNE", "0")
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from sfast.engine import UNet2DEngine  # noqa: E402
+from sfast.engine.unet_spec import SD15_CONFIG, random_params  # noqa: E402
+from sfast.hip import lib as L  # noqa: E402
+
+PROBES = [
+    ("down_blocks.0.attentions.0.transformer_blocks.0.ff.geglu", [(11, 1), (16, 1), (1, 1), (3, 1)]),
+    ("down_blocks.0.attentions.0.transformer_blocks.0.ff.out", [(13, 1), (18, 1), (3, 1)]),
+    ("down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_out", [(13, 1), (3, 1)]),
+    ("down_blocks.0.resnets.0.conv2", [(12, 2), (15, 2), (2, 4)]),
+    ("up_blocks.3.resnets.0.conv1", [(15, 4), (2, 4)]),
+    ("down_blocks.2.resnets.1.conv2", [(15, 12), (5, 12)]),
+]
+
+
+def pct(a, q):
+    return float(np.percentile(a, q)) / 100.0  # ticks (10 ns) -> us
+
+
+def main():
+    dev = torch.device("cuda")
+    eng = UNet2DEngine(SD15_CONFIG, random_params(SD15_CONFIG, device=dev))
+    plan = eng.build_plan(2, 64, 64, 77)
+    lib = L.load()
+    ws = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    trace = torch.zeros(8 * 65536, dtype=torch.int64, device=dev)
+    sp = torch.cuda.current_stream().cuda_stream
+    ops = {op.name: op for op in plan.ops}
+    names = ["setup", "issue", "1st-tile", "k-loop", "epi", "drain", "total"]
+    for name, cfgs in PROBES:
+        op = ops[name]
+        p, launch_with = op.tune
+        for v, s in cfgs:
+            p.variant, p.split_k = v, s
+            for _ in range(3):
+                assert launch_with(sp, ws.data_ptr(), ws.numel()) == 0
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(10):
+                launch_with(sp, ws.data_ptr(), ws.numel())
+            b.record()
+            b.synchronize()
+            t_us = a.elapsed_time(b) * 100
+            kern = L.last_kernel()
+            trace.zero_()
+            lib.sfast_hip_set_trace(trace.data_ptr())
+            launch_with(sp, ws.data_ptr(), ws.numel())
+            torch.cuda.synchronize()
+            lib.sfast_hip_set_trace(None)
+            t = trace.cpu().numpy().reshape(-1, 8)
+            t = t[t[:, 0] != 0]
+            n = len(t)
+            st = t[:, :7].astype(np.int64)
+            t0 = st[:, 0].min()
+            span = (st[:, 6].max() - t0) / 100.0
+            d = np.stack([st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2], st[:, 4] - st[:, 3],
+                          st[:, 5] - st[:, 4], st[:, 6] - st[:, 5], st[:, 6] - st[:, 0]], 1)
+            hw = t[:, 7].astype(np.uint64)
+            cu = ((hw >> np.uint64(32)) & np.uint64(0xF)) * np.uint64(256) + ((hw >> np.uint64(8)) & np.uint64(0xFF))
+            ncu = len(np.unique(cu))
+            # peak concurrent workgroups on one CU
+            peak = 0
+            for c in np.unique(cu)[:32]:
+                m = cu == c
+                ev = sorted([(x, 1) for x in st[m, 0]] + [(x, -1) for x in st[m, 6]])
+                cur = 0
+                for _, dlt in ev:
+                    cur += dlt
+                    peak = max(peak, cur)
+            start = st[:, 0] - t0
+            print(f"{name[-34:]:34s} {kern:42s} {t_us:6.1f} us/launch | traced span {span:6.1f} us, {n} WGs on {ncu} CUs, "
+                  f"peak {peak} WG/CU")
+            print("      phase med/p90 us: " + "  ".join(
+                f"{nm} {pct(d[:, i], 50):.2f}/{pct(d[:, i], 90):.2f}" for i, nm in enumerate(names)))
+            print(f"      WG start offsets us: p10 {pct(start, 10):.2f} p50 {pct(start, 50):.2f} p90 {pct(start, 90):.2f} "
+                  f"max {pct(start, 100):.2f}; first-round WGs (start < 1 us): {(start < 100).sum()}")
+        p.variant, p.split_k = 0, 0
+
+
+if __name__ == "__main__":
+    main()
