@@ -25,6 +25,15 @@ if [ "$MODE" = "micro" ]; then
   cut -c1-300 gpurun_out/session.log
   exit 0
 fi
+if [ "$MODE" = "prof" ]; then
+  run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -o bench -- python $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline > $OLDPWD/gpurun_out/rocprof.log 2>&1 )
+  echo "rocprof exit=$?" >> gpurun_out/session.log
+  for db in $(find gpurun_out/prof -name "*.db"); do python tools/rocpd_summary.py $db --csv gpurun_out/kernel_stats.csv --top 60 > gpurun_out/kernel_stats.txt; done
+  rm -rf gpurun_out/prof
+  cut -c1-300 gpurun_out/session.log
+  exit 0
+fi
 run t_norm   600 $PYT tests/test_ops_gpu.py -k "group_norm or layer_norm"
 run t_gemm   900 $PYT tests/test_ops_gpu.py -k "geglu or linear or gemv"
 run t_conv   900 $PYT tests/test_ops_gpu.py -k "conv"
