@@ -47,8 +47,11 @@ def parse():
     return ap.parse_args()
 
 
-def per_op_timing(loop, reps=3):
-    """Eager replay of the step with HIP events around every launch (same stream as the launches)."""
+def per_op_timing(loop, reps=2, burst=4):
+    """Eager replay of the step with HIP events on the launch stream. Every op is launched `burst` times back to
+    back between one event pair (the pair's own ~2-3 us of record overhead would otherwise be charged to every
+    5-15 us kernel), `reps` rounds; seconds = mean per launch. Runs after the timed region: repeating in-place
+    residual ops leaves garbage in the activation pool, which nothing reads afterwards."""
     from sfast.hip import lib as L
     plan = loop.plan
     stream = torch.cuda.current_stream()
@@ -61,36 +64,59 @@ def per_op_timing(loop, reps=3):
         for i, op in enumerate(plan.ops):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(stream)
-            op.launch(sp)
+            for _ in range(burst):
+                op.launch(sp)
             b.record(stream)
             names[i] = L.last_kernel()
             evs.append((a, b))
         torch.cuda.synchronize()
         for i, (a, b) in enumerate(evs):
-            tot[i] += a.elapsed_time(b) * 1e-3
+            tot[i] += a.elapsed_time(b) * 1e-3 / burst
     rows = []
     for i, op in enumerate(plan.ops):
         rows.append(dict(kind=op.kind, name=op.name, kernel=names[i], seconds=tot[i] / reps, flops=op.flops, bytes=op.bytes))
     return rows
 
 
+_IGEMM_WAVES = {("128x128", False): (2, 2), ("128x160", False): (4, 1), ("64x64", False): (2, 2), ("64x160", False): (2, 1),
+                ("256x128", False): (4, 2), ("128x128", True): (2, 2), ("64x128", True): (2, 2)}
+
+
+def kernel_symbol(variant):
+    """Device symbol (as rocprofv3 / profiles/*.csv print it) of a library kernel-variant string; split-K launches
+    of one tile shape share a symbol, so the split factor is dropped."""
+    import re
+    m = re.match(r"igemm_(conv|lin)_(f16|bf16)(_geglu)?\[(\d+x\d+),split=\d+,(reg|dma(\d)|ws(\d))\]", variant)
+    if not m:
+        return variant.split("[")[0]
+    mode = 1 if m.group(1) == "conv" else 0
+    t = "DF16_" if m.group(2) == "f16" else "DF16b"
+    geglu = m.group(3) is not None
+    bm, bn = m.group(4).split("x")
+    wm, wn = _IGEMM_WAVES[(m.group(4), geglu)]
+    if m.group(5) == "reg":
+        return f"_ZN5sfast12igemm_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi{mode}ELb{int(geglu)}EEEvNS_9IgemmArgsE"
+    if m.group(5).startswith("ws"):
+        return f"_ZN5sfast20igemm_glds_ws_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi4ELi{m.group(7)}ELi{mode}ELb{int(geglu)}EEEvNS_9IgemmArgsE"
+    if m.group(5).startswith("ws"):
+        return f"_ZN5sfast20igemm_glds_ws_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi4ELi{m.group(7)}ELi{mode}ELb{int(geglu)}EEEvNS_9IgemmArgsE"
+    return f"_ZN5sfast17igemm_glds_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi{m.group(6)}ELi{mode}ELb{int(geglu)}ELi0EEEvNS_9IgemmArgsE"
+
+
 def roofline_from(rows):
     by_kernel = {}
     for r in rows:
-        k = by_kernel.setdefault(r["kernel"], dict(seconds=0.0, flops=0.0, bytes=0.0, launches=0, kinds=set()))
+        sym = kernel_symbol(r["kernel"])
+        k = by_kernel.setdefault(sym, dict(seconds=0.0, flops=0.0, bytes=0.0, launches=0, kinds={}, variants=set()))
         k["seconds"] += r["seconds"]
         k["flops"] += r["flops"]
         k["bytes"] += r["bytes"]
         k["launches"] += 1
-        k["kinds"].add(r["kind"])
+        k["kinds"][r["kind"]] = k["kinds"].get(r["kind"], 0) + 1
+        k["variants"].add(r["kernel"])
     total = sum(v["seconds"] for v in by_kernel.values())
-    # dominant = the kernel variant with the largest time share inside the dominant op family of the step
-    fam_time = {}
-    for r in rows:
-        fam_time[r["kind"]] = fam_time.get(r["kind"], 0.0) + r["seconds"]
-    dom_family = max(fam_time.items(), key=lambda kv: kv[1])[0]
-    in_family = {r["kernel"] for r in rows if r["kind"] == dom_family}
-    dom_name, dom = max(((k, v) for k, v in by_kernel.items() if k in in_family), key=lambda kv: kv[1]["seconds"])
+    # dominant kernel = the device symbol with the largest share of the step (what `rocprofv3 --stats` ranks first)
+    dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["seconds"])
     mfma = dom["flops"] > 0 and (dom["flops"] / MFMA_PEAK_TFLOPS / 1e12) > (dom["bytes"] / HBM_PEAK_GBS / 1e9)
     if mfma:
         achieved = dom["flops"] / dom["seconds"] / 1e12
@@ -98,7 +124,7 @@ def roofline_from(rows):
     else:
         achieved = dom["bytes"] / dom["seconds"] / 1e9
         roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS)
-    roof.update(kernel=dom_name, family=dom_family, family_share_of_step=fam_time[dom_family] / total,
+    roof.update(kernel=dom_name, variants=sorted(dom["variants"])[:6], op_kinds=dom["kinds"],
                 launches_per_step=dom["launches"], avg_launch_us=dom["seconds"] / dom["launches"] * 1e6,
                 share_of_step=dom["seconds"] / total, algorithmic_gflop_per_launch=dom["flops"] / dom["launches"] / 1e9,
                 algorithmic_mbytes_per_launch=dom["bytes"] / dom["launches"] / 1e6, traffic=None)

@@ -80,11 +80,8 @@ const char *sfast_hip_last_error(void);
 /* name of the kernel variant chosen by the most recent gemm / conv2d / attention call on this
  * thread (diagnostics, tests and bench roofline bookkeeping). */
 const char *sfast_hip_last_kernel(void);
-/* profiling ablations of the LDS-DMA GEMM pipe (bit0: skip the MFMA phase, bit1: skip in-loop refills);
- * results are garbage while set. Returns the previous flags; 0 (default) = production behaviour. */
-int sfast_hip_set_debug(int flags);
-/* profiling: while `buf` is non-NULL every MFMA GEMM workgroup writes 8 uint64 (100 MHz wall-clock stamps of
- * its phases + HW_ID) at buf[(blockIdx.y*gridDim.x+blockIdx.x)*8]; the caller sizes buf for the launch
+/* profiling: while `buf` is non-NULL every MFMA GEMM workgroup writes 16 uint64 (100 MHz wall-clock stamps of
+ * its phases, HW_ID, shader-clock counter at entry/exit) at buf[(blockIdx.y*gridDim.x+blockIdx.x)*16]; the caller sizes buf for the launch
  * (sfast_hip_igemm_plan gives the grid). NULL (default) = production behaviour. */
 int sfast_hip_set_trace(void *buf);
 
@@ -150,7 +147,8 @@ int sfast_hip_gemm(const void *x, const void *const *w_segs, const void *bias,
 
 /* diagnostic, host-only: the tile / split-K choice the MFMA path would make for an [M,N,K] problem.
  * out = {BM, BN (weight rows per tile), splits, k_tiles_per_split, variant id}; variant ids 1..5 are the
- * register-staged pipe, 11..15 the LDS-DMA ring with the same tile shapes. */
+ * register-staged pipe, 11..18 the LDS-DMA ring (same tile shapes, ring depths 2..5), 21..23 the wave-specialised
+ * LDS-DMA pipe (producer waves + consumer waves). */
 int sfast_hip_igemm_plan(int32_t M, int32_t N, int32_t K, int32_t geglu, int32_t variant, int32_t split_k,
                          int32_t out[5]);
 

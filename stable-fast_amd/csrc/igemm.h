@@ -19,7 +19,6 @@ struct IgemmArgs {
     int H, W, C1, C2, Ho, Wo, KH, KW, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, ups;
     int tiles_m, tiles_n, ktiles, ktiles_per_split, splits;
     unsigned long long *trace;  // profiling: per-workgroup phase timestamps (8 slots each); nullptr in production
-    int dbg;  // profiling ablation (SFAST_IGEMM_DBG): bit0 skip MFMA phase, bit1 skip in-loop refills. 0 in production.
 };
 
 // mode: 0 = linear (x row m at x + m*ldx), 1 = conv (implicit im2col over dense NHWC x / x2).

@@ -54,6 +54,8 @@ __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, 2 * 
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    touch_args(a);
+    if (MODE == 1) touch_conv_args(a);
     trace_mark(a, 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
@@ -261,28 +263,83 @@ __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, 2 * 
 // split-K reduce + epilogue: one thread per 4 consecutive output columns.
 template <typename T, bool GEGLU>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const IgemmArgs a) {
-    const int64_t n4 = a.N / 4;
+    typedef const u32x2 __attribute__((address_space(1))) * g2_ptr;
+    const g2_ptr zero = (g2_ptr)(const void *)g_zero16;
+    const int n4 = a.N / 4;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int64_t)a.M * n4) return;
-    const int m = (int)(idx / n4);
-    const int n = (int)(idx % n4) * 4;
+    const int64_t total = (int64_t)a.M * n4;
+    if (idx >= total) return;
+    int m;
+    if (total <= (1 << 22)) {
+        m = fdiv22((int)idx, n4, __builtin_amdgcn_rcpf((float)n4));
+    } else {
+        m = (int)(idx / n4);
+    }
+    const int n = ((int)(idx - (int64_t)m * n4)) * 4;
     const int64_t NP = GEGLU ? 2 * (int64_t)a.N : (int64_t)a.N;
+    // epilogue operands first: their round trip overlaps the slab reads instead of following them
+    u32x2 vb = *(a.bias ? (g2_ptr)(const void *)((const T *)a.bias + n) : zero);
+    u32x2 vb2, vr;
+    if (GEGLU) {
+        vb2 = *(a.bias ? (g2_ptr)(const void *)((const T *)a.bias + a.N + n) : zero);
+        vr = u32x2{0u, 0u};
+    } else {
+        const BatchOfRow batch_of(a);
+        const int bi = a.rowbias ? batch_of(m) : 0;
+        vb2 = *(a.rowbias ? (g2_ptr)(const void *)((const T *)a.rowbias + (int64_t)bi * a.ld_rowbias + n) : zero);
+        vr = *(a.res ? (g2_ptr)(const void *)((const T *)a.res + (int64_t)m * a.ldr + n) : zero);
+    }
     float v[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < a.splits; ++z) {
-        const float *p = a.partial + ((int64_t)z * a.M + m) * NP;
-        const f32x4 t = *reinterpret_cast<const f32x4 *>(p + n);
+    const float *p0 = a.partial + (int64_t)m * NP + n;
+    const int64_t zstride = (int64_t)a.M * NP;
+    int z = 0;
+    for (; z + 3 < a.splits; z += 4) {  // four slab loads in flight, summation order z = 0, 1, 2, ...
+        f32x4 t[4], u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            t[k] = *reinterpret_cast<const f32x4 *>(p0 + (z + k) * zstride);
+            if (GEGLU) u[k] = *reinterpret_cast<const f32x4 *>(p0 + (z + k) * zstride + a.N);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] += t[k][i];
+                if (GEGLU) g[i] += u[k][i];
+            }
+    }
+    for (; z < a.splits; ++z) {
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(p0 + z * zstride);
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] += t[i];
         if (GEGLU) {
-            const f32x4 u = *reinterpret_cast<const f32x4 *>(p + a.N + n);
+            const f32x4 u = *reinterpret_cast<const f32x4 *>(p0 + z * zstride + a.N);
 #pragma unroll
             for (int i = 0; i < 4; ++i) g[i] += u[i];
         }
     }
-    if (GEGLU)
-        epilogue4_geglu<T>(a, m, n, v, g);
-    else
-        epilogue4<T>(a, m, n, v);
+    float b0[4], b1[4], r[4], o[4];
+    unpack4<T>(vb, b0);
+    unpack4<T>(vb2, b1);
+    unpack4<T>(vr, r);
+    if (GEGLU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (v[i] + b0[i]) * act_gelu_erf(g[i] + b1[i]);
+    } else {
+        const bool res_now = a.res_before_act || a.act == SFAST_ACT_NONE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = v[i] + b0[i] + b1[i] + (res_now ? r[i] * a.alpha : -0.0f);
+        if (a.act != SFAST_ACT_NONE) {
+            f32x4 ov = {o[0], o[1], o[2], o[3]};
+#pragma unroll 1
+            for (int i = 0; i < 4; ++i) ov[i] = apply_act(ov[i], a.act);  // rolled: one copy of the activation switch
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = ov[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] += res_now ? -0.0f : r[i] * a.alpha;
+        }
+    }
+    *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = pack4<T>(o[0], o[1], o[2], o[3]);
 }
 
 // ---- host side: variants, heuristics, launch -------------------------------------------------------
@@ -299,13 +356,18 @@ static const Variant kVariants[] = {
     {12, 128, 160, 4, 1, 1, 4, 1.00f}, {13, 64, 64, 2, 2, 1, 5, 0.60f},   {14, 64, 160, 2, 1, 1, 4, 0.80f},
     {15, 256, 128, 4, 2, 1, 3, 1.10f}, {16, 128, 128, 2, 2, 1, 2, 1.00f}, {17, 128, 160, 4, 1, 1, 2, 1.00f},
     {18, 64, 64, 2, 2, 1, 3, 0.60f},
+    // pipe 2: wave-specialised LDS-DMA (igemm_glds_ws.hip): 4 producer waves + WM*WN consumer waves
+    {21, 128, 128, 2, 2, 2, 4, 1.00f}, {22, 128, 160, 4, 1, 2, 4, 1.00f}, {23, 64, 64, 2, 2, 2, 4, 0.60f},
 };
 static const Variant kGegluVariants[] = {
     {1, 128, 128, 2, 2, 0, 2, 1.00f},  {3, 64, 128, 2, 2, 0, 2, 0.75f},  {11, 128, 128, 2, 2, 1, 4, 1.00f},
     {13, 64, 128, 2, 2, 1, 5, 0.75f},  {16, 128, 128, 2, 2, 1, 2, 1.00f}, {18, 64, 128, 2, 2, 1, 3, 0.75f},
+    {21, 128, 128, 2, 2, 2, 4, 1.00f}, {23, 64, 128, 2, 2, 2, 3, 0.75f},
 };
 
 extern unsigned long long *g_igemm_trace;  // igemm_glds.hip
+int igemm_glds_ws_init();  // igemm_glds_ws.hip
+int igemm_glds_ws_launch(const IgemmArgs &a, int dtype, int mode, bool geglu, int BM, int BN, int NS, hipStream_t st);
 int igemm_glds_init();                                                                               // igemm_glds.hip
 int igemm_glds_launch(const IgemmArgs &a, int dtype, int mode, bool geglu, int BM, int BN, int NS, hipStream_t st);  // igemm_glds.hip
 
@@ -355,6 +417,7 @@ int igemm_init() {
     SFAST_FOR_GEGLU_VARIANTS(bf16, INIT_OP)
 #undef INIT_OP
     if (!rc) rc = igemm_glds_init();
+    if (!rc) rc = igemm_glds_ws_init();
     const char *e = getenv("SFAST_IGEMM_PIPE");
     if (e && e[0] == 'r') g_pipe_pref = 0;
     if (e && e[0] == 'g') g_pipe_pref = 1;
@@ -404,10 +467,10 @@ static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, 
         } else {
             if (v.BM == 64 && v.BN == 160) continue;  // never the measured optimum on MI355X sweeps
             if (v.id >= 16) continue;                  // shallow rings are autotuner candidates only
-            if (v.pipe == 1 && (!glds_ok || g_pipe_pref == 0)) continue;
+            if (v.pipe >= 1 && (!glds_ok || g_pipe_pref == 0)) continue;
             if (v.pipe == 0 && glds_ok && g_pipe_pref == 1) continue;
         }
-        if (v.pipe == 1 && !glds_ok) continue;
+        if (v.pipe >= 1 && !glds_ok) continue;
         const int bno = geglu ? v.BN / 2 : v.BN;
         const int tm = ceil_div(M, v.BM), tn = ceil_div(N, bno);
         const int tiles = tm * tn;
@@ -486,7 +549,10 @@ size_t igemm_workspace_bytes(int M, int N, int K, bool geglu, int variant, int s
 // The LDS-DMA pipe takes every linear problem; conv problems need uniform taps per K-tile.
 bool igemm_glds_eligible(const IgemmArgs &a, int mode) {
     if (mode == 0) return true;
-    return !a.ups && a.C1 % 64 == 0 && a.C2 % 64 == 0 && a.KH * a.KW <= 32;
+    // the LDS-DMA kernel addresses activations with 32-bit element offsets
+    const int64_t batch = (a.Ho > 0 && a.Wo > 0) ? (int64_t)a.M / ((int64_t)a.Ho * a.Wo) : 0;
+    const int64_t elems = batch * a.H * a.W * (int64_t)(a.C1 > a.C2 ? a.C1 : a.C2);
+    return !a.ups && a.C1 % 64 == 0 && a.C2 % 64 == 0 && a.KH * a.KW <= 32 && elems < (1ll << 31);
 }
 
 // entry used by api_gemm_conv.hip. mode: 0 linear, 1 conv. Fills plan fields of `a`.
@@ -507,11 +573,13 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
         a.partial = (float *)ws;
     }
     char pipe[8];
-    snprintf(pipe, sizeof(pipe), p.v.pipe ? "dma%d" : "reg", p.v.ns);
+    snprintf(pipe, sizeof(pipe), p.v.pipe == 2 ? "ws%d" : p.v.pipe ? "dma%d" : "reg", p.v.ns);
     set_kernel_name("igemm_%s_%s%s[%dx%d,split=%d,%s]", mode ? "conv" : "lin", dtype == SFAST_F16 ? "f16" : "bf16",
                     geglu ? "_geglu" : "", p.v.BM, p.v.BN, p.splits, pipe);
     int rc;
-    if (p.v.pipe == 1)
+    if (p.v.pipe == 2)
+        rc = igemm_glds_ws_launch(a, dtype, mode, geglu, p.v.BM, p.v.BN, p.v.ns, st);
+    else if (p.v.pipe == 1)
         rc = igemm_glds_launch(a, dtype, mode, geglu, p.v.BM, p.v.BN, p.v.ns, st);
     else if (dtype == SFAST_F16)
         rc = mode ? dispatch_variant<f16, 1>(a, p.v, geglu, st) : dispatch_variant<f16, 0>(a, p.v, geglu, st);

@@ -6,11 +6,14 @@
 namespace sfast {
 
 // Profiling only (sfast_hip_set_trace): thread 0 of every workgroup stamps the 100 MHz wall clock into
-// slot `slot` of its 8-slot record. One uniform scalar branch when tracing is off.
+// slot `slot` of its 16-slot record. One uniform scalar branch when tracing is off.
 __device__ __forceinline__ void trace_mark(const IgemmArgs &a, int slot) {
     if (a.trace != nullptr) {
-        if (threadIdx.x == 0)
-            a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + slot] = wall_clock64();
+        if (threadIdx.x == 0) {
+            unsigned long long *rec = a.trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
+            rec[slot] = wall_clock64();
+            if (slot == 0) rec[8] = clock64();  // shader-clock counter: (rec[9] - rec[8]) / wall time = effective clock
+        }
     }
 }
 __device__ __forceinline__ void trace_finish(const IgemmArgs &a) {
@@ -19,14 +22,14 @@ __device__ __forceinline__ void trace_finish(const IgemmArgs &a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         trace_mark(a, 6);
         if (threadIdx.x == 0) {
+            unsigned long long *rec = a.trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
+            rec[9] = clock64();
             const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
             const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
-            a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = ((unsigned long long)xcc << 32) | hw;
+            rec[7] = ((unsigned long long)xcc << 32) | hw;
         }
     }
 }
-
-
 __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
@@ -45,6 +48,20 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 constexpr int igemm_min_waves(int threads, int lds_bytes) {
     const int w = (163840 / lds_bytes) * (threads / 256);
     return w < 1 ? 1 : (w > 3 ? 3 : w);
+}
+
+// Requests the whole argument block in one burst of scalar loads behind ONE wait. Left alone, the compiler fetches
+// kernarg fields lazily, group by group, each group behind its own `s_waitcnt lgkmcnt(0)`: six serialized scalar
+// round trips (~1 us) at the top of every workgroup of a 6-13 us kernel.
+__device__ __forceinline__ void touch_args(const IgemmArgs &a) {
+    asm volatile("" ::"s"(a.x), "s"(a.x2), "s"(a.w[0]), "s"(a.w[1]), "s"(a.w[2]), "s"(a.w[3]), "s"(a.bias), "s"(a.rowbias), "s"(a.res),
+                 "s"(a.out), "s"(a.partial), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.ldx), "s"(a.ldw), "s"(a.ldo), "s"(a.ldr),
+                 "s"(a.ld_rowbias), "s"(a.rows_per_seg), "s"(a.rows_per_batch), "s"(a.act), "s"(a.res_before_act), "s"(a.alpha));
+    asm volatile("" ::"s"(a.tiles_m), "s"(a.tiles_n), "s"(a.ktiles), "s"(a.ktiles_per_split), "s"(a.splits), "s"(a.trace));
+}
+__device__ __forceinline__ void touch_conv_args(const IgemmArgs &a) {
+    asm volatile("" ::"s"(a.H), "s"(a.W), "s"(a.C1), "s"(a.C2), "s"(a.Ho), "s"(a.Wo), "s"(a.KH), "s"(a.KW), "s"(a.stride_h), "s"(a.stride_w),
+                 "s"(a.pad_h), "s"(a.pad_w), "s"(a.dil_h), "s"(a.dil_w), "s"(a.ups));
 }
 
 // floor(n / d) for 0 <= n <= 2^22 and d >= 1 with a precomputed rd = rcp((float)d): float(n) is exact and the
@@ -104,74 +121,6 @@ template <int FN, int FM, int FH> __device__ __forceinline__ void apply_act_tile
         }
 }
 
-// final epilogue for 4 consecutive columns n..n+3 of row m (fp32 in, T out) -- split-K reduce kernel
-template <typename T>
-__device__ __forceinline__ void epilogue4(const IgemmArgs &a, int m, int n, float (&v)[4]) {
-    if (a.bias) {
-        float b[4];
-        unpack4<T>(*reinterpret_cast<const u32x2 *>((const T *)a.bias + n), b);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] += b[i];
-    }
-    if (a.rowbias) {
-        float b[4];
-        const int bi = m / a.rows_per_batch;
-        unpack4<T>(*reinterpret_cast<const u32x2 *>((const T *)a.rowbias + (int64_t)bi * a.ld_rowbias + n), b);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] += b[i];
-    }
-    float r[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.res) {
-        unpack4<T>(*reinterpret_cast<const u32x2 *>((const T *)a.res + (int64_t)m * a.ldr + n), r);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] *= a.alpha;
-    }
-    if (a.res_before_act) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] += r[i];
-    }
-    if (a.act != SFAST_ACT_NONE) {
-        switch (a.act) {
-        case SFAST_ACT_SILU:
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = act_silu(v[i]);
-            break;
-        case SFAST_ACT_GELU:
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = act_gelu_erf(v[i]);
-            break;
-        default:
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], a.act);
-            break;
-        }
-    }
-    if (!a.res_before_act) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] += r[i];
-    }
-    *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
-}
-
-template <typename T>
-__device__ __forceinline__ void epilogue4_geglu(const IgemmArgs &a, int m, int n, float (&h)[4], float (&g)[4]) {
-    if (a.bias) {
-        float bh[4], bg[4];
-        unpack4<T>(*reinterpret_cast<const u32x2 *>((const T *)a.bias + n), bh);
-        unpack4<T>(*reinterpret_cast<const u32x2 *>((const T *)a.bias + a.N + n), bg);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            h[i] += bh[i];
-            g[i] += bg[i];
-        }
-    }
-    float v[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = h[i] * act_gelu_erf(g[i]);
-    *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
-}
-
-
 // ---- whole-tile epilogue ---------------------------------------------------------------------------------
 // acc[fn][fm] holds D[n][m] fragments (32x32 C/D layout). Every bias / row-bias / residual vector of the
 // tile is requested unconditionally in ONE batch (absent operands and out-of-range groups are redirected
@@ -182,6 +131,22 @@ __device__ __forceinline__ void epilogue4_geglu(const IgemmArgs &a, int m, int n
 // whole main loop instead of being paid once more at the end of every workgroup -- the short-K GEMMs of
 // the transformer blocks are chains of exposed memory round trips otherwise) and consumed by
 // epilogue_finish(). Split-K launches skip both (the reduce kernel applies the epilogue).
+// Epilogue operand addressing. One row base per operand and per 32-row fragment, with absence folded in (a missing
+// operand or an out-of-range row points at the device zero block); a load is then base + (in range ? n : 0) halves:
+// a predicate AND, a select and one 64-bit add. The first version re-derived `present && in range ? ptr : zero`
+// per load -- ~30 instructions each, 1800 for a 128x160 tile, most of a 2 us workgroup prologue.
+template <typename T> struct EpiRow {
+    typedef const u32x2 __attribute__((address_space(1))) * g2_ptr;
+    typedef const T __attribute__((address_space(1))) * gT_ptr;
+    gT_ptr base;
+    bool have;
+    __device__ __forceinline__ EpiRow(const void *p, int64_t elem_off, bool row_ok) {
+        have = row_ok & (p != nullptr);
+        base = have ? (gT_ptr)p + elem_off : (gT_ptr)(const void *)g_zero16;
+    }
+    __device__ __forceinline__ u32x2 load(int n, bool nok) const { return *(g2_ptr)(base + ((have & nok) ? n : 0)); }
+};
+
 template <int FH, int FM> struct EpiOperands {
     u32x2 vb[FH][4];       // bias (GEGLU: bias of the h half)
     u32x2 vb2[FM][FH][4];  // row-bias (GEGLU: bias of the g half, index [0])
@@ -191,18 +156,17 @@ template <int FH, int FM> struct EpiOperands {
 template <typename T, int FN, int FM, bool GEGLU>
 __device__ __forceinline__ void epilogue_prefetch(const IgemmArgs &a, EpiOperands<(GEGLU ? FN / 2 : FN), FM> &e, int mbase, int nbase,
                                                   int l31, int hi) {
-    typedef const u32x2 __attribute__((address_space(1))) * g2_ptr;
-    const g2_ptr zero = (g2_ptr)(const void *)g_zero16;
     constexpr int FH = GEGLU ? FN / 2 : FN;
     if (a.splits > 1) return;
+    const EpiRow<T> bias(a.bias, 0, true), bias_g(a.bias, a.N, true);
 #pragma unroll
     for (int fh = 0; fh < FH; ++fh)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = nbase + fh * 32 + 8 * g + 4 * hi;
             const bool nok = n < a.N;
-            e.vb[fh][g] = *((nok && a.bias) ? (g2_ptr)(const void *)((const T *)a.bias + n) : zero);
-            if (GEGLU) e.vb2[0][fh][g] = *((nok && a.bias) ? (g2_ptr)(const void *)((const T *)a.bias + a.N + n) : zero);
+            e.vb[fh][g] = bias.load(n, nok);
+            if (GEGLU) e.vb2[0][fh][g] = bias_g.load(n, nok);
         }
     if (GEGLU) return;
     const BatchOfRow batch_of(a);
@@ -211,14 +175,15 @@ __device__ __forceinline__ void epilogue_prefetch(const IgemmArgs &a, EpiOperand
         const int m = mbase + fm * 32 + l31;
         const bool mok = m < a.M;
         const int bi = a.rowbias ? batch_of(m) : 0;
+        const EpiRow<T> rowbias(a.rowbias, (int64_t)bi * a.ld_rowbias, mok), res(a.res, (int64_t)m * a.ldr, mok);
 #pragma unroll
         for (int fh = 0; fh < FH; ++fh)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = nbase + fh * 32 + 8 * g + 4 * hi;
-                const bool ok = mok && n < a.N;
-                e.vb2[fm][fh][g] = *((ok && a.rowbias) ? (g2_ptr)(const void *)((const T *)a.rowbias + (int64_t)bi * a.ld_rowbias + n) : zero);
-                e.vr[fm][fh][g] = *((ok && a.res) ? (g2_ptr)(const void *)((const T *)a.res + (int64_t)m * a.ldr + n) : zero);
+                const bool nok = n < a.N;
+                e.vb2[fm][fh][g] = rowbias.load(n, nok);
+                e.vr[fm][fh][g] = res.load(n, nok);
             }
     }
 }
@@ -301,11 +266,11 @@ __device__ __forceinline__ void epilogue_act_tail(const IgemmArgs &a, f32x16 (&a
     auto fetch = [&](int f, int buf) {
         const int fm = f / FN, fh = f % FN;
         const int m = mbase + fm * 32 + l31;
+        const EpiRow<T> res(a.res, (int64_t)m * a.ldr, post && m < a.M);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = nbase + fh * 32 + 8 * g + 4 * hi;
-            const bool ok = post && m < a.M && n < a.N;
-            vr[buf][g] = *(ok ? (g2_ptr)(const void *)((const T *)a.res + (int64_t)m * a.ldr + n) : zero);
+            vr[buf][g] = res.load(n, n < a.N);
         }
     };
     fetch(0, 0);
@@ -373,18 +338,20 @@ __device__ __forceinline__ void epilogue_late(const IgemmArgs &a, f32x16 (&acc)[
     }
     const BatchOfRow batch_of(a);
     u32x2 vb[2][4], vb2[2][4], vr[2][4];
+    const EpiRow<T> bias(a.bias, 0, true);
     auto fetch = [&](int f, int buf) {
         const int fm = f / FN, fh = f % FN;
         const int m = mbase + fm * 32 + l31;
         const bool mok = m < a.M;
         const int bi = a.rowbias ? batch_of(m) : 0;
+        const EpiRow<T> rowbias(a.rowbias, (int64_t)bi * a.ld_rowbias, mok), res(a.res, (int64_t)m * a.ldr, mok);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = nbase + fh * 32 + 8 * g + 4 * hi;
-            const bool ok = mok && n < a.N;
-            vb[buf][g] = *((ok && a.bias) ? (g2_ptr)(const void *)((const T *)a.bias + n) : zero);
-            vb2[buf][g] = *((ok && a.rowbias) ? (g2_ptr)(const void *)((const T *)a.rowbias + (int64_t)bi * a.ld_rowbias + n) : zero);
-            vr[buf][g] = *((ok && a.res) ? (g2_ptr)(const void *)((const T *)a.res + (int64_t)m * a.ldr + n) : zero);
+            const bool nok = n < a.N;
+            vb[buf][g] = bias.load(n, nok);
+            vb2[buf][g] = rowbias.load(n, nok);
+            vr[buf][g] = res.load(n, nok);
         }
     };
     fetch(0, 0);

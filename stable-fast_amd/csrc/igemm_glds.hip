@@ -24,6 +24,8 @@
 //     conv_in). Problems outside that envelope (upsample-fused convs, odd channel counts) keep using
 //     the register-staged kernel.
 #include "igemm_device.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace sfast {
 
@@ -34,7 +36,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 typedef const u32x4 __attribute__((address_space(1))) * glds_src_t;
 typedef __attribute__((address_space(3))) void *glds_dst_t;
 
-template <typename T, int BM, int BN, int WM, int WN, int NS, int MODE, bool GEGLU>
+// EXP != 0: profiling experiments (tools/trace_igemm.py, only instantiated for two tiles): bit0 no MFMAs, bit1 no
+// fragment reads, bit2 no in-loop LDS-DMA requests, bit3 no per-tile barrier. Results are garbage.
+template <typename T, int BM, int BN, int WM, int WN, int NS, int MODE, bool GEGLU, int EXP = 0>
 __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, NS *(BM + BN) * 128)) igemm_glds_kernel(const IgemmArgs a) {
     using vec8 = typename Elem<T>::vec8;
     constexpr int NT = WM * WN * 64;
@@ -54,6 +58,8 @@ __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, NS *
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    touch_args(a);
+    if (MODE == 1) touch_conv_args(a);
     trace_mark(a, 0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,17 +82,25 @@ __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, NS *
     // LOGICAL chunk kc (source-side swizzle; RPP % 16 == 0 keeps it independent of i)
     const int rbase = tid >> 3;
     const int kc = (tid & 7) ^ ((rbase >> 1) & 7);
+    const glds_src_t zero_src = (glds_src_t)(const void *)g_zero16;
 
-    // ---- activation-row metadata -------------------------------------------------------------------
-    const T *xrow[XCH];  // MODE 0: row pointer or nullptr
-    int xpix[XCH];       // MODE 1: pixel index of tap (0,0) (may be negative), in input pixels
+    // ---- per-row staging metadata, computed once ------------------------------------------------------------
+    // Everything lane-dependent about a load's address is folded into a per-row value here; per K-tile the
+    // address is that value plus a wave-uniform (scalar) term. The in-loop cost of one LDS-DMA request is then
+    // a validity test, one 64-bit add and the zero-block select -- no integer multiply, no division.
+    const T *xrow[XCH];   // MODE 0: row pointer at column kc*8, or nullptr
+    int xoffB[XCH];       // MODE 1: element offset of (tap (0,0), channel kc*8) in source 2 (pitch C2, virtual concat)
+    int xdAB[XCH];        //         (same offset in source 1, pitch C1) - xoffB: blended in with a uniform mask
     unsigned xmask[XCH];  // MODE 1: bit (r*KW+s) set when that tap is inside the image
     const PixelDecoder decode(a);
+    unsigned rep_all = 0;  // bit r*KW set for every tap row r (uniform)
+    if (MODE == 1)
+        for (int r = 0; r < a.KH; ++r) rep_all |= 1u << (r * a.KW);
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
         const int m = m0 + rbase + i * RPP;
         if (MODE == 0) {
-            xrow[i] = (m < a.M) ? (const T *)a.x + (int64_t)m * a.ldx : nullptr;
+            xrow[i] = (m < a.M) ? (const T *)a.x + (int64_t)m * a.ldx + kc * 8 : nullptr;
         } else {
             unsigned mask = 0;
             int pix = 0;
@@ -95,16 +109,28 @@ __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, NS *
                 decode(m, b, ho, wo);
                 const int h0 = ho * a.stride_h - a.pad_h, w0 = wo * a.stride_w - a.pad_w;
                 pix = (b * a.H + h0) * a.W + w0;
-                // validity is separable: KW column bits, replicated into every valid tap row
-                unsigned cols = 0;
-                for (int s = 0; s < a.KW; ++s) cols |= ((unsigned)(w0 + s * a.dil_w) < (unsigned)a.W ? 1u : 0u) << s;
-                for (int r = 0; r < a.KH; ++r) mask |= ((unsigned)(h0 + r * a.dil_h) < (unsigned)a.H ? cols : 0u) << (r * a.KW);
+                if (a.dil_h == 1 && a.dil_w == 1) {
+                    // closed form: taps s in [s_lo, s_hi) x r in [r_lo, r_hi) are inside the image
+                    const int s_lo = max(0, -w0), s_hi = min(a.KW, a.W - w0);
+                    const int r_lo = max(0, -h0), r_hi = min(a.KH, a.H - h0);
+                    if (s_hi > s_lo && r_hi > r_lo) {
+                        const unsigned cols = ((1u << s_hi) - 1u) & ~((1u << s_lo) - 1u);
+                        const unsigned lo_bits = r_lo * a.KW, hi_bits = r_hi * a.KW;  // <= 32
+                        const unsigned upto = hi_bits >= 32 ? 0xffffffffu : ((1u << hi_bits) - 1u);
+                        mask = cols * (rep_all & upto & ~((1u << lo_bits) - 1u));  // no carries: cols < 2^KW
+                    }
+                } else {
+                    unsigned cols = 0;
+                    for (int s = 0; s < a.KW; ++s) cols |= ((unsigned)(w0 + s * a.dil_w) < (unsigned)a.W ? 1u : 0u) << s;
+                    for (int r = 0; r < a.KH; ++r) mask |= ((unsigned)(h0 + r * a.dil_h) < (unsigned)a.H ? cols : 0u) << (r * a.KW);
+                }
             }
-            xpix[i] = pix;
+            xoffB[i] = pix * a.C2 + kc * 8;
+            xdAB[i] = pix * (a.C1 - a.C2);
             xmask[i] = mask;
         }
     }
-    const T *wrow[WCH];
+    const T *wrow[WCH];  // weight row pointer at column kc*8, or nullptr
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
         const int j = rbase + i * RPP;
@@ -112,21 +138,21 @@ __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, NS *
             const int grp = j / WNB, within = j % WNB;
             const int half = within / (WNB / 2), i2 = within % (WNB / 2);
             const int ncol = n0 + grp * (WNB / 2) + i2;
-            wrow[i] = (ncol < a.N) ? (const T *)a.w[0] + ((int64_t)half * a.N + ncol) * a.ldw : nullptr;
+            wrow[i] = (ncol < a.N) ? (const T *)a.w[0] + ((int64_t)half * a.N + ncol) * a.ldw + kc * 8 : nullptr;
         } else {
             const int n = n0 + j;
             if (n < a.N) {
                 const int rs = a.rows_per_seg;
                 const int seg = (n >= rs) + (n - rs >= rs) + (n - rs - rs >= rs);
                 const void *base = seg == 0 ? a.w[0] : seg == 1 ? a.w[1] : seg == 2 ? a.w[2] : a.w[3];
-                wrow[i] = (const T *)base + (int64_t)(n - seg * a.rows_per_seg) * a.ldw;
+                wrow[i] = (const T *)base + (int64_t)(n - seg * rs) * a.ldw + kc * 8;
             } else {
                 wrow[i] = nullptr;
             }
         }
     }
 
-    // ---- wave-uniform conv tap state of the NEXT tile to be issued ---------------------------------------
+    // ---- wave-uniform state of the NEXT tile to be issued ------------------------------------------------------
     const int cin = a.C1 + a.C2;
     int t_tap = 0, t_r = 0, t_s = 0, t_c = 0;
     if (MODE == 1) {
@@ -136,46 +162,41 @@ __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, NS *
         t_r = t_tap / a.KW;
         t_s = t_tap - t_r * a.KW;
     }
+    int issued = kt_begin, istage = 0;
 
-    auto issue = [&](int kt, int stage) {
-        char *sx = smem + stage * STAGE + wave * 1024;
+    // One LDS-DMA request of the next tile: slice l < XCH is activation row-pass l, the others weight row-passes.
+    // Requests are unconditional; an invalid chunk (image border, row >= M, k >= K) is redirected to the device
+    // zero block. `l` is a compile-time constant at every call site.
+    auto issue_slice = [&](int l) {
+        char *sx = smem + istage * STAGE + wave * 1024;
         char *sw = sx + BM * 128;
-        const int k = kt * 64 + kc * 8;
-        if (MODE == 0) {
-            const bool kvalid = k < a.K;
-#pragma unroll
-            for (int i = 0; i < XCH; ++i) {
-                const bool ok = kvalid & (xrow[i] != nullptr);
-                const glds_src_t src = ok ? (glds_src_t)(const void *)(xrow[i] + k) : (glds_src_t)(const void *)g_zero16;
-                __builtin_amdgcn_global_load_lds(src, (glds_dst_t)(sx + i * (RPP * 128)), 16, 0, 0);
+        const bool tile_ok = issued < kt_end;  // uniform; tiles past the end are all-zero requests (see the ring below)
+        if (l < XCH) {
+            glds_src_t src;
+            if (MODE == 0) {
+                const int k = issued * 64;  // uniform
+                const bool ok = tile_ok & (xrow[l] != nullptr) & (k + kc * 8 < a.K);
+                src = ok ? (glds_src_t)(const void *)(xrow[l] + k) : zero_src;
+            } else {
+                const bool first = t_c < a.C1;  // uniform: which concat source this K-tile reads
+                const T *sbase = first ? (const T *)a.x + ((t_r * a.dil_h * a.W + t_s * a.dil_w) * a.C1 + t_c)
+                                       : (const T *)a.x2 + ((t_r * a.dil_h * a.W + t_s * a.dil_w) * a.C2 + (t_c - a.C1));
+                const int off = xoffB[l] + (xdAB[l] & (first ? -1 : 0));  // arithmetic blend: a select of two arrays is lowered through scratch
+                const bool ok = tile_ok & (((xmask[l] >> (t_tap & 31)) & 1u) != 0);
+                src = ok ? (glds_src_t)(const void *)(sbase + off) : zero_src;
             }
-#pragma unroll
-            for (int i = 0; i < WCH; ++i) {
-                const bool ok = kvalid & (wrow[i] != nullptr);
-                const glds_src_t src = ok ? (glds_src_t)(const void *)(wrow[i] + k) : (glds_src_t)(const void *)g_zero16;
-                __builtin_amdgcn_global_load_lds(src, (glds_dst_t)(sw + i * (RPP * 128)), 16, 0, 0);
-            }
+            __builtin_amdgcn_global_load_lds(src, (glds_dst_t)(sx + l * (RPP * 128)), 16, 0, 0);
         } else {
-            // uniform: which tap / source tensor / channel window this K-tile covers
-            const bool first = t_c < a.C1;
-            const T *base = first ? (const T *)a.x : (const T *)a.x2;
-            const int pitch = first ? a.C1 : a.C2;
-            const int cc = (first ? t_c : t_c - a.C1) + kc * 8;
-            const int dpix = t_r * a.dil_h * a.W + t_s * a.dil_w;
-#pragma unroll
-            for (int i = 0; i < XCH; ++i) {
-                const bool ok = (xmask[i] >> t_tap) & 1u;
-                const int64_t off = (int64_t)(xpix[i] + dpix) * pitch + cc;
-                const glds_src_t src = ok ? (glds_src_t)(const void *)(base + off) : (glds_src_t)(const void *)g_zero16;
-                __builtin_amdgcn_global_load_lds(src, (glds_dst_t)(sx + i * (RPP * 128)), 16, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < WCH; ++i) {
-                const bool ok = wrow[i] != nullptr;
-                const glds_src_t src = ok ? (glds_src_t)(const void *)(wrow[i] + k) : (glds_src_t)(const void *)g_zero16;
-                __builtin_amdgcn_global_load_lds(src, (glds_dst_t)(sw + i * (RPP * 128)), 16, 0, 0);
-            }
-            // advance the uniform tap state by one K-tile (Cin % 64 == 0: at most one wrap)
+            const int i = l - XCH;
+            const int k = issued * 64;  // uniform
+            const bool ok = tile_ok & (wrow[i] != nullptr) & (MODE == 1 || k + kc * 8 < a.K);
+            const glds_src_t src = ok ? (glds_src_t)(const void *)(wrow[i] + k) : zero_src;
+            __builtin_amdgcn_global_load_lds(src, (glds_dst_t)(sw + i * (RPP * 128)), 16, 0, 0);
+        }
+    };
+    // after the last slice of a tile: advance the uniform state by one K-tile (Cin % 64 == 0: at most one wrap)
+    auto issue_advance = [&]() {
+        if (MODE == 1) {
             t_c += 64;
             if (t_c >= cin) {
                 t_c -= cin;
@@ -186,11 +207,13 @@ __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, NS *
                 }
             }
         }
+        ++issued;
+        istage = (istage + 1 == NS) ? 0 : istage + 1;
     };
 
     // epilogue operands (bias / row-bias / residual) are requested now and consumed after the K loop when the
     // tile shape leaves registers for them (the 5-fragment tiles would drop to one wave per SIMD)
-    constexpr bool EPI_EARLY = GEGLU || FN * FM <= 4 || NS >= 3;  // ring depth >= 3: one workgroup per CU anyway
+    constexpr bool EPI_EARLY = GEGLU || FN * FM <= 4;
     EpiOperands<(EPI_EARLY ? (GEGLU ? FN / 2 : FN) : 1), (EPI_EARLY ? FM : 1)> epi;
     if constexpr (EPI_EARLY) epilogue_prefetch<T, FN, FM, GEGLU>(a, epi, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi);
 
@@ -202,13 +225,26 @@ __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, NS *
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[fn][fm][r] = 0.f;
 
-    // fragment reads run one 16-wide K step AHEAD of the MFMAs that consume them (two register sets): at one wave per
-    // SIMD nothing else hides the ds_read latency
+    // One K-tile of MFMAs. Fragment reads run one 16-wide K step AHEAD of the MFMAs that consume them (two register
+    // sets). With REFILL the L requests of the tile that re-fills the stage freed by the previous iteration are
+    // interleaved one per MFMA: the address arithmetic of a request (~10 VALU/SALU ops) then issues while the matrix
+    // pipe is busy with the MFMA before it. Issued as one block ahead of the MFMAs it cost about as long as the MFMAs
+    // themselves (0.9 us per 128x160x64 tile against 0.27 us of MFMA time, profiles/r01_igemm_phase_trace.log).
     auto compute = [&](int stage) {
         const char *xs = smem + stage * STAGE;
         const char *ws = xs + BM * 128;
         vec8 af[2][FN], bf[2][FM];
+        if constexpr ((EXP & 2) != 0) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn) af[q][fn] = vec8{};
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm) bf[q][fm] = vec8{};
+            }
+        }
         auto read_frags = [&](int ks, int set) {
+            if constexpr ((EXP & 2) != 0) return;
             const int chunk = ks * 2 + hi;
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
@@ -225,41 +261,40 @@ __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, NS *
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
-                for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = mfma32(af[ks & 1][fn], bf[ks & 1][fm], acc[fn][fm]);
+                for (int fm = 0; fm < FM; ++fm) {
+                    if constexpr ((EXP & 1) == 0) acc[fn][fm] = mfma32(af[ks & 1][fn], bf[ks & 1][fm], acc[fn][fm]);
+                    const int j = (ks * FN + fn) * FM + fm;  // compile-time after unrolling
+                    if (j < L && (EXP & 4) == 0) {
+                        issue_slice(j);
+                        __builtin_amdgcn_sched_barrier(0);  // pin: MFMA j, request j, MFMA j+1, ...
+                    }
+                }
         }
+        static_assert(L <= 4 * FN * FM, "one request per MFMA");
+        issue_advance();
     };
 
     // ---- NS-stage ring: tiles kt+1 .. kt+NS-2 stay in flight while tile kt is multiplied ------------------
+    // Every iteration issues exactly one tile (L requests per thread), tiles past kt_end as all-zero requests into
+    // stages nobody reads again: the outstanding-request count is then the same in every iteration and the wait is
+    // ONE constant `s_waitcnt vmcnt(L*(NS-2))` -- tile kt has landed, tiles kt+1 .. kt+NS-2 may still be in flight.
     trace_mark(a, 1);
-    int issued = kt_begin, istage = 0;
-    for (int s = 0; s < NS - 1 && issued < kt_end; ++s) {
-        issue(issued, istage);
-        ++issued;
-        istage = (istage + 1 == NS) ? 0 : istage + 1;
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) issue_slice(l);
+        issue_advance();
     }
     trace_mark(a, 2);
     int cstage = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int inflight = issued - kt - 1;  // tiles younger than kt that may stay outstanding
-        if (NS > 2 && inflight >= NS - 2) {
-            wait_vmcnt<L *(NS > 2 ? NS - 2 : 0)>();
-        } else if (NS > 3 && inflight == NS - 3) {
-            wait_vmcnt<L *(NS > 3 ? NS - 3 : 0)>();
-        } else if (NS > 4 && inflight == NS - 4) {
-            wait_vmcnt<L *(NS > 4 ? NS - 4 : 0)>();
-        } else {
-            wait_vmcnt<0>();
-        }
-        __builtin_amdgcn_s_barrier();
+        wait_vmcnt<((EXP & 4) ? 0 : L *(NS - 2))>();
+        if constexpr ((EXP & 8) == 0) __builtin_amdgcn_s_barrier();
         if (kt == kt_begin) trace_mark(a, 3);
-        if (issued < kt_end) {
-            if (!(a.dbg & 2)) issue(issued, istage);
-            ++issued;
-            istage = (istage + 1 == NS) ? 0 : istage + 1;
-        }
-        if (!(a.dbg & 1)) compute(cstage);
+        compute(cstage);
         cstage = (cstage + 1 == NS) ? 0 : cstage + 1;
     }
+    wait_vmcnt<0>();  // the zero-filled tail requests must have landed before this workgroup's LDS is released
 
     // ---- epilogue: batched operand loads, fp32 math, 8-byte stores (igemm_device.h) -------------------------
     trace_mark(a, 4);
@@ -314,8 +349,8 @@ int igemm_glds_init() {
     return rc;
 }
 
-int g_igemm_dbg = 0;  // set through sfast_hip_set_debug (profiling ablations only)
 unsigned long long *g_igemm_trace = nullptr;  // set through sfast_hip_set_trace (profiling only)
+int g_igemm_exp = 0;  // SFAST_IGEMM_EXP, latched by sfast_hip_set_trace: selects an experiment instantiation
 
 template <typename T, int MODE>
 static int glds_dispatch(const IgemmArgs &a, int BM_, int BN_, int NS_, bool geglu, hipStream_t st) {
@@ -324,6 +359,22 @@ static int glds_dispatch(const IgemmArgs &a, int BM_, int BN_, int NS_, bool geg
         auto kern = igemm_glds_kernel<TT, BM, BN, WM, WN, NS, MODE_, G_>;                                    \
         hipLaunchKernelGGL(kern, dim3(a.tiles_m *a.tiles_n, a.splits), dim3(WM *WN * 64), NS *(BM + BN) * 128, st, a); \
         return check_launch("igemm_glds");                                                                   \
+    }
+    if constexpr (std::is_same<T, f16>::value) {
+        if (g_igemm_exp != 0 && !geglu) {  // profiling experiments: two representative tiles only
+#define LAUNCH_EXP(BM, BN, WM, WN, NS, MODE_, E)                                                                        \
+    if (BM_ == BM && BN_ == BN && NS_ == NS && MODE == MODE_ && g_igemm_exp == E) {                                     \
+        auto kern = igemm_glds_kernel<f16, BM, BN, WM, WN, NS, MODE_, false, E>;                                        \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, NS *(BM + BN) * 128); \
+        hipLaunchKernelGGL(kern, dim3(a.tiles_m *a.tiles_n, a.splits), dim3(WM *WN * 64), NS *(BM + BN) * 128, st, a);  \
+        return check_launch("igemm_glds_exp");                                                                          \
+    }
+            LAUNCH_EXP(128, 160, 4, 1, 4, 1, 1) LAUNCH_EXP(128, 160, 4, 1, 4, 1, 2) LAUNCH_EXP(128, 160, 4, 1, 4, 1, 3)
+            LAUNCH_EXP(128, 160, 4, 1, 4, 1, 4) LAUNCH_EXP(128, 160, 4, 1, 4, 1, 8) LAUNCH_EXP(128, 160, 4, 1, 4, 1, 7)
+            LAUNCH_EXP(64, 64, 2, 2, 3, 0, 1) LAUNCH_EXP(64, 64, 2, 2, 3, 0, 2) LAUNCH_EXP(64, 64, 2, 2, 3, 0, 3)
+            LAUNCH_EXP(64, 64, 2, 2, 3, 0, 4) LAUNCH_EXP(64, 64, 2, 2, 3, 0, 8) LAUNCH_EXP(64, 64, 2, 2, 3, 0, 7)
+#undef LAUNCH_EXP
+        }
     }
     if (!geglu) {
         SFAST_FOR_GLDS_VARIANTS(T, MODE, LAUNCH_OP)
@@ -339,7 +390,6 @@ static int glds_dispatch(const IgemmArgs &a, int BM_, int BN_, int NS_, bool geg
 
 int igemm_glds_launch(const IgemmArgs &a_in, int dtype, int mode, bool geglu, int BM, int BN, int NS, hipStream_t st) {
     IgemmArgs a = a_in;
-    a.dbg = g_igemm_dbg;
     a.trace = g_igemm_trace;
     if (dtype == SFAST_F16) return mode ? glds_dispatch<f16, 1>(a, BM, BN, NS, geglu, st) : glds_dispatch<f16, 0>(a, BM, BN, NS, geglu, st);
     return mode ? glds_dispatch<bf16, 1>(a, BM, BN, NS, geglu, st) : glds_dispatch<bf16, 0>(a, BM, BN, NS, geglu, st);

@@ -1,0 +1,330 @@
+// Wave-specialised LDS-DMA implicit GEMM: PW producer waves stream K-tiles into the LDS ring, WM*WN consumer
+// waves only read fragments and issue MFMAs.
+//
+// Why a third main-loop structure. The experiment instantiations of igemm_glds.hip (EXP, tools/trace_igemm.py,
+// profiles/r01_igemm_kloop_experiments.log) split one 128x160x64 K-tile at one workgroup per CU into
+//     LDS-DMA requests alone 0.50 us   |   MFMA + fragment reads alone 0.52 us   |   both 0.94 us
+// i.e. fetch and compute did NOT overlap although three tiles were in flight: a wave that issues
+// `global_load_lds` faster than the texture-address path of its CU drains them (~28 cycles per 1 KiB request,
+// four waves sharing it) stalls AT ISSUE, in order, and the MFMAs behind the request in its instruction stream
+// wait with it. Interleaving one request per MFMA did not help for the same reason. Here the waves that stall
+// on the memory pipe are not the waves that feed the matrix pipe:
+//   producers   prologue: NS-1 tiles; per K-tile: s_waitcnt vmcnt(L*(NS-2)) (tile kt landed) -> s_barrier ->
+//               L requests of tile kt+NS-1 into the stage the consumers released at that barrier
+//   consumers   per K-tile: s_barrier -> 4 x (fragment reads one step ahead, FN*FM MFMAs); epilogue
+// One barrier per K-tile for everybody, same LDS image / swizzle / zero-block redirect / tap masks as
+// igemm_glds.hip, same epilogue (igemm_device.h). Register budget: 8 waves per CU -> 256 registers per lane.
+#include "igemm_device.h"
+
+namespace sfast {
+
+template <int N> __device__ __forceinline__ void ws_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+typedef const u32x4 __attribute__((address_space(1))) * ws_src_t;
+typedef __attribute__((address_space(3))) void *ws_dst_t;
+
+template <typename T, int BM, int BN, int WM, int WN, int PW, int NS, int MODE, bool GEGLU>
+__global__ void __launch_bounds__((WM * WN + PW) * 64, igemm_min_waves((WM * WN + PW) * 64, NS *(BM + BN) * 128))
+    igemm_glds_ws_kernel(const IgemmArgs a) {
+    using vec8 = typename Elem<T>::vec8;
+    constexpr int NC = WM * WN * 64;  // consumer threads
+    constexpr int NP = PW * 64;       // producer threads
+    constexpr int FM = BM / (WM * 32);
+    constexpr int FN = BN / (WN * 32);
+    constexpr int XCH = BM * 8 / NP;
+    constexpr int WCH = BN * 8 / NP;
+    constexpr int RPP = NP / 8;
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int BNO = GEGLU ? BN / 2 : BN;
+    constexpr int WNB = FN * 32;
+    constexpr int L = XCH + WCH;  // LDS-DMA requests per producer thread per K-tile
+    static_assert((BM * 8) % NP == 0 && (BN * 8) % NP == 0, "staging mismatch");
+    static_assert(RPP % 16 == 0, "swizzle phase must not depend on the staging pass");
+    static_assert(L * (NS - 2) <= 63, "vmcnt field");
+    static_assert(NS >= 3 && NS <= 5, "ring depth");
+    static_assert(!GEGLU || (FN % 2 == 0), "GEGLU needs paired fragments");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    touch_args(a);
+    if (MODE == 1) touch_conv_args(a);
+    trace_mark(a, 0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int lid;
+    {
+        const int nblk = a.tiles_m * a.tiles_n;
+        const int bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_n = lid % a.tiles_n, tile_m = lid / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BNO;
+    const int kt_begin = blockIdx.y * a.ktiles_per_split;
+    const int kt_end = min(a.ktiles, kt_begin + a.ktiles_per_split);
+
+    if (wave >= WM * WN) {
+        // =============================== producer wave ===============================================
+        const int ptid = tid - NC;
+        const int pwave = wave - WM * WN;
+        const int rbase = ptid >> 3;
+        const int kc = (ptid & 7) ^ ((rbase >> 1) & 7);  // source-side swizzle (LDS-DMA writes lane-linearly)
+        const ws_src_t zero_src = (ws_src_t)(const void *)g_zero16;
+
+        const T *xrow[XCH];   // MODE 0: row pointer at column kc*8, or nullptr
+        int xoffB[XCH];       // MODE 1: element offset of (tap (0,0), channel kc*8) in source 2 (pitch C2)
+        int xdAB[XCH];        //         (the same in source 1, pitch C1) - xoffB
+        unsigned xmask[XCH];  // MODE 1: bit (r*KW+s) set when that tap is inside the image
+        const PixelDecoder decode(a);
+        unsigned rep_all = 0;
+        if (MODE == 1)
+            for (int r = 0; r < a.KH; ++r) rep_all |= 1u << (r * a.KW);
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int m = m0 + rbase + i * RPP;
+            if (MODE == 0) {
+                xrow[i] = (m < a.M) ? (const T *)a.x + (int64_t)m * a.ldx + kc * 8 : nullptr;
+            } else {
+                unsigned mask = 0;
+                int pix = 0;
+                if (m < a.M) {
+                    int b, ho, wo;
+                    decode(m, b, ho, wo);
+                    const int h0 = ho * a.stride_h - a.pad_h, w0 = wo * a.stride_w - a.pad_w;
+                    pix = (b * a.H + h0) * a.W + w0;
+                    if (a.dil_h == 1 && a.dil_w == 1) {
+                        const int s_lo = max(0, -w0), s_hi = min(a.KW, a.W - w0);
+                        const int r_lo = max(0, -h0), r_hi = min(a.KH, a.H - h0);
+                        if (s_hi > s_lo && r_hi > r_lo) {
+                            const unsigned cols = ((1u << s_hi) - 1u) & ~((1u << s_lo) - 1u);
+                            const unsigned lo_bits = r_lo * a.KW, hi_bits = r_hi * a.KW;
+                            const unsigned upto = hi_bits >= 32 ? 0xffffffffu : ((1u << hi_bits) - 1u);
+                            mask = cols * (rep_all & upto & ~((1u << lo_bits) - 1u));
+                        }
+                    } else {
+                        unsigned cols = 0;
+                        for (int s = 0; s < a.KW; ++s) cols |= ((unsigned)(w0 + s * a.dil_w) < (unsigned)a.W ? 1u : 0u) << s;
+                        for (int r = 0; r < a.KH; ++r) mask |= ((unsigned)(h0 + r * a.dil_h) < (unsigned)a.H ? cols : 0u) << (r * a.KW);
+                    }
+                }
+                xoffB[i] = pix * a.C2 + kc * 8;
+                xdAB[i] = pix * (a.C1 - a.C2);
+                xmask[i] = mask;
+            }
+        }
+        const T *wrow[WCH];
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int j = rbase + i * RPP;
+            if (GEGLU) {
+                const int grp = j / WNB, within = j % WNB;
+                const int half = within / (WNB / 2), i2 = within % (WNB / 2);
+                const int ncol = n0 + grp * (WNB / 2) + i2;
+                wrow[i] = (ncol < a.N) ? (const T *)a.w[0] + ((int64_t)half * a.N + ncol) * a.ldw + kc * 8 : nullptr;
+            } else {
+                const int n = n0 + j;
+                if (n < a.N) {
+                    const int rs = a.rows_per_seg;
+                    const int seg = (n >= rs) + (n - rs >= rs) + (n - rs - rs >= rs);
+                    const void *base = seg == 0 ? a.w[0] : seg == 1 ? a.w[1] : seg == 2 ? a.w[2] : a.w[3];
+                    wrow[i] = (const T *)base + (int64_t)(n - seg * rs) * a.ldw + kc * 8;
+                } else {
+                    wrow[i] = nullptr;
+                }
+            }
+        }
+
+        const int cin = a.C1 + a.C2;
+        int t_tap = 0, t_r = 0, t_s = 0, t_c = 0;
+        if (MODE == 1) {
+            const int k0 = kt_begin * 64;
+            t_tap = k0 / cin;
+            t_c = k0 - t_tap * cin;
+            t_r = t_tap / a.KW;
+            t_s = t_tap - t_r * a.KW;
+        }
+        int issued = kt_begin, istage = 0;
+
+        // all L requests of the next tile; tiles past kt_end are all-zero requests (constant vmcnt bookkeeping)
+        auto issue_tile = [&]() {
+            char *sx = smem + istage * STAGE + pwave * 1024;
+            char *sw = sx + BM * 128;
+            const bool tile_ok = issued < kt_end;
+            const int k = issued * 64;
+            if (MODE == 0) {
+#pragma unroll
+                for (int i = 0; i < XCH; ++i) {
+                    const bool ok = tile_ok & (xrow[i] != nullptr) & (k + kc * 8 < a.K);
+                    const ws_src_t src = ok ? (ws_src_t)(const void *)(xrow[i] + k) : zero_src;
+                    __builtin_amdgcn_global_load_lds(src, (ws_dst_t)(sx + i * (RPP * 128)), 16, 0, 0);
+                }
+            } else {
+                const bool first = t_c < a.C1;
+                const T *sbase = first ? (const T *)a.x + ((t_r * a.dil_h * a.W + t_s * a.dil_w) * a.C1 + t_c)
+                                       : (const T *)a.x2 + ((t_r * a.dil_h * a.W + t_s * a.dil_w) * a.C2 + (t_c - a.C1));
+                const int fmask = first ? -1 : 0;
+#pragma unroll
+                for (int i = 0; i < XCH; ++i) {
+                    const int off = xoffB[i] + (xdAB[i] & fmask);
+                    const bool ok = tile_ok & (((xmask[i] >> (t_tap & 31)) & 1u) != 0);
+                    const ws_src_t src = ok ? (ws_src_t)(const void *)(sbase + off) : zero_src;
+                    __builtin_amdgcn_global_load_lds(src, (ws_dst_t)(sx + i * (RPP * 128)), 16, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < WCH; ++i) {
+                const bool ok = tile_ok & (wrow[i] != nullptr) & (MODE == 1 || k + kc * 8 < a.K);
+                const ws_src_t src = ok ? (ws_src_t)(const void *)(wrow[i] + k) : zero_src;
+                __builtin_amdgcn_global_load_lds(src, (ws_dst_t)(sw + i * (RPP * 128)), 16, 0, 0);
+            }
+            if (MODE == 1) {
+                t_c += 64;
+                if (t_c >= cin) {
+                    t_c -= cin;
+                    ++t_tap;
+                    if (++t_s == a.KW) {
+                        t_s = 0;
+                        ++t_r;
+                    }
+                }
+            }
+            ++issued;
+            istage = (istage + 1 == NS) ? 0 : istage + 1;
+        };
+
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s) issue_tile();
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            ws_wait_vmcnt<L *(NS - 2)>();     // tile kt has landed (this wave's share)
+            __builtin_amdgcn_s_barrier();     // consumers finished tile kt-1: its stage is free
+            issue_tile();                     // tile kt+NS-1 -> that stage
+        }
+        ws_wait_vmcnt<0>();  // the zero-filled tail requests must have landed before the LDS is released
+        return;
+    }
+
+    // =================================== consumer wave ===============================================
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    constexpr bool EPI_EARLY = GEGLU || FN * FM <= 4;
+    EpiOperands<(EPI_EARLY ? (GEGLU ? FN / 2 : FN) : 1), (EPI_EARLY ? FM : 1)> epi;
+    if constexpr (EPI_EARLY) epilogue_prefetch<T, FN, FM, GEGLU>(a, epi, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi);
+
+    f32x16 acc[FN][FM];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[fn][fm][r] = 0.f;
+
+    trace_mark(a, 1);
+    trace_mark(a, 2);
+    int cstage = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        if (kt == kt_begin) trace_mark(a, 3);
+        const char *xs = smem + cstage * STAGE;
+        const char *ws = xs + BM * 128;
+        vec8 af[2][FN], bf[2][FM];
+        auto read_frags = [&](int ks, int set) {
+            const int chunk = ks * 2 + hi;
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+                af[set][fn] = *reinterpret_cast<const vec8 *>(ws + lds_off(wn * WNB + fn * 32 + l31, chunk));
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm)
+                bf[set][fm] = *reinterpret_cast<const vec8 *>(xs + lds_off(wm * (FM * 32) + fm * 32 + l31, chunk));
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) read_frags(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs (the scheduler sinks them otherwise)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = mfma32(af[ks & 1][fn], bf[ks & 1][fm], acc[fn][fm]);
+        }
+        cstage = (cstage + 1 == NS) ? 0 : cstage + 1;
+    }
+
+    trace_mark(a, 4);
+    if constexpr (!EPI_EARLY)
+        epilogue_late<T, FN, FM>(a, acc, m0 + wm * (FM * 32), n0 + wn * WNB, l31, hi, blockIdx.y);
+    else
+        epilogue_finish<T, FN, FM, GEGLU>(a, acc, epi, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi, blockIdx.y);
+    trace_finish(a);
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+// variant ids 21.. (igemm.hip kVariants, pipe 2): tile, consumer waves WM x WN, producer waves, ring depth
+#define SFAST_FOR_WS_VARIANTS(T, MODE, OP) \
+    OP(T, 128, 128, 2, 2, 4, 4, MODE, false) \
+    OP(T, 128, 160, 4, 1, 4, 4, MODE, false) \
+    OP(T, 64, 64, 2, 2, 4, 4, MODE, false)
+
+#define SFAST_FOR_WS_GEGLU_VARIANTS(T, OP) \
+    OP(T, 128, 128, 2, 2, 4, 4, 0, true)   \
+    OP(T, 64, 128, 2, 2, 4, 3, 0, true)
+
+template <typename T, int BM, int BN, int WM, int WN, int PW, int NS, int MODE, bool GEGLU>
+static int ws_set_attr() {
+    constexpr int smem = NS * (BM + BN) * 128;
+    auto kern = igemm_glds_ws_kernel<T, BM, BN, WM, WN, PW, NS, MODE, GEGLU>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(igemm_glds_ws %dx%dx%d): %s", BM, BN, NS, hipGetErrorString(e));
+        return SFAST_ERR_LAUNCH;
+    }
+    return 0;
+}
+
+int igemm_glds_ws_init() {
+    int rc = 0;
+#define INIT_OP(T, BM, BN, WM, WN, PW, NS, MODE, G) \
+    if (!rc) rc = ws_set_attr<T, BM, BN, WM, WN, PW, NS, MODE, G>();
+    SFAST_FOR_WS_VARIANTS(f16, 0, INIT_OP)
+    SFAST_FOR_WS_VARIANTS(f16, 1, INIT_OP)
+    SFAST_FOR_WS_VARIANTS(bf16, 0, INIT_OP)
+    SFAST_FOR_WS_VARIANTS(bf16, 1, INIT_OP)
+    SFAST_FOR_WS_GEGLU_VARIANTS(f16, INIT_OP)
+    SFAST_FOR_WS_GEGLU_VARIANTS(bf16, INIT_OP)
+#undef INIT_OP
+    return rc;
+}
+
+extern unsigned long long *g_igemm_trace;  // igemm_glds.hip
+
+template <typename T, int MODE>
+static int ws_dispatch(const IgemmArgs &a, int BM_, int BN_, int NS_, bool geglu, hipStream_t st) {
+#define LAUNCH_OP(TT, BM, BN, WM, WN, PW, NS, MODE_, G_)                                                                       \
+    if (BM_ == BM && BN_ == BN && NS_ == NS && geglu == G_) {                                                                  \
+        auto kern = igemm_glds_ws_kernel<TT, BM, BN, WM, WN, PW, NS, MODE_, G_>;                                               \
+        hipLaunchKernelGGL(kern, dim3(a.tiles_m *a.tiles_n, a.splits), dim3((WM * WN + PW) * 64), NS *(BM + BN) * 128, st, a); \
+        return check_launch("igemm_glds_ws");                                                                                  \
+    }
+    if (!geglu) {
+        SFAST_FOR_WS_VARIANTS(T, MODE, LAUNCH_OP)
+    } else {
+        if (MODE == 0) {
+            SFAST_FOR_WS_GEGLU_VARIANTS(T, LAUNCH_OP)
+        }
+    }
+#undef LAUNCH_OP
+    set_error("igemm_glds_ws: no kernel for tile %dx%d ring %d", BM_, BN_, NS_);
+    return SFAST_ERR_UNSUPPORTED;
+}
+
+int igemm_glds_ws_launch(const IgemmArgs &a_in, int dtype, int mode, bool geglu, int BM, int BN, int NS, hipStream_t st) {
+    IgemmArgs a = a_in;
+    a.trace = g_igemm_trace;
+    if (dtype == SFAST_F16) return mode ? ws_dispatch<f16, 1>(a, BM, BN, NS, geglu, st) : ws_dispatch<f16, 0>(a, BM, BN, NS, geglu, st);
+    return mode ? ws_dispatch<bf16, 1>(a, BM, BN, NS, geglu, st) : ws_dispatch<bf16, 0>(a, BM, BN, NS, geglu, st);
+}
+
+}  // namespace sfast

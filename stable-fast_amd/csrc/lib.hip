@@ -1,5 +1,6 @@
 // Library-level entry points: version, init, thread-local error / kernel-name strings.
 #include "common.h"
+#include <stdlib.h>
 #include <string.h>
 
 namespace sfast {
@@ -28,8 +29,8 @@ int check_launch(const char *what) {
     return SFAST_OK;
 }
 
-extern int g_igemm_dbg;  // igemm_glds.hip
 extern unsigned long long *g_igemm_trace;  // igemm_glds.hip
+extern int g_igemm_exp;                    // igemm_glds.hip
 int igemm_init();      // igemm.hip
 int attention_init();  // attention.hip
 
@@ -50,14 +51,10 @@ int sfast_hip_init(void) {
     return rc;
 }
 
-int sfast_hip_set_debug(int flags) {
-    const int prev = sfast::g_igemm_dbg;
-    sfast::g_igemm_dbg = flags;
-    return prev;
-}
-
 int sfast_hip_set_trace(void *buf) {
     sfast::g_igemm_trace = (unsigned long long *)buf;
+    const char *e = getenv("SFAST_IGEMM_EXP");  // profiling experiments exist only while tracing
+    sfast::g_igemm_exp = (buf && e) ? atoi(e) : 0;
     return 0;
 }
 

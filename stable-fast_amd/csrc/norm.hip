@@ -62,8 +62,7 @@ __global__ void gn_nhwc_stats_kernel(const T *__restrict__ x, const T *__restric
             const int nb = min(8, (g0 + 1) * g.cpg - c);
             const float sh0 = (float)*gn_src(x, x2, g, b, 0, g0 * g.cpg);
             const float sh1 = (nb < 8) ? (float)*gn_src(x, x2, g, b, 0, (g0 + 1) * g.cpg) : 0.f;
-            for (int r = r0 + ty; r < r1; r += g.TY) {
-                const u32x4 raw = *reinterpret_cast<const u32x4 *>(gn_src(x, x2, g, b, r, c));
+            auto accumulate = [&](const u32x4 &raw) {
                 float f[8];
                 unpack8<T>(raw, f);
 #pragma unroll
@@ -78,7 +77,18 @@ __global__ void gn_nhwc_stats_kernel(const T *__restrict__ x, const T *__restric
                         s2b += d * d;
                     }
                 }
+            };
+            // four independent row loads in flight per thread (a one-load-per-iteration loop left a workgroup with
+            // 8 KB outstanding: ~8 GB/s per CU); accumulation order is unchanged, so results are too
+            int r = r0 + ty;
+            for (; r + 3 * g.TY < r1; r += 4 * g.TY) {
+                u32x4 raw[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const u32x4 *>(gn_src(x, x2, g, b, r + u * g.TY, c));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) accumulate(raw[u]);
             }
+            for (; r < r1; r += g.TY) accumulate(*reinterpret_cast<const u32x4 *>(gn_src(x, x2, g, b, r, c)));
         }
         if (tid < NT) {
             red[tid * 4 + 0] = s1a;
@@ -151,7 +161,19 @@ __global__ void gn_nhwc_apply_kernel(const T *__restrict__ x, const T *__restric
     if (tid < g.G * RS) {
         const int grp = tid / RS, j = tid % RS;
         float s1 = 0.f, s2 = 0.f;
-        for (int s = j; s < nsplit; s += RS) {
+        int s = j;
+        for (; s + 3 * RS < nsplit; s += 4 * RS) {  // loads batched, summation order unchanged
+            float2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                v[u] = *reinterpret_cast<const float2 *>(partial + (((int64_t)b * nsplit + s + u * RS) * g.G + grp) * 2);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s1 += v[u].x;
+                s2 += v[u].y;
+            }
+        }
+        for (; s < nsplit; s += RS) {
             const float *p = partial + (((int64_t)b * nsplit + s) * g.G + grp) * 2;
             s1 += p[0];
             s2 += p[1];
@@ -193,8 +215,7 @@ __global__ void gn_nhwc_apply_kernel(const T *__restrict__ x, const T *__restric
             a[i] = rstd[grp] * ga;
             bb[i] = be - mean[grp] * a[i];
         }
-        for (int r = r0 + ty; r < r1; r += g.TY) {
-            const u32x4 raw = *reinterpret_cast<const u32x4 *>(gn_src(x, x2, g, b, r, c));
+        auto finish = [&](const u32x4 &raw, int r) {
             float f[8];
             unpack8<T>(raw, f);
 #pragma unroll
@@ -204,7 +225,16 @@ __global__ void gn_nhwc_apply_kernel(const T *__restrict__ x, const T *__restric
                 f[i] = v;
             }
             *reinterpret_cast<u32x4 *>(y + ((int64_t)b * g.HW + r) * g.C + c) = pack8<T>(f);
+        };
+        int r = r0 + ty;
+        for (; r + 3 * g.TY < r1; r += 4 * g.TY) {  // four row loads in flight per thread
+            u32x4 raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const u32x4 *>(gn_src(x, x2, g, b, r + u * g.TY, c));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) finish(raw[u], r + u * g.TY);
         }
+        for (; r < r1; r += g.TY) finish(*reinterpret_cast<const u32x4 *>(gn_src(x, x2, g, b, r, c)), r);
     }
 }
 
@@ -404,11 +434,11 @@ static GnPlan gn_plan(const sfast_gn_params *p) {
     if (g.TY < 1) g.TY = 1;
     if (g.TY > p->HW) g.TY = p->HW;
     const int max_split = ceil_div(p->HW, g.TY);
-    // ~one workgroup per CU in each pass. The split count is capped at 32 because every apply
-    // workgroup re-reads all G x nsplit partial sums in its prologue (8 KB at 32 splits): with
+    // ~one workgroup per CU in the apply pass, half that in the stats pass: every apply workgroup re-reads
+    // all G x nsplit partial sums in its prologue (16 KB at 64 splits, two batched loads per thread); with
     // 128 splits and 684 apply workgroups that prologue traffic exceeded the tensor itself.
     int want = ceil_div(256, p->N);
-    if (want > 32) want = 32;
+    if (want > 64) want = 64;
     pl.nsplit = want < max_split ? want : max_split;
     if (pl.nsplit < 1) pl.nsplit = 1;
     pl.rows_stats = ceil_div(p->HW, pl.nsplit);

@@ -191,33 +191,50 @@ __global__ void __launch_bounds__(256) conv_small_n_kernel(const SmallConvArgs a
     const int cpc = a.Cin / 8;           // chunks per tap
     const int nch = a.KH * a.KW * cpc;   // chunks in K
     const int64_t wstride = (int64_t)a.KH * a.KW * a.Cin;
+    typedef const u32x4 __attribute__((address_space(1))) * g4_ptr;
+    const g4_ptr zero = (g4_ptr)(const void *)g_zero16;
+    const float r_cpc = __builtin_amdgcn_rcpf((float)cpc), r_kw = __builtin_amdgcn_rcpf((float)a.KW);
+    const int HH = a.ups ? 2 * a.H : a.H, WW = a.ups ? 2 * a.W : a.W;
     for (int j = lane; j < nch; j += 64) {
-        const int tap = j / cpc, cch = j - tap * cpc;
-        const int r = tap / a.KW, s = tap - r * a.KW;
-        float wf[8][8];
+        // nch <= 2^22 always (KH*KW*Cin/8): reciprocal division, exact after the +-1 fix-up
+        int tap = (int)((float)j * r_cpc);
+        tap += (j - tap * cpc >= cpc) ? 1 : 0;
+        tap -= (j - tap * cpc < 0) ? 1 : 0;
+        const int cch = j - tap * cpc;
+        int r = (int)((float)tap * r_kw);
+        r += (tap - r * a.KW >= a.KW) ? 1 : 0;
+        r -= (tap - r * a.KW < 0) ? 1 : 0;
+        const int s = tap - r * a.KW;
+        // every load of the iteration is issued unconditionally (border taps read a device zero block): a load
+        // inside `if (ok)` is an exec-masked branch with its own wait -- PX serial round trips per iteration
+        u32x4 wraw[8], xraw[PX];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            if (c < a.Cout) unpack8<T>(*reinterpret_cast<const u32x4 *>((const T *)a.w + c * wstride + (int64_t)j * 8), wf[c]);
+            const bool cok = c < a.Cout;
+            wraw[c] = *(cok ? (g4_ptr)(const void *)((const T *)a.w + c * wstride + (int64_t)j * 8) : zero);
         }
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
             int hi = ph[i] * a.stride_h - a.pad_h + r * a.dil_h;
             int wi = pw[i] * a.stride_w - a.pad_w + s * a.dil_w;
-            const int HH = a.ups ? 2 * a.H : a.H, WW = a.ups ? 2 * a.W : a.W;
-            bool ok = pv[i] && (unsigned)hi < (unsigned)HH && (unsigned)wi < (unsigned)WW;
+            const bool ok = pv[i] & ((unsigned)hi < (unsigned)HH) & ((unsigned)wi < (unsigned)WW);
             if (a.ups) {
                 hi >>= 1;
                 wi >>= 1;
             }
-            if (ok) {
-                float xf[8];
-                unpack8<T>(*reinterpret_cast<const u32x4 *>((const T *)a.x + (((int64_t)pb[i] * a.H + hi) * a.W + wi) * a.Cin + cch * 8), xf);
+            xraw[i] = *(ok ? (g4_ptr)(const void *)((const T *)a.x + (((int64_t)pb[i] * a.H + hi) * a.W + wi) * a.Cin + cch * 8) : zero);
+        }
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    if (c < a.Cout) {
+        for (int c = 0; c < 8; ++c) {
+            if (c < a.Cout) {
+                float wf[8];
+                unpack8<T>(wraw[c], wf);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[i][c] = fmaf(xf[e], wf[c][e], acc[i][c]);
-                    }
+                for (int i = 0; i < PX; ++i) {
+                    float xf[8];
+                    unpack8<T>(xraw[i], xf);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[i][c] = fmaf(xf[e], wf[e], acc[i][c]);
                 }
             }
         }
@@ -236,23 +253,50 @@ __global__ void __launch_bounds__(256) conv_small_n_kernel(const SmallConvArgs a
 
 // Cin*KH*KW small: weights staged in LDS as fp32 [K][Cout]; thread = (pixel, 8 output channels).
 // x read through strides (NCHW or NHWC), output dense NHWC-style through strides with os[3] == 1.
-template <typename T>
+// Every global load is issued in a batch of independent, unconditional requests (invalid taps / k >= K read a
+// device zero block): the first version had one load per loop iteration -- 72 serial round trips to stage the
+// weights and 36 per output vector, 85 us for SD's 4->320 conv_in.
+// KMAX > 0: K <= KMAX, the whole receptive field of a pixel is fetched in ONE batch (k decode is scalar work on
+// compile-time k). KMAX == 0: any K, 8 channels of one tap per batch.
+template <typename T, int KMAX>
 __global__ void __launch_bounds__(256) conv_small_c_kernel(const SmallConvArgs a, int pix_per_block) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];  // [K][Cout]
+    typedef const T __attribute__((address_space(1))) * gelem_ptr;
+    const gelem_ptr zero = (gelem_ptr)(const void *)g_zero16;
     const int K = a.KH * a.KW * a.Cin;
-    for (int i = threadIdx.x; i < K * a.Cout; i += 256) {
-        const int co = i % a.Cout;
-        const int k = i / a.Cout;
-        const int c = k % a.Cin;
-        const int tap = k / a.Cin;
-        const int r = tap / a.KW, s = tap % a.KW;
-        wsm[i] = Elem<T>::to_f32(((const T *)a.w)[co * a.ws[0] + c * a.ws[1] + r * a.ws[2] + s * a.ws[3]]);
+    for (int co = threadIdx.x; co < a.Cout; co += 256) {
+        const T *wrow = (const T *)a.w + (int64_t)co * a.ws[0];
+        int c = 0, r = 0, s = 0;  // uniform (r, s, c) of the next k, advanced incrementally: scalar ALU, no division
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = k0 + u;
+                const T *src = wrow + ((int64_t)c * a.ws[1] + (int64_t)r * a.ws[2] + (int64_t)s * a.ws[3]);
+                v[u] = Elem<T>::to_f32(*(k < K ? (gelem_ptr)(const void *)src : zero));
+                if (++c == a.Cin) {
+                    c = 0;
+                    if (++s == a.KW) {
+                        s = 0;
+                        ++r;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (k0 + u < K) wsm[(k0 + u) * a.Cout + co] = v[u];
+        }
     }
     __syncthreads();
     const int cch = a.Cout / 8;
     const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
     const int64_t p_begin = (int64_t)blockIdx.x * pix_per_block;
     const int ntask = pix_per_block * cch;
+    const int HH = a.ups ? 2 * a.H : a.H, WW = a.ups ? 2 * a.W : a.W;
+    auto x_ptr = [&](int b, int hs, int wsrc, int c) -> const T * {
+        return (c < a.C1) ? (const T *)a.x + (b * a.xs[0] + hs * a.xs[1] + wsrc * a.xs[2] + c * a.xs[3])
+                          : (const T *)a.x2 + (b * a.x2s[0] + hs * a.x2s[1] + wsrc * a.x2s[2] + (c - a.C1) * a.x2s[3]);
+    };
     for (int t = threadIdx.x; t < ntask; t += 256) {
         const int64_t p = p_begin + t / cch;
         if (p >= M) break;
@@ -261,22 +305,61 @@ __global__ void __launch_bounds__(256) conv_small_c_kernel(const SmallConvArgs a
         const int b = (int)(p / hw);
         const int rem = (int)(p % hw);
         const int ho = rem / a.Wo, wo = rem % a.Wo;
+        const int h0 = ho * a.stride_h - a.pad_h, w0 = wo * a.stride_w - a.pad_w;
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-        int k = 0;
-        for (int r = 0; r < a.KH; ++r) {
-            const int hi = ho * a.stride_h - a.pad_h + r * a.dil_h;
-            for (int s = 0; s < a.KW; ++s) {
-                const int wi = wo * a.stride_w - a.pad_w + s * a.dil_w;
-                for (int c = 0; c < a.Cin; ++c, ++k) {
-                    const float xv = conv_load_x<T>(a, b, hi, wi, c);
-                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wsm + k * a.Cout + co0);
-                    const f32x4 w1 = *reinterpret_cast<const f32x4 *>(wsm + k * a.Cout + co0 + 4);
+        auto fma8 = [&](float xv, int k) {
+            const f32x4 w0v = *reinterpret_cast<const f32x4 *>(wsm + k * a.Cout + co0);
+            const f32x4 w1v = *reinterpret_cast<const f32x4 *>(wsm + k * a.Cout + co0 + 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc[e] = fmaf(xv, w0[e], acc[e]);
-                        acc[4 + e] = fmaf(xv, w1[e], acc[4 + e]);
+            for (int q = 0; q < 4; ++q) {
+                acc[q] = fmaf(xv, w0v[q], acc[q]);
+                acc[4 + q] = fmaf(xv, w1v[q], acc[4 + q]);
+            }
+        };
+        if constexpr (KMAX > 0) {
+            float xv[KMAX];
+            int c = 0, r = 0, s = 0;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                int hi = h0 + r * a.dil_h, wi = w0 + s * a.dil_w;
+                const bool ok = (k < K) & ((unsigned)hi < (unsigned)HH) & ((unsigned)wi < (unsigned)WW);
+                if (a.ups) {
+                    hi >>= 1;
+                    wi >>= 1;
+                }
+                xv[k] = Elem<T>::to_f32(*(ok ? (gelem_ptr)(const void *)x_ptr(b, hi, wi, c < a.Cin ? c : 0) : zero));
+                if (++c == a.Cin) {
+                    c = 0;
+                    if (++s == a.KW) {
+                        s = 0;
+                        ++r;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < K) fma8(xv[k], k);
+        } else {
+            for (int r = 0; r < a.KH; ++r) {
+                const int hi = h0 + r * a.dil_h;
+                for (int s = 0; s < a.KW; ++s) {
+                    const int wi = w0 + s * a.dil_w;
+                    const bool ok = ((unsigned)hi < (unsigned)HH) & ((unsigned)wi < (unsigned)WW);
+                    const int hs = a.ups ? hi >> 1 : hi, wsrc = a.ups ? wi >> 1 : wi;
+                    const int kbase = (r * a.KW + s) * a.Cin;
+                    for (int c0 = 0; c0 < a.Cin; c0 += 8) {
+                        float xv[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int c = c0 + e;
+                            const bool v = ok & (c < a.Cin);
+                            xv[e] = Elem<T>::to_f32(*(v ? (gelem_ptr)(const void *)x_ptr(b, hs, wsrc, c) : zero));
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (c0 + e < a.Cin) fma8(xv[e], kbase + c0 + e);
                     }
                 }
             }
@@ -355,11 +438,18 @@ int small_conv_c(const SmallConvArgs &a, int dtype, hipStream_t st) {
     int ppb = 32;
     while (ppb > 4 && ceil_div64(M, ppb) < 256) ppb >>= 1;
     const dim3 grid((unsigned)ceil_div64(M, ppb));
-    if (dtype == SFAST_F16)
-        hipLaunchKernelGGL(conv_small_c_kernel<f16>, grid, dim3(256), smem, st, a, ppb);
-    else if (dtype == SFAST_BF16)
-        hipLaunchKernelGGL(conv_small_c_kernel<bf16>, grid, dim3(256), smem, st, a, ppb);
-    else {
+    const bool tiny = K <= 40;
+    if (dtype == SFAST_F16) {
+        if (tiny)
+            hipLaunchKernelGGL((conv_small_c_kernel<f16, 40>), grid, dim3(256), smem, st, a, ppb);
+        else
+            hipLaunchKernelGGL((conv_small_c_kernel<f16, 0>), grid, dim3(256), smem, st, a, ppb);
+    } else if (dtype == SFAST_BF16) {
+        if (tiny)
+            hipLaunchKernelGGL((conv_small_c_kernel<bf16, 40>), grid, dim3(256), smem, st, a, ppb);
+        else
+            hipLaunchKernelGGL((conv_small_c_kernel<bf16, 0>), grid, dim3(256), smem, st, a, ppb);
+    } else {
         set_error("conv_small_c: dtype %d", dtype);
         return SFAST_ERR_UNSUPPORTED;
     }

@@ -23,8 +23,8 @@ _cache_lock = threading.Lock()
 _loaded_files = set()
 
 SPLITS = (1, 2, 3, 4, 6, 8, 12, 16, 24)
-VARIANTS = (1, 2, 3, 5, 11, 12, 13, 15, 16, 17, 18)
-GEGLU_VARIANTS = (1, 3, 11, 13, 16, 18)
+VARIANTS = (1, 2, 3, 5, 11, 12, 13, 15, 16, 17, 18, 21, 22, 23)
+GEGLU_VARIANTS = (1, 3, 11, 13, 16, 18, 21, 23)
 MAX_SLAB_BYTES = 192 << 20
 
 
@@ -144,7 +144,8 @@ def tune_plan(plan, device, dtype_tag="f16", verbose=False):
                 p.variant, p.split_k = v, s
                 if launch_with(sp, ws.data_ptr(), ws.numel()) != 0:
                     continue
-                if (v >= 10) != ("dma" in L.last_kernel()):
+                k = L.last_kernel()
+                if ("ws" if v >= 20 else "dma" if v >= 10 else "reg") not in k.split(",")[-1]:
                     continue  # pipe not applicable to this problem: the library substituted another
                 t = _time(lambda: launch_with(sp, ws.data_ptr(), ws.numel()), stream)
                 if best is None or t < best[0]:

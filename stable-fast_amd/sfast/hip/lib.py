@@ -27,7 +27,7 @@ EXPORTS = [
     "sfast_hip_gemm_workspace_bytes", "sfast_hip_gemm",
     "sfast_hip_conv2d_workspace_bytes", "sfast_hip_conv2d",
     "sfast_hip_attention", "sfast_hip_strided_copy", "sfast_hip_timestep_embedding",
-    "sfast_hip_cfg_ddim_step", "sfast_hip_igemm_plan", "sfast_hip_set_debug", "sfast_hip_set_trace",
+    "sfast_hip_cfg_ddim_step", "sfast_hip_igemm_plan", "sfast_hip_set_trace",
 ]
 
 
@@ -114,8 +114,6 @@ def _declare(lib):
     lib.sfast_hip_strided_copy.argtypes = [vp, vp, C.POINTER(CopyParams), vp]
     lib.sfast_hip_timestep_embedding.restype = C.c_int
     lib.sfast_hip_timestep_embedding.argtypes = [vp, vp, C.POINTER(TembParams), vp]
-    lib.sfast_hip_set_debug.restype = C.c_int
-    lib.sfast_hip_set_debug.argtypes = [C.c_int]
     lib.sfast_hip_set_trace.restype = C.c_int
     lib.sfast_hip_set_trace.argtypes = [C.c_void_p]
     lib.sfast_hip_igemm_plan.restype = C.c_int

@@ -132,7 +132,7 @@ def test_geglu_reference_grid(dtype, bias, inf, outf, N):
 
 
 @pytest.mark.parametrize("M,K,N", [(8192, 320, 1280), (2048, 640, 2560), (512, 1280, 5120), (128, 1280, 5120), (100, 320, 1280)])
-@pytest.mark.parametrize("variant", [0, 1, 3, 11, 13, 16, 18])
+@pytest.mark.parametrize("variant", [0, 1, 3, 11, 13, 16, 18, 21, 23])
 def test_geglu_unet_shapes(M, K, N, variant):
     x = rnd(M, K, seed=33)
     w = rnd(2 * N, K, seed=34, scale=K ** -0.5)
@@ -150,23 +150,26 @@ def test_geglu_split_k(split):
     y2 = F().linear(x, w, b, geglu=True, variant=11, split_k=split)
     assert f"split={split},dma" in last_kernel()
     compare(f"geglu dma split{split}", y2, R.linear_ref(x, w, b, geglu=True), *tol(x.dtype), kernel=last_kernel())
+    y3 = F().linear(x, w, b, geglu=True, variant=21, split_k=split)
+    assert f"split={split},ws" in last_kernel()
+    compare(f"geglu ws split{split}", y3, R.linear_ref(x, w, b, geglu=True), *tol(x.dtype), kernel=last_kernel())
     compare(f"geglu split{split}", y, R.linear_ref(x, w, b, geglu=True), *tol(x.dtype), kernel=last_kernel())
 
 
 @pytest.mark.parametrize("M,K,N", [(8192, 320, 320), (8192, 320, 960), (2048, 2560, 640), (512, 1280, 1280), (154, 768, 640),
                                    (4095, 328, 324), (77, 64, 36), (130, 1280, 1280)])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23])
 def test_linear_variants(M, K, N, variant):
     x = rnd(M, K, seed=40)
     w = rnd(N, K, seed=41, scale=K ** -0.5)
     b = rnd(N, seed=42, scale=0.1)
     y = F().linear(x, w, b, variant=variant)
-    assert "igemm_lin" in last_kernel() and (variant < 10 or "dma" in last_kernel())
+    assert "igemm_lin" in last_kernel() and (variant < 10 or ("ws" if variant > 20 else "dma") in last_kernel())
     compare(f"linear M{M} K{K} N{N} v{variant}", y, R.linear_ref(x, w, b), *tol(x.dtype), kernel=last_kernel())
 
 
 @pytest.mark.parametrize("split", [2, 3, 8])
-@pytest.mark.parametrize("variant", [1, 2, 4, 11, 13, 15])
+@pytest.mark.parametrize("variant", [1, 2, 4, 11, 13, 15, 21, 22, 23])
 def test_linear_split_k(split, variant):
     x, w, b = rnd(128, 5120, seed=43), rnd(1280, 5120, seed=44, scale=5120 ** -0.5), rnd(1280, seed=45)
     r = rnd(128, 1280, seed=46)
@@ -212,7 +215,7 @@ def test_linear_epilogues(dtype, epi):
     compare(f"linear_epi {epi} {dtype}", y, want, *tol(dtype, 2.0), kernel=last_kernel())
 
 
-@pytest.mark.parametrize("variant", [11, 12, 13, 15])
+@pytest.mark.parametrize("variant", [11, 12, 13, 15, 21, 22, 23])
 def test_dma_pipe_epilogues_bf16(variant):
     M, K, N = 700, 1280, 640
     dt = torch.bfloat16
@@ -300,7 +303,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23])
 def test_conv_igemm(case, variant):
     name, B, Cin, H, W, Cout, k, stride, pad, ex = case
     x = cl(rnd(B, Cin, H, W, seed=70))
@@ -327,9 +330,9 @@ def test_conv_split_k(split):
     y = F().conv2d(x, w, b, z=z, padding=1, split_k=split, variant=4)
     assert f"split={split}" in last_kernel()
     compare(f"conv split{split}", y, R.conv2d_ref(x, w, b, z, 1.0, 1, 1), *tol(x.dtype, 2.0), kernel=last_kernel())
-    for v in (11, 13):
+    for v in (11, 13, 21, 22, 23):
         y = F().conv2d(x, w, b, z=z, padding=1, split_k=split, variant=v)
-        assert f"split={split},dma" in last_kernel()
+        assert f"split={split},{'ws' if v > 20 else 'dma'}" in last_kernel()
         compare(f"conv dma v{v} split{split}", y, R.conv2d_ref(x, w, b, z, 1.0, 1, 1), *tol(x.dtype, 2.0), kernel=last_kernel())
 
 

@@ -14,5 +14,6 @@ pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_IN
 pass sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD
 pass tcc1 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 pass tcc2 FETCH_SIZE
+pass tcc3 WRITE_SIZE
 pass tcp1 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TA_TCP_STATE_READ_sum GRBM_GUI_ACTIVE
 ls gpurun_out/pmc

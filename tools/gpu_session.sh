@@ -25,11 +25,21 @@ if [ "$MODE" = "micro" ]; then
   cut -c1-300 gpurun_out/session.log
   exit 0
 fi
+if [ "$MODE" = "testprof" ]; then
+  run t_norm   600 $PYT tests/test_ops_gpu.py -k "group_norm or layer_norm"
+  run t_gemm   900 $PYT tests/test_ops_gpu.py -k "geglu or linear or gemv"
+  run t_conv   900 $PYT tests/test_ops_gpu.py -k "conv"
+  run t_misc   600 $PYT tests/test_ops_gpu.py -k "copy or timestep or cfg or golden"
+  run t_refapi 900 $PYT tests/test_reference_api_gpu.py
+  run t_unet  1200 $PYT tests/test_unet_gpu.py
+  MODE=prof
+fi
 if [ "$MODE" = "prof" ]; then
+  export SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_cache.json
   run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json
   ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -o bench -- python $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline > $OLDPWD/gpurun_out/rocprof.log 2>&1 )
   echo "rocprof exit=$?" >> gpurun_out/session.log
-  for db in $(find gpurun_out/prof -name "*.db"); do python tools/rocpd_summary.py $db --csv gpurun_out/kernel_stats.csv --top 60 > gpurun_out/kernel_stats.txt; done
+  for db in $(find gpurun_out/prof -name "*.db"); do python tools/rocpd_summary.py $db --csv gpurun_out/kernel_stats.csv --top 70 --step-marker cfg_ddim --steps 8 > gpurun_out/kernel_stats.txt; done
   rm -rf gpurun_out/prof
   cut -c1-300 gpurun_out/session.log
   exit 0
@@ -44,7 +54,6 @@ run t_unet  1200 $PYT tests/test_unet_gpu.py
 run smoke    600 python __graft_entry__.py smoke
 run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json
 run bench2 600 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-roofline
-run ablate 600 python tools/ablate_igemm.py
 run bench_sdxl 900 python bench.py --config sdxl --steps 10 --warmup 2 --no-cpu-baseline
 if [ "$MODE" = "full" ] || [ "$MODE" = "tune" ]; then
   run tune 900 bash -c "python tools/tune_igemm.py > gpurun_out/tune.json 2> gpurun_out/tune.txt"

@@ -18,13 +18,16 @@ from sfast.engine.unet_spec import SD15_CONFIG, random_params  # noqa: E402
 
 REPS = int(os.environ.get("PROBE_REPS", "5"))
 PROBES = [
-    # op name, variant, split
-    ("down_blocks.0.resnets.0.conv2", 2, 1),
-    ("down_blocks.0.resnets.0.conv2", 2, 4),
-    ("down_blocks.0.resnets.0.conv2", 1, 1),
-    ("down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_qkv", 1, 1),
-    ("down_blocks.0.attentions.0.transformer_blocks.0.ff.out", 3, 1),
-    ("down_blocks.2.resnets.1.conv2", 1, 12),
+    # op name, variant, split  (variants: include/sfast_hip.h / igemm.hip kVariants)
+    ("up_blocks.3.resnets.0.conv1", 15, 4),   # 256x128 dma3
+    ("up_blocks.3.resnets.0.conv1", 17, 4),   # 128x160 dma2
+    ("up_blocks.3.resnets.0.conv1", 2, 4),    # 128x160 reg
+    ("down_blocks.0.resnets.0.conv2", 18, 1),  # 64x64 dma3
+    ("down_blocks.0.resnets.0.conv2", 12, 2),  # 128x160 dma4
+    ("down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_qkv", 18, 1),
+    ("down_blocks.0.attentions.0.transformer_blocks.0.ff.out", 18, 1),
+    ("down_blocks.0.attentions.0.transformer_blocks.0.ff.geglu", 16, 1),
+    ("down_blocks.2.resnets.1.conv2", 15, 12),
     ("down_blocks.0.attentions.0.transformer_blocks.0.attn1", 0, 0),
     ("down_blocks.0.resnets.0.norm1", 0, 0),
     ("down_blocks.0.attentions.0.transformer_blocks.0.norm1", 0, 0),

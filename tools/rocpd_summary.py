@@ -20,9 +20,31 @@ def main():
     ap.add_argument("db")
     ap.add_argument("--csv", default=None)
     ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--step-marker", default=None,
+                    help="kernel-name substring that ends one step (e.g. cfg_ddim): restrict to the last --steps steps")
+    ap.add_argument("--steps", type=int, default=8)
     a = ap.parse_args()
     con = sqlite3.connect(a.db)
-    rows = con.execute("select name, grid_x, grid_y, grid_z, workgroup_x, duration from kernels").fetchall()
+    rows = con.execute("select name, grid_x, grid_y, grid_z, workgroup_x, duration, start, end from kernels order by start").fetchall()
+    if a.step_marker:
+        marks = [r for r in rows if a.step_marker in r[0]]
+        if len(marks) > a.steps:
+            t0, t1 = marks[-a.steps - 1][7], marks[-1][7]
+            rows = [r for r in rows if r[6] >= t0 and r[7] <= t1]
+            # union of busy intervals (kernels may overlap across streams)
+            busy, cur_s, cur_e = 0, None, None
+            for r in rows:
+                if cur_e is None or r[6] > cur_e:
+                    if cur_e is not None:
+                        busy += cur_e - cur_s
+                    cur_s, cur_e = r[6], r[7]
+                else:
+                    cur_e = max(cur_e, r[7])
+            busy += cur_e - cur_s
+            n = a.steps
+            print(f"# steady window: {n} steps, {(t1 - t0) / n / 1e6:.3f} ms/step wall, {busy / n / 1e6:.3f} ms/step GPU-busy (union), "
+                  f"{sum(r[5] for r in rows) / n / 1e6:.3f} ms/step summed kernel time, {len(rows) / n:.0f} dispatches/step")
+    rows = [r[:6] for r in rows]
     agg = {}
     for name, gx, gy, gz, wx, dur in rows:
         k = short(name)

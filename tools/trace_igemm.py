@@ -17,13 +17,21 @@ from sfast.engine import UNet2DEngine  # noqa: E402
 from sfast.engine.unet_spec import SD15_CONFIG, random_params  # noqa: E402
 from sfast.hip import lib as L  # noqa: E402
 
+# (op, variant, split): each also traced under the kernel's experiment instantiations (SFAST_IGEMM_EXP)
+EXPERIMENTS = [
+    ("down_blocks.0.resnets.0.conv2", 12, 2),
+    ("down_blocks.0.attentions.0.transformer_blocks.0.ff.out", 18, 1),
+]
+EXP_NAMES = {0: "full", 1: "no MFMA", 2: "no LDS reads", 3: "no MFMA, no LDS reads", 4: "no in-loop DMA", 8: "no barrier",
+             7: "loop skeleton (wait + barrier only)"}
+
 PROBES = [
-    ("down_blocks.0.attentions.0.transformer_blocks.0.ff.geglu", [(11, 1), (16, 1), (1, 1), (3, 1)]),
-    ("down_blocks.0.attentions.0.transformer_blocks.0.ff.out", [(13, 1), (18, 1), (3, 1)]),
-    ("down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_out", [(13, 1), (3, 1)]),
-    ("down_blocks.0.resnets.0.conv2", [(12, 2), (15, 2), (2, 4)]),
-    ("up_blocks.3.resnets.0.conv1", [(15, 4), (2, 4)]),
-    ("down_blocks.2.resnets.1.conv2", [(15, 12), (5, 12)]),
+    ("down_blocks.0.attentions.0.transformer_blocks.0.ff.geglu", [(11, 1), (16, 1), (21, 1), (23, 1), (1, 1)]),
+    ("down_blocks.0.attentions.0.transformer_blocks.0.ff.out", [(13, 1), (18, 1), (23, 1), (21, 1), (3, 1)]),
+    ("down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_out", [(13, 1), (23, 1), (3, 1)]),
+    ("down_blocks.0.resnets.0.conv2", [(12, 2), (22, 2), (22, 1), (21, 2), (23, 1), (18, 1), (2, 4)]),
+    ("up_blocks.3.resnets.0.conv1", [(15, 4), (22, 4), (22, 2), (21, 4), (2, 4)]),
+    ("down_blocks.2.resnets.1.conv2", [(15, 12), (22, 12), (21, 12), (5, 12)]),
 ]
 
 
@@ -37,10 +45,31 @@ def main():
     plan = eng.build_plan(2, 64, 64, 77)
     lib = L.load()
     ws = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
-    trace = torch.zeros(8 * 65536, dtype=torch.int64, device=dev)
+    trace = torch.zeros(16 * 65536, dtype=torch.int64, device=dev)
     sp = torch.cuda.current_stream().cuda_stream
     ops = {op.name: op for op in plan.ops}
     names = ["setup", "issue", "1st-tile", "k-loop", "epi", "drain", "total"]
+    for name, v, sk in EXPERIMENTS:
+        op = ops[name]
+        p, launch_with = op.tune
+        p.variant, p.split_k = v, sk
+        for ex in (0, 1, 2, 3, 4, 8, 7):
+            os.environ["SFAST_IGEMM_EXP"] = str(ex)
+            trace.zero_()
+            lib.sfast_hip_set_trace(trace.data_ptr())
+            for _ in range(2):
+                assert launch_with(sp, ws.data_ptr(), ws.numel()) == 0
+            torch.cuda.synchronize()
+            kern = L.last_kernel()
+            lib.sfast_hip_set_trace(None)
+            t = trace.cpu().numpy().reshape(-1, 16)
+            t = t[t[:, 0] != 0]
+            st = t[:, :7].astype(np.int64)
+            kl = st[:, 4] - st[:, 3]
+            tot = st[:, 6] - st[:, 0]
+            print(f"EXP {name[-28:]:28s} {kern:40s} {EXP_NAMES[ex]:36s} k-loop med {pct(kl, 50):6.2f} us  WG total {pct(tot, 50):6.2f} us")
+        os.environ.pop("SFAST_IGEMM_EXP", None)
+        p.variant, p.split_k = 0, 0
     for name, cfgs in PROBES:
         op = ops[name]
         p, launch_with = op.tune
@@ -62,7 +91,7 @@ def main():
             launch_with(sp, ws.data_ptr(), ws.numel())
             torch.cuda.synchronize()
             lib.sfast_hip_set_trace(None)
-            t = trace.cpu().numpy().reshape(-1, 8)
+            t = trace.cpu().numpy().reshape(-1, 16)
             t = t[t[:, 0] != 0]
             n = len(t)
             st = t[:, :7].astype(np.int64)
@@ -87,6 +116,11 @@ def main():
                   f"peak {peak} WG/CU")
             print("      phase med/p90 us: " + "  ".join(
                 f"{nm} {pct(d[:, i], 50):.2f}/{pct(d[:, i], 90):.2f}" for i, nm in enumerate(names)))
+            wall = (st[:, 6] - st[:, 0]).astype(np.float64)  # 10 ns ticks
+            cyc = (t[:, 9] - t[:, 8]).astype(np.float64)
+            ok = wall > 50
+            mhz = float(np.median(cyc[ok] / wall[ok]) * 100.0) if ok.any() else 0.0
+            print(f"      clock64 ticks per us over a workgroup's life (median): {mhz:.0f}")
             print(f"      WG start offsets us: p10 {pct(start, 10):.2f} p50 {pct(start, 50):.2f} p90 {pct(start, 90):.2f} "
                   f"max {pct(start, 100):.2f}; first-round WGs (start < 1 us): {(start < 100).sum()}")
         p.variant, p.split_k = 0, 0
