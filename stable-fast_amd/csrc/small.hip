@@ -319,19 +319,26 @@ __global__ void __launch_bounds__(256) conv_small_c_kernel(const SmallConvArgs a
             }
         };
         if constexpr (KMAX > 0) {
+            // fast form (host guarantees: no upsample, no concat, KH*KW <= 32): one 64-bit pixel base per output
+            // vector, tap validity as a bit mask, and per k only a wave-uniform (scalar) offset -- the generic
+            // 4-stride 64-bit address per element was ~45 instructions each, 80 us for SD's conv_in
+            const T *pbase = (const T *)a.x + ((int64_t)b * a.xs[0] + (int64_t)h0 * a.xs[1] + (int64_t)w0 * a.xs[2]);
+            unsigned tapmask = 0;
+            for (int r = 0; r < a.KH; ++r)
+                for (int s = 0; s < a.KW; ++s) {
+                    const bool ok = ((unsigned)(h0 + r * a.dil_h) < (unsigned)a.H) & ((unsigned)(w0 + s * a.dil_w) < (unsigned)a.W);
+                    tapmask |= (ok ? 1u : 0u) << (r * a.KW + s);
+                }
             float xv[KMAX];
-            int c = 0, r = 0, s = 0;
+            int c = 0, r = 0, s = 0, tap = 0;
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) {
-                int hi = h0 + r * a.dil_h, wi = w0 + s * a.dil_w;
-                const bool ok = (k < K) & ((unsigned)hi < (unsigned)HH) & ((unsigned)wi < (unsigned)WW);
-                if (a.ups) {
-                    hi >>= 1;
-                    wi >>= 1;
-                }
-                xv[k] = Elem<T>::to_f32(*(ok ? (gelem_ptr)(const void *)x_ptr(b, hi, wi, c < a.Cin ? c : 0) : zero));
+                const int64_t soff = (int64_t)(r * a.dil_h) * a.xs[1] + (int64_t)(s * a.dil_w) * a.xs[2] + (int64_t)c * a.xs[3];  // uniform
+                const bool ok = (k < K) & (((tapmask >> (tap & 31)) & 1u) != 0);
+                xv[k] = Elem<T>::to_f32(*(ok ? (gelem_ptr)(const void *)(pbase + soff) : zero));
                 if (++c == a.Cin) {
                     c = 0;
+                    ++tap;
                     if (++s == a.KW) {
                         s = 0;
                         ++r;
@@ -438,7 +445,7 @@ int small_conv_c(const SmallConvArgs &a, int dtype, hipStream_t st) {
     int ppb = 32;
     while (ppb > 4 && ceil_div64(M, ppb) < 256) ppb >>= 1;
     const dim3 grid((unsigned)ceil_div64(M, ppb));
-    const bool tiny = K <= 40;
+    const bool tiny = K <= 40 && !a.ups && a.C1 == a.Cin && a.KH * a.KW <= 32;
     if (dtype == SFAST_F16) {
         if (tiny)
             hipLaunchKernelGGL((conv_small_c_kernel<f16, 40>), grid, dim3(256), smem, st, a, ppb);

@@ -26,11 +26,12 @@ EXP_NAMES = {0: "full", 1: "no MFMA", 2: "no LDS reads", 3: "no MFMA, no LDS rea
              7: "loop skeleton (wait + barrier only)"}
 
 PROBES = [
-    ("down_blocks.0.attentions.0.transformer_blocks.0.ff.geglu", [(11, 1), (16, 1), (21, 1), (23, 1), (1, 1)]),
-    ("down_blocks.0.attentions.0.transformer_blocks.0.ff.out", [(13, 1), (18, 1), (23, 1), (21, 1), (3, 1)]),
+    ("down_blocks.0.attentions.0.transformer_blocks.0.ff.geglu", [(16, 1), (21, 1), (23, 1), (1, 1)]),
+    ("down_blocks.0.attentions.0.transformer_blocks.0.ff.out", [(18, 1), (23, 1), (3, 1)]),
+    ("down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_qkv", [(18, 1), (23, 1), (3, 1)]),
     ("down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_out", [(13, 1), (23, 1), (3, 1)]),
-    ("down_blocks.0.resnets.0.conv2", [(12, 2), (22, 2), (22, 1), (21, 2), (23, 1), (18, 1), (2, 4)]),
-    ("up_blocks.3.resnets.0.conv1", [(15, 4), (22, 4), (22, 2), (21, 4), (2, 4)]),
+    ("down_blocks.0.resnets.0.conv2", [(12, 2), (22, 2), (23, 1), (18, 1), (2, 4)]),
+    ("up_blocks.3.resnets.0.conv1", [(15, 4), (22, 4), (22, 2), (2, 4)]),
     ("down_blocks.2.resnets.1.conv2", [(15, 12), (22, 12), (21, 12), (5, 12)]),
 ]
 
