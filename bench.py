@@ -36,8 +36,8 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="sd15", choices=["sd15", "sdxl"])
     ap.add_argument("--images", type=int, default=1, help="images per GPU (UNet batch is 2x this: CFG)")
     ap.add_argument("--no-graph", action="store_true")
@@ -249,6 +249,7 @@ def main():
             "gpu_ms_per_step_events": gpu_ms / args.steps, "outputs_finite": finite,
             "reference_published_other_hw": {"H100": 104.6, "A100": 61.8, "RTX4080": 51.6, "source": "BASELINE.md section 1 (stable-fast README)"},
             "kernel_launches_per_step": len(loop.plan.ops) + 1, "graph_side_lanes": bool(getattr(loop, "graph_forked", False)),
+            "graph_calibration_ms": getattr(loop.plan, "graph_calibration_ms", None),
             "activation_pool_mb": loop.plan.pool.total_bytes() / 1e6,
         }
         if world > 1:

@@ -23,6 +23,7 @@
 //   * softmax in fp32 with exp2 and a folded scale*log2(e); accumulate fp32; global loads of tile
 //     t+1 are issued before the MFMAs of tile t (register prefetch).
 #include "common.h"
+#include <type_traits>
 #include <math.h>
 
 namespace sfast {
@@ -77,11 +78,19 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
     const T *Kp = (const T *)a.k + (int64_t)b * a.ks[0] + (int64_t)h * a.ks[2];
     const T *Vp = (const T *)a.v + (int64_t)b * a.vs[0] + (int64_t)h * a.vs[2];
 
-    // zero the V^T rows that pad D up to DO in both stages (never written by the tile loads)
-    for (int i = tid; i < 2 * (DO - D) * (VSTR / 2); i += NT) {
-        const int st = i / ((DO - D) * (VSTR / 2) > 0 ? (DO - D) * (VSTR / 2) : 1);
-        const int j = i - st * ((DO - D) * (VSTR / 2));
-        reinterpret_cast<uint32_t *>(smem + st * STAGE + 64 * KSTR * 2 + D * VSTR * 2)[j] = 0u;
+    // V^T rows D..DO-1 pad the head dim up to the MFMA block in both stages (never written by the tile loads).
+    // Row D is set to ONES instead of zero when there is padding: O^T[D][q] then accumulates sum_k P[q][k] -- the
+    // softmax denominator -- inside the PV MFMA, rescaled with the rest of O for free. That removes 32 VALU adds per
+    // 64-key tile from a loop that is VALU-bound for the small head dims (exp2 + max + convert outweigh 14 MFMAs).
+    constexpr bool MFMA_ROWSUM = DO > D;
+    {
+        constexpr int PADW = (DO - D) * (VSTR / 2);  // dwords of padding rows per stage
+        const uint32_t one2 = std::is_same<T, f16>::value ? 0x3C003C00u : 0x3F803F80u;
+        for (int i = tid; i < 2 * PADW; i += NT) {
+            const int st = i / (PADW > 0 ? PADW : 1);
+            const int j = i - st * PADW;
+            reinterpret_cast<uint32_t *>(smem + st * STAGE + 64 * KSTR * 2 + D * VSTR * 2)[j] = (j < VSTR / 2) ? one2 : 0u;
+        }
     }
 
     // ---- Q fragments (B operand), kept in registers for the whole kernel -------------------------
@@ -200,7 +209,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
             const float m_new = fmaxf(m_run, mloc);
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
             m_run = m_new;
-            l_run *= alpha;
+            if constexpr (!MFMA_ROWSUM) l_run *= alpha;
 #pragma unroll
             for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -214,10 +223,10 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, -mc));
                 s[kb][r] = p;
-                rowsum += p;
+                if constexpr (!MFMA_ROWSUM) rowsum += p;
             }
         }
-        l_run += rowsum;
+        if constexpr (!MFMA_ROWSUM) l_run += rowsum;
 
         // ---- P^T fragments: registers [8*s2, 8*s2+8) of block kb, converted in place -----------------
         vec8 pf[2][2];
@@ -227,6 +236,20 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) pf[kb][s2][jj] = Elem<T>::from_f32(s[kb][8 * s2 + jj]);
+        if constexpr (std::is_same<T, f16>::value && MFMA_ROWSUM) {
+            // f16: packed round-toward-zero converts (one instruction per pair instead of three). The denominator comes
+            // from the SAME rounded probabilities through the ones-row, so the rounding bias cancels in O / l.
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    u32x4 w;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        w[jj] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(s[kb][8 * s2 + 2 * jj], s[kb][8 * s2 + 2 * jj + 1]));
+                    pf[kb][s2] = __builtin_bit_cast(vec8, w);
+                }
+        }
 
         // ---- O^T += V^T . P^T ------------------------------------------------------------------------------
 #pragma unroll
@@ -251,7 +274,16 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
     }
 
     // ---- epilogue: normalise and store 4 consecutive d per lane ----------------------------------------
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l_tot;
+    if constexpr (MFMA_ROWSUM) {
+        // O^T row D of query l31: block D/32, row D%32 = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+        constexpr int RR = D % 32;
+        constexpr int LREG = (RR & 3) + 4 * (RR >> 3);
+        constexpr int LHI = (RR >> 2) & 1;
+        l_tot = __shfl(o[D / 32][LREG], l31 + 32 * LHI, 64);
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    }
     const float inv = 1.0f / l_tot;
     if (qrow < a.Sq) {
         T *Op = (T *)a.out + (int64_t)b * a.os[0] + (int64_t)qrow * a.os[1] + (int64_t)h * a.os[2];

@@ -192,6 +192,9 @@ def capture_plan_graph(plan, stream, pool=None, tail=None, calibrate=True):
                 b.synchronize()
                 ts.append(a.elapsed_time(b))
             t = sorted(ts)[2]
+            cal = getattr(plan, "graph_calibration_ms", None) or {}
+            cal["forked" if forked else "serial"] = t
+            plan.graph_calibration_ms = cal
             if best is None or t < best[0]:
                 best = (t, forked, g)
     return best[2], best[1]
