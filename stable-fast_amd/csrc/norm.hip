@@ -157,6 +157,14 @@ __global__ void gn_nhwc_apply_kernel(const T *__restrict__ x, const T *__restric
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     constexpr int RS = 8;
+    // requests that do not depend on the statistics go out first (shift value, this thread's gamma / beta vectors of
+    // the first channel pass): their round trips overlap the partial-sum reduction instead of following it
+    const float sh_early = (tid < g.G) ? (float)*gn_src(x, x2, g, b, 0, tid * g.cpg) : 0.f;
+    const int tx0 = tid % g.TXB;
+    const bool pre_ok = tx0 < g.CX && tid < g.TXB * g.TY;
+    u32x4 ga_raw = {0u, 0u, 0u, 0u}, be_raw = {0u, 0u, 0u, 0u};
+    if (pre_ok && gamma) ga_raw = *reinterpret_cast<const u32x4 *>(gamma + tx0 * 8);
+    if (pre_ok && beta) be_raw = *reinterpret_cast<const u32x4 *>(beta + tx0 * 8);
     // combine the per-split partial sums: (group, lane-of-8) then 8 -> 1, fixed order.
     if (tid < g.G * RS) {
         const int grp = tid / RS, j = tid % RS;
@@ -190,7 +198,7 @@ __global__ void gn_nhwc_apply_kernel(const T *__restrict__ x, const T *__restric
             s2 += tmp[(tid * RS + j) * 2 + 1];
         }
         const float n = (float)g.HW * (float)g.cpg;
-        const float sh = (float)*gn_src(x, x2, g, b, 0, tid * g.cpg);
+        const float sh = sh_early;
         const float m1 = s1 / n;
         const float var = fmaxf(s2 / n - m1 * m1, 0.f);  // biased variance (group_norm.py:48)
         mean[tid] = sh + m1;
@@ -206,12 +214,20 @@ __global__ void gn_nhwc_apply_kernel(const T *__restrict__ x, const T *__restric
         const int cx = cxb + tx;
         if (cx >= g.CX) continue;
         const int c = cx * 8;
-        float a[8], bb[8];
+        float a[8], bb[8], gaf[8], bef[8];
+        if (cxb != 0) {  // later channel passes (C > 8 * 512 only): fetch here
+            if (gamma) ga_raw = *reinterpret_cast<const u32x4 *>(gamma + c);
+            if (beta) be_raw = *reinterpret_cast<const u32x4 *>(beta + c);
+        }
+        unpack8<T>(ga_raw, gaf);
+        unpack8<T>(be_raw, bef);
+        const int g0 = c / g.cpg;               // an 8-channel chunk touches at most two groups (cpg >= 8)
+        const int nb = (g0 + 1) * g.cpg - c;    // channels of the chunk that belong to g0
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int grp = (c + i) / g.cpg;
-            const float ga = gamma ? (float)gamma[c + i] : 1.f;
-            const float be = beta ? (float)beta[c + i] : 0.f;
+            const int grp = g0 + (i >= nb ? 1 : 0);
+            const float ga = gamma ? gaf[i] : 1.f;
+            const float be = beta ? bef[i] : 0.f;
             a[i] = rstd[grp] * ga;
             bb[i] = be - mean[grp] * a[i];
         }
@@ -506,7 +522,8 @@ extern "C" int sfast_hip_group_norm(const void *x, const void *x2, const void *g
                   "group_norm: concat needs x2 and NHWC");
     hipStream_t st = (hipStream_t)stream;
     GnPlan pl = gn_plan(p);
-    const bool ptr_ok = aligned16(x) && aligned16(y) && (p->C1 == p->C || aligned16(x2));
+    const bool ptr_ok = aligned16(x) && aligned16(y) && (p->C1 == p->C || aligned16(x2)) && (!gamma || aligned16(gamma)) &&
+                        (!beta || aligned16(beta));
     if (pl.fast && ptr_ok) {
         const size_t need = sfast_hip_group_norm_workspace_bytes(p);
         SFAST_REQUIRE(workspace && workspace_bytes >= need, SFAST_ERR_WORKSPACE,

@@ -123,6 +123,46 @@ __device__ __forceinline__ void conv_store(const SmallConvArgs &a, int b, int ho
     ((T *)a.out)[b * a.os[0] + ho * a.os[1] + wo * a.os[2] + co * a.os[3]] = Elem<T>::from_f32(v);
 }
 
+// 8 consecutive output channels co0..co0+7 of one pixel: operands as 16-byte vectors requested together and
+// unconditionally (absent operands read the device zero block), one activation loop, one 16-byte store.
+// Caller guarantees the layout (vec_epilogue_ok). The scalar conv_store costs three dependent load round trips and a
+// full activation switch PER ELEMENT.
+template <typename T>
+__device__ __forceinline__ void conv_store8(const SmallConvArgs &a, int b, int ho, int wo, int co0, const float (&acc)[8]) {
+    typedef const u32x4 __attribute__((address_space(1))) * g4_ptr;
+    const g4_ptr zero = (g4_ptr)(const void *)g_zero16;
+    const u32x4 vb = *(a.bias ? (g4_ptr)(const void *)((const T *)a.bias + co0) : zero);
+    const u32x4 vrb = *(a.rowbias ? (g4_ptr)(const void *)((const T *)a.rowbias + (int64_t)b * a.ld_rowbias + co0) : zero);
+    const u32x4 vz = *(a.z ? (g4_ptr)(const void *)((const T *)a.z + (b * a.zs[0] + ho * a.zs[1] + wo * a.zs[2] + co0)) : zero);
+    float fb[8], frb[8], fz[8], v[8];
+    unpack8<T>(vb, fb);
+    unpack8<T>(vrb, frb);
+    unpack8<T>(vz, fz);
+    const bool res_now = a.res_before_act || a.act == SFAST_ACT_NONE;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = acc[e] + fb[e] + frb[e] + (res_now ? a.alpha * fz[e] : -0.0f);
+    if (a.act != SFAST_ACT_NONE) {
+        f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+#pragma unroll 1
+        for (int e = 0; e < 4; ++e) {  // rolled: one copy of the activation switch
+            lo[e] = apply_act(lo[e], a.act);
+            hi[e] = apply_act(hi[e], a.act);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = lo[e] + (res_now ? -0.0f : a.alpha * fz[e]);
+            v[4 + e] = hi[e] + (res_now ? -0.0f : a.alpha * fz[4 + e]);
+        }
+    }
+    *reinterpret_cast<u32x4 *>((T *)a.out + (b * a.os[0] + ho * a.os[1] + wo * a.os[2] + co0)) = pack8<T>(v);
+}
+__device__ __forceinline__ bool vec_epilogue_ok(const SmallConvArgs &a) {
+    auto al = [](const void *p) { return (((uintptr_t)p) & 15) == 0; };
+    bool ok = a.os[3] == 1 && al(a.out) && a.os[0] % 8 == 0 && a.os[1] % 8 == 0 && a.os[2] % 8 == 0;
+    ok = ok && (!a.bias || al(a.bias)) && (!a.rowbias || (al(a.rowbias) && a.ld_rowbias % 8 == 0));
+    ok = ok && (!a.z || (a.zs[3] == 1 && al(a.z) && a.zs[0] % 8 == 0 && a.zs[1] % 8 == 0 && a.zs[2] % 8 == 0));
+    return ok;
+}
 template <typename T>
 __device__ __forceinline__ float conv_load_x(const SmallConvArgs &a, int b, int hi, int wi, int c) {
     // (hi, wi) in the (possibly 2x-upsampled) input frame; returns 0 outside
@@ -284,11 +324,12 @@ __global__ void __launch_bounds__(256) conv_small_c_kernel(const SmallConvArgs a
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u)
-                if (k0 + u < K) wsm[(k0 + u) * a.Cout + co] = v[u];
+                if (k0 + u < K) wsm[(k0 + u) * a.Cout + ((co >> 2) & 1) * (a.Cout / 2) + (co >> 3) * 4 + (co & 3)] = v[u];
         }
     }
     __syncthreads();
     const int cch = a.Cout / 8;
+    const bool vec_out = vec_epilogue_ok(a);
     const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
     const int64_t p_begin = (int64_t)blockIdx.x * pix_per_block;
     const int ntask = pix_per_block * cch;
@@ -310,8 +351,9 @@ __global__ void __launch_bounds__(256) conv_small_c_kernel(const SmallConvArgs a
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
         auto fma8 = [&](float xv, int k) {
-            const f32x4 w0v = *reinterpret_cast<const f32x4 *>(wsm + k * a.Cout + co0);
-            const f32x4 w1v = *reinterpret_cast<const f32x4 *>(wsm + k * a.Cout + co0 + 4);
+            // LDS image [k][half][chunk][4]: each of a lane's two 16-byte reads is lane-contiguous (stride 16 B)
+            const f32x4 w0v = *reinterpret_cast<const f32x4 *>(wsm + k * a.Cout + (co0 >> 1));
+            const f32x4 w1v = *reinterpret_cast<const f32x4 *>(wsm + k * a.Cout + a.Cout / 2 + (co0 >> 1));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 acc[q] = fmaf(xv, w0v[q], acc[q]);
@@ -371,8 +413,12 @@ __global__ void __launch_bounds__(256) conv_small_c_kernel(const SmallConvArgs a
                 }
             }
         }
+        if (vec_out) {
+            conv_store8<T>(a, b, ho, wo, co0, acc);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) conv_store<T>(a, b, ho, wo, co0 + e, acc[e]);
+            for (int e = 0; e < 8; ++e) conv_store<T>(a, b, ho, wo, co0 + e, acc[e]);
+        }
     }
 }
 
