@@ -131,6 +131,17 @@ def roofline_from(rows):
                 launches_per_step=dom["launches"], avg_launch_us=dom["seconds"] / dom["launches"] * 1e6,
                 share_of_step=dom["seconds"] / total, algorithmic_gflop_per_launch=dom["flops"] / dom["launches"] / 1e9,
                 algorithmic_mbytes_per_launch=dom["bytes"] / dom["launches"] / 1e6, traffic=None)
+    # HBM-side bytes per launch from the PMC counters: collected in their own rocprofv3 --pmc passes over this same
+    # command (tools/gpu_pmc_bench.sh: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB units) and committed under profiles/
+    try:
+        here = os.path.dirname(os.path.abspath(__file__))
+        with open(os.path.join(here, "profiles", "r01_pmc_traffic_by_symbol.json")) as f:
+            t = json.load(f).get(dom_name)
+        if t:
+            roof["traffic"] = t["bytes_per_launch"]
+            roof["traffic_source"] = "profiles/r01_pmc_traffic_by_symbol.json (separate --pmc passes; includes Infinity-Cache hits)"
+    except (OSError, ValueError):
+        pass
     fam = {}
     for r in rows:
         f = fam.setdefault(r["kind"], dict(seconds=0.0, flops=0.0, bytes=0.0, launches=0))
