@@ -149,9 +149,16 @@ def roofline_from(rows):
         f["flops"] += r["flops"]
         f["bytes"] += r["bytes"]
         f["launches"] += 1
+    # per family: absolute rates and the fraction of the roofline SURVEY section 8(d) assigns to it (MFMA for
+    # attention / conv / GEMM main loops, HBM for the normalisations and the weight-streaming GEMVs)
+    mfma_fams = ("conv3x3", "conv1x1", "linear", "geglu", "attn_self", "attn_cross")
     families = {k: dict(ms=v["seconds"] * 1e3, launches=v["launches"],
                         tflops=(v["flops"] / v["seconds"] / 1e12 if v["flops"] else None),
-                        gbs=v["bytes"] / v["seconds"] / 1e9) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["seconds"])}
+                        gbs=v["bytes"] / v["seconds"] / 1e9,
+                        roofline=("mfma" if k in mfma_fams else "hbm"),
+                        frac=(v["flops"] / v["seconds"] / 1e12 / MFMA_PEAK_TFLOPS if k in mfma_fams
+                              else v["bytes"] / v["seconds"] / 1e9 / HBM_PEAK_GBS))
+                for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["seconds"])}
     return roof, families, total
 
 
@@ -253,7 +260,8 @@ def main():
         out = {
             "metric": "UNet iters/sec SD1.5 512x512 bs=1 fp16" if args.config == "sd15" else "UNet iters/sec SDXL 1024x1024 bs=1 fp16",
             "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_image_50_steps_unet_and_scheduler": elapsed / args.steps * 1e3 * 50 / max(1, args.images), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{'SD1.5 512x512' if args.config == 'sd15' else 'SDXL 1024x1024'} bs={args.images} fp16, 50-step DDIM "
                                    f"schedule, one step = CFG batch-{2 * args.images} UNet forward + guidance combine + DDIM update, "
