@@ -113,6 +113,19 @@ typedef struct {
 int sfast_hip_layer_norm(const void *x, const void *gamma, const void *beta, void *y,
                          const sfast_ln_params *p, sfast_stream_t stream);
 
+/* ---- row softmax: y[m][:] = softmax(scale * x[m][:]) over N, fp32 math ------------------------
+ * The VAE decoder's single-head attention (head dim 512, /root/reference compile_vae path,
+ * compilers/diffusion_pipeline_compiler.py:154-190 -> diffusers AttnProcessor) runs as
+ * GEMM(Q.K^T) -> this kernel -> GEMM(P.V): its head dim is outside the flash kernel's register budget. */
+typedef struct {
+    int32_t dtype; /* f16 / bf16 */
+    int32_t M, N;  /* N % 8 == 0 */
+    int64_t ldx, ldy; /* row strides in elements (multiples of 8); y may alias x */
+    float scale;
+} sfast_softmax_params;
+
+int sfast_hip_softmax_rows(const void *x, void *y, const sfast_softmax_params *p, sfast_stream_t stream);
+
 /* ---- GEMM: out[M,N] = epilogue(x[M,K] . W[N,K]^T) ----------------------------------------
  * epilogue (fp32):  v = acc + bias[n] + rowbias[m / rows_per_batch][n]
  *                   res_before_act:  out = act(v + alpha*res[m][n])     (cuDNN-style z add)

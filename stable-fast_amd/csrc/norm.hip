@@ -17,7 +17,7 @@
 namespace sfast {
 
 // =================================================================================================
-// NHWC fast path: C % 8 == 0, C1 % 8 == 0, C/G >= 8, f16 / bf16.
+// NHWC fast path: C % 8 == 0, C1 % 8 == 0, C/G >= 8 or == 4 (an 8-channel chunk then touches at most two groups), f16 / bf16.
 // thread (tx, ty): tx -> one 8-channel chunk column, ty -> pixel row phase.
 // =================================================================================================
 struct GnGeom {
@@ -436,7 +436,7 @@ static GnPlan gn_plan(const sfast_gn_params *p) {
     GnPlan pl{};
     const int cpg = p->G > 0 ? p->C / p->G : 0;
     pl.fast = p->layout == SFAST_NHWC && p->dtype != SFAST_F32 && p->G > 0 && p->C % p->G == 0 &&
-              p->C % 8 == 0 && p->C1 % 8 == 0 && cpg >= 8 && p->G * 8 <= 256 && p->HW > 0;
+              p->C % 8 == 0 && p->C1 % 8 == 0 && (cpg >= 8 || cpg == 4) && p->G * 8 <= 256 && p->HW > 0;
     if (!pl.fast) return pl;
     GnGeom &g = pl.g;
     g.HW = p->HW;
@@ -496,6 +496,84 @@ static int gn_launch_generic(const void *x, const void *x2, const void *gamma, c
                        (const T *)gamma, (const T *)beta, (T *)y, p->layout, p->HW, p->C, p->C1, p->C / p->G,
                        p->eps, p->act);
     return check_launch("group_norm_generic");
+}
+
+
+// ---- row softmax ------------------------------------------------------------------------------------
+// One workgroup per row, 16-byte chunks, the row is held in registers between the three passes (max, exp-sum,
+// normalise): one read and one write of the row. Fixed reduction order -> bitwise reproducible.
+template <typename T, int MAXCH>
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const T *x, T *y, int M, int N, int64_t ldx,
+                                                           int64_t ldy, float scale_log2e) {
+    __shared__ float red[8];
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nch = N / 8;
+    const T *xr = x + (int64_t)row * ldx;
+    u32x4 cache[MAXCH];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) {
+        const int ch = tid + j * 256;
+        if (ch < nch) cache[j] = *reinterpret_cast<const u32x4 *>(xr + ch * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) {
+        const int ch = tid + j * 256;
+        if (ch < nch) {
+            float f[8];
+            unpack8<T>(cache[j], f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mx = fmaxf(mx, f[i]);
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float mc = mx * scale_log2e;
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) {
+        const int ch = tid + j * 256;
+        if (ch < nch) {
+            float f[8];
+            unpack8<T>(cache[j], f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sum += __builtin_amdgcn_exp2f(fmaf(f[i], scale_log2e, -mc));
+        }
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (((red[4] + red[5]) + red[6]) + red[7]);
+    T *yr = y + (int64_t)row * ldy;
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) {
+        const int ch = tid + j * 256;
+        if (ch < nch) {
+            float f[8];
+            unpack8<T>(cache[j], f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = __builtin_amdgcn_exp2f(fmaf(f[i], scale_log2e, -mc)) * inv;
+            *reinterpret_cast<u32x4 *>(yr + ch * 8) = pack8<T>(f);
+        }
+    }
+}
+
+template <typename T>
+static int softmax_launch(const void *x, void *y, const sfast_softmax_params *p, hipStream_t st) {
+    const float c = p->scale * 1.44269504088896340736f;
+    const int nch = p->N / 8;
+    const dim3 grid(p->M), block(256);
+#define SM_LAUNCH(MC) hipLaunchKernelGGL((softmax_rows_kernel<T, MC>), grid, block, 0, st, (const T *)x, (T *)y, p->M, p->N, p->ldx, p->ldy, c)
+    if (nch <= 256) SM_LAUNCH(1);
+    else if (nch <= 512) SM_LAUNCH(2);
+    else if (nch <= 1024) SM_LAUNCH(4);
+    else if (nch <= 2048) SM_LAUNCH(8);
+    else SM_LAUNCH(16);
+#undef SM_LAUNCH
+    return check_launch("softmax_rows");
 }
 
 }  // namespace sfast
@@ -586,5 +664,20 @@ extern "C" int sfast_hip_layer_norm(const void *x, const void *gamma, const void
     case SFAST_F32: return ln_launch<float>(x, gamma, beta, y, p, st, false);
     }
     set_error("layer_norm: bad dtype %d", p->dtype);
+    return SFAST_ERR_UNSUPPORTED;
+}
+
+extern "C" int sfast_hip_softmax_rows(const void *x, void *y, const sfast_softmax_params *p, sfast_stream_t stream) {
+    SFAST_REQUIRE(p && x && y, SFAST_ERR_INVALID, "softmax_rows: null argument");
+    SFAST_REQUIRE(p->M > 0 && p->N > 0 && p->N % 8 == 0 && p->N <= 8 * 256 * 16, SFAST_ERR_UNSUPPORTED,
+                  "softmax_rows: N=%d must be a multiple of 8, at most 32768", p->N);
+    SFAST_REQUIRE(p->ldx % 8 == 0 && p->ldy % 8 == 0 && p->ldx >= p->N && p->ldy >= p->N && aligned16(x) && aligned16(y),
+                  SFAST_ERR_UNSUPPORTED, "softmax_rows: rows must be 16-byte aligned");
+    SFAST_REQUIRE(p->scale > 0.f, SFAST_ERR_INVALID, "softmax_rows: scale must be positive");
+    set_kernel_name("softmax_rows");
+    hipStream_t st = (hipStream_t)stream;
+    if (p->dtype == SFAST_F16) return softmax_launch<f16>(x, y, p, st);
+    if (p->dtype == SFAST_BF16) return softmax_launch<bf16>(x, y, p, st);
+    set_error("softmax_rows: dtype %d unsupported", p->dtype);
     return SFAST_ERR_UNSUPPORTED;
 }

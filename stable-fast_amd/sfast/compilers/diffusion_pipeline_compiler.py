@@ -234,9 +234,86 @@ def compile_unet(m, config):
     return m
 
 
+class _NativeVaeDecoderForward:
+    """Replacement for `vae.decoder.forward`: per-shape plan cache (+ hipGraph replay when enabled)."""
+
+    def __init__(self, module, engine, orig_forward, enable_graph):
+        self.module, self.engine, self.orig_forward, self.enable_graph = module, engine, orig_forward, enable_graph
+        self._cached = {}
+        self._lock = threading.Lock()
+        self._warned = False
+        self.__self__ = module
+        self.__name__ = "forward"
+
+    def _prepare(self, key, z):
+        eng = self.engine
+        B, H, W = key
+        plan = eng.get_plan(B, H, W)
+        graph = None
+        torch.cuda.synchronize(eng.device)
+        with torch.cuda.device(eng.device), torch.cuda.stream(torch.cuda.Stream(device=eng.device)):
+            eng.load_inputs(plan, z)
+            plan.run(torch.cuda.current_stream(eng.device).cuda_stream)  # validates every launch before capture
+        torch.cuda.synchronize(eng.device)
+        if self.enable_graph:
+            from ..engine import capture_plan_graph
+            env = get_per_device_graph_execution_env(eng.device)
+            with env.lock:
+                with torch.cuda.device(eng.device):
+                    graph, _ = capture_plan_graph(plan, env.stream, pool=env.mempool)
+                torch.cuda.synchronize(eng.device)
+        return plan, graph
+
+    def __call__(self, sample, latent_embeds=None, *args, **kwargs):
+        eng = self.engine
+        if (latent_embeds is not None or args or kwargs or not torch.is_tensor(sample) or sample.device.type != "cuda"
+                or sample.dtype != eng.dtype or sample.ndim != 4 or sample.shape[1] != eng.in_ch):
+            if not self._warned:
+                logger.warning("sfast: VAE decoder call not handled by the native engine; running the original forward")
+                self._warned = True
+            if latent_embeds is not None:
+                return self.orig_forward(sample, latent_embeds, *args, **kwargs)
+            return self.orig_forward(sample, *args, **kwargs)
+        B, _, H, W = sample.shape
+        key = (B, H, W)
+        entry = self._cached.get(key)
+        if entry is None:
+            with self._lock:
+                entry = self._cached.get(key)
+                if entry is None:
+                    entry = self._prepare(key, sample)
+                    self._cached[key] = entry
+        plan, graph = entry
+        eng.load_inputs(plan, sample)
+        if graph is not None:
+            graph.replay()
+        else:
+            plan.run(torch.cuda.current_stream(eng.device).cuda_stream)
+        return plan.static_out.clone()
+
+
+def _looks_like_vae_decoder(d):
+    return d is not None and all(hasattr(d, a) for a in ("conv_in", "mid_block", "up_blocks", "conv_norm_out", "conv_out"))
+
+
 def compile_vae(m, config):
-    # The VAE is outside the UNet hot path: only the memory-format
-    # conversion of the reference (:165-166) is applied; the decoder keeps running on PyTorch-ROCm.
+    # reference: compilers/diffusion_pipeline_compiler.py:154-190 (memory format, xformers patch, TorchScript fusion of the
+    # whole VAE; CUDA graphs deliberately left off there). Here the DECODER -- the part every text-to-image call runs --
+    # is handed to the native engine (SURVEY.md section 8f rank 1); the encoder keeps running on PyTorch-ROCm.
+    device = _device_of(m)
+    enable_cuda_graph = config.enable_cuda_graph and device.type == "cuda"
     if config.memory_format is not None:
         apply_memory_format(m, memory_format=config.memory_format)
+    dec = getattr(m, "decoder", None)
+    if config.enable_jit and device.type == "cuda" and _looks_like_vae_decoder(dec):
+        from ..engine import UnsupportedUNet, VaeDecoderEngine
+        try:
+            native = VaeDecoderEngine.from_module(dec, config=getattr(m, "config", None))
+        except UnsupportedUNet as e:
+            logger.warning("sfast: %s is outside the native VAE engine's coverage (%s); keeping the eager decoder",
+                           type(dec).__name__, e)
+            native = None
+        if native is not None:
+            dec.forward = _NativeVaeDecoderForward(dec, native, dec.forward, enable_cuda_graph)
+            m._sfast_vae_engine = native
     return m

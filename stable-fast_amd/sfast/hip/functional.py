@@ -128,6 +128,19 @@ def layer_norm(x, normalized_shape: Sequence[int], weight=None, bias=None, eps=1
     return y
 
 
+def softmax_rows(x, scale=1.0, out=None):
+    """softmax(scale * x) over the last dim of a 2-D f16/bf16 tensor whose rows are 16-byte aligned (fp32 math)."""
+    _require_cuda(x)
+    lib = L.init_device()
+    if x.ndim != 2 or x.stride(1) != 1:
+        raise L.SfastHipError("softmax_rows: need a 2-D tensor with contiguous rows")
+    y = out if out is not None else torch.empty((x.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
+    p = L.SoftmaxParams(_dtype(x), x.shape[0], x.shape[1], x.stride(0), y.stride(0), float(scale))
+    rc = lib.sfast_hip_softmax_rows(_ptr(x), _ptr(y), C.byref(p), _stream(x))
+    L.check(rc, "sfast_hip_softmax_rows")
+    return y
+
+
 def linear(x, weight, bias=None, *, act=None, residual=None, alpha=1.0, res_before_act=False,
            geglu=False, rowbias=None, rows_per_batch=0, in_act=None, variant=0, split_k=0, out=None):
     """out[..., N] = epilogue(x[..., K] @ W[N, K]^T). `weight` may be a list of <= 4 equally sized

@@ -23,7 +23,7 @@ MAX_WSEG = 4
 
 EXPORTS = [
     "sfast_hip_abi_version", "sfast_hip_init", "sfast_hip_last_error", "sfast_hip_last_kernel",
-    "sfast_hip_group_norm_workspace_bytes", "sfast_hip_group_norm", "sfast_hip_layer_norm",
+    "sfast_hip_group_norm_workspace_bytes", "sfast_hip_group_norm", "sfast_hip_layer_norm", "sfast_hip_softmax_rows",
     "sfast_hip_gemm_workspace_bytes", "sfast_hip_gemm",
     "sfast_hip_conv2d_workspace_bytes", "sfast_hip_conv2d",
     "sfast_hip_attention", "sfast_hip_strided_copy", "sfast_hip_timestep_embedding",
@@ -39,6 +39,11 @@ class GnParams(C.Structure):
 
 class LnParams(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("eps", C.c_float)]
+
+
+class SoftmaxParams(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("ldx", C.c_int64), ("ldy", C.c_int64),
+                ("scale", C.c_float)]
 
 
 class GemmParams(C.Structure):
@@ -100,6 +105,8 @@ def _declare(lib):
     lib.sfast_hip_group_norm.argtypes = [vp, vp, vp, vp, vp, C.POINTER(GnParams), vp, sz, vp]
     lib.sfast_hip_layer_norm.restype = C.c_int
     lib.sfast_hip_layer_norm.argtypes = [vp, vp, vp, vp, C.POINTER(LnParams), vp]
+    lib.sfast_hip_softmax_rows.restype = C.c_int
+    lib.sfast_hip_softmax_rows.argtypes = [vp, vp, C.POINTER(SoftmaxParams), vp]
     lib.sfast_hip_gemm_workspace_bytes.restype = sz
     lib.sfast_hip_gemm_workspace_bytes.argtypes = [C.POINTER(GemmParams)]
     lib.sfast_hip_gemm.restype = C.c_int

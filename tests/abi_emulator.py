@@ -102,6 +102,14 @@ class EmuLib:
         _flat(y, p.M * p.N, p.dtype).reshape(p.M, p.N).copy_(R.layer_norm_ref(xin, (p.N,), g, b, p.eps))
         return 0
 
+    def sfast_hip_softmax_rows(self, x, y, ref, stream):
+        p = _p(ref)
+        self.calls.append("softmax_rows")
+        xin = _flat(x, (p.M - 1) * p.ldx + p.N, p.dtype).as_strided((p.M, p.N), (p.ldx, 1))
+        out = torch.softmax(xin.float() * p.scale, dim=-1).to(xin.dtype)
+        _flat(y, (p.M - 1) * p.ldy + p.N, p.dtype).as_strided((p.M, p.N), (p.ldy, 1)).copy_(out)
+        return 0
+
     def sfast_hip_gemm(self, x, segs, bias, rowbias, res, out, ref, ws, ws_bytes, stream):
         p = _p(ref)
         self.calls.append("gemm")

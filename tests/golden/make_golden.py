@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 
 from oracle import ops_ref as R  # noqa: E402
 from oracle import unet_ref as U  # noqa: E402
+from oracle import vae_ref as V  # noqa: E402
 
 
 def g(seed):
@@ -82,6 +83,14 @@ def main():
         y2 = m(sample, torch.tensor([981.0, 1.0]), ehs).sample
     torch.save(dict(config="tiny", seed=1234, sample=sample.half(), encoder_hidden_states=ehs.half(), timestep=981, y=y,
                     timesteps_b=[981.0, 1.0], y_b=y2), os.path.join(HERE, "unet_tiny.pt"))
+    # tiny VAE decoder (AutoencoderKL.decoder topology): fp16-representable weights, fp32 oracle output
+    vcfg = dict(block_out_channels=(64, 128), norm_num_groups=8, layers_per_block=1)
+    d = V.build("tiny", seed=4321, **vcfg)
+    d.load_state_dict({k_: h(v_) for k_, v_ in d.state_dict().items()})
+    zlat = h(torch.randn(2, 4, 8, 8, generator=g(30)))
+    with torch.no_grad():
+        yimg = d(zlat)
+    torch.save(dict(config=vcfg, seed=4321, z=zlat.half(), y=yimg), os.path.join(HERE, "vae_tiny.pt"))
     print("wrote", sorted(os.listdir(HERE)))
 
 

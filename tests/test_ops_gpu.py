@@ -60,7 +60,8 @@ def test_group_norm_reference_selftest_shape(silu, cl):
 
 
 @pytest.mark.parametrize("shape", [(2, 320, 64, 64), (2, 640, 32, 32), (2, 1280, 8, 8), (1, 2560, 16, 16), (2, 1920, 32, 32),
-                                   (2, 960, 64, 64), (1, 1280, 16, 16), (3, 640, 24, 40)])
+                                   (2, 960, 64, 64), (1, 1280, 16, 16), (3, 640, 24, 40),
+                                   (1, 128, 64, 64), (2, 256, 32, 32), (1, 512, 16, 16)])  # last row: VAE decoder widths (C/G = 4, 8, 16)
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_group_norm_silu_unet_shapes(shape, dtype):
     x = rnd(*shape, dtype=dtype, seed=4, scale=2.0, shift=3.0).contiguous(memory_format=torch.channels_last)

@@ -1,0 +1,89 @@
+"""VAE decoder path on CPU: the oracle pins and the engine's host logic against the C-ABI
+emulator. No GPU, no kernel launches."""
+import os
+
+import pytest
+import torch
+
+from abi_emulator import EmuLib
+from oracle import vae_ref as V
+from parity import rel_l2
+from sfast.engine import UnsupportedVae, VaeDecoderEngine
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TINY = dict(block_out_channels=(64, 128), norm_num_groups=8, layers_per_block=1)
+
+
+def test_decoder_topology_known_answer_param_count():
+    # AutoencoderKL (SD1.x/2.x/SDXL VAE): 83,653,863 parameters = encoder 34,163,592 + decoder 49,490,179 + 72 + 20
+    assert V.param_count(V.build("sd")) == V.SD_VAE_DECODER_PARAMS == 49_490_179
+
+
+def test_decoder_state_dict_keys_follow_diffusers_naming():
+    keys = set(V.build("sd").state_dict().keys())
+    for k in ("conv_in.weight", "mid_block.resnets.0.norm1.weight", "mid_block.attentions.0.group_norm.weight",
+              "mid_block.attentions.0.to_q.bias", "mid_block.attentions.0.to_out.0.weight", "up_blocks.0.upsamplers.0.conv.weight",
+              "up_blocks.2.resnets.0.conv_shortcut.weight", "up_blocks.3.resnets.2.conv2.bias", "conv_norm_out.bias", "conv_out.weight"):
+        assert k in keys, k
+    assert "up_blocks.3.upsamplers.0.conv.weight" not in keys and "up_blocks.0.resnets.0.conv_shortcut.weight" not in keys
+
+
+def test_oracle_reproduces_golden_vae():
+    gold = torch.load(os.path.join(GOLDEN, "vae_tiny.pt"))
+    d = V.build("tiny", seed=gold["seed"], **gold["config"])
+    d.load_state_dict({k: v.half().float() for k, v in d.state_dict().items()})
+    with torch.no_grad():
+        y = d(gold["z"].float())
+    torch.testing.assert_close(y, gold["y"], rtol=1e-3, atol=1e-4)
+
+
+def _pair(seed, **cfg):
+    m16 = V.build("tiny", seed=seed, dtype=torch.float16, **cfg)
+    m32 = V.build("tiny", seed=seed, **cfg)
+    m32.load_state_dict({k: v.float() for k, v in m16.state_dict().items()})
+    return m16, m32
+
+
+def test_plan_executes_tiny_decoder(built_lib):
+    m16, m32 = _pair(5, **TINY)
+    emu = EmuLib()
+    eng = VaeDecoderEngine.from_module(m16, _lib=emu)
+    z = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(0)).half()
+    y = eng.forward(z)
+    with torch.no_grad():
+        want = m32(z.float())
+    assert y.shape == (2, 3, 16, 16) and rel_l2(y, want) < 3e-3
+    # second signature: new plan, shared (live) parameters, non-square latent
+    z2 = torch.randn(1, 4, 8, 16, generator=torch.Generator().manual_seed(1)).half()
+    with torch.no_grad():
+        want2 = m32(z2.float())
+    assert rel_l2(eng.forward(z2), want2) < 3e-3 and len(eng._plans) == 2
+    inv = eng.get_plan(2, 8, 8).summary()
+    # conv_in + 2 mid resnets + 2x2 up resnets (2 convs each) + 1 upsampler conv + conv_out; one attention with 2 samples
+    assert inv["conv3x3"]["count"] == 13 and inv["gn_silu"]["count"] == 13 and inv["gn"]["count"] == 1
+    assert inv["softmax"]["count"] == 2 and inv["attn_vae"]["count"] == 4 and inv["conv1x1"]["count"] == 1
+    assert {"softmax_rows", "strided_copy", "group_norm", "conv2d", "gemm"} <= set(emu.calls)
+
+
+def test_live_parameters_are_read_at_every_run(built_lib):
+    m16, m32 = _pair(6, **TINY)
+    eng = VaeDecoderEngine.from_module(m16, _lib=EmuLib())
+    z = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(2)).half()
+    y0 = eng.forward(z)
+    with torch.no_grad():
+        m16.conv_out.bias.add_(1.0)  # in-place update (the LoRA / fine-tune contract of the reference, README.md:228-265)
+        m16.mid_block.attentions[0].to_v.bias.mul_(0.0)
+    y1 = eng.forward(z)
+    m32.load_state_dict({k: v.float() for k, v in m16.state_dict().items()})
+    with torch.no_grad():
+        want = m32(z.float())
+    assert rel_l2(y1, want) < 3e-3 and rel_l2(y1, y0) > 1e-2
+
+
+def test_unsupported_decoders_are_rejected(built_lib):
+    m32 = V.build("tiny", **TINY)
+    with pytest.raises(UnsupportedVae):
+        VaeDecoderEngine.from_module(m32, _lib=EmuLib())  # fp32 parameters
+    bad = V.build("tiny", dtype=torch.float16, block_out_channels=(36, 72), norm_num_groups=4, layers_per_block=1)
+    with pytest.raises(UnsupportedVae):
+        VaeDecoderEngine.from_module(bad, _lib=EmuLib())  # channel counts not multiples of 8

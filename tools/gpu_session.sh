@@ -16,6 +16,12 @@ run() { # name, timeout, command...
 rm -f gpurun_out/parity.jsonl gpurun_out/session.log
 rocminfo 2>/dev/null | grep -E "gfx|Compute Unit" | head -4 >> gpurun_out/session.log
 nproc >> gpurun_out/session.log
+if [ "$MODE" = "vae" ]; then
+  run t_vae    900 $PYT tests/test_vae_gpu.py
+  run bench_vae 600 python tools/bench_vae.py
+  cut -c1-600 gpurun_out/session.log
+  exit 0
+fi
 if [ "$MODE" = "micro" ]; then
   run t_gemm   900 $PYT tests/test_ops_gpu.py -k "geglu or linear or gemv"
   run t_conv   900 $PYT tests/test_ops_gpu.py -k "conv"
@@ -51,6 +57,7 @@ run t_attn   900 $PYT tests/test_ops_gpu.py -k "attention"
 run t_misc   600 $PYT tests/test_ops_gpu.py -k "copy or timestep or cfg or golden"
 run t_refapi 900 $PYT tests/test_reference_api_gpu.py
 run t_unet  1200 $PYT tests/test_unet_gpu.py
+run t_vae    900 $PYT tests/test_vae_gpu.py
 run smoke    600 python __graft_entry__.py smoke
 run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json
 run bench2 600 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-roofline
