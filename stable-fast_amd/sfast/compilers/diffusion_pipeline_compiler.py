@@ -5,7 +5,7 @@ Same names, arguments and in-place semantics as the reference module
   CompilationConfig.Default  (:22-78)   the same 11 fields
   compile(m, config)         (:81-124)  mutates and returns the pipeline (duck-typed on .unet, .vae, ...)
   compile_unet(m, config)    (:127-151)
-  compile_vae(m, config)     (:154-190)
+  compile_vae(m, config)     (:154-190)  the DECODER runs on the native engine too (sfast.engine.VaeDecoderEngine)
 
 What changed is what happens behind `unet.forward`: instead of TorchScript trace + pattern passes +
 CUDA graph, the UNet is handed to `sfast.engine.UNet2DEngine`, which runs the forward as a static
