@@ -23,6 +23,7 @@
  *                             strided views (libs/diffusers/xformers_attention.py:37-69)
  *   sfast_hip_strided_copy <- sfast_triton::contiguous / clone / reshape
  *                             (triton/torch_ops.py:24-106, triton/ops/copy.py:184-270)
+ *   sfast_hip_image_postprocess <- patched VaeImageProcessor (libs/diffusers/image_processor.py:13-108)
  *   sfast_hip_timestep_embedding, sfast_hip_cfg_ddim_step
  *                          <- host-side glue of the denoise loop that the reference leaves to
  *                             diffusers / trace_scheduler (compilers/diffusion_pipeline_compiler.py:103-107)
@@ -239,6 +240,19 @@ int sfast_hip_timestep_embedding(const float *timesteps /* [B] device */, void *
 int sfast_hip_cfg_ddim_step(const void *eps_uc, const void *latents, void *latents_out,
                             void *unet_in, const float *coef, float guidance, int64_t numel,
                             int32_t dtype, sfast_stream_t stream);
+
+/* ---- image post-process: NCHW f16/bf16/f32 image -> NHWC uint8 or float32 ----------------------
+ * replaces the reference's patched VaeImageProcessor.postprocess / pt_to_pil / pt_to_numpy
+ * (libs/diffusers/image_processor.py:23-108: denormalize (x/2+0.5).clamp(0,1), permute(0,2,3,1), and for PIL
+ * output mul(255).round().to(uint8) -- all on the GPU so that only the final bytes cross PCIe). */
+typedef struct {
+    int32_t dtype;       /* input dtype */
+    int32_t B, C, H, W;  /* input is dense NCHW */
+    int32_t denormalize; /* 1: (x/2 + 0.5).clamp(0, 1) first */
+    int32_t to_uint8;    /* 1: out = uint8 round(255*x) ; 0: out = float32 */
+} sfast_image_params;
+
+int sfast_hip_image_postprocess(const void *image, void *out, const sfast_image_params *p, sfast_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -68,6 +68,28 @@ __global__ void __launch_bounds__(256) cfg_ddim_kernel(const T *__restrict__ eps
     }
 }
 
+// NCHW image -> NHWC uint8 / float32 (VAE output -> PIL / numpy layout). One thread per output pixel-channel group:
+// reads are strided by H*W per channel (coalesced along W across lanes), writes are contiguous.
+template <typename T, bool U8>
+__global__ void __launch_bounds__(256) image_post_kernel(const T *__restrict__ img, void *__restrict__ out, int B, int Cc, int HW,
+                                                         int denorm) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (b, pixel)
+    if (idx >= (int64_t)B * HW) return;
+    const int b = (int)(idx / HW);
+    const int p = (int)(idx - (int64_t)b * HW);
+    const T *src = img + (int64_t)b * Cc * HW + p;
+    for (int c = 0; c < Cc; ++c) {
+        float v = Elem<T>::to_f32(src[(int64_t)c * HW]);
+        if (denorm) v = fminf(fmaxf(v * 0.5f + 0.5f, 0.f), 1.f);
+        if (U8) {
+            // torch: x.float().mul(255).round().to(uint8); round-half-even like torch.round
+            ((uint8_t *)out)[idx * Cc + c] = (uint8_t)(int)fminf(fmaxf(rintf(v * 255.0f), 0.f), 255.f);
+        } else {
+            ((float *)out)[idx * Cc + c] = v;
+        }
+    }
+}
+
 }  // namespace sfast
 
 using namespace sfast;
@@ -154,4 +176,26 @@ extern "C" int sfast_hip_cfg_ddim_step(const void *eps_uc, const void *latents, 
     default: set_error("cfg_ddim_step: dtype %d", dtype); return SFAST_ERR_UNSUPPORTED;
     }
     return check_launch("cfg_ddim_step");
+}
+
+extern "C" int sfast_hip_image_postprocess(const void *image, void *out, const sfast_image_params *p, sfast_stream_t stream) {
+    SFAST_REQUIRE(p && image && out, SFAST_ERR_INVALID, "image_postprocess: null argument");
+    SFAST_REQUIRE(p->B > 0 && p->C > 0 && p->H > 0 && p->W > 0, SFAST_ERR_INVALID, "image_postprocess: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const int HW = p->H * p->W;
+    const dim3 grid((unsigned)ceil_div64((int64_t)p->B * HW, 256));
+    set_kernel_name("image_postprocess");
+#define IMG_LAUNCH(T)                                                                                                        \
+    if (p->to_uint8)                                                                                                         \
+        hipLaunchKernelGGL((image_post_kernel<T, true>), grid, dim3(256), 0, st, (const T *)image, out, p->B, p->C, HW, p->denormalize); \
+    else                                                                                                                     \
+        hipLaunchKernelGGL((image_post_kernel<T, false>), grid, dim3(256), 0, st, (const T *)image, out, p->B, p->C, HW, p->denormalize);
+    switch (p->dtype) {
+    case SFAST_F16: IMG_LAUNCH(f16) break;
+    case SFAST_BF16: IMG_LAUNCH(bf16) break;
+    case SFAST_F32: IMG_LAUNCH(float) break;
+    default: set_error("image_postprocess: dtype %d", p->dtype); return SFAST_ERR_UNSUPPORTED;
+    }
+#undef IMG_LAUNCH
+    return check_launch("image_postprocess");
 }

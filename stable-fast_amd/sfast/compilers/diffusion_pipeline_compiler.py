@@ -183,6 +183,11 @@ def compile(m, config):
     if getattr(m, "vae", None) is not None:
         m.vae = compile_vae(m.vae, config)
 
+    if getattr(m, "image_processor", None) is not None:
+        # reference :117-122: post-processing moved onto the GPU
+        from ..libs.diffusers.image_processor import patch_image_prcessor
+        patch_image_prcessor(m.image_processor)
+
     if enable_cuda_graph:
         for name in ("text_encoder", "text_encoder_2", "image_encoder"):
             enc = getattr(m, name, None)

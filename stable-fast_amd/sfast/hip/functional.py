@@ -128,6 +128,21 @@ def layer_norm(x, normalized_shape: Sequence[int], weight=None, bias=None, eps=1
     return y
 
 
+def image_postprocess(image, denormalize=True, to_uint8=True):
+    """NCHW image tensor -> NHWC uint8 (round(255 * x)) or float32, optionally denormalised from [-1, 1] first."""
+    _require_cuda(image)
+    lib = L.init_device()
+    if image.ndim != 4:
+        raise L.SfastHipError("image_postprocess: need a [B, C, H, W] tensor")
+    image = image.contiguous()
+    B, Cc, H, W = image.shape
+    out = torch.empty((B, H, W, Cc), dtype=torch.uint8 if to_uint8 else torch.float32, device=image.device)
+    p = L.ImageParams(_dtype(image), B, Cc, H, W, int(bool(denormalize)), int(bool(to_uint8)))
+    rc = lib.sfast_hip_image_postprocess(_ptr(image), _ptr(out), C.byref(p), _stream(image))
+    L.check(rc, "sfast_hip_image_postprocess")
+    return out
+
+
 def softmax_rows(x, scale=1.0, out=None):
     """softmax(scale * x) over the last dim of a 2-D f16/bf16 tensor whose rows are 16-byte aligned (fp32 math)."""
     _require_cuda(x)

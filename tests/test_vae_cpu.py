@@ -87,3 +87,41 @@ def test_unsupported_decoders_are_rejected(built_lib):
     bad = V.build("tiny", dtype=torch.float16, block_out_channels=(36, 72), norm_num_groups=4, layers_per_block=1)
     with pytest.raises(UnsupportedVae):
         VaeDecoderEngine.from_module(bad, _lib=EmuLib())  # channel counts not multiples of 8
+
+
+class _FakeProcessor:
+    """Duck-typed stand-in for diffusers' VaeImageProcessor (not installable here)."""
+
+    def __init__(self):
+        import types
+        self.config = types.SimpleNamespace(do_normalize=True)
+
+    def postprocess(self, image, output_type="pil", do_denormalize=None):
+        raise AssertionError("patched away")
+
+    @staticmethod
+    def pt_to_numpy(images):
+        raise AssertionError("patched away")
+
+    @staticmethod
+    def pt_to_pil(images):
+        raise AssertionError("patched away")
+
+
+def test_image_processor_patch_cpu_tensors_keep_reference_semantics():
+    from sfast.libs.diffusers.image_processor import patch_image_prcessor
+    proc = patch_image_prcessor(_FakeProcessor())
+    img = torch.rand(2, 3, 8, 6, generator=torch.Generator().manual_seed(0)) * 2 - 1
+    want = (img / 2 + 0.5).clamp(0, 1)
+    assert torch.equal(proc.postprocess(img, "pt"), want)
+    assert proc.postprocess(img, "latent") is img
+    arr = proc.postprocess(img, "np")
+    assert arr.shape == (2, 8, 6, 3) and arr.dtype.name == "float32"
+    torch.testing.assert_close(torch.from_numpy(arr), want.permute(0, 2, 3, 1))
+    pil = proc.postprocess(img, "pil")
+    assert len(pil) == 2 and pil[0].size == (6, 8) and pil[0].mode == "RGB"
+    with pytest.raises(ValueError):
+        proc.postprocess([1, 2, 3])
+    # unsupported processors are left alone (reference :18-20)
+    other = object()
+    assert patch_image_prcessor(other) is other

@@ -130,6 +130,42 @@ def test_compile_vae_drop_in(graph):
     err = rel_l2(y.float(), want.float())
     log_value(f"compile_vae() tiny decoder graph={graph} vs eager fp16", rel_l2=err)
     assert err < 1e-2 and torch.equal(y, y_again)
+    # a different latent through the cached plan / graph (a stale or empty graph would return the previous image)
+    z2 = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(10)).to(DEV, torch.float16)
+    with torch.no_grad():
+        err2 = rel_l2(vae.decoder(z2).float(), eager(z2).float())
+    assert err2 < 1e-2, err2
     # a call the engine does not cover (extra latent_embeds argument) is routed to the original forward
     with pytest.raises(TypeError):
         vae.decoder(z, torch.zeros(1, device=DEV))  # the oracle Decoder takes no latent_embeds: proves the fallback ran
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+def test_image_postprocess_kernel(dtype):
+    from sfast.hip import functional as F
+    img = (torch.rand(2, 3, 40, 24, generator=torch.Generator().manual_seed(1)) * 2.4 - 1.2).to(DEV, dtype)
+    den = (img.float() / 2 + 0.5).clamp(0, 1)
+    f = F.image_postprocess(img, denormalize=True, to_uint8=False)
+    assert f.shape == (2, 40, 24, 3) and f.dtype == torch.float32
+    torch.testing.assert_close(f, den.permute(0, 2, 3, 1), rtol=0, atol=1e-6)
+    u = F.image_postprocess(img, denormalize=True, to_uint8=True)
+    want = den.permute(0, 2, 3, 1).mul(255).round().to(torch.uint8)
+    assert u.dtype == torch.uint8 and torch.equal(u, want)
+    raw = F.image_postprocess(den.to(dtype), denormalize=False, to_uint8=True)
+    assert torch.equal(raw, den.to(dtype).float().permute(0, 2, 3, 1).mul(255).round().to(torch.uint8))
+
+
+def test_image_processor_patch_gpu():
+    from sfast.libs.diffusers.image_processor import patch_image_prcessor
+    proc = patch_image_prcessor(types.SimpleNamespace(config=types.SimpleNamespace(do_normalize=True), postprocess=None,
+                                                      pt_to_numpy=None, pt_to_pil=None))
+    img = (torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(2)) * 2 - 1).to(DEV, torch.float16)
+    pil = proc.postprocess(img, "pil")
+    import numpy as np
+    got = np.asarray(pil[0])
+    # the reference denormalises in the tensor's own dtype (fp16) before the fp32 mul(255).round(); fp32 throughout here
+    want = ((img / 2 + 0.5).clamp(0, 1)).permute(0, 2, 3, 1).float().mul(255).round().to(torch.uint8).cpu().numpy()[0]
+    diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert got.shape == (64, 64, 3) and diff.max() <= 1 and (diff > 0).mean() < 0.02
+    arr = proc.postprocess(img, "np")
+    assert arr.shape == (1, 64, 64, 3) and abs(float(arr.mean()) - 0.5) < 0.05
