@@ -29,8 +29,10 @@ using f16 = _Float16;
 using bf16 = __bf16;
 
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -41,12 +43,14 @@ template <typename T> struct Elem;
 template <> struct Elem<f16> {
     using vec8 = f16x8;
     using vec4 = f16x4;
+    using vec2 = f16x2;
     static __device__ __forceinline__ float to_f32(f16 v) { return (float)v; }
     static __device__ __forceinline__ f16 from_f32(float v) { return (f16)v; }
 };
 template <> struct Elem<bf16> {
     using vec8 = bf16x8;
     using vec4 = bf16x4;
+    using vec2 = bf16x2;
     static __device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
     static __device__ __forceinline__ bf16 from_f32(float v) { return (bf16)v; }
 };

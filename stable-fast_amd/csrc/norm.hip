@@ -425,6 +425,147 @@ __global__ void __launch_bounds__(256) ln_generic_kernel(const T *__restrict__ x
     }
 }
 
+// =================================================================================================
+// Small-group single-kernel path (NHWC): one workgroup per (sample, group) keeps the whole group -- HW x C/G
+// halves, at most 32 KB -- in LDS between the statistics pass and the normalisation pass: ONE launch, one read and
+// one write of the tensor. The two-kernel path above costs two ~5.7 us launches however small the tensor is (every
+// kernel of the step's graph has a ~4 us floor); at the 32x32 / 16x16 / 8x8 levels of the UNet that was the whole cost
+// of a GroupNorm. Same arithmetic as the large path (shifted sums, biased variance, fixed reduction order).
+// Granularity is 2 channels (one dword): C/G and C1 only need to be even.
+// =================================================================================================
+template <typename T, bool SILU>
+__global__ void __launch_bounds__(512) gn_small_kernel(const T *__restrict__ x, const T *__restrict__ x2, const T *__restrict__ gamma,
+                                                       const T *__restrict__ beta, T *__restrict__ y, int HW, int C, int C1, int cpg,
+                                                       float eps) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t gsm[];  // [HW][cpg/2] dwords
+    __shared__ float red[2][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = blockIdx.x, b = blockIdx.y;
+    const int dpg = cpg / 2;           // dwords per pixel of this group
+    const int total = HW * dpg;
+    const int c0 = grp * cpg;          // first channel of the group
+    const int C2 = C - C1;
+    typedef typename Elem<T>::vec2 vec2;
+    // shift = first element of the group (as in the large path)
+    const float sh = (c0 < C1) ? Elem<T>::to_f32(x[(int64_t)b * HW * C1 + c0]) : Elem<T>::to_f32(x2[(int64_t)b * HW * C2 + (c0 - C1)]);
+    float s1 = 0.f, s2 = 0.f;
+    // element i = tid + 512*k  <->  (pixel p, dword j): advanced incrementally (one division per thread, not per element);
+    // eight independent loads in flight per thread (a one-load-per-iteration loop is a chain of exposed round trips)
+    const int step_p = 512 / dpg, step_j = 512 - step_p * dpg;
+    int p = tid / dpg, j = tid - p * dpg;
+    auto src_of = [&](int pp, int jj) -> const T * {
+        const int c = c0 + 2 * jj;
+        return (c < C1) ? x + ((int64_t)b * HW + pp) * C1 + c : x2 + ((int64_t)b * HW + pp) * C2 + (c - C1);
+    };
+    auto advance = [&](int &pp, int &jj) {
+        pp += step_p;
+        jj += step_j;
+        if (jj >= dpg) {
+            jj -= dpg;
+            ++pp;
+        }
+    };
+    int i = tid;
+    for (; i + 7 * 512 < total; i += 8 * 512) {
+        uint32_t raw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            raw[u] = *reinterpret_cast<const uint32_t *>(src_of(p, j));
+            advance(p, j);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            gsm[i + u * 512] = raw[u];
+            const vec2 v = __builtin_bit_cast(vec2, raw[u]);
+            const float d0 = (float)v[0] - sh, d1 = (float)v[1] - sh;
+            s1 += d0 + d1;
+            s2 += d0 * d0 + d1 * d1;
+        }
+    }
+    for (; i < total; i += 512) {
+        const uint32_t raw = *reinterpret_cast<const uint32_t *>(src_of(p, j));
+        advance(p, j);
+        gsm[i] = raw;
+        const vec2 v = __builtin_bit_cast(vec2, raw);
+        const float d0 = (float)v[0] - sh, d1 = (float)v[1] - sh;
+        s1 += d0 + d1;
+        s2 += d0 * d0 + d1 * d1;
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+        red[0][wave] = s1;
+        red[1][wave] = s2;
+    }
+    __syncthreads();
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        t1 += red[0][w];
+        t2 += red[1][w];
+    }
+    const float n = (float)HW * (float)cpg;
+    const float m1 = t1 / n;
+    const float var = fmaxf(t2 / n - m1 * m1, 0.f);
+    const float mean = sh + m1;
+    const float rstd = rsqrtf(var + eps);
+    p = tid / dpg;
+    j = tid - p * dpg;
+    for (int k = tid; k < total; k += 512) {
+        const int c = c0 + 2 * j;
+        const vec2 v = __builtin_bit_cast(vec2, gsm[k]);
+        float ga0 = 1.f, ga1 = 1.f, be0 = 0.f, be1 = 0.f;
+        if (gamma) {
+            const vec2 g2 = __builtin_bit_cast(vec2, *reinterpret_cast<const uint32_t *>(gamma + c));
+            ga0 = (float)g2[0];
+            ga1 = (float)g2[1];
+        }
+        if (beta) {
+            const vec2 b2 = __builtin_bit_cast(vec2, *reinterpret_cast<const uint32_t *>(beta + c));
+            be0 = (float)b2[0];
+            be1 = (float)b2[1];
+        }
+        float o0 = ((float)v[0] - mean) * rstd * ga0 + be0;
+        float o1 = ((float)v[1] - mean) * rstd * ga1 + be1;
+        if (SILU) {
+            o0 = act_silu(o0);
+            o1 = act_silu(o1);
+        }
+        vec2 o;
+        o[0] = Elem<T>::from_f32(o0);
+        o[1] = Elem<T>::from_f32(o1);
+        *reinterpret_cast<uint32_t *>(y + ((int64_t)b * HW + p) * C + c) = __builtin_bit_cast(uint32_t, o);
+        advance(p, j);
+    }
+}
+
+// applicable: NHWC f16/bf16, even C/G and C1, group at most 32 KB (N x G workgroups of that size finish in a few
+// load round trips), and the tensor is small enough that the
+// two-kernel path would be launch-bound anyway (<= 4 MB)
+static bool gn_small_ok(const sfast_gn_params *p) {
+    if (p->layout != SFAST_NHWC || p->dtype == SFAST_F32 || p->G <= 0 || p->C % p->G) return false;
+    const int cpg = p->C / p->G;
+    if ((cpg & 1) || (p->C1 & 1)) return false;
+    const int64_t group_bytes = (int64_t)p->HW * cpg * 2;
+    const int64_t tensor_bytes = (int64_t)p->N * p->HW * p->C * 2;
+    return group_bytes <= 32 * 1024 && tensor_bytes <= (4 << 20);
+}
+
+template <typename T>
+static int gn_launch_small(const void *x, const void *x2, const void *gamma, const void *beta, void *y, const sfast_gn_params *p,
+                           hipStream_t st) {
+    const int cpg = p->C / p->G;
+    const size_t smem = (size_t)p->HW * cpg * 2;
+    const dim3 grid(p->G, p->N);
+    if (p->act == SFAST_ACT_SILU)
+        hipLaunchKernelGGL((gn_small_kernel<T, true>), grid, dim3(512), smem, st, (const T *)x, (const T *)x2, (const T *)gamma,
+                           (const T *)beta, (T *)y, p->HW, p->C, p->C1, cpg, p->eps);
+    else
+        hipLaunchKernelGGL((gn_small_kernel<T, false>), grid, dim3(512), smem, st, (const T *)x, (const T *)x2, (const T *)gamma,
+                           (const T *)beta, (T *)y, p->HW, p->C, p->C1, cpg, p->eps);
+    return check_launch("group_norm_small");
+}
+
 // ---- host-side planning ----------------------------------------------------------------------
 struct GnPlan {
     bool fast;
@@ -602,6 +743,13 @@ extern "C" int sfast_hip_group_norm(const void *x, const void *x2, const void *g
     GnPlan pl = gn_plan(p);
     const bool ptr_ok = aligned16(x) && aligned16(y) && (p->C1 == p->C || aligned16(x2)) && (!gamma || aligned16(gamma)) &&
                         (!beta || aligned16(beta));
+    const bool al4 = ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)(x2 ? x2 : x)) | ((uintptr_t)(gamma ? gamma : x)) |
+                       ((uintptr_t)(beta ? beta : x))) & 3) == 0;
+    if (gn_small_ok(p) && al4) {
+        set_kernel_name("gn_small[cpg=%d,hw=%d]", p->C / p->G, p->HW);
+        if (p->dtype == SFAST_F16) return gn_launch_small<f16>(x, x2, gamma, beta, y, p, st);
+        return gn_launch_small<bf16>(x, x2, gamma, beta, y, p, st);
+    }
     if (pl.fast && ptr_ok) {
         const size_t need = sfast_hip_group_norm_workspace_bytes(p);
         SFAST_REQUIRE(workspace && workspace_bytes >= need, SFAST_ERR_WORKSPACE,
