@@ -298,7 +298,9 @@ __global__ void __launch_bounds__(256) conv_small_n_kernel(const SmallConvArgs a
 // weights and 36 per output vector, 85 us for SD's 4->320 conv_in.
 // KMAX > 0: K <= KMAX, the whole receptive field of a pixel is fetched in ONE batch (k decode is scalar work on
 // compile-time k). KMAX == 0: any K, 8 channels of one tap per batch.
-template <typename T, int KMAX>
+// G8 = 8-channel chunks per task (1 or 4): with 4 the receptive field of a pixel is fetched once per 32 outputs
+// instead of once per 8, and a task's chunks are strided by Cout/32 so that a wave's LDS reads stay lane-contiguous.
+template <typename T, int KMAX, int G8>
 __global__ void __launch_bounds__(256) conv_small_c_kernel(const SmallConvArgs a, int pix_per_block) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];  // [K][Cout]
     typedef const T __attribute__((address_space(1))) * gelem_ptr;
@@ -328,7 +330,7 @@ __global__ void __launch_bounds__(256) conv_small_c_kernel(const SmallConvArgs a
         }
     }
     __syncthreads();
-    const int cch = a.Cout / 8;
+    const int cch = a.Cout / 8 / G8;  // tasks per pixel
     const bool vec_out = vec_epilogue_ok(a);
     const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
     const int64_t p_begin = (int64_t)blockIdx.x * pix_per_block;
@@ -341,23 +343,29 @@ __global__ void __launch_bounds__(256) conv_small_c_kernel(const SmallConvArgs a
     for (int t = threadIdx.x; t < ntask; t += 256) {
         const int64_t p = p_begin + t / cch;
         if (p >= M) break;
-        const int co0 = (t % cch) * 8;
+        const int j0 = t % cch;  // chunks j0 + g*cch, g < G8
         const int hw = a.Ho * a.Wo;
         const int b = (int)(p / hw);
         const int rem = (int)(p % hw);
         const int ho = rem / a.Wo, wo = rem % a.Wo;
         const int h0 = ho * a.stride_h - a.pad_h, w0 = wo * a.stride_w - a.pad_w;
-        float acc[8];
+        float acc[G8][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int g = 0; g < G8; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
         auto fma8 = [&](float xv, int k) {
-            // LDS image [k][half][chunk][4]: each of a lane's two 16-byte reads is lane-contiguous (stride 16 B)
-            const f32x4 w0v = *reinterpret_cast<const f32x4 *>(wsm + k * a.Cout + (co0 >> 1));
-            const f32x4 w1v = *reinterpret_cast<const f32x4 *>(wsm + k * a.Cout + a.Cout / 2 + (co0 >> 1));
+            // LDS image [k][half][chunk][4]: each of a lane's 16-byte reads is lane-contiguous (stride 16 B)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc[q] = fmaf(xv, w0v[q], acc[q]);
-                acc[4 + q] = fmaf(xv, w1v[q], acc[4 + q]);
+            for (int g = 0; g < G8; ++g) {
+                const int ch4 = (j0 + g * cch) * 4;
+                const f32x4 w0v = *reinterpret_cast<const f32x4 *>(wsm + k * a.Cout + ch4);
+                const f32x4 w1v = *reinterpret_cast<const f32x4 *>(wsm + k * a.Cout + a.Cout / 2 + ch4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[g][q] = fmaf(xv, w0v[q], acc[g][q]);
+                    acc[g][4 + q] = fmaf(xv, w1v[q], acc[g][4 + q]);
+                }
             }
         };
         if constexpr (KMAX > 0) {
@@ -413,11 +421,15 @@ __global__ void __launch_bounds__(256) conv_small_c_kernel(const SmallConvArgs a
                 }
             }
         }
-        if (vec_out) {
-            conv_store8<T>(a, b, ho, wo, co0, acc);
-        } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) conv_store<T>(a, b, ho, wo, co0 + e, acc[e]);
+        for (int g = 0; g < G8; ++g) {
+            const int co0 = (j0 + g * cch) * 8;
+            if (vec_out) {
+                conv_store8<T>(a, b, ho, wo, co0, acc[g]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) conv_store<T>(a, b, ho, wo, co0 + e, acc[g][e]);
+            }
         }
     }
 }
@@ -488,24 +500,37 @@ int small_conv_c(const SmallConvArgs &a, int dtype, hipStream_t st) {
     const int K = a.KH * a.KW * a.Cin;
     const size_t smem = (size_t)K * a.Cout * sizeof(float);
     const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
+    const bool tiny = K <= 40 && !a.ups && a.C1 == a.Cin && a.KH * a.KW <= 32;
+    const bool wide = a.Cout % 32 == 0;
     int ppb = 32;
     while (ppb > 4 && ceil_div64(M, ppb) < 256) ppb >>= 1;
+    if (tiny && wide) {
+        // tasks per pixel = Cout/32: size the block so that its tasks fill the 256 threads about once
+        const int tpp = a.Cout / 32;
+        int want = 256 / (tpp > 0 ? tpp : 1);
+        if (want < 1) want = 1;
+        if (want < ppb) ppb = want;
+    }
     const dim3 grid((unsigned)ceil_div64(M, ppb));
-    const bool tiny = K <= 40 && !a.ups && a.C1 == a.Cin && a.KH * a.KW <= 32;
+#define CSC_LAUNCH(T, KM, G)                                                                                      \
+    hipLaunchKernelGGL((conv_small_c_kernel<T, KM, G>), grid, dim3(256), smem, st, a, ppb)
+#define CSC_DISPATCH(T)        \
+    if (tiny && wide)          \
+        CSC_LAUNCH(T, 40, 4);  \
+    else if (tiny)             \
+        CSC_LAUNCH(T, 40, 1);  \
+    else                       \
+        CSC_LAUNCH(T, 0, 1);
     if (dtype == SFAST_F16) {
-        if (tiny)
-            hipLaunchKernelGGL((conv_small_c_kernel<f16, 40>), grid, dim3(256), smem, st, a, ppb);
-        else
-            hipLaunchKernelGGL((conv_small_c_kernel<f16, 0>), grid, dim3(256), smem, st, a, ppb);
+        CSC_DISPATCH(f16)
     } else if (dtype == SFAST_BF16) {
-        if (tiny)
-            hipLaunchKernelGGL((conv_small_c_kernel<bf16, 40>), grid, dim3(256), smem, st, a, ppb);
-        else
-            hipLaunchKernelGGL((conv_small_c_kernel<bf16, 0>), grid, dim3(256), smem, st, a, ppb);
+        CSC_DISPATCH(bf16)
     } else {
         set_error("conv_small_c: dtype %d", dtype);
         return SFAST_ERR_UNSUPPORTED;
     }
+#undef CSC_DISPATCH
+#undef CSC_LAUNCH
     return check_launch("conv_small_c");
 }
 
