@@ -23,6 +23,8 @@
  *                             strided views (libs/diffusers/xformers_attention.py:37-69)
  *   sfast_hip_strided_copy <- sfast_triton::contiguous / clone / reshape
  *                             (triton/torch_ops.py:24-106, triton/ops/copy.py:184-270)
+ *   sfast_hip_softmax_rows  <- the VAE decoder's single-head attention (compile_vae path), between two sfast_hip_gemm calls
+ *   sfast_hip_add_strided   <- ControlNet residual adds of UNet2DConditionModel.forward
  *   sfast_hip_image_postprocess <- patched VaeImageProcessor (libs/diffusers/image_processor.py:13-108)
  *   sfast_hip_timestep_embedding, sfast_hip_cfg_ddim_step
  *                          <- host-side glue of the denoise loop that the reference leaves to
@@ -218,6 +220,19 @@ typedef struct {
 
 int sfast_hip_strided_copy(const void *src, void *dst, const sfast_copy_params *p,
                            sfast_stream_t stream);
+
+/* ---- strided accumulate: dst[i0..i3] += src[i0..i3] (fp32 add) ------------------------------------
+ * ControlNet residuals (diffusers UNet2DConditionModel.forward: `down_block_additional_residuals`,
+ * `mid_block_additional_residual`; reference compile() keeps ControlNet pipelines working,
+ * compilers/diffusion_pipeline_compiler.py:89-90) arrive NCHW and are added onto the engine's NHWC skip tensors. */
+typedef struct {
+    int32_t dtype;      /* f16 / bf16 / f32 (src and dst) */
+    int32_t ndim;       /* <= 4 */
+    int64_t shape[4];
+    int64_t src_strides[4], dst_strides[4]; /* in elements */
+} sfast_add_params;
+
+int sfast_hip_add_strided(const void *src, void *dst, const sfast_add_params *p, sfast_stream_t stream);
 
 /* ---- sinusoidal timestep embedding -> out[B, dim] ------------------------------------------ */
 typedef struct {

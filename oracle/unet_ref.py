@@ -324,7 +324,8 @@ class UNet2DConditionModel(nn.Module):
     def device(self):
         return self.conv_in.weight.device
 
-    def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, return_dict=True, **_):
+    def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, return_dict=True,
+                down_block_additional_residuals=None, mid_block_additional_residual=None, **_):
         c = self.config
         B = sample.shape[0]
         t = timestep
@@ -343,7 +344,14 @@ class UNet2DConditionModel(nn.Module):
         skips = [h]
         for blk in self.down_blocks:
             h = blk(h, emb, encoder_hidden_states, skips)
+        if down_block_additional_residuals is not None:
+            # ControlNet (diffusers UNet2DConditionModel.forward): residuals are added to COPIES of the skip tensors,
+            # the mid block still sees the un-augmented activation
+            assert len(down_block_additional_residuals) == len(skips)
+            skips = [s_ + r_ for s_, r_ in zip(skips, down_block_additional_residuals)]
         h = self.mid_block(h, emb, encoder_hidden_states)
+        if mid_block_additional_residual is not None:
+            h = h + mid_block_additional_residual
         for blk in self.up_blocks:
             h = blk(h, emb, encoder_hidden_states, skips)
         out = self.conv_out(F.silu(self.conv_norm_out(h)))

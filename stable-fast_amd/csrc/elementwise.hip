@@ -68,6 +68,22 @@ __global__ void __launch_bounds__(256) cfg_ddim_kernel(const T *__restrict__ eps
     }
 }
 
+template <typename T> __global__ void __launch_bounds__(256) strided_add_kernel(const CopyArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < a.total; idx += stride) {
+        int64_t t = idx;
+        const int64_t i3 = t % a.shape[3];
+        t /= a.shape[3];
+        const int64_t i2 = t % a.shape[2];
+        t /= a.shape[2];
+        const int64_t i1 = t % a.shape[1];
+        const int64_t i0 = t / a.shape[1];
+        T *d = (T *)a.dst + (i0 * a.ds[0] + i1 * a.ds[1] + i2 * a.ds[2] + i3 * a.ds[3]);
+        const T v = ((const T *)a.src)[i0 * a.ss[0] + i1 * a.ss[1] + i2 * a.ss[2] + i3 * a.ss[3]];
+        *d = Elem<T>::from_f32(Elem<T>::to_f32(*d) + Elem<T>::to_f32(v));
+    }
+}
+
 // NCHW image -> NHWC uint8 / float32 (VAE output -> PIL / numpy layout). One thread per output pixel-channel group:
 // reads are strided by H*W per channel (coalesced along W across lanes), writes are contiguous.
 template <typename T, bool U8>
@@ -198,4 +214,40 @@ extern "C" int sfast_hip_image_postprocess(const void *image, void *out, const s
     }
 #undef IMG_LAUNCH
     return check_launch("image_postprocess");
+}
+
+extern "C" int sfast_hip_add_strided(const void *src, void *dst, const sfast_add_params *p, sfast_stream_t stream) {
+    SFAST_REQUIRE(p && src && dst, SFAST_ERR_INVALID, "add_strided: null argument");
+    SFAST_REQUIRE(p->ndim >= 1 && p->ndim <= 4, SFAST_ERR_UNSUPPORTED, "add_strided: ndim=%d", p->ndim);
+    CopyArgs a{};
+    a.src = src;
+    a.dst = dst;
+    a.total = 1;
+    const int pad = 4 - p->ndim;
+    for (int i = 0; i < 4; ++i) {
+        if (i < pad) {
+            a.shape[i] = 1;
+            a.ss[i] = 0;
+            a.ds[i] = 0;
+        } else {
+            a.shape[i] = p->shape[i - pad];
+            a.ss[i] = p->src_strides[i - pad];
+            a.ds[i] = p->dst_strides[i - pad];
+        }
+        SFAST_REQUIRE(a.shape[i] >= 0, SFAST_ERR_INVALID, "add_strided: negative extent");
+        a.total *= a.shape[i];
+    }
+    if (a.total == 0) return SFAST_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int64_t blocks = ceil_div64(a.total, 256);
+    if (blocks > 65536) blocks = 65536;
+    const dim3 grid((unsigned)blocks);
+    set_kernel_name("add_strided");
+    switch (p->dtype) {
+    case SFAST_F16: hipLaunchKernelGGL(strided_add_kernel<f16>, grid, dim3(256), 0, st, a); break;
+    case SFAST_BF16: hipLaunchKernelGGL(strided_add_kernel<bf16>, grid, dim3(256), 0, st, a); break;
+    case SFAST_F32: hipLaunchKernelGGL(strided_add_kernel<float>, grid, dim3(256), 0, st, a); break;
+    default: set_error("add_strided: dtype %d", p->dtype); return SFAST_ERR_UNSUPPORTED;
+    }
+    return check_launch("add_strided");
 }

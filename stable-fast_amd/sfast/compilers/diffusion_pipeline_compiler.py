@@ -102,16 +102,16 @@ class _NativeUNetForward:
             self._warned = True
         return self.orig_forward(*args, **kwargs)
 
-    def _prepare(self, key, sample, timestep, ehs, added):
+    def _prepare(self, key, sample, timestep, ehs, added, down_res, mid_res):
         eng = self.engine
-        B, H, W, S = key
-        plan = eng.get_plan(B, H, W, S)
+        B, H, W, S, ctrl = key
+        plan = eng.get_plan(B, H, W, S, ctrl)
         env = get_per_device_graph_execution_env(eng.device)
         graph = None
         # warm-up: runs the whole plan eagerly (also validates every launch before capture)
         torch.cuda.synchronize(eng.device)
         with torch.cuda.device(eng.device), torch.cuda.stream(torch.cuda.Stream(device=eng.device)):
-            eng.load_inputs(plan, sample, timestep, ehs, added)
+            eng.load_inputs(plan, sample, timestep, ehs, added, down_res, mid_res)
             for _ in range(self.warmups if self.enable_graph else 1):
                 plan.run(torch.cuda.current_stream(eng.device).cuda_stream)
         torch.cuda.synchronize(eng.device)
@@ -128,14 +128,22 @@ class _NativeUNetForward:
                  down_block_additional_residuals=None, mid_block_additional_residual=None,
                  down_intrablock_additional_residuals=None, encoder_attention_mask=None, return_dict=True):
         extra = dict(class_labels=class_labels, timestep_cond=timestep_cond, attention_mask=attention_mask,
-                     down_block_additional_residuals=down_block_additional_residuals,
-                     mid_block_additional_residual=mid_block_additional_residual,
                      down_intrablock_additional_residuals=down_intrablock_additional_residuals,
                      encoder_attention_mask=encoder_attention_mask)
         bad = [k for k, v in extra.items() if v is not None]
         if cross_attention_kwargs:
             bad.append("cross_attention_kwargs")
         eng = self.engine
+        # ControlNet residuals (reference keeps ControlNet pipelines on the compiled UNet, :89-90): taken natively when
+        # both kinds are present as tensors of the engine's dtype on its device
+        ctrl = down_block_additional_residuals is not None or mid_block_additional_residual is not None
+        if ctrl:
+            ok = (down_block_additional_residuals is not None and mid_block_additional_residual is not None
+                  and torch.is_tensor(mid_block_additional_residual)
+                  and all(torch.is_tensor(r) and r.device.type == "cuda" and r.dtype == eng.dtype
+                          for r in list(down_block_additional_residuals) + [mid_block_additional_residual]))
+            if not ok:
+                bad.append("controlnet residuals (need both kinds, engine dtype, on the GPU)")
         if (bad or encoder_hidden_states is None or not torch.is_tensor(sample) or sample.device.type != "cuda"
                 or sample.dtype != eng.dtype or sample.ndim != 4):
             return self._fallback(", ".join(bad) or "input device/dtype", sample, timestep,
@@ -146,18 +154,20 @@ class _NativeUNetForward:
                                   mid_block_additional_residual=mid_block_additional_residual,
                                   encoder_attention_mask=encoder_attention_mask, return_dict=return_dict)
         B, _, H, W = sample.shape
-        key = (B, H, W, encoder_hidden_states.shape[1])
+        key = (B, H, W, encoder_hidden_states.shape[1], ctrl)
         entry = self._cached.get(key)
         if entry is None:
             with self._lock:
                 entry = self._cached.get(key)
                 if entry is None:
                     logger.info("sfast: building native UNet plan for %s (graph=%s)", key, self.enable_graph)
-                    entry = self._prepare(key, sample, timestep, encoder_hidden_states, added_cond_kwargs)
+                    entry = self._prepare(key, sample, timestep, encoder_hidden_states, added_cond_kwargs,
+                                          down_block_additional_residuals, mid_block_additional_residual)
                     self._cached[key] = entry
         plan, graph, env = entry
         with env.lock:
-            eng.load_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs)
+            eng.load_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs,
+                            down_block_additional_residuals, mid_block_additional_residual)
             if graph is not None:
                 graph.replay()
             else:

@@ -409,6 +409,19 @@ class UNet2DEngine:
                   needs=LANE_TEMB if rowbias is not None else None)
         return Ho, Wo
 
+    def _op_add_nchw(self, plan, name, src_nchw, dst_nhwc, B, Cc, Hh, Ww):
+        """dst[b][h][w][c] += src[b][c][h][w] (dense NHWC buffer += NCHW tensor)."""
+        lib = self.lib
+        ap = L.AddParams()
+        ap.dtype, ap.ndim = self.dt, 4
+        ap.shape = (C.c_int64 * 4)(B, Hh, Ww, Cc)
+        ap.src_strides = (C.c_int64 * 4)(Cc * Hh * Ww, Ww, 1, Hh * Ww)
+        ap.dst_strides = (C.c_int64 * 4)(Hh * Ww * Cc, Ww * Cc, Cc, 1)
+        plan.keep.append(ap)
+        sp, dp = src_nchw.data_ptr(), dst_nhwc.data_ptr()
+        self._add(plan, "misc", name, 0.0, 3.0 * B * Cc * Hh * Ww * self.esize,
+                  lambda s, ap=ap: L.check(lib.sfast_hip_add_strided(sp, dp, C.byref(ap), s), name))
+
     def _op_attn(self, plan, name, q, k, v, out, B, Hh, Sq, Skv, D, qs, ks, vs, os_, q_off=0, k_off=0, v_off=0):
         lib = self.lib
         p = L.AttnParams()
@@ -540,7 +553,9 @@ class UNet2DEngine:
         return names
 
     # ------------------------------------------------------------------------------------------
-    def build_plan(self, B, H, W, S_ctx):
+    def build_plan(self, B, H, W, S_ctx, ctrl=False):
+        """`ctrl`: the plan also takes ControlNet residuals (one NCHW tensor per skip connection + one for the mid block,
+        diffusers `down_block_additional_residuals` / `mid_block_additional_residual`) as static inputs."""
         if not self._emulated:
             L.init_device()
         nlev = len(self.boc)
@@ -632,6 +647,7 @@ class UNet2DEngine:
         self._op_conv(plan, "conv_in", sample, None, P["conv_in.weight"], P["conv_in.bias"], h, B, H, W, self.in_ch, 0, c0, 3, 1, 1,
                       xs=(self.in_ch * H * W, W, 1, H * W), kind="conv_in")
         skips = [(h, c0)]
+        skip_dims = [(c0, H, W)]  # (channels, height, width) of every skip tensor, in creation order
         ch = c0
         cH, cW = H, W
         # ---- down ---------------------------------------------------------------------------------
@@ -647,6 +663,7 @@ class UNet2DEngine:
                     hn = ha
                 h = hn
                 skips.append((h, ch))
+                skip_dims.append((ch, cH, cW))
             if i < nlev - 1:
                 dn = f"down_blocks.{i}.downsamplers.0.conv"
                 hd = pool.get(B * (cH // 2) * (cW // 2) * ch)
@@ -654,6 +671,7 @@ class UNet2DEngine:
                 cH, cW = cH // 2, cW // 2
                 h = hd
                 skips.append((h, ch))
+                skip_dims.append((ch, cH, cW))
         # ---- mid -----------------------------------------------------------------------------------
         rn = "mid_block.resnets.0"
         hm = self._resnet(plan, rn, h, None, ch, 0, ch, B, cH, cW, temb_all, tot, offs[rn])
@@ -663,6 +681,19 @@ class UNet2DEngine:
         h = self._resnet(plan, rn, ha, None, ch, 0, ch, B, cH, cW, temb_all, tot, offs[rn])
         pool.put(ha)
         # (the last skip tensor is the mid-block input; it stays alive in `skips`)
+        if ctrl:
+            # ControlNet residuals. diffusers adds them to COPIES of the skip tensors after the down path, so the mid
+            # block still sees the un-augmented activation: here the in-place adds are emitted after the mid block
+            # (which has consumed the last skip by now), then the mid residual goes onto the mid-block output.
+            ctrl_in = []
+            for k, ((buf, _), (cc, sh_, sw_)) in enumerate(zip(skips, skip_dims)):
+                r = torch.zeros((B, cc, sh_, sw_), dtype=dt, device=dev)
+                ctrl_in.append(r)
+                self._op_add_nchw(plan, f"controlnet.down_residual.{k}", r, buf, B, cc, sh_, sw_)
+            rm = torch.zeros((B, ch, cH, cW), dtype=dt, device=dev)
+            self._op_add_nchw(plan, "controlnet.mid_residual", rm, h, B, ch, cH, cW)
+            plan.static_in["down_block_additional_residuals"] = ctrl_in
+            plan.static_in["mid_block_additional_residual"] = rm
         # ---- up ------------------------------------------------------------------------------------
         rboc = self.boc[::-1]
         rheads, rdepth = self.heads[::-1], self.depth[::-1]
@@ -713,18 +744,19 @@ class UNet2DEngine:
         return plan
 
     # ------------------------------------------------------------------------------------------
-    def get_plan(self, B, H, W, S_ctx):
-        key = (B, H, W, S_ctx)
+    def get_plan(self, B, H, W, S_ctx, ctrl=False):
+        key = (B, H, W, S_ctx, bool(ctrl))
         plan = self._plans.get(key)
         if plan is None:
             with self._lock:
                 plan = self._plans.get(key)
                 if plan is None:
-                    plan = self.build_plan(B, H, W, S_ctx)
+                    plan = self.build_plan(B, H, W, S_ctx, ctrl) if ctrl else self.build_plan(B, H, W, S_ctx)
                     self._plans[key] = plan
         return plan
 
-    def load_inputs(self, plan, sample, timestep, encoder_hidden_states, added_cond_kwargs=None):
+    def load_inputs(self, plan, sample, timestep, encoder_hidden_states, added_cond_kwargs=None,
+                    down_block_additional_residuals=None, mid_block_additional_residual=None):
         si = plan.static_in
         si["sample"].copy_(sample)
         if torch.is_tensor(timestep):
@@ -737,11 +769,22 @@ class UNet2DEngine:
                 raise ValueError("added_cond_kwargs with text_embeds and time_ids is required (addition_embed_type=text_time)")
             si["text_embeds"].copy_(added_cond_kwargs["text_embeds"])
             si["time_ids"].copy_(added_cond_kwargs["time_ids"].reshape(-1).to(torch.float32))
+        if "down_block_additional_residuals" in si:
+            want = si["down_block_additional_residuals"]
+            if (down_block_additional_residuals is None or mid_block_additional_residual is None
+                    or len(down_block_additional_residuals) != len(want)):
+                raise ValueError(f"this plan takes {len(want)} ControlNet down residuals and one mid residual")
+            for dst, src in zip(want, down_block_additional_residuals):
+                dst.copy_(src)
+            si["mid_block_additional_residual"].copy_(mid_block_additional_residual)
 
-    def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None):
+    def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, down_block_additional_residuals=None,
+                mid_block_additional_residual=None):
         """Eager (no graph) execution on the current stream; returns a fresh NCHW tensor."""
         B, _, H, W = sample.shape
-        plan = self.get_plan(B, H, W, encoder_hidden_states.shape[1])
-        self.load_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs)
+        ctrl = down_block_additional_residuals is not None
+        plan = self.get_plan(B, H, W, encoder_hidden_states.shape[1], ctrl)
+        self.load_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs, down_block_additional_residuals,
+                         mid_block_additional_residual)
         plan.run(None if self._emulated else torch.cuda.current_stream(self.device).cuda_stream)
         return plan.static_out.clone()

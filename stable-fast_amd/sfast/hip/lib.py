@@ -27,7 +27,7 @@ EXPORTS = [
     "sfast_hip_gemm_workspace_bytes", "sfast_hip_gemm",
     "sfast_hip_conv2d_workspace_bytes", "sfast_hip_conv2d",
     "sfast_hip_attention", "sfast_hip_strided_copy", "sfast_hip_timestep_embedding",
-    "sfast_hip_cfg_ddim_step", "sfast_hip_igemm_plan", "sfast_hip_set_trace", "sfast_hip_image_postprocess",
+    "sfast_hip_cfg_ddim_step", "sfast_hip_igemm_plan", "sfast_hip_set_trace", "sfast_hip_image_postprocess", "sfast_hip_add_strided",
 ]
 
 
@@ -39,6 +39,11 @@ class GnParams(C.Structure):
 
 class LnParams(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("eps", C.c_float)]
+
+
+class AddParams(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("ndim", C.c_int32), ("shape", C.c_int64 * 4),
+                ("src_strides", C.c_int64 * 4), ("dst_strides", C.c_int64 * 4)]
 
 
 class ImageParams(C.Structure):
@@ -110,6 +115,8 @@ def _declare(lib):
     lib.sfast_hip_group_norm.argtypes = [vp, vp, vp, vp, vp, C.POINTER(GnParams), vp, sz, vp]
     lib.sfast_hip_layer_norm.restype = C.c_int
     lib.sfast_hip_layer_norm.argtypes = [vp, vp, vp, vp, C.POINTER(LnParams), vp]
+    lib.sfast_hip_add_strided.restype = C.c_int
+    lib.sfast_hip_add_strided.argtypes = [vp, vp, C.POINTER(AddParams), vp]
     lib.sfast_hip_image_postprocess.restype = C.c_int
     lib.sfast_hip_image_postprocess.argtypes = [vp, vp, C.POINTER(ImageParams), vp]
     lib.sfast_hip_softmax_rows.restype = C.c_int

@@ -102,6 +102,15 @@ class EmuLib:
         _flat(y, p.M * p.N, p.dtype).reshape(p.M, p.N).copy_(R.layer_norm_ref(xin, (p.N,), g, b, p.eps))
         return 0
 
+    def sfast_hip_add_strided(self, src, dst, ref, stream):
+        p = _p(ref)
+        self.calls.append("add_strided")
+        shape = [p.shape[i] for i in range(p.ndim)]
+        a = _strided(src, shape, [p.src_strides[i] for i in range(p.ndim)], p.dtype)
+        d = _strided(dst, shape, [p.dst_strides[i] for i in range(p.ndim)], p.dtype)
+        d.copy_((d.float() + a.float()).to(d.dtype))
+        return 0
+
     def sfast_hip_softmax_rows(self, x, y, ref, stream):
         p = _p(ref)
         self.calls.append("softmax_rows")

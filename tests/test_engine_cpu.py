@@ -137,3 +137,32 @@ def test_param_inventory_matches_oracle_state_dict(name):
     assert got == want
     if name == "sd15":
         assert S.SD15_CONFIG == U.SD15_CONFIG and S.SDXL_CONFIG == U.SDXL_CONFIG
+
+
+def test_controlnet_residuals_through_the_plan(built_lib):
+    """`down_block_additional_residuals` / `mid_block_additional_residual` are taken by the
+    native plan (added after the mid block has consumed the last skip, as diffusers adds them to copies)."""
+    cfg = U.tiny_config()
+    m16, m32 = _pair(cfg, 9)
+    emu = EmuLib()
+    eng = UNet2DEngine.from_module(m16, _lib=emu)
+    g = torch.Generator().manual_seed(4)
+    s = torch.randn(2, 4, 16, 16, generator=g).half()
+    e = torch.randn(2, 77, 64, generator=g).half()
+    plan = eng.get_plan(2, 16, 16, 77, True)
+    shapes = [tuple(t.shape) for t in plan.static_in["down_block_additional_residuals"]]
+    assert len(shapes) == 1 + len(cfg["block_out_channels"]) * cfg["layers_per_block"] + len(cfg["block_out_channels"]) - 1
+    down = [(0.3 * torch.randn(*sh, generator=g)).half() for sh in shapes]
+    mid = (0.3 * torch.randn(*plan.static_in["mid_block_additional_residual"].shape, generator=g)).half()
+    y = eng.forward(s, 500, e, down_block_additional_residuals=down, mid_block_additional_residual=mid)
+    with torch.no_grad():
+        want = m32(s.float(), 500, e.float(), down_block_additional_residuals=[d.float() for d in down],
+                   mid_block_additional_residual=mid.float()).sample
+        base = m32(s.float(), 500, e.float()).sample
+    assert rel_l2(y, want) < 3e-3 and rel_l2(y, base) > 5e-2  # the residuals matter
+    assert emu.calls.count("add_strided") >= len(shapes) + 1
+    # the plain plan of the same shape is a separate cache entry and ignores nothing silently
+    y0 = eng.forward(s, 500, e)
+    assert rel_l2(y0, base) < 3e-3 and len(eng._plans) == 2
+    with pytest.raises(ValueError):
+        eng.load_inputs(plan, s, 500, e)

@@ -233,3 +233,73 @@ def test_rccl_weight_broadcast_single_rank():
         assert all(torch.equal(params[k], ref[k]) and params[k].data_ptr() == ptrs[k] for k in params)
     finally:
         dist.destroy_process_group()
+
+
+def test_add_strided_kernel():
+    from sfast.hip import lib as L
+    import ctypes as C
+    lib = L.init_device()
+    for dt, code in ((torch.float16, L.F16), (torch.bfloat16, L.BF16), (torch.float32, L.F32)):
+        g = torch.Generator().manual_seed(3)
+        src = torch.randn(2, 24, 5, 7, generator=g).to(DEV, dt)          # NCHW
+        dst = torch.randn(2, 5, 7, 24, generator=g).to(DEV, dt)          # NHWC
+        want = (dst.float() + src.float().permute(0, 2, 3, 1)).to(dt)
+        ap = L.AddParams()
+        ap.dtype, ap.ndim = code, 4
+        ap.shape = (C.c_int64 * 4)(2, 5, 7, 24)
+        ap.src_strides = (C.c_int64 * 4)(24 * 35, 7, 1, 35)
+        ap.dst_strides = (C.c_int64 * 4)(35 * 24, 7 * 24, 24, 1)
+        L.check(lib.sfast_hip_add_strided(src.data_ptr(), dst.data_ptr(), C.byref(ap), torch.cuda.current_stream().cuda_stream), "add")
+        torch.cuda.synchronize()
+        assert torch.equal(dst, want), dt
+
+
+def test_controlnet_residuals_native_and_through_compile():
+    """ControlNet residual inputs stay on the native engine (eager plan, hipGraph, compile())."""
+    from sfast.compilers.diffusion_pipeline_compiler import CompilationConfig, compile_unet
+    cfg = U.tiny_config()
+    m = U.build(cfg, seed=13, dtype=torch.float16, device=DEV)
+    ref = U.build(cfg, seed=13, device=DEV)
+    ref.load_state_dict({k: v.float() for k, v in m.state_dict().items()})
+    eng = _engine(m)
+    sample, ehs = _inputs(cfg, 2, seed=5)
+    plan = eng.get_plan(2, cfg["sample_size"], cfg["sample_size"], 77, True)
+    g = torch.Generator().manual_seed(6)
+    down = [(0.3 * torch.randn(*t.shape, generator=g)).to(DEV, torch.float16) for t in plan.static_in["down_block_additional_residuals"]]
+    mid = (0.3 * torch.randn(*plan.static_in["mid_block_additional_residual"].shape, generator=g)).to(DEV, torch.float16)
+    y = eng.forward(sample, 321, ehs, down_block_additional_residuals=down, mid_block_additional_residual=mid)
+    with torch.no_grad():
+        want = ref(sample.float(), 321, ehs.float(), down_block_additional_residuals=[d.float() for d in down],
+                   mid_block_additional_residual=mid.float()).sample
+        base = ref(sample.float(), 321, ehs.float()).sample
+    err = rel_l2(y.float(), want)
+    log_value("tiny unet + controlnet residuals vs fp32 oracle", rel_l2=err)
+    assert err < 4e-3 and rel_l2(y.float(), base) > 5e-2
+    # behind compile_unet(): same call signature as diffusers, graph replay, and it must NOT take the eager fallback
+    c = CompilationConfig.Default()
+    c.enable_cuda_graph = True
+    unet = compile_unet(m, c)
+    for _ in range(2):
+        o = unet(sample, 321, encoder_hidden_states=ehs, down_block_additional_residuals=down, mid_block_additional_residual=mid,
+                 return_dict=False)[0]
+        assert rel_l2(o.float(), want) < 4e-3
+    assert not unet.forward._warned and len(unet.forward._cached) == 1
+    down2 = [d * 0 for d in down]
+    o0 = unet(sample, 321, encoder_hidden_states=ehs, down_block_additional_residuals=down2, mid_block_additional_residual=mid * 0,
+              return_dict=False)[0]
+    assert rel_l2(o0.float(), base) < 4e-3  # zero residuals == plain UNet, through the same cached graph
+
+
+def test_tiny_unet_bf16():
+    cfg = U.tiny_config()
+    m = U.build(cfg, seed=17, dtype=torch.bfloat16, device=DEV)
+    ref = U.build(cfg, seed=17, device=DEV)
+    ref.load_state_dict({k: v.float() for k, v in m.state_dict().items()})
+    sample, ehs = _inputs(cfg, 2, seed=8, dtype=torch.bfloat16)
+    y = _engine(m).forward(sample, 700, ehs)
+    with torch.no_grad():
+        want = ref(sample.float(), 700, ehs.float()).sample
+        eager = m(sample, 700, ehs).sample
+    e_eng, e_eager = rel_l2(y.float(), want), rel_l2(eager.float(), want)
+    log_value("tiny unet bf16", engine_vs_fp32=e_eng, eager_bf16_vs_fp32=e_eager)
+    assert torch.isfinite(y).all() and e_eng < 3e-2 and e_eng < 1.5 * e_eager + 5e-3, (e_eng, e_eager)
