@@ -178,6 +178,98 @@ class _NativeUNetForward:
         return _make_output(out)
 
 
+class ControlNetOutput:
+    """Stand-in for diffusers' ControlNetOutput when diffusers is not importable."""
+
+    def __init__(self, down_block_res_samples, mid_block_res_sample):
+        self.down_block_res_samples = down_block_res_samples
+        self.mid_block_res_sample = mid_block_res_sample
+
+    def __getitem__(self, i):
+        return (self.down_block_res_samples, self.mid_block_res_sample)[i]
+
+    def __iter__(self):
+        return iter((self.down_block_res_samples, self.mid_block_res_sample))
+
+
+class _NativeControlNetForward:
+    """Replacement for `controlnet.forward` (diffusers ControlNetModel): per-signature plan cache + hipGraph replay."""
+
+    def __init__(self, module, engine, orig_forward, enable_graph):
+        self.module, self.engine, self.orig_forward, self.enable_graph = module, engine, orig_forward, enable_graph
+        self._cached = {}
+        self._lock = threading.Lock()
+        self._warned = False
+        self.__self__ = module
+        self.__name__ = "forward"
+
+    def _prepare(self, key, sample, timestep, ehs, cond):
+        eng = self.engine
+        B, H, W, S = key
+        plan = eng.get_plan(B, H, W, S)
+        graph = None
+        torch.cuda.synchronize(eng.device)
+        with torch.cuda.device(eng.device), torch.cuda.stream(torch.cuda.Stream(device=eng.device)):
+            eng.load_inputs(plan, sample, timestep, ehs, cond)
+            plan.run(torch.cuda.current_stream(eng.device).cuda_stream)
+        torch.cuda.synchronize(eng.device)
+        env = get_per_device_graph_execution_env(eng.device)
+        if self.enable_graph:
+            from ..engine import capture_plan_graph
+            with env.lock:
+                with torch.cuda.device(eng.device):
+                    graph, _ = capture_plan_graph(plan, env.stream, pool=env.mempool)
+                torch.cuda.synchronize(eng.device)
+        return plan, graph, env
+
+    def __call__(self, sample, timestep, encoder_hidden_states=None, controlnet_cond=None, conditioning_scale=1.0,
+                 class_labels=None, timestep_cond=None, attention_mask=None, added_cond_kwargs=None, cross_attention_kwargs=None,
+                 guess_mode=False, return_dict=True):
+        eng = self.engine
+        bad = [k for k, v in dict(class_labels=class_labels, timestep_cond=timestep_cond, attention_mask=attention_mask,
+                                  added_cond_kwargs=added_cond_kwargs).items() if v is not None]
+        if cross_attention_kwargs:
+            bad.append("cross_attention_kwargs")
+        if guess_mode:
+            bad.append("guess_mode")
+        if (bad or encoder_hidden_states is None or controlnet_cond is None or not torch.is_tensor(sample)
+                or sample.device.type != "cuda" or sample.dtype != eng.dtype or sample.ndim != 4
+                or not isinstance(conditioning_scale, (int, float))):
+            if not self._warned:
+                logger.warning("sfast: ControlNet call not handled by the native engine (%s); running the original forward",
+                               ", ".join(bad) or "inputs")
+                self._warned = True
+            return self.orig_forward(sample, timestep, encoder_hidden_states=encoder_hidden_states, controlnet_cond=controlnet_cond,
+                                     conditioning_scale=conditioning_scale, class_labels=class_labels, timestep_cond=timestep_cond,
+                                     attention_mask=attention_mask, added_cond_kwargs=added_cond_kwargs,
+                                     cross_attention_kwargs=cross_attention_kwargs, guess_mode=guess_mode, return_dict=return_dict)
+        B, _, H, W = sample.shape
+        key = (B, H, W, encoder_hidden_states.shape[1])
+        entry = self._cached.get(key)
+        if entry is None:
+            with self._lock:
+                entry = self._cached.get(key)
+                if entry is None:
+                    entry = self._prepare(key, sample, timestep, encoder_hidden_states, controlnet_cond)
+                    self._cached[key] = entry
+        plan, graph, env = entry
+        with env.lock:
+            eng.load_inputs(plan, sample, timestep, encoder_hidden_states, controlnet_cond.to(eng.dtype))
+            if graph is not None:
+                graph.replay()
+            else:
+                plan.run(torch.cuda.current_stream(eng.device).cuda_stream)
+            down, mid = eng.outputs(plan, float(conditioning_scale))
+        if not return_dict:
+            return down, mid
+        return ControlNetOutput(down, mid)
+
+
+def _looks_like_controlnet(m):
+    return all(hasattr(m, a) for a in ("conv_in", "time_embedding", "down_blocks", "mid_block", "controlnet_cond_embedding",
+                                       "controlnet_down_blocks", "controlnet_mid_block", "config"))
+
+
 def _looks_like_unet2d_condition(m):
     return all(hasattr(m, a) for a in ("conv_in", "time_embedding", "down_blocks", "mid_block", "up_blocks",
                                        "conv_norm_out", "conv_out", "config"))
@@ -233,6 +325,18 @@ def compile_unet(m, config):
         apply_memory_format(m, memory_format=config.memory_format)
 
     native = None
+    if config.enable_jit and device.type == "cuda" and _looks_like_controlnet(m):
+        from ..engine import ControlNetEngine, UnsupportedUNet
+        try:
+            cn = ControlNetEngine.from_module(m)
+        except UnsupportedUNet as e:
+            logger.warning("sfast: %s is outside the native ControlNet engine's coverage (%s); keeping the eager forward",
+                           type(m).__name__, e)
+            cn = None
+        if cn is not None:
+            m.forward = _NativeControlNetForward(m, cn, m.forward, enable_cuda_graph)
+            m._sfast_engine = cn
+            return m
     if config.enable_jit and device.type == "cuda" and _looks_like_unet2d_condition(m):
         from ..engine import UNet2DEngine, UnsupportedUNet
         try:

@@ -257,7 +257,8 @@ class UNet2DEngine:
                 raise UnsupportedUNet("per-block layers_per_block")
             self.layers = self.layers[0]
         self.down_types = tuple(g("down_block_types"))
-        self.up_types = tuple(g("up_block_types"))
+        self.up_types = tuple(g("up_block_types") or ())
+        self.is_controlnet = "controlnet_mid_block.weight" in self.params  # diffusers ControlNetModel: no up path
         for t in self.down_types:
             if t not in ("CrossAttnDownBlock2D", "DownBlock2D"):
                 raise UnsupportedUNet(f"down block {t}")
@@ -366,7 +367,7 @@ class UNet2DEngine:
                   tune=(p, launch_with), lane=lane)
 
     def _op_conv(self, plan, name, x, x2, w, bias, out, B, H, W, C1, C2, Cout, k, stride, pad, *, ups=False, rowbias=None,
-                 ld_rowbias=0, rowbias_offset=0, z=None, xs=None, os_=None, kind=None):
+                 ld_rowbias=0, rowbias_offset=0, z=None, xs=None, os_=None, kind=None, act=L.ACT_NONE):
         lib = self.lib
         Cin = C1 + C2
         p = L.ConvParams()
@@ -383,7 +384,7 @@ class UNet2DEngine:
         p.ws = (C.c_int64 * 4)(w.stride(0), w.stride(1), w.stride(2), w.stride(3))
         p.os = (C.c_int64 * 4)(*(os_ or (Ho * Wo * Cout, Wo * Cout, Cout, 1)))
         p.zs = (C.c_int64 * 4)(*((Ho * Wo * Cout, Wo * Cout, Cout, 1) if z is not None else (0, 0, 0, 0)))
-        p.act, p.res_before_act, p.alpha = L.ACT_NONE, 1, 1.0
+        p.act, p.res_before_act, p.alpha = act, 1, 1.0
         p.ld_rowbias, p.variant, p.split_k = ld_rowbias, 0, 0
         self._need_ws(plan, lib.sfast_hip_conv2d_workspace_bytes(C.byref(p)))
         xp = x.data_ptr()
@@ -646,6 +647,8 @@ class UNet2DEngine:
         h = pool.get(B * H * W * c0)
         self._op_conv(plan, "conv_in", sample, None, P["conv_in.weight"], P["conv_in.bias"], h, B, H, W, self.in_ch, 0, c0, 3, 1, 1,
                       xs=(self.in_ch * H * W, W, 1, H * W), kind="conv_in")
+        if self.is_controlnet:
+            h = self._controlnet_cond_embedding(plan, h, B, H, W, c0)
         skips = [(h, c0)]
         skip_dims = [(c0, H, W)]  # (channels, height, width) of every skip tensor, in creation order
         ch = c0
@@ -681,6 +684,22 @@ class UNet2DEngine:
         h = self._resnet(plan, rn, ha, None, ch, 0, ch, B, cH, cW, temb_all, tot, offs[rn])
         pool.put(ha)
         # (the last skip tensor is the mid-block input; it stays alive in `skips`)
+        if self.is_controlnet:
+            # ControlNetModel: one 1x1 "zero conv" per skip tensor + one on the mid-block output, written NCHW (what
+            # UNet2DConditionModel.forward takes as down_block_additional_residuals / mid_block_additional_residual)
+            outs = []
+            for k, ((buf, _), (cc, sh_, sw_)) in enumerate(zip(skips, skip_dims)):
+                o = torch.zeros((B, cc, sh_, sw_), dtype=dt, device=dev)
+                zn = f"controlnet_down_blocks.{k}"
+                self._op_conv(plan, zn, buf, None, P[zn + ".weight"], P[zn + ".bias"], o, B, sh_, sw_, cc, 0, cc, 1, 1, 0,
+                              os_=(cc * sh_ * sw_, sw_, 1, sh_ * sw_))
+                outs.append(o)
+            om = torch.zeros((B, ch, cH, cW), dtype=dt, device=dev)
+            self._op_conv(plan, "controlnet_mid_block", h, None, P["controlnet_mid_block.weight"], P["controlnet_mid_block.bias"], om,
+                          B, cH, cW, ch, 0, ch, 1, 1, 0, os_=(ch * cH * cW, cW, 1, cH * cW))
+            plan.static_out = {"down_block_res_samples": outs, "mid_block_res_sample": om}
+            self._finish_plan(plan)
+            return plan
         if ctrl:
             # ControlNet residuals. diffusers adds them to COPIES of the skip tensors after the down path, so the mid
             # block still sees the un-augmented activation: here the in-place adds are emitted after the mid block
@@ -726,8 +745,13 @@ class UNet2DEngine:
         self._op_conv(plan, "conv_out", nout, None, P["conv_out.weight"], P["conv_out.bias"], out, B, H, W, ch, 0, self.out_ch, 3, 1, 1,
                       os_=(self.out_ch * H * W, W, 1, H * W), kind="conv_out")
         pool.put(nout)
+        self._finish_plan(plan)
+        return plan
+
+    def _finish_plan(self, plan):
         # measured tile / pipe / split-K selection per distinct GEMM / conv problem (cuDNN-benchmark style)
         from . import autotune
+        lib, dev = self.lib, self.device
         if not self._emulated and autotune.enabled():
             autotune.tune_plan(plan, dev, "f16" if self.dtype == torch.float16 else "bf16")
             for op in plan.ops:
@@ -741,7 +765,43 @@ class UNet2DEngine:
             plan.ws_side[0] = torch.empty(plan.ws_side[1], dtype=torch.uint8, device=dev)
         if not self._emulated:
             plan.side_stream = torch.cuda.Stream(device=dev)
-        return plan
+
+    def _controlnet_cond_embedding(self, plan, h, B, H, W, c0):
+        """ControlNetConditioningEmbedding on the NCHW conditioning image; its conv_out is fused with the add onto
+        conv_in(sample) (residual operand of the conv epilogue). Returns the new hidden-state buffer."""
+        pool, P = plan.pool, self.params
+        dev, dt = self.device, self.dtype
+        pre = "controlnet_cond_embedding"
+        nblk = 0
+        while f"{pre}.blocks.{nblk}.weight" in P:
+            nblk += 1
+        f = 1 << (nblk // 2)
+        cin = P[f"{pre}.conv_in.weight"].shape[1]
+        cond = torch.zeros((B, cin, H * f, W * f), dtype=dt, device=dev)
+        plan.static_in["controlnet_cond"] = cond
+        cH, cW = H * f, W * f
+        c = P[f"{pre}.conv_in.weight"].shape[0]
+        cur = pool.get(B * cH * cW * c)
+        self._op_conv(plan, f"{pre}.conv_in", cond, None, P[f"{pre}.conv_in.weight"], P[f"{pre}.conv_in.bias"], cur, B, cH, cW, cin, 0, c,
+                      3, 1, 1, xs=(cin * cH * cW, cW, 1, cH * cW), act=L.ACT_SILU, kind="conv_in")
+        for i in range(nblk):
+            w = P[f"{pre}.blocks.{i}.weight"]
+            co = w.shape[0]
+            stride = 2 if i % 2 else 1
+            oH, oW = (cH + 2 - 3) // stride + 1, (cW + 2 - 3) // stride + 1
+            nxt = pool.get(B * oH * oW * co)
+            self._op_conv(plan, f"{pre}.blocks.{i}", cur, None, w, P[f"{pre}.blocks.{i}.bias"], nxt, B, cH, cW, c, 0, co, 3, stride, 1,
+                          act=L.ACT_SILU)
+            pool.put(cur)
+            cur, c, cH, cW = nxt, co, oH, oW
+        if (cH, cW) != (H, W):
+            raise UnsupportedUNet("conditioning image size does not reduce to the latent size")
+        out = pool.get(B * H * W * c0)
+        self._op_conv(plan, f"{pre}.conv_out", cur, None, P[f"{pre}.conv_out.weight"], P[f"{pre}.conv_out.bias"], out, B, H, W, c, 0, c0,
+                      3, 1, 1, z=h)
+        pool.put(cur)
+        pool.put(h)
+        return out
 
     # ------------------------------------------------------------------------------------------
     def get_plan(self, B, H, W, S_ctx, ctrl=False):
@@ -788,3 +848,37 @@ class UNet2DEngine:
                          mid_block_additional_residual)
         plan.run(None if self._emulated else torch.cuda.current_stream(self.device).cuda_stream)
         return plan.static_out.clone()
+
+
+class ControlNetEngine(UNet2DEngine):
+    """Executor for diffusers `ControlNetModel` parameter sets: the UNet's down path + mid block, the conditioning
+    embedding and the 1x1 output convs, as one plan of the same C-ABI launches."""
+
+    def __init__(self, config, params, device=None, dtype=None, _lib=None):
+        super().__init__(config, params, device=device, dtype=dtype, _lib=_lib)
+        if not self.is_controlnet:
+            raise UnsupportedUNet("parameters do not look like a ControlNetModel (no controlnet_mid_block)")
+        if self.add_type is not None:
+            raise UnsupportedUNet("ControlNet with addition_embed_type (SDXL ControlNet) is not covered yet")
+
+    def load_inputs(self, plan, sample, timestep, encoder_hidden_states, controlnet_cond=None, **_):
+        super().load_inputs(plan, sample, timestep, encoder_hidden_states)
+        if controlnet_cond is None:
+            raise ValueError("controlnet_cond is required")
+        plan.static_in["controlnet_cond"].copy_(controlnet_cond)
+
+    def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0):
+        """Eager (no graph) execution on the current stream; returns (down_block_res_samples, mid_block_res_sample)
+        as fresh NCHW tensors, ready to be passed to UNet2DConditionModel.forward / UNet2DEngine.forward."""
+        B, _, H, W = sample.shape
+        plan = self.get_plan(B, H, W, encoder_hidden_states.shape[1])
+        self.load_inputs(plan, sample, timestep, encoder_hidden_states, controlnet_cond)
+        plan.run(None if self._emulated else torch.cuda.current_stream(self.device).cuda_stream)
+        return self.outputs(plan, conditioning_scale)
+
+    @staticmethod
+    def outputs(plan, conditioning_scale=1.0):
+        so = plan.static_out
+        if conditioning_scale == 1.0:
+            return [t.clone() for t in so["down_block_res_samples"]], so["mid_block_res_sample"].clone()
+        return [t * conditioning_scale for t in so["down_block_res_samples"]], so["mid_block_res_sample"] * conditioning_scale

@@ -258,17 +258,7 @@ class VaeDecoderEngine(UNet2DEngine):
         self._op_conv(plan, "conv_out", nout, None, P["conv_out.weight"], P["conv_out.bias"], img, B, cH, cW, ch, 0, self.out_ch, 3, 1, 1,
                       os_=(self.out_ch * cH * cW, cW, 1, cH * cW), kind="conv_out")
         pool.put(nout)
-        from . import autotune
-        if not self._emulated and autotune.enabled():
-            autotune.tune_plan(plan, dev, "f16" if self.dtype == torch.float16 else "bf16")
-            lib = self.lib
-            for op in plan.ops:
-                if op.tune is not None:
-                    p = op.tune[0]
-                    q = lib.sfast_hip_gemm_workspace_bytes if isinstance(p, L.GemmParams) else lib.sfast_hip_conv2d_workspace_bytes
-                    self._need_ws(plan, q(C.byref(p)), op.lane)
-        if plan.ws[1]:
-            plan.ws[0] = torch.empty(plan.ws[1], dtype=torch.uint8, device=dev)
+        self._finish_plan(plan)
         return plan
 
     def get_plan(self, B, H, W, S_ctx=0):

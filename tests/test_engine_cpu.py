@@ -166,3 +166,36 @@ def test_controlnet_residuals_through_the_plan(built_lib):
     assert rel_l2(y0, base) < 3e-3 and len(eng._plans) == 2
     with pytest.raises(ValueError):
         eng.load_inputs(plan, s, 500, e)
+
+
+def test_controlnet_engine_on_the_emulator(built_lib):
+    """ControlNetModel as a native plan (conditioning embedding + down path + mid block + 1x1 output convs), and its
+    outputs fed to the UNet plan: the pair reproduces the oracle ControlNet -> UNet chain."""
+    from oracle import controlnet_ref as CN
+    from sfast.engine import ControlNetEngine
+    ccfg = CN.tiny_config()
+    c16 = CN.build(ccfg, seed=21, dtype=torch.float16)
+    c32 = CN.build(ccfg, seed=21)
+    c32.load_state_dict({k: v.float() for k, v in c16.state_dict().items()})
+    emu = EmuLib()
+    ceng = ControlNetEngine.from_module(c16, _lib=emu)
+    g = torch.Generator().manual_seed(7)
+    s = torch.randn(2, 4, 16, 16, generator=g).half()
+    e = torch.randn(2, 77, 64, generator=g).half()
+    cond = torch.rand(2, 3, 64, 64, generator=g).half()
+    down, mid = ceng.forward(s, 300, e, cond)
+    with torch.no_grad():
+        wd, wm = c32(s.float(), 300, e.float(), cond.float(), return_dict=False)
+    assert len(down) == len(wd) == 6 and all(rel_l2(a, b) < 3e-3 for a, b in zip(down, wd)) and rel_l2(mid, wm) < 3e-3
+    assert [tuple(t.shape) for t in down] == [tuple(t.shape) for t in wd]
+    d2, m2 = ceng.forward(s, 300, e, cond, conditioning_scale=0.5)
+    assert rel_l2(d2[0], 0.5 * wd[0]) < 3e-3 and rel_l2(m2, 0.5 * wm) < 3e-3
+    # chain into the UNet plan
+    m16, m32 = _pair(U.tiny_config(), 22)
+    ueng = UNet2DEngine.from_module(m16, _lib=EmuLib())
+    y = ueng.forward(s, 300, e, down_block_additional_residuals=down, mid_block_additional_residual=mid)
+    with torch.no_grad():
+        want = m32(s.float(), 300, e.float(), down_block_additional_residuals=wd, mid_block_additional_residual=wm).sample
+    assert rel_l2(y, want) < 4e-3
+    with pytest.raises(UnsupportedUNet):
+        ControlNetEngine.from_module(m16, _lib=EmuLib())  # a UNet is not a ControlNet

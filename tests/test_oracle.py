@@ -114,3 +114,13 @@ def test_oracle_reproduces_golden_unet():
         yb = m(gold["sample"].float(), torch.tensor(gold["timesteps_b"]), gold["encoder_hidden_states"].float()).sample
     torch.testing.assert_close(y, gold["y"], rtol=1e-3, atol=1e-4)
     torch.testing.assert_close(yb, gold["y_b"], rtol=1e-3, atol=1e-4)
+
+
+def test_controlnet_and_vae_topology_known_answers():
+    from oracle import controlnet_ref as CN
+    assert CN.param_count(CN.build("sd15")) == CN.SD15_CONTROLNET_PARAMS == 361_279_120
+    keys = set(CN.build("tiny").state_dict().keys())
+    for k in ("controlnet_cond_embedding.conv_in.weight", "controlnet_cond_embedding.blocks.3.bias", "controlnet_cond_embedding.conv_out.weight",
+              "controlnet_down_blocks.0.weight", "controlnet_down_blocks.5.bias", "controlnet_mid_block.weight", "mid_block.resnets.1.conv2.weight"):
+        assert k in keys, k
+    assert not any(k.startswith("up_blocks") or k.startswith("conv_out") for k in keys)

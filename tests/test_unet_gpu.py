@@ -303,3 +303,37 @@ def test_tiny_unet_bf16():
     e_eng, e_eager = rel_l2(y.float(), want), rel_l2(eager.float(), want)
     log_value("tiny unet bf16", engine_vs_fp32=e_eng, eager_bf16_vs_fp32=e_eager)
     assert torch.isfinite(y).all() and e_eng < 3e-2 and e_eng < 1.5 * e_eager + 5e-3, (e_eng, e_eager)
+
+
+def test_controlnet_engine_and_compiled_chain():
+    """ControlNetModel on the native engine, behind compile_unet(), chained into the compiled UNet."""
+    from oracle import controlnet_ref as CN
+    from sfast.compilers.diffusion_pipeline_compiler import CompilationConfig, compile_unet
+    ccfg, ucfg = CN.tiny_config(), U.tiny_config()
+    cnet = CN.build(ccfg, seed=41, dtype=torch.float16, device=DEV)
+    cref = CN.build(ccfg, seed=41, device=DEV)
+    cref.load_state_dict({k: v.float() for k, v in cnet.state_dict().items()})
+    unet = U.build(ucfg, seed=42, dtype=torch.float16, device=DEV)
+    uref = U.build(ucfg, seed=42, device=DEV)
+    uref.load_state_dict({k: v.float() for k, v in unet.state_dict().items()})
+    sample, ehs = _inputs(ucfg, 2, seed=9)
+    cond = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(10)).to(DEV, torch.float16)
+    with torch.no_grad():
+        wd, wm = cref(sample.float(), 444, ehs.float(), cond.float(), return_dict=False)
+        want = uref(sample.float(), 444, ehs.float(), down_block_additional_residuals=wd, mid_block_additional_residual=wm).sample
+    c = CompilationConfig.Default()
+    c.enable_cuda_graph = True
+    cnet = compile_unet(cnet, c)
+    unet = compile_unet(unet, c)
+    assert type(cnet._sfast_engine).__name__ == "ControlNetEngine"
+    for _ in range(2):
+        out = cnet(sample, 444, encoder_hidden_states=ehs, controlnet_cond=cond, return_dict=True)
+        down, mid = out.down_block_res_samples, out.mid_block_res_sample
+        errs = [rel_l2(a.float(), b) for a, b in zip(down, wd)] + [rel_l2(mid.float(), wm)]
+        y = unet(sample, 444, encoder_hidden_states=ehs, down_block_additional_residuals=down, mid_block_additional_residual=mid,
+                 return_dict=False)[0]
+    log_value("tiny controlnet vs fp32 oracle", max_rel_l2=max(errs), chained_unet=rel_l2(y.float(), want))
+    assert max(errs) < 4e-3 and rel_l2(y.float(), want) < 4e-3
+    assert not cnet.forward._warned and not unet.forward._warned
+    d2, m2 = cnet(sample, 444, encoder_hidden_states=ehs, controlnet_cond=cond, conditioning_scale=0.5, return_dict=False)
+    assert rel_l2(m2.float(), 0.5 * wm) < 4e-3
