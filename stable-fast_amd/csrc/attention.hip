@@ -20,8 +20,15 @@
 //     ds_write_b32); V^T fragments are two 8-byte reads. K rows are padded to an odd number of
 //     16-byte slots -> conflict-free ds_read_b128.
 //   * head dims 40 / 80 (SD1.5) are zero-padded to the MFMA K-step inside LDS/registers only.
-//   * softmax in fp32 with exp2 and a folded scale*log2(e); accumulate fp32; global loads of tile
-//     t+1 are issued before the MFMAs of tile t (register prefetch).
+//   * softmax in fp32 with exp2 and a folded scale*log2(e) (`exp2(fma(s, c, -m*c))`, the running max tracked on raw
+//     scores); the O / l rescale is skipped while no lane's running max moves (exact); accumulate fp32.
+//   * K / V^T tiles are double-buffered in dynamic LDS: global loads of tile t+1 are issued before the MFMAs of tile
+//     t (register prefetch) and written to the other stage after them -- one barrier per tile.
+//   * head dims below the 32-row MFMA block (40 -> 64, 80 -> 96) carry a ONES row in the V^T padding, so the softmax
+//     denominator is accumulated by the PV MFMA itself (O^T[D][q] = sum_k P[q][k]) instead of 32 VALU adds per tile;
+//     f16 probabilities then use packed round-toward-zero converts (the bias cancels in O / l).
+//   * built with the VGPR form of the MFMAs (build.py EXTRA_FLAGS): the softmax reads every S accumulator on the
+//     VALU each tile, AGPR-allocated results cost ~150 v_accvgpr moves per tile.
 #include "common.h"
 #include <type_traits>
 #include <math.h>

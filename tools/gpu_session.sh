@@ -62,6 +62,8 @@ run smoke    600 python __graft_entry__.py smoke
 run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json
 run bench2 600 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-roofline
 run bench_sdxl 900 python bench.py --config sdxl --steps 10 --warmup 2 --no-cpu-baseline
+run bench_default 900 python bench.py --no-cpu-baseline --no-roofline
+run bench_torchrun 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --no-roofline
 if [ "$MODE" = "full" ] || [ "$MODE" = "tune" ]; then
   run tune 900 bash -c "python tools/tune_igemm.py > gpurun_out/tune.json 2> gpurun_out/tune.txt"
 fi
