@@ -38,7 +38,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="sd15", choices=["sd15", "sdxl"])
+    ap.add_argument("--config", default="sd15", choices=["sd15", "sdxl", "vae"],
+                    help="sd15 (the BASELINE metric) | sdxl | vae (SD VAE decode 64x64 latent -> 512x512, SURVEY 8f rank 1)")
     ap.add_argument("--images", type=int, default=1, help="images per GPU (UNet batch is 2x this: CFG)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -189,6 +190,94 @@ def cpu_baseline(cfg_name, images):
                        f"median {med:.2f} s/forward; diffusers itself is not installable here")
 
 
+def bench_vae(args, dev, rank, world, use_dist):
+    """`--config vae`: one step = one VAE decode (64x64 latent -> 512x512 image, bs = --images, fp16) replayed as a hipGraph."""
+    from sfast.engine import VaeDecoderEngine, capture_plan_graph
+    from sfast.engine.unet_spec import SD_VAE_DECODER_CONFIG, random_vae_decoder_params
+    cfg = SD_VAE_DECODER_CONFIG
+    params = random_vae_decoder_params(cfg, seed=0, dtype=torch.float16, device=dev)
+    eng = VaeDecoderEngine(cfg, params)
+    hw = 64
+    z = torch.randn(args.images, 4, hw, hw, generator=torch.Generator(device=dev).manual_seed(1 + rank), device=dev).half()
+    plan = eng.get_plan(args.images, hw, hw)
+    eng.load_inputs(plan, z)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        plan.run(stream.cuda_stream)
+    torch.cuda.synchronize()
+    graph, _ = capture_plan_graph(plan, stream)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            graph.replay()
+    sync_all()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        for _ in range(args.steps):
+            graph.replay()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+    if rank != 0:
+        return
+    ms = elapsed / args.steps * 1e3
+    out = {"metric": "SD VAE decode 64x64 latent -> 512x512 image fp16 (images/s)", "value": world * args.images * args.steps / elapsed,
+           "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+           "config": {"workload": f"AutoencoderKL decoder (SD1.x VAE, 49.5 M parameters), {args.images} x [4,64,64] latent -> [3,512,512] per GPU, "
+                                  "hipGraph replay, seeded random-init weights", "images_per_gpu": args.images, "parallelism": f"replicas x{world}"},
+           "outputs_finite": bool(torch.isfinite(plan.static_out).all()), "kernel_launches_per_step": len(plan.ops)}
+    if not args.no_roofline and world == 1:
+        class _L:  # per_op_timing expects an object with .plan
+            pass
+        holder = _L()
+        holder.plan = plan
+        rows = per_op_timing(holder)
+        roof, families, total = roofline_from(rows)
+        out["roofline"], out["kernel_families"], out["sum_of_kernel_ms_eager"] = roof, families, total * 1e3
+    if not args.no_cpu_baseline and world == 1:
+        # baselines beside it: the oracle restatement of the same decoder (a) eagerly on this GPU through PyTorch-ROCm,
+        # (b) in fp32 on the host cores (one decode, no warm-up: bounded)
+        sys.path.insert(0, ROOT)
+        from oracle import vae_ref as V
+        ref16 = V.Decoder(**cfg).to(dev, torch.float16).eval().to(memory_format=torch.channels_last)
+        ref16.load_state_dict({k: v for k, v in params.items()})
+        with torch.no_grad():
+            y_ref = ref16(z)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                ref16(z)
+            torch.cuda.synchronize()
+            t_eager = (time.perf_counter() - t0) / 5
+        eng.load_inputs(plan, z)
+        graph.replay()
+        torch.cuda.synchronize()
+        out["pytorch_rocm_eager_baseline"] = {"ms": t_eager * 1e3, "speedup": t_eager * 1e3 / ms,
+                                              "rel_l2_engine_vs_eager_fp16": float((plan.static_out.float() - y_ref.float()).norm() / y_ref.float().norm())}
+        ref32 = V.Decoder(**cfg).eval()
+        ref32.load_state_dict({k: v.float().cpu() for k, v in params.items()})
+        torch.set_num_threads(os.cpu_count() or 1)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            y32 = ref32(z[:1].float().cpu())
+            t_cpu = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": "one fp32 decode of the oracle restatement (oracle/vae_ref.py) on the host cores, no warm-up",
+                               "rel_l2_engine_vs_fp32": float((plan.static_out[:1].float().cpu() - y32).norm() / y32.norm())}
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,6 +291,12 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.config == "vae":
+        bench_vae(args, dev, rank, world, use_dist)
+        if use_dist:
+            dist.destroy_process_group()
+        return
 
     from sfast.engine import UNet2DEngine
     from sfast.engine.denoise import DenoiseLoop

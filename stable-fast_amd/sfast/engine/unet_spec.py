@@ -144,3 +144,72 @@ def random_params(cfg: dict, seed: int = 0, dtype=torch.float16, device="cuda") 
             t = t.contiguous(memory_format=torch.channels_last)
         params[name] = t
     return params
+
+
+SD_VAE_DECODER_CONFIG = dict(latent_channels=4, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
+                             norm_num_groups=32)
+
+
+def vae_decoder_param_shapes(cfg: dict) -> Dict[str, Tuple[int, ...]]:
+    """Parameter inventory of diffusers `AutoencoderKL.decoder` (names as in its state dict); 49,490,179 parameters
+    for SD_VAE_DECODER_CONFIG."""
+    boc = tuple(cfg["block_out_channels"])
+    shapes: Dict[str, Tuple[int, ...]] = {}
+
+    def conv(name, cout, cin, k):
+        shapes[name + ".weight"] = (cout, cin, k, k)
+        shapes[name + ".bias"] = (cout,)
+
+    def norm(name, c):
+        shapes[name + ".weight"] = (c,)
+        shapes[name + ".bias"] = (c,)
+
+    def lin(name, cout, cin):
+        shapes[name + ".weight"] = (cout, cin)
+        shapes[name + ".bias"] = (cout,)
+
+    def resnet(name, cin, cout):
+        norm(name + ".norm1", cin)
+        conv(name + ".conv1", cout, cin, 3)
+        norm(name + ".norm2", cout)
+        conv(name + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(name + ".conv_shortcut", cout, cin, 1)
+
+    c = boc[-1]
+    conv("conv_in", c, cfg["latent_channels"], 3)
+    resnet("mid_block.resnets.0", c, c)
+    norm("mid_block.attentions.0.group_norm", c)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        lin("mid_block.attentions.0." + n, c, c)
+    resnet("mid_block.resnets.1", c, c)
+    rev = boc[::-1]
+    prev = rev[0]
+    for i, ch in enumerate(rev):
+        for j in range(cfg["layers_per_block"] + 1):
+            resnet(f"up_blocks.{i}.resnets.{j}", prev if j == 0 else ch, ch)
+        if i != len(rev) - 1:
+            conv(f"up_blocks.{i}.upsamplers.0.conv", ch, ch, 3)
+        prev = ch
+    norm("conv_norm_out", boc[0])
+    conv("conv_out", cfg["out_channels"], boc[0], 3)
+    return shapes
+
+
+def random_vae_decoder_params(cfg: dict, seed: int = 0, dtype=torch.float16, device="cuda") -> Dict[str, torch.Tensor]:
+    """Seeded synthetic decoder weights (variance-preserving), 4-D weights in channels_last."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    params = {}
+    for name, shape in vae_decoder_param_shapes(cfg).items():
+        if len(shape) == 1:
+            t = (1.0 if ("norm" in name and name.endswith("weight")) else 0.0) + 0.05 * torch.randn(shape, generator=g, device=device)
+        else:
+            fan_in = 1
+            for s_ in shape[1:]:
+                fan_in *= s_
+            t = torch.randn(shape, generator=g, device=device) * (1.0 / math.sqrt(fan_in))
+        t = t.to(dtype)
+        if t.ndim == 4:
+            t = t.contiguous(memory_format=torch.channels_last)
+        params[name] = t
+    return params

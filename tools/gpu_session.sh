@@ -18,7 +18,7 @@ rocminfo 2>/dev/null | grep -E "gfx|Compute Unit" | head -4 >> gpurun_out/sessio
 nproc >> gpurun_out/session.log
 if [ "$MODE" = "vae" ]; then
   run t_vae    900 $PYT tests/test_vae_gpu.py
-  run bench_vae 600 python tools/bench_vae.py
+  run bench_vae 900 python bench.py --config vae --steps 30 --warmup 5
   cut -c1-600 gpurun_out/session.log
   exit 0
 fi
@@ -63,6 +63,7 @@ run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out
 run bench2 600 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-roofline
 run bench_sdxl 900 python bench.py --config sdxl --steps 10 --warmup 2 --no-cpu-baseline
 run bench_default 900 python bench.py --no-cpu-baseline --no-roofline
+run bench_vae 900 python bench.py --config vae --steps 30 --warmup 5
 run bench_torchrun 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --no-roofline
 if [ "$MODE" = "full" ] || [ "$MODE" = "tune" ]; then
   run tune 900 bash -c "python tools/tune_igemm.py > gpurun_out/tune.json 2> gpurun_out/tune.txt"
