@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define SFAST_HIP_ABI_VERSION 1
+#define SFAST_HIP_ABI_VERSION 2
 
 typedef void *sfast_stream_t; /* hipStream_t */
 
@@ -175,7 +175,8 @@ int sfast_hip_igemm_plan(int32_t M, int32_t N, int32_t K, int32_t geglu, int32_t
  * both expressible; the MFMA implicit-GEMM path needs dense NHWC activations and K-contiguous
  * (channels_last) weights, everything else runs on the generic kernel.
  * upsample2x: the conv reads nearest-neighbour 2x upsampled x without materialising it.
- * C1 < Cin: input channels [C1,Cin) come from x2 (virtual concat, as in GroupNorm).          */
+ * C1 < Cin: input channels [C1,Cin) come from x2 (virtual concat, as in GroupNorm).
+ * Output size: Ho = (Hin + 2*pad_h + pad_h_extra - dil_h*(KH-1) - 1) / stride_h + 1 (Hin = 2H when upsample2x). */
 typedef struct {
     int32_t dtype;
     int32_t B, H, W, Cin, Cout, KH, KW;
@@ -190,6 +191,9 @@ typedef struct {
     float alpha;
     int64_t ld_rowbias; /* rowbias[b][cout] row stride; ignored when rowbias == NULL */
     int32_t variant, split_k;
+    /* ABI 2: extra zero padding at the bottom / right on top of the symmetric pad_h / pad_w (0 = symmetric).
+     * diffusers' Downsample2D in the VAE encoder pads (0,1,0,1) before a stride-2 conv: pad 0, extra 1. */
+    int32_t pad_h_extra, pad_w_extra;
 } sfast_conv_params;
 
 size_t sfast_hip_conv2d_workspace_bytes(const sfast_conv_params *p);

@@ -128,8 +128,74 @@ class Decoder(nn.Module):
         return self.conv_out(F.silu(self.conv_norm_out(h)))
 
 
+class Downsample2D(nn.Module):
+    """diffusers Downsample2D with padding=0: F.pad(x, (0, 1, 0, 1)) then a stride-2 3x3 conv."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, stride=2, padding=0)
+
+    def forward(self, x):
+        return self.conv(F.pad(x, (0, 1, 0, 1)))
+
+
+class DownEncoderBlock2D(nn.Module):
+    def __init__(self, cin, cout, layers, groups, down):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if j == 0 else cout, cout, groups) for j in range(layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if down else None
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        if self.downsamplers is not None:
+            x = self.downsamplers[0](x)
+        return x
+
+
+class Encoder(nn.Module):
+    """`AutoencoderKL.encoder`: conv_in(3 -> 128) -> 4 x DownEncoderBlock2D (2 resnets, stride-2 conv on all but the last)
+    -> mid block -> GroupNorm -> SiLU -> conv_out(512 -> 2 * latent_channels). 34,163,592 parameters for the SD VAE."""
+
+    def __init__(self, **cfg):
+        super().__init__()
+        c = SimpleNamespace(**cfg)
+        self.config = c
+        boc = tuple(c.block_out_channels)
+        g = c.norm_num_groups
+        self.conv_in = nn.Conv2d(c.out_channels, boc[0], 3, padding=1)  # image channels = the decoder's out_channels
+        blocks, prev = [], boc[0]
+        for i, ch in enumerate(boc):
+            blocks.append(DownEncoderBlock2D(prev, ch, c.layers_per_block, g, down=i != len(boc) - 1))
+            prev = ch
+        self.down_blocks = nn.ModuleList(blocks)
+        self.mid_block = MidBlock(boc[-1], g)
+        self.conv_norm_out = nn.GroupNorm(g, boc[-1], eps=1e-6)
+        self.conv_out = nn.Conv2d(boc[-1], 2 * c.latent_channels, 3, padding=1)
+
+    def forward(self, x):
+        h = self.conv_in(x)
+        for b in self.down_blocks:
+            h = b(h)
+        h = self.mid_block(h)
+        return self.conv_out(F.silu(self.conv_norm_out(h)))
+
+
+SD_VAE_ENCODER_PARAMS = 34_163_592
+
+
 def param_count(m):
     return sum(p.numel() for p in m.parameters())
+
+
+def build_encoder(config="sd", seed=0, dtype=torch.float32, device="cpu", **over):
+    cfg = dict(SD_VAE_DECODER_CONFIG if config == "sd" else tiny_config())
+    cfg.update(over)
+    torch.manual_seed(seed)
+    m = Encoder(**cfg).to(device=device, dtype=dtype).eval()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    return m
 
 
 def build(config="sd", seed=0, dtype=torch.float32, device="cpu", **over):
@@ -142,4 +208,4 @@ def build(config="sd", seed=0, dtype=torch.float32, device="cpu", **over):
     return m
 
 
-__all__ = ["Decoder", "build", "tiny_config", "param_count", "SD_VAE_DECODER_CONFIG", "SD_VAE_DECODER_PARAMS", "math"]
+__all__ = ["Decoder", "Encoder", "build", "build_encoder", "SD_VAE_ENCODER_PARAMS", "tiny_config", "param_count", "SD_VAE_DECODER_CONFIG", "SD_VAE_DECODER_PARAMS", "math"]

@@ -59,8 +59,8 @@ struct ConvGeom {
 ConvGeom conv_geom(const sfast_conv_params *p, const void *z) {
     ConvGeom g{};
     const int Hin = p->upsample2x ? 2 * p->H : p->H, Win = p->upsample2x ? 2 * p->W : p->W;
-    g.Ho = (Hin + 2 * p->pad_h - p->dil_h * (p->KH - 1) - 1) / p->stride_h + 1;
-    g.Wo = (Win + 2 * p->pad_w - p->dil_w * (p->KW - 1) - 1) / p->stride_w + 1;
+    g.Ho = (Hin + 2 * p->pad_h + p->pad_h_extra - p->dil_h * (p->KH - 1) - 1) / p->stride_h + 1;
+    g.Wo = (Win + 2 * p->pad_w + p->pad_w_extra - p->dil_w * (p->KW - 1) - 1) / p->stride_w + 1;
     const int C1 = p->C1, C2 = p->Cin - p->C1;
     g.x_dense = p->xs[3] == 1 && p->xs[2] == C1 && p->xs[1] == (int64_t)p->W * C1 && p->xs[0] == (int64_t)p->H * p->W * C1;
     g.x2_dense = C2 == 0 || (p->x2s[3] == 1 && p->x2s[2] == C2 && p->x2s[1] == (int64_t)p->W * C2 &&
@@ -121,7 +121,8 @@ int validate_conv(const void *x, const void *x2, const void *w, const void *out,
     SFAST_REQUIRE(p && x && w && out, SFAST_ERR_INVALID, "conv2d: null argument");
     SFAST_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0 && p->Cin > 0 && p->Cout > 0 && p->KH > 0 && p->KW > 0,
                   SFAST_ERR_INVALID, "conv2d: bad shape");
-    SFAST_REQUIRE(p->stride_h > 0 && p->stride_w > 0 && p->dil_h > 0 && p->dil_w > 0 && p->pad_h >= 0 && p->pad_w >= 0,
+    SFAST_REQUIRE(p->stride_h > 0 && p->stride_w > 0 && p->dil_h > 0 && p->dil_w > 0 && p->pad_h >= 0 && p->pad_w >= 0 &&
+                      p->pad_h_extra >= 0 && p->pad_w_extra >= 0,
                   SFAST_ERR_INVALID, "conv2d: bad stride/dilation/padding");
     SFAST_REQUIRE(p->C1 > 0 && p->C1 <= p->Cin, SFAST_ERR_INVALID, "conv2d: bad C1=%d", p->C1);
     SFAST_REQUIRE(p->C1 == p->Cin || x2, SFAST_ERR_INVALID, "conv2d: concat needs x2");

@@ -417,8 +417,9 @@ def _looks_like_vae_decoder(d):
 
 def compile_vae(m, config):
     # reference: compilers/diffusion_pipeline_compiler.py:154-190 (memory format, xformers patch, TorchScript fusion of the
-    # whole VAE; CUDA graphs deliberately left off there). Here the DECODER -- the part every text-to-image call runs --
-    # is handed to the native engine; the encoder keeps running on PyTorch-ROCm.
+    # whole VAE; CUDA graphs deliberately left off there). Here the decoder (every text-to-image call) and the encoder
+    # (img2img / inpainting) are handed to the native engine; quant_conv / post_quant_conv
+    # (1x1, 8 / 4 channels) and the Gaussian sampling stay on PyTorch-ROCm.
     device = _device_of(m)
     enable_cuda_graph = config.enable_cuda_graph and device.type == "cuda"
     if config.memory_format is not None:
@@ -435,4 +436,18 @@ def compile_vae(m, config):
         if native is not None:
             dec.forward = _NativeVaeDecoderForward(dec, native, dec.forward, enable_cuda_graph)
             m._sfast_vae_engine = native
+    enc = getattr(m, "encoder", None)
+    if config.enable_jit and device.type == "cuda" and enc is not None and all(
+            hasattr(enc, a) for a in ("conv_in", "down_blocks", "mid_block", "conv_norm_out", "conv_out")):
+        from ..engine import UnsupportedUNet, VaeEncoderEngine
+        try:
+            native_enc = VaeEncoderEngine.from_module(enc, config=getattr(m, "config", None))
+        except UnsupportedUNet as e:
+            logger.warning("sfast: %s is outside the native VAE engine's coverage (%s); keeping the eager encoder",
+                           type(enc).__name__, e)
+            native_enc = None
+        if native_enc is not None:
+            # same wrapper: one NCHW tensor in, one NCHW tensor out, per-shape plan cache (+ hipGraph)
+            enc.forward = _NativeVaeDecoderForward(enc, native_enc, enc.forward, enable_cuda_graph)
+            m._sfast_vae_encoder_engine = native_enc
     return m

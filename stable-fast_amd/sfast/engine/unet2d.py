@@ -367,7 +367,7 @@ class UNet2DEngine:
                   tune=(p, launch_with), lane=lane)
 
     def _op_conv(self, plan, name, x, x2, w, bias, out, B, H, W, C1, C2, Cout, k, stride, pad, *, ups=False, rowbias=None,
-                 ld_rowbias=0, rowbias_offset=0, z=None, xs=None, os_=None, kind=None, act=L.ACT_NONE):
+                 ld_rowbias=0, rowbias_offset=0, z=None, xs=None, os_=None, kind=None, act=L.ACT_NONE, pad_extra=0):
         lib = self.lib
         Cin = C1 + C2
         p = L.ConvParams()
@@ -377,8 +377,9 @@ class UNet2DEngine:
         p.dil_h = p.dil_w = 1
         p.upsample2x, p.C1 = int(ups), C1
         Hin, Win = (2 * H, 2 * W) if ups else (H, W)
-        Ho = (Hin + 2 * pad - (k - 1) - 1) // stride + 1
-        Wo = (Win + 2 * pad - (k - 1) - 1) // stride + 1
+        Ho = (Hin + 2 * pad + pad_extra - (k - 1) - 1) // stride + 1
+        Wo = (Win + 2 * pad + pad_extra - (k - 1) - 1) // stride + 1
+        p.pad_h_extra = p.pad_w_extra = pad_extra
         p.xs = (C.c_int64 * 4)(*(xs or (H * W * C1, W * C1, C1, 1)))
         p.x2s = (C.c_int64 * 4)(*((H * W * C2, W * C2, C2, 1) if C2 else (0, 0, 0, 0)))
         p.ws = (C.c_int64 * 4)(w.stride(0), w.stride(1), w.stride(2), w.stride(3))

@@ -274,3 +274,89 @@ class VaeDecoderEngine(UNet2DEngine):
         self.load_inputs(plan, z)
         plan.run(None if self._emulated else torch.cuda.current_stream(self.device).cuda_stream)
         return plan.static_out.clone()
+
+
+class VaeEncoderEngine(VaeDecoderEngine):
+    """Executor for `AutoencoderKL.encoder` parameter sets: conv_in -> DownEncoderBlock2D x N (ResnetBlock2D pairs, a
+    stride-2 3x3 conv over F.pad(x, (0,1,0,1)) = conv with `pad_extra`) -> mid block -> GroupNorm+SiLU -> conv_out.
+    Output = the moments tensor [B, 2*latent, H/2^(N-1), W/2^(N-1)] (quant_conv and the Gaussian sampling stay in
+    the caller, as in diffusers' AutoencoderKL.encode)."""
+
+    def _parse_config(self):
+        P = self.params
+        g = lambda k, d=None: _cfg_get(self.cfg, k, d)
+        self.in_ch = P["conv_in.weight"].shape[1]
+        self.out_ch = P["conv_out.weight"].shape[0]
+        self.groups = g("norm_num_groups", 32)
+        self.eps = 1e-6
+        n = 0
+        while f"down_blocks.{n}.resnets.0.conv1.weight" in P:
+            n += 1
+        if n == 0:
+            raise UnsupportedVae("no down_blocks.*.resnets found")
+        self.n_down = n
+        self.n_res, self.down_out = [], []
+        for i in range(n):
+            j = 0
+            while f"down_blocks.{i}.resnets.{j}.conv1.weight" in P:
+                j += 1
+            self.n_res.append(j)
+            self.down_out.append(P[f"down_blocks.{i}.resnets.0.conv1.weight"].shape[0])
+        self.mid_ch = P["conv_out.weight"].shape[1]
+        self.has_attn = "mid_block.attentions.0.to_q.weight" in P
+        if not self.has_attn and any(k.startswith("mid_block.attentions.0.") for k in P):
+            raise UnsupportedVae("mid-block attention uses the deprecated query/key/value parameter names")
+        for c in self.down_out:
+            if c % self.groups or c % 8:
+                raise UnsupportedVae(f"channel count {c} (needs a multiple of 8 and of the group count)")
+
+    def build_plan(self, B, H, W, S_ctx=0):
+        if not self._emulated:
+            L.init_device()
+        P = self.params
+        dev, dt = self.device, self.dtype
+        n_ds = sum(1 for i in range(self.n_down) if f"down_blocks.{i}.downsamplers.0.conv.weight" in P)
+        if H % (1 << n_ds) or W % (1 << n_ds):
+            raise UnsupportedVae(f"image {H}x{W} not divisible by {1 << n_ds}")
+        plan = UNetPlan(self, B, H, W, 0)
+        pool = plan.pool = _Pool(dev, dt)
+        img = torch.zeros((B, self.in_ch, H, W), dtype=dt, device=dev)
+        out = torch.zeros((B, self.out_ch, H >> n_ds, W >> n_ds), dtype=dt, device=dev)
+        plan.static_in = {"sample": img}
+        plan.static_out = out
+        c = P["conv_in.weight"].shape[0]
+        h = pool.get(B * H * W * c)
+        self._op_conv(plan, "conv_in", img, None, P["conv_in.weight"], P["conv_in.bias"], h, B, H, W, self.in_ch, 0, c, 3, 1, 1,
+                      xs=(self.in_ch * H * W, W, 1, H * W), kind="conv_in")
+        cH, cW, ch = H, W, c
+        for i in range(self.n_down):
+            co = self.down_out[i]
+            for j in range(self.n_res[i]):
+                hn = self._vae_resnet(plan, f"down_blocks.{i}.resnets.{j}", h, ch, co, B, cH, cW)
+                pool.put(h)
+                h, ch = hn, co
+            dn = f"down_blocks.{i}.downsamplers.0.conv"
+            if (dn + ".weight") in P:
+                hd = pool.get(B * (cH // 2) * (cW // 2) * ch)
+                self._op_conv(plan, dn, h, None, P[dn + ".weight"], P[dn + ".bias"], hd, B, cH, cW, ch, 0, ch, 3, 2, 0, pad_extra=1)
+                pool.put(h)
+                h = hd
+                cH, cW = cH // 2, cW // 2
+        hn = self._vae_resnet(plan, "mid_block.resnets.0", h, ch, ch, B, cH, cW)
+        pool.put(h)
+        h = hn
+        if self.has_attn:
+            hn = self._vae_attention(plan, "mid_block.attentions.0", h, ch, B, cH, cW)
+            pool.put(h)
+            h = hn
+        hn = self._vae_resnet(plan, "mid_block.resnets.1", h, ch, ch, B, cH, cW)
+        pool.put(h)
+        h = hn
+        nout = pool.get(B * cH * cW * ch)
+        self._op_gn(plan, "conv_norm_out", h, None, ch, ch, B, cH * cW, nout, self.eps, True, "conv_norm_out")
+        pool.put(h)
+        self._op_conv(plan, "conv_out", nout, None, P["conv_out.weight"], P["conv_out.bias"], out, B, cH, cW, ch, 0, self.out_ch, 3, 1, 1,
+                      os_=(self.out_ch * cH * cW, cW, 1, cH * cW), kind="conv_out")
+        pool.put(nout)
+        self._finish_plan(plan)
+        return plan

@@ -235,9 +235,10 @@ def _nhwc_strides(t):
 
 def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dilation=1, act=None,
            res_before_act=True, x2=None, upsample2x=False, rowbias=None, variant=0, split_k=0,
-           channels_last_out: Optional[bool] = None):
+           channels_last_out: Optional[bool] = None, pad_extra=0):
     """y = act(conv2d(x, w) + bias + rowbias[b] + alpha*z) on logical NCHW tensors of any strides.
-    x2: optional tensor concatenated to x along channels (virtual). upsample2x: nearest 2x first."""
+    x2: optional tensor concatenated to x along channels (virtual). upsample2x: nearest 2x first.
+    pad_extra: additional zero rows / columns at the bottom / right on top of `padding` (F.pad(x, (0, e, 0, e)))."""
     _require_cuda(x, weight, bias, z, x2, rowbias)
     lib = L.init_device()
     if x.ndim != 4 or weight.ndim != 4:
@@ -254,8 +255,9 @@ def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dila
     if weight.dtype != x.dtype:
         raise L.SfastHipError("conv2d: input / weight dtype mismatch")
     Hin, Win = (2 * H, 2 * W) if upsample2x else (H, W)
-    Ho = (Hin + 2 * ph - dh * (KH - 1) - 1) // sh + 1
-    Wo = (Win + 2 * pw - dw * (KW - 1) - 1) // sw + 1
+    eh, ew = pair(pad_extra)
+    Ho = (Hin + 2 * ph + eh - dh * (KH - 1) - 1) // sh + 1
+    Wo = (Win + 2 * pw + ew - dw * (KW - 1) - 1) // sw + 1
     if channels_last_out is None:
         # cudnn_conv_suggest_memory_format semantics (reference cudnn_convolution_impl.cc:1023-1025)
         def _is_cl(t):
@@ -277,6 +279,7 @@ def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dila
     p = L.ConvParams()
     p.dtype, p.B, p.H, p.W, p.Cin, p.Cout, p.KH, p.KW = _dtype(x), B, H, W, Cin, Cout, KH, KW
     p.stride_h, p.stride_w, p.pad_h, p.pad_w, p.dil_h, p.dil_w = sh, sw, ph, pw, dh, dw
+    p.pad_h_extra, p.pad_w_extra = eh, ew
     p.upsample2x, p.C1 = 1 if upsample2x else 0, C1
     p.xs = _i64x4(_nhwc_strides(x))
     p.x2s = _i64x4(_nhwc_strides(x2) if x2 is not None else (0, 0, 0, 0))

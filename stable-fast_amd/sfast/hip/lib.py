@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "_lib", "libsfast_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # enums (include/sfast_hip.h)
 F16, BF16, F32 = 0, 1, 2
@@ -74,7 +74,8 @@ class ConvParams(C.Structure):
                 ("xs", C.c_int64 * 4), ("x2s", C.c_int64 * 4), ("ws", C.c_int64 * 4),
                 ("os", C.c_int64 * 4), ("zs", C.c_int64 * 4),
                 ("act", C.c_int32), ("res_before_act", C.c_int32), ("alpha", C.c_float),
-                ("ld_rowbias", C.c_int64), ("variant", C.c_int32), ("split_k", C.c_int32)]
+                ("ld_rowbias", C.c_int64), ("variant", C.c_int32), ("split_k", C.c_int32),
+                ("pad_h_extra", C.c_int32), ("pad_w_extra", C.c_int32)]
 
 
 class AttnParams(C.Structure):

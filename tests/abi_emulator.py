@@ -152,8 +152,11 @@ class EmuLib:
         x2in = nchw(x2, C2, p.H, p.W, p.x2s) if C2 else None
         wt = _strided(w, (p.Cout, p.Cin, p.KH, p.KW), tuple(p.ws), p.dtype)
         Hin, Win = (2 * p.H, 2 * p.W) if p.upsample2x else (p.H, p.W)
-        Ho = (Hin + 2 * p.pad_h - p.dil_h * (p.KH - 1) - 1) // p.stride_h + 1
-        Wo = (Win + 2 * p.pad_w - p.dil_w * (p.KW - 1) - 1) // p.stride_w + 1
+        Ho = (Hin + 2 * p.pad_h + p.pad_h_extra - p.dil_h * (p.KH - 1) - 1) // p.stride_h + 1
+        Wo = (Win + 2 * p.pad_w + p.pad_w_extra - p.dil_w * (p.KW - 1) - 1) // p.stride_w + 1
+        if p.pad_h_extra or p.pad_w_extra:  # extra zero rows / columns at the bottom / right (no concat / upsample with it)
+            assert x2in is None and not p.upsample2x
+            xin = torch.nn.functional.pad(xin.float(), (0, p.pad_w_extra, 0, p.pad_h_extra)).to(xin.dtype)
         b = _flat(bias, p.Cout, p.dtype) if bias else None
         rb = _strided(rowbias, (p.B, p.Cout), (p.ld_rowbias, 1), p.dtype) if rowbias else None
         zz = nchw(z, p.Cout, Ho, Wo, p.zs).clone() if z else None

@@ -33,7 +33,7 @@ def test_ctypes_structs_match_the_c_header(built_lib):
                "sfast_temb_params": L.TembParams, "sfast_softmax_params": L.SoftmaxParams, "sfast_image_params": L.ImageParams, "sfast_add_params": L.AddParams}
     body = "".join(f'printf("%zu\\n", sizeof({n}));' for n in structs)
     probes = [("sfast_gemm_params", "ld_rowbias"), ("sfast_gemm_params", "split_k"), ("sfast_conv_params", "xs"),
-              ("sfast_conv_params", "ld_rowbias"), ("sfast_attn_params", "scale"), ("sfast_copy_params", "dst_strides"),
+              ("sfast_conv_params", "ld_rowbias"), ("sfast_conv_params", "pad_w_extra"), ("sfast_attn_params", "scale"), ("sfast_copy_params", "dst_strides"),
               ("sfast_softmax_params", "ldx"), ("sfast_softmax_params", "scale"), ("sfast_image_params", "to_uint8"), ("sfast_add_params", "dst_strides")]
     body += "".join(f'printf("%zu\\n", offsetof({s}, {f}));' for s, f in probes)
     with tempfile.TemporaryDirectory() as d:

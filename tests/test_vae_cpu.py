@@ -125,3 +125,22 @@ def test_image_processor_patch_cpu_tensors_keep_reference_semantics():
     # unsupported processors are left alone (reference :18-20)
     other = object()
     assert patch_image_prcessor(other) is other
+
+
+def test_encoder_topology_and_plan(built_lib):
+    from sfast.engine import VaeEncoderEngine
+    assert V.param_count(V.build_encoder("sd")) == V.SD_VAE_ENCODER_PARAMS == 34_163_592
+    cfg = dict(block_out_channels=(64, 128, 128), norm_num_groups=8, layers_per_block=1)
+    m16 = V.build_encoder("tiny", seed=8, dtype=torch.float16, **cfg)
+    m32 = V.build_encoder("tiny", seed=8, **cfg)
+    m32.load_state_dict({k: v.float() for k, v in m16.state_dict().items()})
+    emu = EmuLib()
+    eng = VaeEncoderEngine.from_module(m16, _lib=emu)
+    x = torch.randn(2, 3, 16, 24, generator=torch.Generator().manual_seed(3)).half()
+    y = eng.forward(x)
+    with torch.no_grad():
+        want = m32(x.float())
+    # two stride-2 convs over F.pad(x, (0,1,0,1)) (conv `pad_extra`): 16x24 -> 4x6, 2*latent channels
+    assert y.shape == (2, 8, 4, 6) and rel_l2(y, want) < 3e-3
+    with pytest.raises(UnsupportedVae):
+        eng.forward(torch.zeros(1, 3, 18, 16).half())  # not divisible by 4

@@ -169,3 +169,49 @@ def test_image_processor_patch_gpu():
     assert got.shape == (64, 64, 3) and diff.max() <= 1 and (diff > 0).mean() < 0.02
     arr = proc.postprocess(img, "np")
     assert arr.shape == (1, 64, 64, 3) and abs(float(arr.mean()) - 0.5) < 0.05
+
+
+def test_conv_pad_extra_matches_f_pad():
+    """ABI 2: `pad_extra` = F.pad(x, (0, e, 0, e)) before the conv (diffusers Downsample2D in the VAE encoder)."""
+    import torch.nn.functional as TF
+    from sfast.hip import functional as F
+    from sfast.hip.lib import last_kernel
+    g = torch.Generator().manual_seed(4)
+    for cin, cout, hw in ((64, 64, 16), (128, 128, 33), (8, 16, 10)):
+        x = torch.randn(2, cin, hw, hw + 2, generator=g).to(DEV, torch.float16).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(DEV, torch.float16).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(cout, generator=g).to(DEV, torch.float16)
+        y = F.conv2d(x, w, b, stride=2, padding=0, pad_extra=1)
+        want = TF.conv2d(TF.pad(x.float(), (0, 1, 0, 1)), w.float(), b.float(), stride=2)
+        compare(f"conv pad_extra {cin}->{cout} @{hw}", y, want, 2e-2, 2e-2, kernel=last_kernel())
+
+
+def test_sd_encoder_parity_and_compile_vae():
+    """Full SD VAE encoder (34.2 M parameters), 256x256 image -> 32x32 moments; then both halves behind compile_vae()."""
+    from sfast.compilers.diffusion_pipeline_compiler import CompilationConfig, compile_vae
+    from sfast.engine import VaeEncoderEngine
+    enc = V.build_encoder("sd", seed=12, dtype=torch.float16, device=DEV)
+    ref = V.build_encoder("sd", seed=12)
+    ref.load_state_dict({k: v.float().cpu() for k, v in enc.state_dict().items()})
+    x = (torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(6)) * 2 - 1).to(DEV, torch.float16)
+    y = VaeEncoderEngine.from_module(enc).forward(x)
+    with torch.no_grad():
+        want = ref(x.float().cpu())
+        eager16 = enc(x)
+    e_eng, e_eager = rel_l2(y.float().cpu(), want), rel_l2(eager16.float().cpu(), want)
+    log_value("sd vae encoder 256x256 image", engine_vs_fp32=e_eng, eager16_vs_fp32=e_eager)
+    assert y.shape == (1, 8, 32, 32) and torch.isfinite(y).all()
+    assert e_eng < 4e-3 and e_eng < 1.5 * e_eager + 1e-3, (e_eng, e_eager)
+    # compile_vae patches encoder and decoder
+    cfg = dict(block_out_channels=(64, 128), norm_num_groups=8, layers_per_block=1)
+    vae = types.SimpleNamespace(encoder=V.build_encoder("tiny", seed=5, dtype=torch.float16, device=DEV, **cfg),
+                                decoder=V.build("tiny", seed=6, dtype=torch.float16, device=DEV, **cfg), device=torch.device(DEV),
+                                config=types.SimpleNamespace(norm_num_groups=8))
+    eager_enc = V.build_encoder("tiny", seed=5, dtype=torch.float16, device=DEV, **cfg)
+    c = CompilationConfig.Default()
+    c.memory_format = None
+    compile_vae(vae, c)
+    assert hasattr(vae, "_sfast_vae_encoder_engine") and hasattr(vae, "_sfast_vae_engine")
+    img = torch.randn(2, 3, 16, 16, generator=torch.Generator().manual_seed(7)).to(DEV, torch.float16)
+    with torch.no_grad():
+        assert rel_l2(vae.encoder(img).float(), eager_enc(img).float()) < 1e-2
