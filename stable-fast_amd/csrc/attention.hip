@@ -41,7 +41,10 @@ struct AttnArgs {
     int B, H, Sq, Skv, D;
     int64_t qs[3], ks[3], vs[3], os[3];
     float scale, scale_log2e;
+    uint32_t kspan, vspan;      // bytes spanned by the K / V rows of one (batch, head): buffer-descriptor ranges
+    unsigned long long *trace;  // profiling only (sfast_hip_set_trace): per-workgroup shader-cycle split of the tile loop
 };
+extern unsigned long long *g_igemm_trace;  // igemm_glds.hip
 
 __device__ __forceinline__ f32x16 amfma32(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -57,10 +60,22 @@ template <int D> struct AttnGeom {
     static constexpr int VSTR = 68;                // V^T tile row stride (halves): 136 B
     static constexpr int STAGE = 64 * KSTR * 2 + DO * VSTR * 2;
     static constexpr int LDS = 2 * STAGE;          // double-buffered K / V^T tiles
+    static constexpr int LDS_TOTAL = LDS + 4096 + 16 * VSTR;  // + dump area for idle staging lanes
 };
 
-template <typename T, int D, int NW>
+// TRACE = 1 (profiling instantiation, chosen while a trace buffer is set): wave 0 sums s_memtime deltas of the tile
+// phases -- record [top, phase 1, phase 2, barrier wait, whole kernel, tiles] per workgroup (tools/attn_ab.py --trace).
+template <typename T, int D, int NW, int TRACE = 0>
 __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
+    unsigned long long tr_acc[4] = {0, 0, 0, 0}, tr_t0 = 0, tr_last = 0;
+    if constexpr (TRACE) tr_t0 = __builtin_amdgcn_s_memtime();
+    auto tr_mark = [&](int slot) __attribute__((always_inline)) {
+        if constexpr (TRACE) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (slot >= 0) tr_acc[slot] += now - tr_last;
+            tr_last = now;
+        }
+    };
     using vec8 = typename Elem<T>::vec8;
     using G = AttnGeom<D>;
     constexpr int NT = NW * 64;
@@ -117,48 +132,78 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
     u32x4 kreg[KTASK];
     u32x4 vreg[VTASK][2];
 
-    auto prefetch = [&](int kt) {
-        const int key0 = kt * 64;
+    // LDS destinations of this thread's staging tasks, per stage. Idle lanes (the ragged last task) write to a DUMP area
+    // behind the stages instead of being masked off: exec-masked stores would split the tile body into basic blocks,
+    // and the body must stay ONE block for the MFMA / VALU interleave below.
+    constexpr int DUMP = G::LDS;
+    int kdst[2][KTASK], vdst[2][VTASK];
+#pragma unroll
+    for (int i = 0; i < KTASK; ++i) {
+        const int id = tid + i * NT;
+        const int key = id / KCH, ch = id - key * KCH;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) kdst[st][i] = id < 64 * KCH ? st * STAGE + key * (KSTR * 2) + ch * 16 : DUMP + tid * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < VTASK; ++i) {
+        const int id = tid + i * NT;
+        const int kp = id & 31, ch = id >> 5;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+            vdst[st][i] = ch < VCH ? st * STAGE + 64 * KSTR * 2 + (ch * 8) * (VSTR * 2) + kp * 4 : DUMP + tid * 4;
+    }
+
+    // K / V tiles arrive through raw buffer loads: one descriptor per operand covering the rows of this (batch, head), a
+    // per-lane byte offset advanced by ONE v_add per tile (64-bit address arithmetic per load cost ~250 cycles a tile,
+    // profiles/r01_attn_phase_trace.log). Rows past Skv, the zero padding of the head dim and idle lanes are out of range
+    // of the descriptor and read as 0; idle lanes sit at 2^31, which the advance cannot wrap (spans are < 2^31 bytes).
+    auto make_srd = [&](const T *base, uint32_t bytes) __attribute__((always_inline)) {
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)base);
+        const uint32_t hi32 = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)base >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(((uintptr_t)hi32 << 32) | lo), 0, (int)bytes, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t ksrd = make_srd(Kp, a.kspan), vsrd = make_srd(Vp, a.vspan);
+    const uint32_t ktile_bytes = (uint32_t)a.ks[1] * 128u, vtile_bytes = (uint32_t)a.vs[1] * 128u;
+    uint32_t koff[KTASK], voff[VTASK][2];
+#pragma unroll
+    for (int i = 0; i < KTASK; ++i) {
+        const int id = tid + i * NT;
+        const int key = id / KCH, ch = id - key * KCH;
+        koff[i] = (id < 64 * KCH && ch * 8 < D) ? ((uint32_t)key * (uint32_t)a.ks[1] + ch * 8) * 2u : 0x80000000u;
+    }
+#pragma unroll
+    for (int i = 0; i < VTASK; ++i) {
+        const int id = tid + i * NT;
+        const int kp = id & 31, ch = id >> 5;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            voff[i][j] = ch < VCH ? ((uint32_t)(2 * kp + j) * (uint32_t)a.vs[1] + ch * 8) * 2u : 0x80000000u;
+    }
+    // each call fetches the NEXT tile (tiles are requested strictly in order)
+    auto prefetch_k = [&](u32x4 (&dst)[KTASK]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < KTASK; ++i) {
-            const int id = tid + i * NT;
-            const int key = id / KCH, ch = id - key * KCH;
-            const bool ok = id < 64 * KCH && (key0 + key) < a.Skv && ch * 8 < D;
-            kreg[i] = ldg16(Kp + (int64_t)(key0 + key) * a.ks[1] + ch * 8, ok);
-        }
-#pragma unroll
-        for (int i = 0; i < VTASK; ++i) {
-            const int id = tid + i * NT;
-            const int kp = id & 31, ch = id >> 5;
-            const int key = key0 + 2 * kp;
-            const bool in = ch < VCH;
-            vreg[i][0] = ldg16(Vp + (int64_t)key * a.vs[1] + ch * 8, in && key < a.Skv);
-            vreg[i][1] = ldg16(Vp + (int64_t)(key + 1) * a.vs[1] + ch * 8, in && key + 1 < a.Skv);
+            dst[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ksrd, koff[i], 0, 0));
+            koff[i] += ktile_bytes;
         }
     };
-    auto stage = [&](int st) {
-        char *Ksm = smem + st * STAGE;
-        char *Vsm = Ksm + 64 * KSTR * 2;
+    auto prefetch_v = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < KTASK; ++i) {
-            const int id = tid + i * NT;
-            const int key = id / KCH, ch = id - key * KCH;
-            if (id < 64 * KCH) *reinterpret_cast<u32x4 *>(Ksm + key * (KSTR * 2) + ch * 16) = kreg[i];
-        }
+        for (int i = 0; i < VTASK; ++i)
 #pragma unroll
-        for (int i = 0; i < VTASK; ++i) {
-            const int id = tid + i * NT;
-            const int kp = id & 31, ch = id >> 5;
-            if (ch < VCH) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const uint32_t w0 = vreg[i][0][e >> 1], w1 = vreg[i][1][e >> 1];
-                    const uint32_t lo = (e & 1) ? (w0 >> 16) : (w0 & 0xffffu);
-                    const uint32_t hi16 = (e & 1) ? (w1 & 0xffff0000u) : (w1 << 16);
-                    *reinterpret_cast<uint32_t *>(Vsm + (ch * 8 + e) * (VSTR * 2) + kp * 4) = lo | hi16;
-                }
+            for (int j = 0; j < 2; ++j) {
+                vreg[i][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vsrd, voff[i][j], 0, 0));
+                voff[i][j] += vtile_bytes;
             }
-        }
+    };
+    auto stage_k_one = [&](int st, int i, const u32x4 (&src)[KTASK]) __attribute__((always_inline)) {
+        *reinterpret_cast<u32x4 *>(smem + kdst[st][i]) = src[i];
+    };
+    // V^T element e of task i: keys (2kp, 2kp+1) of channel ch*8+e packed into one dword -- one v_perm_b32
+    auto stage_v_one = [&](int st, int i, int e) __attribute__((always_inline)) {
+        const uint32_t w0 = vreg[i][0][e >> 1], w1 = vreg[i][1][e >> 1];
+        const uint32_t packed = __builtin_amdgcn_perm(w1, w0, (e & 1) ? 0x07060302u : 0x05040100u);
+        *reinterpret_cast<uint32_t *>(smem + vdst[st][i] + e * (VSTR * 2)) = packed;
     };
 
     f32x16 o[DB];
@@ -169,48 +214,97 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
     // running max is tracked on the RAW scores; the softmax scale (> 0) is folded into the exp2 argument
     float m_run = -INFINITY, l_run = 0.f;
     const float c = a.scale_log2e;
-
     const int ntiles = (a.Skv + 63) / 64;
-    prefetch(0);
-    stage(0);
-    __syncthreads();
 
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const bool more = kt + 1 < ntiles;
-        const int cur = kt & 1;
-        const char *Ksm = smem + cur * STAGE;
-        const char *Vsm = Ksm + 64 * KSTR * 2;
-        if (more) prefetch(kt + 1);
+    // S^T tiles: s[t & 1] holds tile t. The loop is software-pipelined over tiles: iteration t issues the QK^T MFMAs of
+    // tile t+1 BETWEEN the exp2 chunks of tile t, and the PV MFMAs of tile t between the row-max of tile t+1 and the LDS
+    // staging of the tiles after it. On gfx950 an MFMA only overlaps with VALU work placed behind it in the SAME wave
+    // (tools/micro/overlap.hip: 5 v_fma/v_max3/v_cvt per MFMA are free in-wave, while the same instructions issued by a
+    // second wave of the SIMD serialise with the MFMA), and the old tile loop measured as the plain SUM of its MFMA,
+    // softmax and staging time (profiles/r01_attn_loop_experiments.log) -- so the interleave is spelled out with
+    // sched_barriers instead of being left to occupancy.
+    f32x16 s[2][2];
+    float mloc;  // row max of the tile about to be exponentiated (own half-wave merged with the other)
 
-        // ---- S^T = K . Q^T  (two 32-key blocks) ----------------------------------------------------
-        f32x16 s[2];
+    auto qk_frag = [&](const char *Ksm, int kb, int kd) __attribute__((always_inline)) -> vec8 {
+        return *reinterpret_cast<const vec8 *>(Ksm + (kb * 32 + l31) * (KSTR * 2) + (kd * 16 + hi * 8) * 2);
+    };
+    auto row_max = [&](const f32x16 (&t)[2]) __attribute__((always_inline)) -> float {
+        float m = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, t[kb][r]);
+        return fmaxf(m, __shfl_xor(m, 32, 64));
+    };
+
+    // K runs one tile further ahead than V: iteration t multiplies with the K(t+1) fragments it READ during iteration t-1
+    // (kf, registers), reads the K(t+2) fragments from LDS under its PV MFMAs and stages K(t+3) -- so no LDS latency sits
+    // between the barrier and the first MFMA. Tile j of K / V lives in stage j & 1.
+    vec8 kf[2][KD];
+    auto read_kf = [&](const char *Ksm) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kd = 0; kd < KD; ++kd)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) kf[kb][kd] = qk_frag(Ksm, kb, kd);
+    };
+
+    // prologue: all four tile loads in flight at once; K(0), V(0) -> stage 0, K(1) -> stage 1; S(0) = K(0) . Q^T and
+    // kf = K(1) fragments; then K(2) -> stage 0 and the loads of K(3), V(1) that iteration 0 stages.
+    {
+        u32x4 k1[KTASK], k2[KTASK];
+        prefetch_k(kreg);
+        prefetch_v();
+        prefetch_k(k1);
+        prefetch_k(k2);
+#pragma unroll
+        for (int i = 0; i < KTASK; ++i) stage_k_one(0, i, kreg);
+#pragma unroll
+        for (int i = 0; i < VTASK; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) stage_v_one(0, i, e);
+#pragma unroll
+        for (int i = 0; i < KTASK; ++i) stage_k_one(1, i, k1);
+        __syncthreads();
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+            for (int r = 0; r < 16; ++r) s[0][kb][r] = 0.f;
 #pragma unroll
-            for (int kd = 0; kd < KD; ++kd) {
-                const vec8 kf = *reinterpret_cast<const vec8 *>(Ksm + (kb * 32 + l31) * (KSTR * 2) + (kd * 16 + hi * 8) * 2);
-                s[kb] = amfma32(kf, qf[kd], s[kb]);
-            }
+            for (int kd = 0; kd < KD; ++kd) s[0][kb] = amfma32(qk_frag(smem, kb, kd), qf[kd], s[0][kb]);
         }
+        read_kf(smem + STAGE);
+        mloc = row_max(s[0]);
+        prefetch_k(kreg);  // K(3), V(1): staged by iteration 0
+        prefetch_v();
+        __syncthreads();  // every wave has read K(0) and K(1)
+#pragma unroll
+        for (int i = 0; i < KTASK; ++i) stage_k_one(0, i, k2);
+        __syncthreads();  // K(2) visible
+    }
 
-        // ---- online softmax (fp32, base-2) -------------------------------------------------------------
-        if ((kt + 1) * 64 > a.Skv) {  // tail tile: mask keys >= Skv
+    constexpr int NQK = 2 * KD;  // QK^T MFMAs per tile
+    constexpr int NPV = 4 * DB;  // PV MFMAs per tile
+    constexpr int NVE = VTASK * 8;
+    using Buf0 = std::integral_constant<int, 0>;
+    using Buf1 = std::integral_constant<int, 1>;
+
+    auto tile = [&](int kt, auto CUR) __attribute__((always_inline)) {
+        constexpr int cur = decltype(CUR)::value, nxt = cur ^ 1;
+        const char *Kn2 = smem + cur * STAGE;                    // K(kt+2)
+        const char *Vcu = smem + cur * STAGE + 64 * KSTR * 2;    // V^T(kt)
+
+        tr_mark(-1);
+        if ((kt + 1) * 64 > a.Skv) {  // tail tile (once per kernel): mask keys >= Skv, redo the row max
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key >= a.Skv) s[kb][r] = -INFINITY;
+                    if (key >= a.Skv) s[cur][kb][r] = -INFINITY;
                 }
+            mloc = row_max(s[cur]);
         }
-        float mloc = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[kb][r]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         // exact lazy rescale: O and l only need rescaling when some row's running max actually grows
         if (__any(mloc > m_run)) {
             const float m_new = fmaxf(m_run, mloc);
@@ -224,62 +318,121 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
         }
         const float mc = m_run * c;
         float rowsum = 0.f;
+
+        // V^T(kt) fragments are read during phase 1: their LDS latency runs under it instead of stalling the PV MFMAs (with
+        // one or two waves per SIMD nothing else hides it -- phase 2 measured 870 cycles for 8 MFMAs before this)
+        auto v_frag = [&](int grp, int db) __attribute__((always_inline)) -> u32x4 {
+            const int base = (grp >> 1) * 32 + 16 * (grp & 1) + 4 * hi;
+            const char *vrow = Vcu + (db * 32 + l31) * (VSTR * 2);
+            const u32x2 v0 = *reinterpret_cast<const u32x2 *>(vrow + base * 2);
+            const u32x2 v1 = *reinterpret_cast<const u32x2 *>(vrow + (base + 8) * 2);
+            return u32x4{v0[0], v0[1], v1[0], v1[1]};
+        };
+        u32x4 vf[4][DB];
+        // ---- phase 1: S^T(kt+1) = K . Q^T  ||  P(kt) = exp2(S(kt) * c - m * c) ---------------------------------------
+        __builtin_amdgcn_sched_barrier(0);
+        tr_mark(0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int g = 0; g < NQK; ++g) {
+            const int kd = g >> 1, kb = g & 1;  // alternate the two accumulators
+            if (kd == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, -mc));
-                s[kb][r] = p;
-                if constexpr (!MFMA_ROWSUM) rowsum += p;
+                for (int r = 0; r < 16; ++r) s[nxt][kb][r] = 0.f;
             }
+            s[nxt][kb] = amfma32(kf[kb][kd], qf[kd], s[nxt][kb]);
+            __builtin_amdgcn_sched_barrier(0);
+            // a slice of the V^T(kt) fragment reads per gap: spread, the four waves of the workgroup do not hit the LDS
+            // with 8 KB each right behind the barrier
+#pragma unroll
+            for (int j = g * NPV / NQK; j < (g + 1) * NPV / NQK; ++j) vf[j / DB][j % DB] = v_frag(j / DB, j % DB);
+#pragma unroll
+            for (int e = g * 32 / NQK; e < (g + 1) * 32 / NQK; ++e) {
+                const float pr = __builtin_amdgcn_exp2f(fmaf(s[cur][e >> 4][e & 15], c, -mc));
+                s[cur][e >> 4][e & 15] = pr;
+                if constexpr (!MFMA_ROWSUM) rowsum += pr;
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (!MFMA_ROWSUM) l_run += rowsum;
+        tr_mark(1);
+        __builtin_amdgcn_sched_barrier(0);
 
-        // ---- P^T fragments: registers [8*s2, 8*s2+8) of block kb, converted in place -----------------
-        vec8 pf[2][2];
+        // ---- phase 2: O^T += V^T . P^T  ||  row max of S(kt+1), staging of K(kt+3) / V(kt+1) ---------------------------
+        float mpart[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int grp = 0; grp < 4; ++grp) {
+            const int kb = grp >> 1, s2 = grp & 1;
+            // P^T fragment: registers [8*s2, 8*s2+8) of block kb, converted in place
+            vec8 pf;
+            if constexpr (std::is_same<T, f16>::value && MFMA_ROWSUM) {
+                // f16: packed round-toward-zero converts (one instruction per pair instead of three). The denominator comes
+                // from the SAME rounded probabilities through the ones-row, so the rounding bias cancels in O / l.
+                u32x4 w;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
+                for (int jj = 0; jj < 4; ++jj)
+                    w[jj] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(s[cur][kb][8 * s2 + 2 * jj], s[cur][kb][8 * s2 + 2 * jj + 1]));
+                pf = __builtin_bit_cast(vec8, w);
+            } else {
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) pf[kb][s2][jj] = Elem<T>::from_f32(s[kb][8 * s2 + jj]);
-        if constexpr (std::is_same<T, f16>::value && MFMA_ROWSUM) {
-            // f16: packed round-toward-zero converts (one instruction per pair instead of three). The denominator comes
-            // from the SAME rounded probabilities through the ones-row, so the rounding bias cancels in O / l.
+                for (int jj = 0; jj < 8; ++jj) pf[jj] = Elem<T>::from_f32(s[cur][kb][8 * s2 + jj]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int db = 0; db < DB; ++db) {
+                const int gap = grp * DB + db;
+                o[db] = amfma32(__builtin_bit_cast(vec8, vf[grp][db]), pf, o[db]);
+                __builtin_amdgcn_sched_barrier(0);
+                // fillers: first half of the gaps take the 16 max3 of S(kt+1), second half the V^T staging, the last the K rows
+                if (gap < NPV / 2) {
+                    // K(kt+2) fragments for the next iteration's phase 1, a slice per gap
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    u32x4 w;
+                    for (int j = gap * NQK / (NPV / 2); j < (gap + 1) * NQK / (NPV / 2); ++j) kf[j & 1][j >> 1] = qk_frag(Kn2, j & 1, j >> 1);
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-                        w[jj] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(s[kb][8 * s2 + 2 * jj], s[kb][8 * s2 + 2 * jj + 1]));
-                    pf[kb][s2] = __builtin_bit_cast(vec8, w);
+                    for (int j = gap * 16 / (NPV / 2); j < (gap + 1) * 16 / (NPV / 2); ++j)
+                        // volatile asm: a plain fmaxf is not ordered against sched_barrier and sinks behind the last MFMA
+                        asm volatile("v_max3_f32 %0, %0, %1, %2"
+                                     : "+v"(mpart[j & 3])
+                                     : "v"(s[nxt][j >> 3][2 * (j & 7)]), "v"(s[nxt][j >> 3][2 * (j & 7) + 1]));
+                } else {
+                    const int hgap = gap - NPV / 2, nh = NPV - NPV / 2;
+#pragma unroll
+                    for (int j = hgap * NVE / nh; j < (hgap + 1) * NVE / nh; ++j) stage_v_one(nxt, j >> 3, j & 7);
+                    if (gap == NPV - 1) {
+#pragma unroll
+                        for (int i = 0; i < KTASK; ++i) stage_k_one(nxt, i, kreg);
+                    }
                 }
-        }
-
-        // ---- O^T += V^T . P^T ------------------------------------------------------------------------------
-#pragma unroll
-        for (int db = 0; db < DB; ++db) {
-            const char *vrow = Vsm + (db * 32 + l31) * (VSTR * 2);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const int base = kb * 32 + 16 * s2 + 4 * hi;
-                    const u32x2 v0 = *reinterpret_cast<const u32x2 *>(vrow + base * 2);
-                    const u32x2 v1 = *reinterpret_cast<const u32x2 *>(vrow + (base + 8) * 2);
-                    const u32x4 vv = {v0[0], v0[1], v1[0], v1[1]};
-                    o[db] = amfma32(__builtin_bit_cast(vec8, vv), pf[kb][s2], o[db]);
-                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-
-        // stage tile kt+1 into the OTHER buffer (last read in iteration kt-1, before the previous barrier)
-        if (more) stage(cur ^ 1);
+        // the staging registers are free again: global loads of K(kt+4), V(kt+2), staged by the NEXT iteration's phase 2 --
+        // a full iteration of flight time. Tiles past the end are out of range and read 0 (unconditional: no branch here).
+        prefetch_k(kreg);
+        prefetch_v();
+        const float m4 = fmaxf(fmaxf(mpart[0], mpart[1]), fmaxf(mpart[2], mpart[3]));
+        mloc = fmaxf(m4, __shfl_xor(m4, 32, 64));
+        tr_mark(2);
         __syncthreads();
-    }
+        tr_mark(3);
+    };
 
+    // whole pairs in the loop, an odd last tile after it (the S buffers and LDS stages are compile-time per half)
+    int kt = 0;
+    for (; kt + 1 < ntiles; kt += 2) {
+        tile(kt, Buf0{});
+        tile(kt + 1, Buf1{});
+    }
+    if (kt < ntiles) tile(kt, Buf0{});
+
+    if constexpr (TRACE) {
+        if (a.trace != nullptr && tid == 0) {
+            unsigned long long *rec = a.trace + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16;
+            for (int i = 0; i < 4; ++i) rec[i] = tr_acc[i];
+            rec[4] = __builtin_amdgcn_s_memtime() - tr_t0;
+            rec[5] = ntiles;
+        }
+    }
     // ---- epilogue: normalise and store 4 consecutive d per lane ----------------------------------------
     float l_tot;
     if constexpr (MFMA_ROWSUM) {
@@ -347,7 +500,7 @@ __global__ void __launch_bounds__(64) attn_naive_kernel(const AttnArgs a) {
 template <typename T, int D, int NW> static int attn_set_attr() {
     auto kern = attn_fwd_kernel<T, D, NW>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       AttnGeom<D>::LDS);
+                                       AttnGeom<D>::LDS_TOTAL);
     if (e != hipSuccess) {
         set_error("hipFuncSetAttribute(attn D=%d): %s", D, hipGetErrorString(e));
         return SFAST_ERR_LAUNCH;
@@ -374,10 +527,16 @@ int attention_init() {
 template <typename T, int D>
 static int attn_launch_d(const AttnArgs &a, int nw, hipStream_t st) {
     const dim3 grid(ceil_div(a.Sq, nw * 32), a.H, a.B);
+    if constexpr (std::is_same<T, f16>::value && (D == 40 || D == 64)) {
+        if (a.trace != nullptr && nw == 4) {
+            hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1>), grid, dim3(256), AttnGeom<D>::LDS_TOTAL, st, a);
+            return check_launch("attention(trace)");
+        }
+    }
     if (nw == 2)
-        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2>), grid, dim3(128), AttnGeom<D>::LDS, st, a);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2>), grid, dim3(128), AttnGeom<D>::LDS_TOTAL, st, a);
     else
-        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4>), grid, dim3(256), AttnGeom<D>::LDS, st, a);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4>), grid, dim3(256), AttnGeom<D>::LDS_TOTAL, st, a);
     return check_launch("attention");
 }
 
@@ -404,6 +563,7 @@ extern "C" int sfast_hip_attention(const void *q, const void *k, const void *v, 
     SFAST_REQUIRE(p->B > 0 && p->H > 0 && p->Sq > 0 && p->Skv > 0 && p->D > 0, SFAST_ERR_INVALID, "attention: bad shape");
     hipStream_t st = (hipStream_t)stream;
     AttnArgs a{};
+    a.trace = g_igemm_trace;
     a.q = q;
     a.k = k;
     a.v = v;
@@ -426,6 +586,12 @@ extern "C" int sfast_hip_attention(const void *q, const void *k, const void *v, 
     bool vec = half && d_ok && aligned16(q) && aligned16(k) && aligned16(v) && aligned8(out);
     for (int i = 0; i < 3; ++i)
         vec = vec && p->qs[i] % 8 == 0 && p->ks[i] % 8 == 0 && p->vs[i] % 8 == 0 && p->os[i] % 4 == 0;
+    // buffer-descriptor ranges of the MFMA kernel: the K / V rows of one (batch, head), < 2^31 bytes each
+    const int64_t kspan = p->ks[1] > 0 ? ((int64_t)(p->Skv - 1) * p->ks[1] + p->D) * 2 : -1;
+    const int64_t vspan = p->vs[1] > 0 ? ((int64_t)(p->Skv - 1) * p->vs[1] + p->D) * 2 : -1;
+    vec = vec && kspan > 0 && vspan > 0 && kspan < (1ll << 31) && vspan < (1ll << 31);
+    a.kspan = (uint32_t)kspan;
+    a.vspan = (uint32_t)vspan;
     if (vec && p->variant != 100 && p->scale > 0.f) {
         int nw = 4;
         const int64_t blocks4 = (int64_t)ceil_div(p->Sq, 128) * p->H * p->B;

@@ -1,0 +1,62 @@
+"""A/B timing of sfast_hip_attention at the UNet's shapes. usage: attn_ab.py [lib-path]  (env SFAST_ATTN_OCC3 switches)"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "stable-fast_amd"))
+import torch  # noqa: E402
+
+from sfast.hip import lib as L  # noqa: E402
+
+if len(sys.argv) > 1 and not sys.argv[1].startswith("--"):
+    L.LIB_PATH = os.path.abspath(sys.argv[1])
+from sfast.hip import functional as F  # noqa: E402
+
+SHAPES = [  # (B, Sq, Skv, H, D)
+    (2, 4096, 4096, 8, 40), (2, 1024, 1024, 8, 80), (2, 256, 256, 8, 160), (2, 4096, 77, 8, 40),
+    (2, 4096, 4096, 10, 64), (2, 1024, 1024, 20, 64), (2, 1024, 77, 20, 64),
+]
+EXP = os.environ.get("SFAST_ATTN_EXP")
+if EXP:
+    SHAPES = SHAPES[:1]
+torch.manual_seed(0)
+out = []
+for B, Sq, Skv, H, D in SHAPES:
+    q = torch.randn(B, Sq, H, D, device="cuda", dtype=torch.float16)
+    k = torch.randn(B, Skv, H, D, device="cuda", dtype=torch.float16)
+    v = torch.randn(B, Skv, H, D, device="cuda", dtype=torch.float16)
+    for _ in range(5):
+        o = F.attention(q, k, v)
+    ref = torch.nn.functional.scaled_dot_product_attention(q.transpose(1, 2).float(), k.transpose(1, 2).float(),
+                                                           v.transpose(1, 2).float()).transpose(1, 2)
+    err = (o.float() - ref).abs().max().item()
+    best = 1e9
+    for rep in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(40):
+            F.attention(q, k, v)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / 40 * 1e3)
+    fl = 4.0 * B * H * Sq * Skv * D
+    out.append(f"D={D:3d} Sq={Sq:4d} Skv={Skv:4d} H={H:2d}: {best:7.1f} us  {fl / best / 1e6:6.1f} TF  err {err:.1e}")
+if "--trace" in sys.argv:
+    import numpy as np
+    lib = L.load()
+    for B, Sq, Skv, H, D in [(1, 4096, 4096, 8, 40), (2, 4096, 4096, 8, 40), (4, 4096, 4096, 8, 40), (2, 4096, 4096, 10, 64)]:
+        q, k, v = [torch.randn(B, S_, H, D, device="cuda", dtype=torch.float16) for S_ in (Sq, Skv, Skv)]
+        trace = torch.zeros(16 * 8192, dtype=torch.int64, device="cuda")
+        lib.sfast_hip_set_trace(trace.data_ptr())
+        F.attention(q, k, v, variant=4)
+        torch.cuda.synchronize()
+        lib.sfast_hip_set_trace(None)
+        nwg = B * H * Sq // 128
+        r = trace.cpu().numpy().reshape(-1, 16)[:nwg].astype(np.float64)
+        t = r[:, 5:6]
+        names = ["top", "phase1 QK||exp", "phase2 PV||max,stage", "barrier"]
+        per = r[:, :4] / t
+        line = "  ".join(f"{n} {per[:, i].mean():6.0f}" for i, n in enumerate(names))
+        out.append(f"trace B={B} D={D} Sq={Sq}: cycles/tile (wave 0 of each WG, mean over {nwg} WGs): {line}  | sum {per.sum(1).mean():6.0f}  "
+                   f"kernel {r[:, 4].mean() / t.mean():6.0f}/tile incl. prologue+epilogue")
+print(os.path.basename(L.LIB_PATH), f"EXP={EXP}" if EXP else "", flush=True)
+print("\n".join(out), flush=True)
