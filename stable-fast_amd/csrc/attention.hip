@@ -22,8 +22,14 @@
 //   * head dims 40 / 80 (SD1.5) are zero-padded to the MFMA K-step inside LDS/registers only.
 //   * softmax in fp32 with exp2 and a folded scale*log2(e) (`exp2(fma(s, c, -m*c))`, the running max tracked on raw
 //     scores); the O / l rescale is skipped while no lane's running max moves (exact); accumulate fp32.
-//   * K / V^T tiles are double-buffered in dynamic LDS: global loads of tile t+1 are issued before the MFMAs of tile
-//     t (register prefetch) and written to the other stage after them -- one barrier per tile.
+//   * K / V^T tiles are double-buffered in dynamic LDS and fetched with raw buffer loads (one descriptor per operand,
+//     rows past Skv / head-dim padding / idle lanes out of range = 0, ONE v_add per load and tile); the loads of the tiles
+//     two (V) and four (K) ahead are issued at the end of an iteration and written to LDS by the next one.
+//   * the tile loop is software-pipelined and hand-interleaved (sched_barrier fences): iteration t issues the QK^T MFMAs of
+//     tile t+1 between the exp2 chunks of tile t, and the PV MFMAs of tile t between the row-max of tile t+1, the LDS
+//     staging and the fragment reads of the tiles after it. Measured on gfx950 (tools/micro/overlap.hip): VALU work only
+//     hides behind an MFMA when it follows it in the SAME wave; from a second wave of the SIMD, 3-operand VALU
+//     (fma, max3, pk_fma) serialises with MFMAs, and the previous tile loop ran at exactly MFMA + softmax + staging time.
 //   * head dims below the 32-row MFMA block (40 -> 64, 80 -> 96) carry a ONES row in the V^T padding, so the softmax
 //     denominator is accumulated by the PV MFMA itself (O^T[D][q] = sum_k P[q][k]) instead of 32 VALU adds per tile;
 //     f16 probabilities then use packed round-toward-zero converts (the bias cancels in O / l).

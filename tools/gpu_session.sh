@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU session: per-family parity tests (separate processes so a fault in one family cannot hide the
 # others), whole-UNet tests, smoke, bench, rocprofv3 kernel trace. Everything lands in gpurun_out/.
-# usage: tools/gpu_session.sh [quick|full]
+# usage: tools/gpu_session.sh [quick|full|final|...]  (final = all tests, smoke, the bench lines and the steady-state rocprof summary)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 MODE=${1:-full}
@@ -27,7 +27,19 @@ if [ "$MODE" = "micro" ]; then
   run t_conv   900 $PYT tests/test_ops_gpu.py -k "conv"
   run t_refapi 900 $PYT tests/test_reference_api_gpu.py
   run trace 600 python tools/trace_igemm.py
-  run bench2 600 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-roofline
+  if [ "$MODE" = "final" ]; then
+  export SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_cache.json
+  run bench_sdxl 900 python bench.py --config sdxl --steps 10 --warmup 2 --no-cpu-baseline
+  run bench_default 900 python bench.py --no-cpu-baseline --no-roofline
+  run bench_vae 900 python bench.py --config vae --steps 30 --warmup 5
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -o bench -- python $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline > $OLDPWD/gpurun_out/rocprof.log 2>&1 )
+  echo "rocprof exit=$?" >> gpurun_out/session.log
+  for db in $(find gpurun_out/prof -name "*.db"); do python tools/rocpd_summary.py $db --csv gpurun_out/kernel_stats.csv --top 70 --step-marker cfg_ddim --steps 8 > gpurun_out/kernel_stats.txt; done
+  rm -rf gpurun_out/prof
+  cut -c1-300 gpurun_out/session.log
+  exit 0
+fi
+run bench2 600 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-roofline
   cut -c1-300 gpurun_out/session.log
   exit 0
 fi
@@ -60,6 +72,18 @@ run t_unet  1200 $PYT tests/test_unet_gpu.py
 run t_vae    900 $PYT tests/test_vae_gpu.py
 run smoke    600 python __graft_entry__.py smoke
 run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json
+if [ "$MODE" = "final" ]; then
+  export SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_cache.json
+  run bench_sdxl 900 python bench.py --config sdxl --steps 10 --warmup 2 --no-cpu-baseline
+  run bench_default 900 python bench.py --no-cpu-baseline --no-roofline
+  run bench_vae 900 python bench.py --config vae --steps 30 --warmup 5
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -o bench -- python $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline > $OLDPWD/gpurun_out/rocprof.log 2>&1 )
+  echo "rocprof exit=$?" >> gpurun_out/session.log
+  for db in $(find gpurun_out/prof -name "*.db"); do python tools/rocpd_summary.py $db --csv gpurun_out/kernel_stats.csv --top 70 --step-marker cfg_ddim --steps 8 > gpurun_out/kernel_stats.txt; done
+  rm -rf gpurun_out/prof
+  cut -c1-300 gpurun_out/session.log
+  exit 0
+fi
 run bench2 600 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-roofline
 run bench_sdxl 900 python bench.py --config sdxl --steps 10 --warmup 2 --no-cpu-baseline
 run bench_default 900 python bench.py --no-cpu-baseline --no-roofline
