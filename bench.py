@@ -90,8 +90,8 @@ def kernel_symbol(variant):
     m = re.match(r"igemm_(conv|lin)_(f16|bf16)(_geglu)?\[(\d+x\d+),split=\d+,(reg|dma(\d)|ws(\d))\]", variant)
     if not m:
         ma = re.match(r"attn_fwd\[D=(\d+),BQ=(\d+)\]", variant)
-        if ma:  # attn_fwd_kernel<T, D, NW>: one wave per 32 queries
-            return f"_ZN5sfast15attn_fwd_kernelIDF16_Li{ma.group(1)}ELi{int(ma.group(2)) // 32}EEEvNS_8AttnArgsE"
+        if ma:  # attn_fwd_kernel<T, D, NW, TRACE = 0>: one wave per 32 queries
+            return f"_ZN5sfast15attn_fwd_kernelIDF16_Li{ma.group(1)}ELi{int(ma.group(2)) // 32}ELi0EEEvNS_8AttnArgsE"
         return variant.split("[")[0]
     mode = 1 if m.group(1) == "conv" else 0
     t = "DF16_" if m.group(2) == "f16" else "DF16b"
@@ -100,8 +100,6 @@ def kernel_symbol(variant):
     wm, wn = _IGEMM_WAVES[(m.group(4), geglu)]
     if m.group(5) == "reg":
         return f"_ZN5sfast12igemm_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi{mode}ELb{int(geglu)}EEEvNS_9IgemmArgsE"
-    if m.group(5).startswith("ws"):
-        return f"_ZN5sfast20igemm_glds_ws_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi4ELi{m.group(7)}ELi{mode}ELb{int(geglu)}EEEvNS_9IgemmArgsE"
     if m.group(5).startswith("ws"):
         return f"_ZN5sfast20igemm_glds_ws_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi4ELi{m.group(7)}ELi{mode}ELb{int(geglu)}EEEvNS_9IgemmArgsE"
     return f"_ZN5sfast17igemm_glds_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi{m.group(6)}ELi{mode}ELb{int(geglu)}ELi0EEEvNS_9IgemmArgsE"

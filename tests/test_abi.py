@@ -118,3 +118,23 @@ def test_ops_reject_cpu_tensors(built_lib):
         raise AssertionError("functional wrapper must reject CPU tensors")
     except RuntimeError as e:
         assert "no CPU path" in str(e)
+
+
+def test_bench_kernel_symbols_name_real_device_kernels(built_lib):
+    """bench.py's `roofline.kernel` must be the symbol rocprofv3 prints: every variant string the library reports for
+    the MFMA kernels has to map (bench.kernel_symbol) onto a kernel that is really in the code object."""
+    import sys
+    from sfast.hip import lib as L
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(L.LIB_PATH, "rb") as f:
+        blob = f.read()
+    variants = ["attn_fwd[D=160,BQ=64]", "attn_fwd[D=40,BQ=128]", "attn_fwd[D=80,BQ=64]", "attn_fwd[D=64,BQ=128]",
+                "igemm_conv_f16[128x128,split=1,ws4]", "igemm_conv_f16[128x128,split=12,reg]", "igemm_conv_f16[128x160,split=2,reg]",
+                "igemm_conv_f16[128x160,split=4,ws4]", "igemm_conv_f16[64x64,split=3,ws4]", "igemm_lin_f16[128x128,split=1,dma2]",
+                "igemm_lin_f16[128x128,split=4,ws4]", "igemm_lin_f16[64x64,split=1,reg]", "igemm_lin_f16[64x64,split=6,ws4]",
+                "igemm_lin_f16_geglu[128x128,split=1,dma2]", "igemm_lin_f16_geglu[64x128,split=1,ws3]", "igemm_lin_bf16[64x64,split=1,ws4]"]
+    for v in variants:
+        sym = bench.kernel_symbol(v)
+        assert sym.startswith("_ZN5sfast"), (v, sym)
+        assert (sym + ".kd").encode() in blob, f"{v} -> {sym} is not a kernel of libsfast_hip.so"

@@ -10,7 +10,7 @@ from sfast.hip import functional as F  # noqa: E402
 D = int(os.environ.get("ATTN_D", "40"))
 H = 8
 S = 4096
-print("EXP", os.environ.get("SFAST_ATTN_EXP"), "D", D, flush=True)
+print("D", D, flush=True)
 for nw in (4, 2):
     for B in (1, 2, 3, 4, 6, 8):
         q, k, v = [torch.randn(B, S, H, D, device="cuda", dtype=torch.float16) for _ in range(3)]
