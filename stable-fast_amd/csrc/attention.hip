@@ -596,6 +596,7 @@ extern "C" int sfast_hip_attention(const void *q, const void *k, const void *v, 
     const int64_t kspan = p->ks[1] > 0 ? ((int64_t)(p->Skv - 1) * p->ks[1] + p->D) * 2 : -1;
     const int64_t vspan = p->vs[1] > 0 ? ((int64_t)(p->Skv - 1) * p->vs[1] + p->D) * 2 : -1;
     vec = vec && kspan > 0 && vspan > 0 && kspan < (1ll << 31) && vspan < (1ll << 31);
+    vec = vec && p->ks[1] < (1 << 24) && p->vs[1] < (1 << 24);  // 64-row tile advance and row offsets stay in 32 bits
     a.kspan = (uint32_t)kspan;
     a.vspan = (uint32_t)vspan;
     if (vec && p->variant != 100 && p->scale > 0.f) {
