@@ -1,4 +1,5 @@
-"""A/B timing of sfast_hip_attention at the UNet's shapes. usage: attn_ab.py [lib-path]  (env SFAST_ATTN_OCC3 switches)"""
+"""Timing (+ error vs torch SDPA) of sfast_hip_attention at the UNet's shapes; `attn_ab.py <other libsfast_hip.so>` times another
+build for a same-box A/B, `--trace` adds the per-phase s_memtime split of the tile loop (sfast_hip_set_trace)."""
 import os
 import sys
 
@@ -15,9 +16,6 @@ SHAPES = [  # (B, Sq, Skv, H, D)
     (2, 4096, 4096, 8, 40), (2, 1024, 1024, 8, 80), (2, 256, 256, 8, 160), (2, 4096, 77, 8, 40),
     (2, 4096, 4096, 10, 64), (2, 1024, 1024, 20, 64), (2, 1024, 77, 20, 64),
 ]
-EXP = os.environ.get("SFAST_ATTN_EXP")
-if EXP:
-    SHAPES = SHAPES[:1]
 torch.manual_seed(0)
 out = []
 for B, Sq, Skv, H, D in SHAPES:
@@ -58,5 +56,5 @@ if "--trace" in sys.argv:
         line = "  ".join(f"{n} {per[:, i].mean():6.0f}" for i, n in enumerate(names))
         out.append(f"trace B={B} D={D} Sq={Sq}: cycles/tile (wave 0 of each WG, mean over {nwg} WGs): {line}  | sum {per.sum(1).mean():6.0f}  "
                    f"kernel {r[:, 4].mean() / t.mean():6.0f}/tile incl. prologue+epilogue")
-print(os.path.basename(L.LIB_PATH), f"EXP={EXP}" if EXP else "", flush=True)
+print(os.path.basename(L.LIB_PATH), flush=True)
 print("\n".join(out), flush=True)
