@@ -23,7 +23,7 @@ if [ "$MODE" = "vae" ]; then
   exit 0
 fi
 if [ "$MODE" = "micro" ]; then
-  run t_gemm   900 $PYT tests/test_ops_gpu.py -k "geglu or linear or gemv"
+  run t_gemm   900 $PYT tests/test_ops_gpu.py -k "geglu or linear or gemv or dma_pipe"
   run t_conv   900 $PYT tests/test_ops_gpu.py -k "conv"
   run t_refapi 900 $PYT tests/test_reference_api_gpu.py
   run trace 600 python tools/trace_igemm.py
@@ -45,7 +45,7 @@ run bench2 600 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-roof
 fi
 if [ "$MODE" = "testprof" ]; then
   run t_norm   600 $PYT tests/test_ops_gpu.py -k "group_norm or layer_norm"
-  run t_gemm   900 $PYT tests/test_ops_gpu.py -k "geglu or linear or gemv"
+  run t_gemm   900 $PYT tests/test_ops_gpu.py -k "geglu or linear or gemv or dma_pipe"
   run t_conv   900 $PYT tests/test_ops_gpu.py -k "conv"
   run t_misc   600 $PYT tests/test_ops_gpu.py -k "copy or timestep or cfg or golden"
   run t_refapi 900 $PYT tests/test_reference_api_gpu.py
@@ -63,7 +63,7 @@ if [ "$MODE" = "prof" ]; then
   exit 0
 fi
 run t_norm   600 $PYT tests/test_ops_gpu.py -k "group_norm or layer_norm"
-run t_gemm   900 $PYT tests/test_ops_gpu.py -k "geglu or linear or gemv"
+run t_gemm   900 $PYT tests/test_ops_gpu.py -k "geglu or linear or gemv or dma_pipe"
 run t_conv   900 $PYT tests/test_ops_gpu.py -k "conv"
 run t_attn   900 $PYT tests/test_ops_gpu.py -k "attention"
 run t_misc   600 $PYT tests/test_ops_gpu.py -k "copy or timestep or cfg or golden"
