@@ -1,28 +1,26 @@
-"""Device capability probes used by CompilationConfig defaults.
+"""Device capability probes behind the CompilationConfig defaults (names and meaning of
+/root/reference/src/sfast/utils/gpu_device.py:4-15).
 
-Mirrors /root/reference/src/sfast/utils/gpu_device.py:4-15 (same names / meaning). On ROCm,
-`torch.cuda.get_device_capability()` reports (9, x) for gfx9xx, so the reference's `major >= 7`
-(tensor cores) and `>= (8, 0)` gates read as "has MFMA matrix cores", which is what they select
-for here.
+PyTorch-ROCm reports gfx9xx parts as compute capability (9, x), so the reference's two gates -- `major >= 7` ("has tensor
+cores") and `>= (8, 0)` -- both read as "has MFMA matrix cores" on an Instinct GPU, which is what they select for here.
 """
 import torch
 
 
-def device_has_tensor_core():
-    if torch.cuda.is_available():
-        major, _ = torch.cuda.get_device_capability()
-        return major >= 7
-    return False
+def _capability():
+    return tuple(torch.cuda.get_device_capability()) if torch.cuda.is_available() else None
 
 
 def device_has_capability(major, minor):
-    if torch.cuda.is_available():
-        return tuple(torch.cuda.get_device_capability()) >= (major, minor)
-    return False
+    cap = _capability()
+    return cap is not None and cap >= (major, minor)
+
+
+def device_has_tensor_core():
+    return device_has_capability(7, 0)
 
 
 def device_is_gfx950():
-    if not torch.cuda.is_available():
+    if _capability() is None:
         return False
-    name = getattr(torch.cuda.get_device_properties(0), "gcnArchName", "")
-    return "gfx950" in name
+    return "gfx950" in getattr(torch.cuda.get_device_properties(0), "gcnArchName", "")

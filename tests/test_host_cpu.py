@@ -30,6 +30,29 @@ def test_tree_copy_roundtrip():
     tree_copy_(dst, src)
     assert torch.equal(dst["a"], src["a"])
 
+    import collections
+    import dataclasses
+    import pytest
+    from sfast.utils.copy import can_be_perfectly_copied
+
+    @dataclasses.dataclass
+    class Out(collections.OrderedDict):  # the shape of diffusers' BaseOutput: a dict AND a dataclass
+        sample: torch.Tensor = None
+
+    Pair = collections.namedtuple("Pair", "x y")
+    tree = [Out(sample=torch.ones(3)), Pair(torch.zeros(2), 7)]
+    clone = tree_copy(tree, detach=True)
+    assert isinstance(clone[0], Out) and torch.equal(clone[0].sample, tree[0].sample) and clone[0].sample is not tree[0].sample
+    assert isinstance(clone[1], Pair) and clone[1].y == 7
+    tree[0].sample.mul_(3)
+    tree_copy_(clone, tree)
+    assert torch.equal(clone[0].sample, torch.full((3,), 3.0))
+    with pytest.raises(ValueError):
+        tree_copy_([torch.zeros(1)], [torch.zeros(1), torch.zeros(1)])
+    with pytest.raises(ValueError):
+        tree_copy_({"a": 1}, {"a": "1"})
+    assert can_be_perfectly_copied(tree) and not can_be_perfectly_copied([object()])
+
 
 def test_compilation_config_surface():
     from sfast.compilers.diffusion_pipeline_compiler import CompilationConfig, compile, compile_unet, compile_vae  # noqa: F401
