@@ -376,6 +376,8 @@ ATTN_CASES = [
     (1, 8, 4096, 4096, 40), (2, 8, 1024, 1024, 80), (2, 8, 256, 256, 160), (2, 8, 64, 64, 160),
     (2, 8, 4096, 77, 40), (2, 8, 1024, 77, 80), (2, 8, 256, 77, 160), (2, 8, 64, 77, 160),
     (1, 10, 4096, 4096, 64), (2, 20, 1024, 77, 64), (1, 4, 70, 130, 64), (1, 2, 100, 100, 128), (2, 3, 33, 1, 40),
+    # odd / even tile counts with ragged tails through the software-pipelined loop (K fragments run two tiles ahead)
+    (1, 2, 200, 320, 80), (1, 3, 97, 193, 40), (1, 1, 32, 448, 160), (1, 2, 129, 65, 128), (2, 2, 64, 128, 64),
 ]
 
 
