@@ -124,3 +124,50 @@ def test_controlnet_and_vae_topology_known_answers():
               "controlnet_down_blocks.0.weight", "controlnet_down_blocks.5.bias", "controlnet_mid_block.weight", "mid_block.resnets.1.conv2.weight"):
         assert k in keys, k
     assert not any(k.startswith("up_blocks") or k.startswith("conv_out") for k in keys)
+
+
+def test_closed_form_known_answers():
+    """Pins that do not lean on another implementation: inputs whose result is known in closed form."""
+    import math
+    from oracle.unet_ref import timestep_embedding
+    # attention: identical keys -> uniform softmax -> the mean of V; one dominant key -> that V row
+    g = torch.Generator().manual_seed(7)
+    q, v = torch.randn(1, 5, 2, 8, generator=g), torch.randn(1, 6, 2, 8, generator=g)
+    k = torch.randn(1, 1, 2, 8, generator=g).expand(1, 6, 2, 8)
+    torch.testing.assert_close(R.attention_ref(q, k, v), v.mean(1, keepdim=True).expand(1, 5, 2, 8), rtol=1e-5, atol=1e-6)
+    k2 = torch.zeros(1, 6, 2, 8)
+    k2[:, 3] = 100.0 * q[:, 0].sign()  # score of key 3 for query 0 = 100 * |q|_1 * scale >> the others (0)
+    torch.testing.assert_close(R.attention_ref(q, k2, v)[:, 0], v[:, 3], rtol=1e-4, atol=1e-5)
+    # GroupNorm: a group holding the values {a, b} equally often normalises them to -/+ 1 (eps -> 0); affine applies per channel
+    x = torch.tensor([1.0, 3.0]).repeat(4)[None, :, None].repeat(1, 1, 5)  # [1, 8, 5], groups of 4 channels
+    y = R.group_norm_ref(x, 2, weight=torch.full((8,), 2.0), bias=torch.full((8,), 0.5), eps=0.0)
+    torch.testing.assert_close(y, torch.tensor([-1.5, 2.5]).repeat(4)[None, :, None].repeat(1, 1, 5))
+    assert float(R.group_norm_ref(x, 2, eps=1e-5, silu=True)[0, 1, 0]) == pytest.approx(1.0 / (1.0 + math.exp(-1.0)), rel=1e-4)
+    # LayerNorm of an arithmetic progression 0..n-1: mean (n-1)/2, biased variance (n^2-1)/12
+    n = 16
+    ln = R.layer_norm_ref(torch.arange(n, dtype=torch.float32)[None], (n,), eps=0.0)
+    torch.testing.assert_close(ln[0], (torch.arange(n) - (n - 1) / 2) / math.sqrt((n * n - 1) / 12.0))
+    # GEGLU: value * gelu(gate); gelu(0) = 0 kills the output, gelu(g) = g for large g
+    w = torch.zeros(4, 2)
+    w[0, 0], w[1, 1] = 1.0, 1.0          # value half: identity on the two inputs
+    w[2, 0], w[3, 1] = 0.0, 50.0         # gate half: 0 for column 0, large for column 1
+    out = R.linear_ref(torch.tensor([[3.0, 2.0]]), w, geglu=True)
+    torch.testing.assert_close(out, torch.tensor([[0.0, 2.0 * 100.0]]))
+    # sinusoidal embedding at t = 0 is cos = 1 / sin = 0; at frequency 1 (index 0) it is cos t / sin t
+    e = timestep_embedding(torch.tensor([0.0, 2.0]), 8, flip_sin_to_cos=True)
+    torch.testing.assert_close(e[0], torch.tensor([1.0, 1, 1, 1, 0, 0, 0, 0]))
+    assert float(e[1, 0]) == pytest.approx(math.cos(2.0), abs=1e-6) and float(e[1, 4]) == pytest.approx(math.sin(2.0), abs=1e-6)
+    # DDIM with eta = 0: with identical t and t_prev constants the latents are unchanged, whatever the noise prediction
+    lat, eps_uc = torch.randn(1, 4, 3, 3, generator=g), torch.randn(2, 4, 3, 3, generator=g)
+    sa, s1a = math.sqrt(0.7), math.sqrt(0.3)
+    torch.testing.assert_close(R.cfg_ddim_ref(eps_uc, lat, (sa, s1a, sa, s1a), 7.5), lat, rtol=1e-5, atol=1e-6)
+    # ... and guidance 1 ignores the unconditional half: x_prev = sp * (x - s1a e_c) / sa + s1p e_c
+    sp, s1p = math.sqrt(0.9), math.sqrt(0.1)
+    want = sp * (lat - s1a * eps_uc[1:]) / sa + s1p * eps_uc[1:]
+    torch.testing.assert_close(R.cfg_ddim_ref(eps_uc, lat, (sa, s1a, sp, s1p), 1.0), want, rtol=1e-5, atol=1e-6)
+    # conv: a 3x3 kernel that is 1 at the centre tap is the identity; stride 2 picks the even pixels
+    img = torch.randn(1, 2, 6, 6, generator=g)
+    wc = torch.zeros(2, 2, 3, 3)
+    wc[0, 0, 1, 1], wc[1, 1, 1, 1] = 1.0, 1.0
+    torch.testing.assert_close(R.conv2d_ref(img, wc, padding=1), img)
+    torch.testing.assert_close(R.conv2d_ref(img, wc, padding=1, stride=2), img[:, :, ::2, ::2])
