@@ -146,13 +146,17 @@ class _NativeUNetForward:
                 bad.append("controlnet residuals (need both kinds, engine dtype, on the GPU)")
         if (bad or encoder_hidden_states is None or not torch.is_tensor(sample) or sample.device.type != "cuda"
                 or sample.dtype != eng.dtype or sample.ndim != 4):
+            # hand the original forward exactly what the caller passed (only the arguments that were given, so older
+            # diffusers signatures without the newer keywords keep working)
+            given = dict(class_labels=class_labels, timestep_cond=timestep_cond, attention_mask=attention_mask,
+                         cross_attention_kwargs=cross_attention_kwargs, added_cond_kwargs=added_cond_kwargs,
+                         down_block_additional_residuals=down_block_additional_residuals,
+                         mid_block_additional_residual=mid_block_additional_residual,
+                         down_intrablock_additional_residuals=down_intrablock_additional_residuals,
+                         encoder_attention_mask=encoder_attention_mask)
             return self._fallback(", ".join(bad) or "input device/dtype", sample, timestep,
-                                  encoder_hidden_states=encoder_hidden_states, class_labels=class_labels,
-                                  timestep_cond=timestep_cond, attention_mask=attention_mask,
-                                  cross_attention_kwargs=cross_attention_kwargs, added_cond_kwargs=added_cond_kwargs,
-                                  down_block_additional_residuals=down_block_additional_residuals,
-                                  mid_block_additional_residual=mid_block_additional_residual,
-                                  encoder_attention_mask=encoder_attention_mask, return_dict=return_dict)
+                                  encoder_hidden_states=encoder_hidden_states, return_dict=return_dict,
+                                  **{k: v for k, v in given.items() if v is not None})
         B, _, H, W = sample.shape
         key = (B, H, W, encoder_hidden_states.shape[1], ctrl)
         entry = self._cached.get(key)

@@ -136,3 +136,25 @@ def test_weight_broadcast_and_sharding_gloo_world2():
         assert p.exitcode == 0
     assert [r[1] for r in res] == [True, True]
     assert res[0][2] == res[1][2] > 0
+
+
+def test_native_unet_forward_fallback_passes_every_given_argument():
+    """A call the engine does not cover must reach the ORIGINAL forward with everything the caller passed -- dropping e.g.
+    `down_intrablock_additional_residuals` (T2I-Adapter) would silently change the result."""
+    from types import SimpleNamespace
+    from sfast.compilers.diffusion_pipeline_compiler import _NativeUNetForward
+    seen = {}
+
+    def orig(sample, timestep, **kw):
+        seen.update(kw)
+        return "eager"
+
+    fwd = _NativeUNetForward(module=None, engine=SimpleNamespace(dtype=torch.float16, device=torch.device("cpu")),
+                             orig_forward=orig, enable_graph=False)
+    x = torch.zeros(1, 4, 8, 8)                       # a CPU tensor: never the native path
+    intr = [torch.ones(1)]
+    out = fwd(x, 10, encoder_hidden_states=torch.zeros(1, 77, 8), down_intrablock_additional_residuals=intr,
+              cross_attention_kwargs={"scale": 0.5}, return_dict=False)
+    assert out == "eager"
+    assert seen["down_intrablock_additional_residuals"] is intr and seen["cross_attention_kwargs"] == {"scale": 0.5}
+    assert seen["return_dict"] is False and "class_labels" not in seen and "encoder_attention_mask" not in seen
