@@ -43,6 +43,20 @@ def test_plan_executes_tiny_sd15_topology(built_lib):
     assert rel_l2(y3, want3) < 3e-3 and len(eng._plans) == 2
 
 
+def test_plan_executes_tiny_sd2_topology(built_lib):
+    # SD2.x = the SD1.5 block layout with Linear proj_in / proj_out and a per-level head count
+    cfg = U.tiny_config(use_linear_projection=True, attention_head_dim=(2, 4, 4), cross_attention_dim=48)
+    m16, m32 = _pair(cfg, 5)
+    eng = UNet2DEngine.from_module(m16, _lib=EmuLib())
+    g = torch.Generator().manual_seed(1)
+    s = torch.randn(2, 4, 16, 16, generator=g).half()
+    e = torch.randn(2, 77, 48, generator=g).half()
+    y = eng.forward(s, 500, e)
+    with torch.no_grad():
+        want = m32(s.float(), 500, e.float()).sample
+    assert rel_l2(y, want) < 3e-3
+
+
 def test_plan_executes_tiny_sdxl_topology(built_lib):
     cfg = U.tiny_config(down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
                         up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),

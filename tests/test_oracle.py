@@ -24,6 +24,12 @@ def test_topology_known_answer_param_counts():
         sdxl = U.UNet2DConditionModel(**U.SDXL_CONFIG)
     assert U.param_count(sd15) == 859_520_964
     assert U.param_count(sdxl) == 2_567_463_684
+    # SD2.1 (stabilityai/stable-diffusion-2-1): the SD1.5 topology with linear proj_in/out, 64-wide heads (5/10/20/20 per
+    # level) and OpenCLIP's 1024-wide text states -- 865,910,724 parameters
+    sd21_cfg = dict(U.SD15_CONFIG, attention_head_dim=(5, 10, 20, 20), cross_attention_dim=1024, use_linear_projection=True)
+    with torch.device("meta"):
+        sd21 = U.UNet2DConditionModel(**sd21_cfg)
+    assert U.param_count(sd21) == 865_910_724
 
 
 def test_state_dict_keys_follow_diffusers_naming():
