@@ -43,6 +43,28 @@ def test_plan_executes_tiny_sd15_topology(built_lib):
     assert rel_l2(y3, want3) < 3e-3 and len(eng._plans) == 2
 
 
+def test_live_unet_parameters_are_read_at_every_run(built_lib):
+    # the LoRA hot-swap contract of the reference (README.md:228-265) on the plan level: an in-place update of conv, fused
+    # QKV-segment and cross-attention weights shows up in the next run of the SAME plan, nothing is re-packed or re-built
+    cfg = U.tiny_config()
+    m16, m32 = _pair(cfg, 9)
+    eng = UNet2DEngine.from_module(m16, _lib=EmuLib())
+    g = torch.Generator().manual_seed(4)
+    s = torch.randn(2, 4, 16, 16, generator=g).half()
+    e = torch.randn(2, 77, 64, generator=g).half()
+    y0 = eng.forward(s, 300, e)
+    with torch.no_grad():
+        for n, p in m16.named_parameters():
+            if n.endswith(("attn1.to_k.weight", "attn2.to_v.weight", "conv2.weight", "time_emb_proj.bias")):
+                p.add_(0.05 * torch.randn(p.shape, generator=g).to(p.dtype))
+    y1 = eng.forward(s, 300, e)
+    m32.load_state_dict({k: v.float() for k, v in m16.state_dict().items()})
+    with torch.no_grad():
+        want = m32(s.float(), 300, e.float()).sample
+    assert len(eng._plans) == 1
+    assert rel_l2(y1, want) < 3e-3 and rel_l2(y0, want) > 1e-2
+
+
 def test_plan_executes_tiny_sd2_topology(built_lib):
     # SD2.x = the SD1.5 block layout with Linear proj_in / proj_out and a per-level head count
     cfg = U.tiny_config(use_linear_projection=True, attention_head_dim=(2, 4, 4), cross_attention_dim=48)
