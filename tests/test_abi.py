@@ -138,3 +138,40 @@ def test_bench_kernel_symbols_name_real_device_kernels(built_lib):
         sym = bench.kernel_symbol(v)
         assert sym.startswith("_ZN5sfast"), (v, sym)
         assert (sym + ".kd").encode() in blob, f"{v} -> {sym} is not a kernel of libsfast_hip.so"
+
+
+def test_plain_c_consumer_links_and_calls_the_library(built_lib):
+    """The boundary is a C ABI, not a Python one: a C99 program that only includes include/sfast_hip.h links against
+    libsfast_hip.so, checks the version, and gets the documented status + message for bad arguments (no GPU needed:
+    validation precedes every launch)."""
+    from sfast.hip import lib as L
+    src = r'''
+#include <stdio.h>
+#include <string.h>
+#include "sfast_hip.h"
+int main(void) {
+    if (sfast_hip_abi_version() != SFAST_HIP_ABI_VERSION) { printf("abi %d\n", sfast_hip_abi_version()); return 2; }
+    sfast_attn_params p;
+    memset(&p, 0, sizeof p);
+    p.dtype = SFAST_F16; p.B = 1; p.H = 1; p.Sq = 0; p.Skv = 4; p.D = 40;   /* Sq = 0: bad shape */
+    int dummy;
+    int rc = sfast_hip_attention(&dummy, &dummy, &dummy, &dummy, &p, NULL);
+    if (rc != SFAST_ERR_INVALID) { printf("rc %d\n", rc); return 3; }
+    if (!strstr(sfast_hip_last_error(), "bad shape")) { printf("msg %s\n", sfast_hip_last_error()); return 4; }
+    sfast_softmax_params s;
+    memset(&s, 0, sizeof s);
+    if (sfast_hip_softmax_rows(NULL, NULL, &s, NULL) == SFAST_OK) return 5;
+    printf("ok %d\n", SFAST_HIP_ABI_VERSION);
+    return 0;
+}
+'''
+    libdir = os.path.dirname(L.LIB_PATH)
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "consumer.c")
+        exe = os.path.join(d, "consumer")
+        with open(c, "w") as f:
+            f.write(src)
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), c, "-o", exe,
+                        "-L", libdir, "-lsfast_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.strip() == f"ok {L.ABI_VERSION}", (r.returncode, r.stdout, r.stderr)
