@@ -276,8 +276,23 @@ def bench_vae(args, dev, rank, world, use_dist):
     print(json.dumps(out))
 
 
+def torchrun_argv(n, argv, port=None):
+    """Command that re-launches this script as `n` ranks of one node (what the driver does itself for N > 1)."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` typed by hand: one process per GPU needs the launcher; become it
+        import subprocess
+        raise SystemExit(subprocess.call(torchrun_argv(args.gpus, sys.argv[1:])))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

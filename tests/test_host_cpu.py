@@ -158,3 +158,20 @@ def test_native_unet_forward_fallback_passes_every_given_argument():
     assert out == "eager"
     assert seen["down_intrablock_additional_residuals"] is intr and seen["cross_attention_kwargs"] == {"scale": 0.5}
     assert seen["return_dict"] is False and "class_labels" not in seen and "encoder_attention_mask" not in seen
+
+
+def test_bench_contract_defaults_and_self_launch(monkeypatch):
+    """bench.py: no flags = 1 GPU with a K / W that finish in minutes; `--gpus N` typed without the launcher re-launches
+    itself as N ranks on 127.0.0.1 (the driver does that itself and sets RANK, in which case nothing is re-launched)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert (a.gpus, a.steps, a.warmup, a.config, a.images) == (1, 200, 20, "sd15", 1)
+    cmd = bench.torchrun_argv(4, ["--gpus", "4", "--steps", "7"], port=29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "7"] and cmd[-5].endswith("bench.py")
+    # a free port is picked when none is given
+    assert int(bench.torchrun_argv(2, [])[bench.torchrun_argv(2, []).index("--master-port") + 1]) > 0
