@@ -298,6 +298,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the HIP path has no CPU fallback")
+    from sfast.hip import lib as _L
+    if not os.path.exists(_L.LIB_PATH) and local == 0 and world == 1:
+        # a checkout without the in-tree .so: build the product library first (hipcc, ~1 min); never a fallback
+        sys.path.insert(0, os.path.join(ROOT, "stable-fast_amd"))
+        import build as _build
+        _build.build(verbose=False)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ  # launched by torch.distributed.run
