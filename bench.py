@@ -301,8 +301,10 @@ def main():
     from sfast.hip import lib as _L
     if not os.path.exists(_L.LIB_PATH) and local == 0 and world == 1:
         # a checkout without the in-tree .so: build the product library first (hipcc, ~1 min); never a fallback
-        sys.path.insert(0, os.path.join(ROOT, "stable-fast_amd"))
-        import build as _build
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("sfast_build", os.path.join(ROOT, "stable-fast_amd", "build.py"))
+        _build = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(_build)
         _build.build(verbose=False)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
