@@ -161,6 +161,36 @@ int sfast_hip_gemm(const void *x, const void *const *w_segs, const void *bias,
                    const sfast_gemm_params *p, void *workspace, size_t workspace_bytes,
                    sfast_stream_t stream);
 
+/* ---- grouped GEMM: n_groups problems of identical shape that share the activation operand -------------
+ * out_g[M,N] = act(x[M,K] . W_g[N,K]^T + bias_g),  g = 0 .. n_groups-1  (<= SFAST_MAX_GEMM_GROUPS), one launch.
+ * The cross-attention K/V projections of all transformer blocks of one UNet level read the same text context
+ * (one sfast::cublas_lowp_linear per to_k / to_v in the reference, csrc/operators/cublas/cublas_gemm.cpp:798-860);
+ * p describes ONE problem (M, N, K, ldx, ldw, ldo, n_wseg <= 2 stacked segments of rows_per_seg rows, act; no residual /
+ * rowbias / geglu / split-K). `w_segs` is a HOST array of n_groups * n_wseg DEVICE pointers (group-major), `bias` a host
+ * array of n_groups device pointers or NULL, `out` a host array of n_groups device pointers. K % 8 == 0, N % 4 == 0. */
+#define SFAST_MAX_GEMM_GROUPS 64
+int sfast_hip_gemm_grouped(const void *x, const void *const *w_segs, const void *const *bias, void *const *out,
+                           const sfast_gemm_params *p, int32_t n_groups, sfast_stream_t stream);
+
+/* ---- grouped GEMV: n_groups independent weight matrices W_g[n_rows[g], K] applied to ONE small input ----
+ * out[m][off_g + n] = act( sum_k in_act(x[m][k]) * W_g[n][k] + bias_g[n] ),  off_g = n_rows[0] + ... + n_rows[g-1].
+ * One launch for the 22 `time_emb_proj` Linear layers of the UNet's resnets: each is a
+ * sfast::cublas_lowp_linear call in the reference (csrc/operators/cublas/cublas_gemm.cpp:798-860) on the same
+ * silu(emb) input, i.e. pure weight streaming that depends only on the timestep. `w` / `bias` are HOST arrays of
+ * n_groups DEVICE pointers (bias may be NULL, or hold NULL entries); the weights are read in place. M <= 64. */
+#define SFAST_MAX_GROUPS 32
+typedef struct {
+    int32_t dtype; /* f16 / bf16 */
+    int32_t M, K;
+    int32_t n_groups;
+    int32_t n_rows[SFAST_MAX_GROUPS];
+    int64_t ldx, ldw, ldo; /* row strides in elements: x, every W_g, out */
+    int32_t act, in_act;
+} sfast_gemv_grouped_params;
+
+int sfast_hip_gemv_grouped(const void *x, const void *const *w, const void *const *bias, void *out,
+                           const sfast_gemv_grouped_params *p, sfast_stream_t stream);
+
 /* diagnostic, host-only: the tile / split-K choice the MFMA path would make for an [M,N,K] problem.
  * out = {BM, BN (weight rows per tile), splits, k_tiles_per_split, variant id}; variant ids 1..5 are the
  * register-staged pipe, 11..18 the LDS-DMA ring (same tile shapes, ring depths 2..5), 21..23 the wave-specialised

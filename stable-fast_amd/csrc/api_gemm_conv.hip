@@ -241,6 +241,49 @@ extern "C" int sfast_hip_gemm(const void *x, const void *const *w_segs, const vo
     return small_gemm_naive(a, p->dtype, st);
 }
 
+extern "C" int sfast_hip_gemm_grouped(const void *x, const void *const *w_segs, const void *const *bias, void *const *out,
+                                      const sfast_gemm_params *p, int32_t n_groups, sfast_stream_t stream) {
+    SFAST_REQUIRE(p && x && w_segs && out, SFAST_ERR_INVALID, "gemm_grouped: null argument");
+    SFAST_REQUIRE(n_groups >= 1 && n_groups <= SFAST_MAX_GEMM_GROUPS, SFAST_ERR_INVALID, "gemm_grouped: n_groups=%d (1..%d)", n_groups,
+                  SFAST_MAX_GEMM_GROUPS);
+    SFAST_REQUIRE(p->M > 0 && p->N > 0 && p->K > 0, SFAST_ERR_INVALID, "gemm_grouped: bad shape %dx%dx%d", p->M, p->N, p->K);
+    SFAST_REQUIRE(p->n_wseg >= 1 && p->n_wseg <= 2 && (int64_t)p->rows_per_seg * p->n_wseg >= p->N, SFAST_ERR_INVALID,
+                  "gemm_grouped: %d segments of %d rows do not cover N=%d (at most 2 segments)", p->n_wseg, p->rows_per_seg, p->N);
+    SFAST_REQUIRE(!p->geglu && p->split_k <= 1 && p->rows_per_batch == 0 && p->in_act == SFAST_ACT_NONE, SFAST_ERR_UNSUPPORTED,
+                  "gemm_grouped: geglu / split-K / rowbias / in_act are not available in grouped launches");
+    SFAST_REQUIRE(is_half(p->dtype), SFAST_ERR_UNSUPPORTED, "gemm_grouped: dtype %d", p->dtype);
+    SFAST_REQUIRE(p->ldx >= p->K && p->ldw >= p->K && p->ldo >= p->N, SFAST_ERR_INVALID, "gemm_grouped: bad leading dims");
+    bool ok = p->K % 8 == 0 && p->ldx % 8 == 0 && p->ldw % 8 == 0 && aligned16(x) && p->N % 4 == 0 && p->ldo % 4 == 0;
+    for (int i = 0; i < n_groups; ++i) {
+        SFAST_REQUIRE(out[i], SFAST_ERR_INVALID, "gemm_grouped: null output %d", i);
+        ok = ok && aligned8(out[i]) && (!bias || !bias[i] || aligned8(bias[i]));
+        for (int j = 0; j < p->n_wseg; ++j) {
+            SFAST_REQUIRE(w_segs[i * p->n_wseg + j], SFAST_ERR_INVALID, "gemm_grouped: null weight %d/%d", i, j);
+            ok = ok && aligned16(w_segs[i * p->n_wseg + j]);
+        }
+    }
+    SFAST_REQUIRE(ok, SFAST_ERR_UNSUPPORTED, "gemm_grouped: operands must be 16-byte aligned rows (K, ldx, ldw % 8, N, ldo % 4)");
+    IgemmArgs a{};
+    a.x = x;
+    a.x2 = nullptr;
+    a.rowbias = nullptr;
+    a.res = nullptr;
+    a.M = p->M;
+    a.N = p->N;
+    a.K = p->K;
+    a.ldx = p->ldx;
+    a.ldw = p->ldw;
+    a.ldo = p->ldo;
+    a.ldr = 0;
+    a.ld_rowbias = 0;
+    a.rows_per_seg = p->rows_per_seg;
+    a.rows_per_batch = 1;
+    a.act = p->act;
+    a.res_before_act = 0;
+    a.alpha = 1.0f;
+    return igemm_run_grouped(a, p->dtype, n_groups, w_segs, p->n_wseg, bias, out, (hipStream_t)stream);
+}
+
 extern "C" size_t sfast_hip_conv2d_workspace_bytes(const sfast_conv_params *p) {
     if (!p || !is_half(p->dtype) || p->Cout < 16) return 0;
     ConvGeom g = conv_geom(p, nullptr);

@@ -29,5 +29,8 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
 void igemm_plan_query(int M, int N, int K, bool geglu, int variant, int split, bool glds_ok, int out[5]);
 size_t igemm_workspace_bytes(int M, int N, int K, bool geglu, int variant, int split, bool glds_ok);
 bool igemm_glds_eligible(const IgemmArgs &a, int mode);
+// grouped launch (register-staged pipe): n_groups problems of identical [M, N, K] sharing x (api: sfast_hip_gemm_grouped)
+int igemm_run_grouped(IgemmArgs &a, int dtype, int n_groups, const void *const *w_segs, int n_wseg, const void *const *bias,
+                      void *const *out, hipStream_t st);
 
 }  // namespace sfast

@@ -37,7 +37,7 @@ namespace sfast {
 
 // MODE 0: linear (row m -> x + m*ldx). MODE 1: conv (implicit im2col, NHWC).
 template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GEGLU>
-__global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, 2 * (BM + BN) * 128)) igemm_kernel(const IgemmArgs a) {
+__device__ __forceinline__ void igemm_body(const IgemmArgs &a) {
     using vec8 = typename Elem<T>::vec8;
     constexpr int NT = WM * WN * 64;
     constexpr int FM = BM / (WM * 32);  // 32-row activation fragments per wave
@@ -260,6 +260,35 @@ __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, 2 * 
     trace_finish(a);
 }
 
+template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GEGLU>
+__global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, 2 * (BM + BN) * 128)) igemm_kernel(const IgemmArgs a) {
+    igemm_body<T, BM, BN, WM, WN, MODE, GEGLU>(a);
+}
+
+// Grouped launch: blockIdx.z selects one of up to SFAST_MAX_GEMM_GROUPS independent problems of identical shape that share the
+// activation operand -- the cross-attention K/V projections of every transformer block read the same text context
+// (libs/xformers + diffusers Attention.to_k / to_v; one cublas_lowp_linear each in the reference). Weight and output
+// pointers of the group travel in the kernel-argument block; everything else is the plain kernel.
+struct IgemmGroupTab {
+    const void *w0[SFAST_MAX_GEMM_GROUPS];
+    const void *w1[SFAST_MAX_GEMM_GROUPS];
+    const void *bias[SFAST_MAX_GEMM_GROUPS];
+    void *out[SFAST_MAX_GEMM_GROUPS];
+};
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, 2 * (BM + BN) * 128))
+    igemm_grouped_kernel(const IgemmArgs a, const IgemmGroupTab g) {
+    IgemmArgs b = a;
+    const int z = blockIdx.z;
+    b.w[0] = g.w0[z];
+    b.w[1] = g.w1[z];
+    b.w[2] = g.w1[z];
+    b.w[3] = g.w1[z];
+    b.bias = g.bias[z];
+    b.out = g.out[z];
+    igemm_body<T, BM, BN, WM, WN, 0, false>(b);
+}
+
 // split-K reduce + epilogue: one thread per 4 consecutive output columns.
 template <typename T, bool GEGLU>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const IgemmArgs a) {
@@ -405,6 +434,7 @@ static int set_attr_one() {
 
 static int g_pipe_pref = -1;  // -1 auto, 0 force register pipe, 1 force LDS-DMA pipe (SFAST_IGEMM_PIPE)
 
+int igemm_grouped_init();
 int igemm_init() {
     int rc = 0;
 #define INIT_OP(T, BM, BN, WM, WN, MODE, G) \
@@ -416,6 +446,7 @@ int igemm_init() {
     SFAST_FOR_GEGLU_VARIANTS(f16, INIT_OP)
     SFAST_FOR_GEGLU_VARIANTS(bf16, INIT_OP)
 #undef INIT_OP
+    if (!rc) rc = igemm_grouped_init();
     if (!rc) rc = igemm_glds_init();
     if (!rc) rc = igemm_glds_ws_init();
     const char *e = getenv("SFAST_IGEMM_PIPE");
@@ -553,6 +584,59 @@ bool igemm_glds_eligible(const IgemmArgs &a, int mode) {
     const int64_t batch = (a.Ho > 0 && a.Wo > 0) ? (int64_t)a.M / ((int64_t)a.Ho * a.Wo) : 0;
     const int64_t elems = batch * a.H * a.W * (int64_t)(a.C1 > a.C2 ? a.C1 : a.C2);
     return !a.ups && a.C1 % 64 == 0 && a.C2 % 64 == 0 && a.KH * a.KW <= 32 && elems < (1ll << 31);
+}
+
+template <typename T, int BM, int BN, int WM, int WN> static int set_attr_grouped() {
+    constexpr int smem = 2 * (BM + BN) * 128;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(igemm_grouped_kernel<T, BM, BN, WM, WN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(igemm_grouped %dx%d): %s", BM, BN, hipGetErrorString(e));
+        return SFAST_ERR_LAUNCH;
+    }
+    return 0;
+}
+int igemm_grouped_init() {
+    int rc = set_attr_grouped<f16, 64, 64, 2, 2>();
+    if (!rc) rc = set_attr_grouped<bf16, 64, 64, 2, 2>();
+    if (!rc) rc = set_attr_grouped<f16, 128, 128, 2, 2>();
+    if (!rc) rc = set_attr_grouped<bf16, 128, 128, 2, 2>();
+    return rc;
+}
+
+// n_groups problems of identical [M, N, K] sharing x; per group up to two stacked weight segments, a bias and an output.
+int igemm_run_grouped(IgemmArgs &a, int dtype, int n_groups, const void *const *w_segs, int n_wseg, const void *const *bias,
+                      void *const *out, hipStream_t st) {
+    IgemmGroupTab g{};
+    for (int i = 0; i < SFAST_MAX_GEMM_GROUPS; ++i) {
+        const int j = i < n_groups ? i : 0;
+        g.w0[i] = w_segs[j * n_wseg];
+        g.w1[i] = w_segs[j * n_wseg + (n_wseg > 1 ? 1 : 0)];
+        g.bias[i] = bias ? bias[j] : nullptr;
+        g.out[i] = out[j];
+    }
+    // tile: 64x64 unless that makes more than ~6 workgroups per CU (then 128x128 halves the operand re-reads)
+    const int64_t wg64 = (int64_t)ceil_div(a.M, 64) * ceil_div(a.N, 64) * n_groups;
+    const bool big = wg64 > 6 * 256 && a.M >= 128;
+    const int BM = big ? 128 : 64, BN = big ? 128 : 64;
+    a.tiles_m = ceil_div(a.M, BM);
+    a.tiles_n = ceil_div(a.N, BN);
+    a.ktiles = ceil_div(a.K, 64);
+    a.ktiles_per_split = a.ktiles;
+    a.splits = 1;
+    a.partial = nullptr;
+    a.trace = nullptr;
+    set_kernel_name("igemm_grouped_%s[%dx%d,G=%d,reg]", dtype == SFAST_F16 ? "f16" : "bf16", BM, BN, n_groups);
+    const dim3 grid(a.tiles_m * a.tiles_n, 1, n_groups);
+#define GROUPED_LAUNCH(T, BM_, BN_) \
+    hipLaunchKernelGGL((igemm_grouped_kernel<T, BM_, BN_, 2, 2>), grid, dim3(256), 2 * (BM_ + BN_) * 128, st, a, g)
+    if (dtype == SFAST_F16) {
+        if (big) GROUPED_LAUNCH(f16, 128, 128); else GROUPED_LAUNCH(f16, 64, 64);
+    } else {
+        if (big) GROUPED_LAUNCH(bf16, 128, 128); else GROUPED_LAUNCH(bf16, 64, 64);
+    }
+#undef GROUPED_LAUNCH
+    return check_launch("igemm_grouped");
 }
 
 // entry used by api_gemm_conv.hip. mode: 0 linear, 1 conv. Fills plan fields of `a`.

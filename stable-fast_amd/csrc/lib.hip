@@ -2,6 +2,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 
 namespace sfast {
 
@@ -41,14 +42,22 @@ extern "C" {
 int sfast_hip_abi_version(void) { return SFAST_HIP_ABI_VERSION; }
 
 int sfast_hip_init(void) {
-    static int done = 0;
-    static int rc = 0;
-    if (!done) {
-        rc = sfast::igemm_init();
-        if (rc == 0) rc = sfast::attention_init();
-        done = 1;
+    // kernel attributes (dynamic-LDS limits) are per device: applied once for every device this is called on (the CURRENT
+    // device of the calling thread), under a lock so concurrent first calls cannot interleave
+    static std::mutex mu;
+    static int state[64];  // 0 = not initialised, 1 = ok, < 0 = the error the first attempt returned
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        sfast::set_error("sfast_hip_init: no usable current HIP device");
+        return SFAST_ERR_LAUNCH;
     }
-    return rc;
+    std::lock_guard<std::mutex> lock(mu);
+    if (state[dev] == 0) {
+        int rc = sfast::igemm_init();
+        if (rc == 0) rc = sfast::attention_init();
+        state[dev] = rc == 0 ? 1 : rc;
+    }
+    return state[dev] == 1 ? 0 : state[dev];
 }
 
 int sfast_hip_set_trace(void *buf) {

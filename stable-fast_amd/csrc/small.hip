@@ -89,6 +89,81 @@ __global__ void __launch_bounds__(256) gemv_small_m_kernel(const SmallGemmArgs a
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Grouped GEMV: out[m][off_g + n] = act(sum_k x[m][k] * W_g[n][k] + bias_g[n]) for G independent weight
+// matrices sharing ONE input -- the UNet's 22 `time_emb_proj` layers all consume silu(emb), which depends on
+// nothing but the timestep ("batch them into one GEMV over concatenated weights").
+// The weights stay where the live parameters are (no concatenated copy): the per-group base pointers travel
+// in the kernel-argument block, one wave per output column finds its group with a uniform scan.
+struct GroupedGemvArgs {
+    const void *x;
+    void *out;
+    const void *w[SFAST_MAX_GROUPS];
+    const void *bias[SFAST_MAX_GROUPS];
+    int n_end[SFAST_MAX_GROUPS];  // exclusive prefix end of every group in the concatenated column space
+    int n_groups, M, K, Ntot;
+    int64_t ldx, ldw, ldo;
+    int act, in_act;
+};
+
+template <typename T, int MB>
+__global__ void __launch_bounds__(256) gemv_grouped_kernel(const GroupedGemvArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= a.Ntot) return;
+    int g = 0;
+    while (g + 1 < a.n_groups && n >= a.n_end[g]) ++g;
+    const int nloc = n - (g ? a.n_end[g - 1] : 0);
+    const T *wr = (const T *)a.w[g] + (int64_t)nloc * a.ldw;
+    const T *bp = (const T *)a.bias[g];
+    const int nch = a.K / 8;
+    for (int mb = 0; mb < a.M; mb += MB) {
+        float acc[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) acc[i] = 0.f;
+        for (int ch = lane; ch < nch; ch += 64) {
+            float wf[8];
+            unpack8<T>(*reinterpret_cast<const u32x4 *>(wr + ch * 8), wf);
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const int m = mb + i;
+                if (m < a.M) {
+                    float xf[8];
+                    unpack8<T>(*reinterpret_cast<const u32x4 *>((const T *)a.x + (int64_t)m * a.ldx + ch * 8), xf);
+                    if (a.in_act != SFAST_ACT_NONE) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) xf[j] = apply_act(xf[j], a.in_act);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[i] = fmaf(xf[j], wf[j], acc[i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            float s = wave_sum(acc[i]);
+            const int m = mb + i;
+            if (lane == 0 && m < a.M) {
+                if (bp) s += Elem<T>::to_f32(bp[nloc]);
+                s = apply_act(s, a.act);
+                ((T *)a.out)[(int64_t)m * a.ldo + n] = Elem<T>::from_f32(s);
+            }
+        }
+    }
+}
+
+template <typename T> static int run_gemv_grouped(const GroupedGemvArgs &a, hipStream_t st) {
+    const dim3 grid(ceil_div(a.Ntot, 4));
+    if (a.M <= 2)
+        hipLaunchKernelGGL((gemv_grouped_kernel<T, 2>), grid, dim3(256), 0, st, a);
+    else if (a.M <= 4)
+        hipLaunchKernelGGL((gemv_grouped_kernel<T, 4>), grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((gemv_grouped_kernel<T, 8>), grid, dim3(256), 0, st, a);
+    return check_launch("gemv_grouped");
+}
+
 // thread per output element, scalar loads; any K / alignment / dtype
 template <typename T>
 __global__ void __launch_bounds__(256) gemm_naive_kernel(const SmallGemmArgs a) {
@@ -535,3 +610,45 @@ int small_conv_c(const SmallConvArgs &a, int dtype, hipStream_t st) {
 }
 
 }  // namespace sfast
+
+using namespace sfast;
+
+extern "C" int sfast_hip_gemv_grouped(const void *x, const void *const *w, const void *const *bias, void *out,
+                                      const sfast_gemv_grouped_params *p, sfast_stream_t stream) {
+    SFAST_REQUIRE(p && x && w && out, SFAST_ERR_INVALID, "gemv_grouped: null argument");
+    SFAST_REQUIRE(p->n_groups >= 1 && p->n_groups <= SFAST_MAX_GROUPS, SFAST_ERR_INVALID, "gemv_grouped: n_groups=%d (1..%d)",
+                  p->n_groups, SFAST_MAX_GROUPS);
+    SFAST_REQUIRE(p->M > 0 && p->M <= 64 && p->K > 0, SFAST_ERR_INVALID, "gemv_grouped: bad shape M=%d K=%d (M <= 64)", p->M, p->K);
+    SFAST_REQUIRE(p->dtype == SFAST_F16 || p->dtype == SFAST_BF16, SFAST_ERR_UNSUPPORTED, "gemv_grouped: dtype %d", p->dtype);
+    SFAST_REQUIRE(p->K % 8 == 0 && p->ldx % 8 == 0 && p->ldw % 8 == 0 && p->ldx >= p->K && p->ldw >= p->K && aligned16(x),
+                  SFAST_ERR_UNSUPPORTED, "gemv_grouped: rows must be 16-byte aligned (K, ldx, ldw multiples of 8)");
+    GroupedGemvArgs a{};
+    a.x = x;
+    a.out = out;
+    int tot = 0;
+    for (int g = 0; g < p->n_groups; ++g) {
+        SFAST_REQUIRE(w[g] && aligned16(w[g]) && p->n_rows[g] > 0, SFAST_ERR_INVALID, "gemv_grouped: bad group %d", g);
+        a.w[g] = w[g];
+        a.bias[g] = bias ? bias[g] : nullptr;
+        tot += p->n_rows[g];
+        a.n_end[g] = tot;
+    }
+    for (int g = p->n_groups; g < SFAST_MAX_GROUPS; ++g) {
+        a.w[g] = w[0];
+        a.bias[g] = nullptr;
+        a.n_end[g] = tot;
+    }
+    SFAST_REQUIRE(p->ldo >= tot, SFAST_ERR_INVALID, "gemv_grouped: ldo %lld < %d output columns", (long long)p->ldo, tot);
+    a.n_groups = p->n_groups;
+    a.M = p->M;
+    a.K = p->K;
+    a.Ntot = tot;
+    a.ldx = p->ldx;
+    a.ldw = p->ldw;
+    a.ldo = p->ldo;
+    a.act = p->act;
+    a.in_act = p->in_act;
+    set_kernel_name("gemv_grouped[G=%d]", p->n_groups);
+    if (p->dtype == SFAST_F16) return run_gemv_grouped<f16>(a, (hipStream_t)stream);
+    return run_gemv_grouped<bf16>(a, (hipStream_t)stream);
+}

@@ -81,6 +81,9 @@ def _device_of(m):
     return torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 
+_FALLBACK = object()  # plan-cache entry of a signature that must run the module's original forward
+
+
 class _NativeUNetForward:
     """Replacement for `unet.forward`: per-signature plan cache + hipGraph replay."""
 
@@ -105,7 +108,11 @@ class _NativeUNetForward:
     def _prepare(self, key, sample, timestep, ehs, added, down_res, mid_res):
         eng = self.engine
         B, H, W, S, ctrl = key
-        plan = eng.get_plan(B, H, W, S, ctrl)
+        # everything below (kernel-attribute setup, autotune launches and their event timing, warm-up, capture) must run with
+        # the MODEL's device current, whatever device the caller has selected (reference: graphs.py wraps capture and replay
+        # in torch.cuda.device(execution_env.device))
+        with torch.cuda.device(eng.device):
+            plan = eng.get_plan(B, H, W, S, ctrl)
         env = get_per_device_graph_execution_env(eng.device)
         graph = None
         # warm-up: runs the whole plan eagerly (also validates every launch before capture)
@@ -165,11 +172,23 @@ class _NativeUNetForward:
                 entry = self._cached.get(key)
                 if entry is None:
                     logger.info("sfast: building native UNet plan for %s (graph=%s)", key, self.enable_graph)
-                    entry = self._prepare(key, sample, timestep, encoder_hidden_states, added_cond_kwargs,
-                                          down_block_additional_residuals, mid_block_additional_residual)
+                    try:
+                        entry = self._prepare(key, sample, timestep, encoder_hidden_states, added_cond_kwargs,
+                                              down_block_additional_residuals, mid_block_additional_residual)
+                    except (NotImplementedError, KeyError) as e:
+                        # this signature is outside the plan's coverage (e.g. a latent size the levels do not divide, a
+                        # parameter the planner expected but a wrapper renamed): keep the module's own forward for it
+                        logger.warning("sfast: no native plan for UNet call %s (%s: %s); this signature runs the original forward",
+                                       key, type(e).__name__, e)
+                        entry = _FALLBACK
                     self._cached[key] = entry
+        if entry is _FALLBACK:
+            given = dict(added_cond_kwargs=added_cond_kwargs, down_block_additional_residuals=down_block_additional_residuals,
+                         mid_block_additional_residual=mid_block_additional_residual)
+            return self.orig_forward(sample, timestep, encoder_hidden_states=encoder_hidden_states, return_dict=return_dict,
+                                     **{k: v for k, v in given.items() if v is not None})
         plan, graph, env = entry
-        with env.lock:
+        with env.lock, torch.cuda.device(eng.device):
             eng.load_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs,
                             down_block_additional_residuals, mid_block_additional_residual)
             if graph is not None:
@@ -210,7 +229,8 @@ class _NativeControlNetForward:
     def _prepare(self, key, sample, timestep, ehs, cond):
         eng = self.engine
         B, H, W, S = key
-        plan = eng.get_plan(B, H, W, S)
+        with torch.cuda.device(eng.device):
+            plan = eng.get_plan(B, H, W, S)
         graph = None
         torch.cuda.synchronize(eng.device)
         with torch.cuda.device(eng.device), torch.cuda.stream(torch.cuda.Stream(device=eng.device)):
@@ -254,10 +274,18 @@ class _NativeControlNetForward:
             with self._lock:
                 entry = self._cached.get(key)
                 if entry is None:
-                    entry = self._prepare(key, sample, timestep, encoder_hidden_states, controlnet_cond)
+                    try:
+                        entry = self._prepare(key, sample, timestep, encoder_hidden_states, controlnet_cond)
+                    except (NotImplementedError, KeyError) as e:
+                        logger.warning("sfast: no native plan for ControlNet call %s (%s: %s); this signature runs the original forward",
+                                       key, type(e).__name__, e)
+                        entry = _FALLBACK
                     self._cached[key] = entry
+        if entry is _FALLBACK:
+            return self.orig_forward(sample, timestep, encoder_hidden_states=encoder_hidden_states, controlnet_cond=controlnet_cond,
+                                     conditioning_scale=conditioning_scale, return_dict=return_dict)
         plan, graph, env = entry
-        with env.lock:
+        with env.lock, torch.cuda.device(eng.device):
             eng.load_inputs(plan, sample, timestep, encoder_hidden_states, controlnet_cond.to(eng.dtype))
             if graph is not None:
                 graph.replay()
@@ -371,21 +399,22 @@ class _NativeVaeDecoderForward:
     def _prepare(self, key, z):
         eng = self.engine
         B, H, W = key
-        plan = eng.get_plan(B, H, W)
+        with torch.cuda.device(eng.device):
+            plan = eng.get_plan(B, H, W)
         graph = None
         torch.cuda.synchronize(eng.device)
         with torch.cuda.device(eng.device), torch.cuda.stream(torch.cuda.Stream(device=eng.device)):
             eng.load_inputs(plan, z)
             plan.run(torch.cuda.current_stream(eng.device).cuda_stream)  # validates every launch before capture
         torch.cuda.synchronize(eng.device)
+        env = get_per_device_graph_execution_env(eng.device)
         if self.enable_graph:
             from ..engine import capture_plan_graph
-            env = get_per_device_graph_execution_env(eng.device)
             with env.lock:
                 with torch.cuda.device(eng.device):
                     graph, _ = capture_plan_graph(plan, env.stream, pool=env.mempool)
                 torch.cuda.synchronize(eng.device)
-        return plan, graph
+        return plan, graph, env
 
     def __call__(self, sample, latent_embeds=None, *args, **kwargs):
         eng = self.engine
@@ -404,15 +433,25 @@ class _NativeVaeDecoderForward:
             with self._lock:
                 entry = self._cached.get(key)
                 if entry is None:
-                    entry = self._prepare(key, sample)
+                    try:
+                        entry = self._prepare(key, sample)
+                    except (NotImplementedError, KeyError) as e:
+                        logger.warning("sfast: no native plan for VAE call %s (%s: %s); this shape runs the original forward",
+                                       key, type(e).__name__, e)
+                        entry = _FALLBACK
                     self._cached[key] = entry
-        plan, graph = entry
-        eng.load_inputs(plan, sample)
-        if graph is not None:
-            graph.replay()
-        else:
-            plan.run(torch.cuda.current_stream(eng.device).cuda_stream)
-        return plan.static_out.clone()
+        if entry is _FALLBACK:
+            return self.orig_forward(sample)
+        plan, graph, env = entry
+        # static buffers and the workspace are shared by every call of this shape: serialised per device, like the UNet
+        # wrapper and the reference's graphed callables (cuda/graphs.py:148)
+        with env.lock, torch.cuda.device(eng.device):
+            eng.load_inputs(plan, sample)
+            if graph is not None:
+                graph.replay()
+            else:
+                plan.run(torch.cuda.current_stream(eng.device).cuda_stream)
+            return plan.static_out.clone()
 
 
 def _looks_like_vae_decoder(d):

@@ -39,7 +39,7 @@ class DenoiseLoop:
         self.engine = engine
         self.images = images
         self.guidance = float(guidance)
-        self.lib = L.init_device()
+        self.lib = L.init_device(engine.device)
         dev, dt = engine.device, engine.dtype
         self.plan = engine.get_plan(2 * images, height, width, ctx_len)
         ts, rows = ddim_schedule(num_steps)

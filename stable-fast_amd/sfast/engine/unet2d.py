@@ -102,6 +102,7 @@ class UNetPlan:
         self.static_out = None
         self.pool = None
         self.keep = []  # ctypes objects / tensors that must outlive the launches
+        self.kv_requests = []  # (name, Wk, Wv, kv buffer, C) of every cross-attention block, grouped at the end of build_plan
 
     def run(self, stream_ptr):
         """Serial execution in program order on one stream (eager mode, tuning, per-op timing)."""
@@ -234,11 +235,18 @@ class UNet2DEngine:
         params = {}
         with torch.no_grad():
             for name, p in m.named_parameters():
-                if p.ndim == 4 and not p.data.is_contiguous(memory_format=torch.channels_last):
-                    # K-contiguous [Cout][kh][kw][Cin] image for the implicit-GEMM kernels; same
-                    # effect as the reference's apply_memory_format (utils/memory_format.py:49-57).
-                    p.data = p.data.contiguous(memory_format=torch.channels_last)
-                params[name] = p.data
+                d = p.data
+                if d.ndim == 4 and not d.is_contiguous(memory_format=torch.channels_last):
+                    # K-contiguous [Cout][kh][kw][Cin] image for the implicit-GEMM kernels; same effect as the reference's
+                    # apply_memory_format (utils/memory_format.py:49-57). 1x1 kernels and single-input-channel weights are
+                    # K-contiguous in either format: their storage is left alone. Otherwise the parameter's storage pointer
+                    # CHANGES here (like `module.to(memory_format=channels_last)`): anything holding the old storage -- an
+                    # optimizer state, an external LoRA merger -- must re-read `p.data` after compile().
+                    if d.shape[2] * d.shape[3] == 1 and d.is_contiguous():
+                        pass
+                    else:
+                        p.data = d = d.contiguous(memory_format=torch.channels_last)
+                params[name] = d
         return cls(cfg, params, _lib=_lib)
 
     def refresh_parameters(self, m):
@@ -295,7 +303,87 @@ class UNet2DEngine:
             raise UnsupportedUNet("resnet_time_scale_shift")
         if g("dual_cross_attention", False) or g("only_cross_attention", False) or g("upcast_attention", False):
             raise UnsupportedUNet("dual/only_cross/upcast attention")
+        self._check_config_whitelist()
         self.temb_dim = self.params["time_embedding.linear_1.weight"].shape[0]
+        self._validate_params()
+
+    # Every config option the planner does NOT implement must hold the value the plan silently assumes; anything else would
+    # engage the native engine and compute a different network than the module defines (diffusers option names).
+    _ASSUMED = {
+        "center_input_sample": (False,), "downsample_padding": (1,), "mid_block_scale_factor": (1, 1.0), "dropout": (0, 0.0),
+        "reverse_transformer_layers_per_block": (None,), "encoder_hid_dim": (None,), "num_class_embeds": (None,),
+        "resnet_skip_time_act": (False,), "resnet_out_scale_factor": (1, 1.0), "time_embedding_dim": (None,),
+        "time_embedding_act_fn": (None,), "timestep_post_act": (None,), "time_cond_proj_dim": (None,), "conv_in_kernel": (3,),
+        "conv_out_kernel": (3,), "attention_type": ("default", None), "class_embeddings_concat": (False,),
+        "mid_block_only_cross_attention": (None, False), "cross_attention_norm": (None,), "attention_bias": (False, None),
+        "global_pool_conditions": (False,), "controlnet_conditioning_channel_order": ("rgb", None),
+        "norm_elementwise_affine": (True, None), "use_timestep_embedding": (True, None), "only_cross_attention": (False, None),
+    }
+    _HANDLED = {
+        "sample_size", "in_channels", "out_channels", "flip_sin_to_cos", "freq_shift", "down_block_types", "mid_block_type",
+        "up_block_types", "block_out_channels", "layers_per_block", "act_fn", "norm_num_groups", "norm_eps", "cross_attention_dim",
+        "transformer_layers_per_block", "encoder_hid_dim_type", "attention_head_dim", "num_attention_heads", "dual_cross_attention",
+        "use_linear_projection", "class_embed_type", "addition_embed_type", "addition_time_embed_dim", "upcast_attention",
+        "resnet_time_scale_shift", "time_embedding_type", "projection_class_embeddings_input_dim", "addition_embed_type_num_heads",
+        "conditioning_embedding_out_channels", "conditioning_channels",
+    }
+
+    def _config_items(self):
+        cfg = self.cfg
+        if isinstance(cfg, dict):
+            return list(cfg.items())
+        if hasattr(cfg, "items"):
+            try:
+                return list(cfg.items())
+            except Exception:
+                pass
+        return [(k, getattr(cfg, k)) for k in dir(cfg) if not k.startswith("_") and not callable(getattr(cfg, k, None))]
+
+    def _check_config_whitelist(self):
+        for k, v in self._config_items():
+            if k.startswith("_") or k in self._HANDLED:
+                continue
+            if isinstance(v, list):
+                v = tuple(v)
+            ok = self._ASSUMED.get(k)
+            if ok is not None:
+                if v not in ok:
+                    raise UnsupportedUNet(f"config option {k}={v!r} is not implemented by the native plan (it assumes {ok[0]!r})")
+            elif v not in (None, False):
+                raise UnsupportedUNet(f"unknown config option {k}={v!r}: refusing to guess its meaning")
+
+    def _validate_params(self):
+        """Parameter inventory check: every tensor the plan will read exists with the expected shape, and the module holds no
+        parameter the plan would ignore (attention biases, gated-attention fusers, LoRA wrappers, class embeddings, ...)."""
+        from .unet_spec import unet2d_param_shapes
+        n = len(self.boc)
+        cfg = dict(block_out_channels=self.boc, layers_per_block=self.layers, down_block_types=self.down_types,
+                   up_block_types=self.up_types if not self.is_controlnet else (), cross_attention_dim=self.ctx_dim,
+                   transformer_layers_per_block=self.depth, use_linear_projection=self.linear_proj, in_channels=self.in_ch,
+                   out_channels=self.out_ch, addition_embed_type=self.add_type,
+                   projection_class_embeddings_input_dim=_cfg_get(self.cfg, "projection_class_embeddings_input_dim"))
+        try:
+            want = unet2d_param_shapes(cfg)
+        except (KeyError, TypeError, IndexError) as e:
+            raise UnsupportedUNet(f"config does not describe a UNet2DConditionModel the plan knows ({e})")
+        if self.is_controlnet:
+            want = {k: v for k, v in want.items() if not k.startswith(("up_blocks.", "conv_norm_out.", "conv_out."))}
+        T = self.temb_dim
+        have = self.params
+        missing = [k for k in want if k not in have]
+        if missing:
+            raise UnsupportedUNet(f"parameters missing for the native plan: {missing[:3]}{' ...' if len(missing) > 3 else ''} "
+                                  "(wrapped / renamed modules such as peft LoRA layers keep the eager forward)")
+        extra = [k for k in have if k not in want and not k.startswith("controlnet_")]
+        if extra:
+            raise UnsupportedUNet(f"module has parameters the native plan would ignore: {extra[:3]}{' ...' if len(extra) > 3 else ''}")
+        for k, shp in want.items():
+            got = tuple(have[k].shape)
+            if "time_emb" in k or "add_embedding" in k or "time_embedding" in k:
+                continue  # widths derive from the embedding dim, checked by the GEMM launches themselves
+            if got != tuple(shp):
+                raise UnsupportedUNet(f"parameter {k} has shape {got}, the plan expects {tuple(shp)}")
+        del n, T
 
     # ------------------------------------------------------------------------------------------
     # plan construction helpers
@@ -365,6 +453,28 @@ class UNet2DEngine:
         nbytes = (M * K + wrows * K + wrows + M * N + (M * N if residual is not None else 0)) * self.esize
         self._add(plan, kind or ("geglu" if geglu else ("gemv" if M <= 16 else "linear")), name, flops, nbytes, launch,
                   tune=(p, launch_with), lane=lane)
+
+    def _op_gemv_grouped(self, plan, name, x, weights, biases, out, M, K, ldx, ldo, *, out_offset=0, act=L.ACT_NONE, lane=LANE_MAIN):
+        """out[m][out_offset + off_g + n] = act(x[m] . W_g[n] + b_g[n]) for every weight matrix of `weights`, one launch."""
+        lib = self.lib
+        p = L.GemvGroupedParams()
+        p.dtype, p.M, p.K, p.n_groups = self.dt, M, K, len(weights)
+        for i, w in enumerate(weights):
+            if w.ndim != 2 or w.shape[1] != K or w.stride() != (w.stride(0), 1) or w.stride(0) != weights[0].stride(0):
+                raise UnsupportedUNet(f"{name}: weight {i} is not a dense [N, {K}] matrix with the common row stride")
+            p.n_rows[i] = w.shape[0]
+        p.ldx, p.ldw, p.ldo, p.act, p.in_act = ldx, weights[0].stride(0), ldo, act, L.ACT_NONE
+        wp = (C.c_void_p * len(weights))(*[w.data_ptr() for w in weights])
+        bp = (C.c_void_p * len(weights))(*[(b.data_ptr() if b is not None else None) for b in biases])
+        xp = x.data_ptr()
+        op = out.data_ptr() + out_offset * self.esize
+        plan.keep += [p, wp, bp]
+
+        def launch(stream, p=p, wp=wp, bp=bp):
+            L.check(lib.sfast_hip_gemv_grouped(xp, wp, bp, op, C.byref(p), stream), name)
+
+        ntot = sum(w.shape[0] for w in weights)
+        self._add(plan, "temb", name, 2.0 * M * ntot * K, (M * K + ntot * K + ntot + M * ntot) * self.esize, launch, lane=lane)
 
     def _op_conv(self, plan, name, x, x2, w, bias, out, B, H, W, C1, C2, Cout, k, stride, pad, *, ups=False, rowbias=None,
                  ld_rowbias=0, rowbias_offset=0, z=None, xs=None, os_=None, kind=None, act=L.ACT_NONE, pad_extra=0):
@@ -520,8 +630,8 @@ class UNet2DEngine:
             # projection can be hoisted onto the side lane of the graph
             kv = torch.empty(B * S_ctx * 2 * Cc, dtype=self.dtype, device=self.device)
             plan.keep.append(kv)
-            self._op_gemm(plan, bp + ".attn2.to_kv", ctx, [P[bp + ".attn2.to_k.weight"], P[bp + ".attn2.to_v.weight"]], None, kv,
-                          B * S_ctx, 2 * Cc, self.ctx_dim, self.ctx_dim, 2 * Cc, lane=LANE_KV)
+            # deferred: all K/V projections of equal width become ONE grouped launch at the top of the plan (_emit_kv_groups)
+            plan.kv_requests.append((bp + ".attn2.to_kv", P[bp + ".attn2.to_k.weight"], P[bp + ".attn2.to_v.weight"], kv, Cc))
             skv = (S_ctx * 2 * Cc, 2 * Cc, D)
             self._op_attn(plan, bp + ".attn2", q, kv, kv, a, B, heads, S, S_ctx, D, (S * Cc, Cc, D), skv, skv, (S * Cc, Cc, D),
                           k_off=0, v_off=Cc)
@@ -559,7 +669,7 @@ class UNet2DEngine:
         """`ctrl`: the plan also takes ControlNet residuals (one NCHW tensor per skip connection + one for the mid block,
         diffusers `down_block_additional_residuals` / `mid_block_additional_residual`) as static inputs."""
         if not self._emulated:
-            L.init_device()
+            L.init_device(self.device)
         nlev = len(self.boc)
         if H % (1 << (nlev - 1)) or W % (1 << (nlev - 1)):
             raise UnsupportedUNet(f"latent {H}x{W} not divisible by {1 << (nlev - 1)}")
@@ -639,10 +749,18 @@ class UNet2DEngine:
             offs[rn] = tot
             tot += P[rn + ".time_emb_proj.weight"].shape[0]
         temb_all = pool.get(B * tot)
-        for rn in rnames:
-            w = P[rn + ".time_emb_proj.weight"]
-            self._op_gemm(plan, rn + ".time_emb_proj", act_emb, [w], P[rn + ".time_emb_proj.bias"], temb_all, B, w.shape[0], T, T, tot,
-                          out_offset=offs[rn], kind="temb", lane=LANE_TEMB)
+        if B <= 64 and T % 8 == 0:
+            # ONE grouped GEMV launch per <= 32 resnets: same input, live weights read in place
+            for g0 in range(0, len(rnames), L.MAX_GROUPS):
+                grp = rnames[g0:g0 + L.MAX_GROUPS]
+                self._op_gemv_grouped(plan, f"time_emb_proj[{g0}:{g0 + len(grp)}]", act_emb,
+                                      [P[rn + ".time_emb_proj.weight"] for rn in grp], [P[rn + ".time_emb_proj.bias"] for rn in grp],
+                                      temb_all, B, T, T, tot, out_offset=offs[grp[0]], lane=LANE_TEMB)
+        else:
+            for rn in rnames:
+                w = P[rn + ".time_emb_proj.weight"]
+                self._op_gemm(plan, rn + ".time_emb_proj", act_emb, [w], P[rn + ".time_emb_proj.bias"], temb_all, B, w.shape[0], T, T, tot,
+                              out_offset=offs[rn], kind="temb", lane=LANE_TEMB)
 
         # ---- conv_in (reads the NCHW sample through strides, writes NHWC) -----------------------
         h = pool.get(B * H * W * c0)
@@ -699,6 +817,7 @@ class UNet2DEngine:
             self._op_conv(plan, "controlnet_mid_block", h, None, P["controlnet_mid_block.weight"], P["controlnet_mid_block.bias"], om,
                           B, cH, cW, ch, 0, ch, 1, 1, 0, os_=(ch * cH * cW, cW, 1, cH * cW))
             plan.static_out = {"down_block_res_samples": outs, "mid_block_res_sample": om}
+            self._emit_kv_groups(plan, ctx, B, S_ctx)
             self._finish_plan(plan)
             return plan
         if ctrl:
@@ -746,8 +865,50 @@ class UNet2DEngine:
         self._op_conv(plan, "conv_out", nout, None, P["conv_out.weight"], P["conv_out.bias"], out, B, H, W, ch, 0, self.out_ch, 3, 1, 1,
                       os_=(self.out_ch * H * W, W, 1, H * W), kind="conv_out")
         pool.put(nout)
+        self._emit_kv_groups(plan, ctx, B, S_ctx)
         self._finish_plan(plan)
         return plan
+
+    def _emit_kv_groups(self, plan, ctx, B, S_ctx):
+        """Cross-attention K/V projections: they depend on the text context only, so every block's `to_k` / `to_v` pair runs at the
+        top of the plan on the side lane -- blocks of equal width (same [M, 2C, ctx_dim] problem) share one grouped GEMM launch."""
+        reqs, plan.kv_requests = plan.kv_requests, []
+        if not reqs:
+            return
+        lib = self.lib
+        M, K = B * S_ctx, self.ctx_dim
+        by_c = defaultdict(list)
+        for r in reqs:
+            by_c[r[4]].append(r)
+        new_ops = []
+        saved, plan.ops = plan.ops, new_ops
+        for Cc, rs in by_c.items():
+            groupable = K % 8 == 0 and all(w.stride() == (K, 1) for r in rs for w in (r[1], r[2]))
+            if not groupable:
+                for (name, wk, wv, kv, _) in rs:
+                    self._op_gemm(plan, name, ctx, [wk, wv], None, kv, M, 2 * Cc, K, K, 2 * Cc, lane=LANE_KV)
+                continue
+            for g0 in range(0, len(rs), L.MAX_GEMM_GROUPS):
+                grp = rs[g0:g0 + L.MAX_GEMM_GROUPS]
+                p = L.GemmParams()
+                p.dtype, p.M, p.N, p.K = self.dt, M, 2 * Cc, K
+                p.ldx, p.ldw, p.ldo, p.ldr = K, K, 2 * Cc, 0
+                p.n_wseg, p.rows_per_seg = 2, Cc
+                p.geglu, p.act, p.res_before_act, p.alpha = 0, L.ACT_NONE, 0, 1.0
+                p.rows_per_batch, p.ld_rowbias, p.in_act, p.variant, p.split_k = 0, 0, 0, 0, 0
+                n = len(grp)
+                wp = (C.c_void_p * (2 * n))(*[w.data_ptr() for r in grp for w in (r[1], r[2])])
+                op = (C.c_void_p * n)(*[r[3].data_ptr() for r in grp])
+                xp = ctx.data_ptr()
+                plan.keep += [p, wp, op]
+                name = f"attn2.to_kv[C={Cc},x{n}]"
+
+                def launch(stream, p=p, wp=wp, op=op, n=n, name=name):
+                    L.check(lib.sfast_hip_gemm_grouped(xp, wp, None, op, C.byref(p), n, stream), name)
+
+                self._add(plan, "linear", name, 2.0 * M * 2 * Cc * K * n, (M * K + n * (2 * Cc * K + M * 2 * Cc)) * self.esize, launch,
+                          lane=LANE_KV)
+        plan.ops = new_ops + saved
 
     def _finish_plan(self, plan):
         # measured tile / pipe / split-K selection per distinct GEMM / conv problem (cuDNN-benchmark style)

@@ -209,7 +209,7 @@ class VaeDecoderEngine(UNet2DEngine):
     # ------------------------------------------------------------------------------------------
     def build_plan(self, B, H, W, S_ctx=0):
         if not self._emulated:
-            L.init_device()
+            L.init_device(self.device)
         P = self.params
         dev, dt = self.device, self.dtype
         plan = UNetPlan(self, B, H, W, 0)
@@ -312,7 +312,7 @@ class VaeEncoderEngine(VaeDecoderEngine):
 
     def build_plan(self, B, H, W, S_ctx=0):
         if not self._emulated:
-            L.init_device()
+            L.init_device(self.device)
         P = self.params
         dev, dt = self.device, self.dtype
         n_ds = sum(1 for i in range(self.n_down) if f"down_blocks.{i}.downsamplers.0.conv.weight" in P)

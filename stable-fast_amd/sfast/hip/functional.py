@@ -8,6 +8,7 @@ into a hipGraph), errors surface as RuntimeError. PyTorch is only the allocator 
 here -- every byte of arithmetic runs in libsfast_hip.so.
 """
 import ctypes as C
+import functools
 from typing import Optional, Sequence
 
 import torch
@@ -18,6 +19,20 @@ _DT = {torch.float16: L.F16, torch.bfloat16: L.BF16, torch.float32: L.F32}
 _ACT = {None: L.ACT_NONE, "none": L.ACT_NONE, "identity": L.ACT_NONE, "relu": L.ACT_RELU,
         "gelu": L.ACT_GELU, "gelu_tanh": L.ACT_GELU_TANH, "silu": L.ACT_SILU,
         "sigmoid": L.ACT_SIGMOID, "tanh": L.ACT_TANH}
+
+
+def _on_device(fn):
+    """Run `fn` with the first tensor argument's device current (the reference's ops run under a DeviceGuard,
+    cutlass_dual_linear_kernel.cu:364-365): the launch stream, the per-device kernel attributes and the workspace
+    allocation all follow the INPUT's device, not whatever device the caller happens to have selected."""
+    @functools.wraps(fn)
+    def wrapper(first, *args, **kwargs):
+        dev = first.device if torch.is_tensor(first) else None
+        if dev is not None and dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
+            with torch.cuda.device(dev):
+                return fn(first, *args, **kwargs)
+        return fn(first, *args, **kwargs)
+    return wrapper
 
 
 def _dtype(t):
@@ -64,6 +79,7 @@ def _i64x3(vals):
 
 
 # --------------------------------------------------------------------------------------------------
+@_on_device
 def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, act=None, x2=None):
     """GroupNorm(+SiLU). x: [N, C, *] (channels_last 4-D is processed natively as NHWC).
     x2: optional second channels_last tensor, normalised as if torch.cat([x, x2], 1)."""
@@ -107,6 +123,7 @@ def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, act=None, x2=Non
     return y
 
 
+@_on_device
 def layer_norm(x, normalized_shape: Sequence[int], weight=None, bias=None, eps=1e-5):
     _require_cuda(x, weight, bias)
     lib = L.init_device()
@@ -128,6 +145,7 @@ def layer_norm(x, normalized_shape: Sequence[int], weight=None, bias=None, eps=1
     return y
 
 
+@_on_device
 def image_postprocess(image, denormalize=True, to_uint8=True):
     """NCHW image tensor -> NHWC uint8 (round(255 * x)) or float32, optionally denormalised from [-1, 1] first."""
     _require_cuda(image)
@@ -143,6 +161,7 @@ def image_postprocess(image, denormalize=True, to_uint8=True):
     return out
 
 
+@_on_device
 def softmax_rows(x, scale=1.0, out=None):
     """softmax(scale * x) over the last dim of a 2-D f16/bf16 tensor whose rows are 16-byte aligned (fp32 math)."""
     _require_cuda(x)
@@ -156,6 +175,7 @@ def softmax_rows(x, scale=1.0, out=None):
     return y
 
 
+@_on_device
 def linear(x, weight, bias=None, *, act=None, residual=None, alpha=1.0, res_before_act=False,
            geglu=False, rowbias=None, rows_per_batch=0, in_act=None, variant=0, split_k=0, out=None):
     """out[..., N] = epilogue(x[..., K] @ W[N, K]^T). `weight` may be a list of <= 4 equally sized
@@ -228,11 +248,71 @@ def linear(x, weight, bias=None, *, act=None, residual=None, alpha=1.0, res_befo
     return out2d.reshape(*lead, N) if out is None else out
 
 
+@_on_device
+def linear_grouped(x, weight_groups, biases=None, act=None):
+    """[act(x @ cat(W_g)^T + b_g) for g]: every group is a list of <= 2 equally sized [n, K] weights stacked along N; all groups
+    have the same shape and share `x` ([M, K]). ONE launch (sfast_hip_gemm_grouped). Returns a list of [M, N] tensors."""
+    groups = [list(g) if isinstance(g, (list, tuple)) else [g] for g in weight_groups]
+    flat = [w for g in groups for w in g]
+    _require_cuda(x, *flat)
+    lib = L.init_device()
+    x2d = x.reshape(-1, x.shape[-1])
+    if x2d.stride(-1) != 1:
+        x2d = x2d.contiguous()
+    M, K = x2d.shape
+    nseg, rows = len(groups[0]), groups[0][0].shape[0]
+    flat = [w.contiguous() for w in flat]
+    N = nseg * rows
+    outs = [torch.empty((M, N), dtype=x.dtype, device=x.device) for _ in groups]
+    bs = None
+    if biases is not None:
+        bs = [None if b is None else b.to(x.dtype).contiguous() for b in biases]
+    p = L.GemmParams()
+    p.dtype, p.M, p.N, p.K = _dtype(x), M, N, K
+    p.ldx, p.ldw, p.ldo, p.ldr = x2d.stride(0) if M > 1 else K, K, N, 0
+    p.n_wseg, p.rows_per_seg, p.act, p.alpha = nseg, rows, _act(act), 1.0
+    wp = (C.c_void_p * len(flat))(*[w.data_ptr() for w in flat])
+    op = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+    bp = (C.c_void_p * len(outs))(*[_ptr(b) for b in bs]) if bs is not None else None
+    L.check(lib.sfast_hip_gemm_grouped(_ptr(x2d), wp, bp, op, C.byref(p), len(groups), _stream(x)), "sfast_hip_gemm_grouped")
+    return outs
+
+
+@_on_device
+def gemv_grouped(x, weights, biases=None, act=None, in_act=None):
+    """out[m, off_g + n] = act(in_act(x)[m] @ W_g[n] + b_g[n]) for every W_g of `weights` ([n_g, K] each, <= 32), ONE launch.
+    Returns [M, sum n_g]."""
+    weights = list(weights)
+    biases = list(biases) if biases is not None else [None] * len(weights)
+    _require_cuda(x, *weights, *[b for b in biases if b is not None])
+    lib = L.init_device()
+    if x.ndim != 2 or x.stride(1) != 1:
+        x = x.reshape(-1, x.shape[-1]).contiguous()
+    M, K = x.shape
+    ws = [w if (w.stride(1) == 1 and w.stride(0) == weights[0].stride(0)) else w.contiguous() for w in weights]
+    if any(w.stride(0) != ws[0].stride(0) for w in ws):
+        ws = [w.contiguous() for w in ws]
+    bs = [None if b is None else b.to(x.dtype).contiguous() for b in biases]
+    ntot = sum(w.shape[0] for w in ws)
+    out = torch.empty((M, ntot), dtype=x.dtype, device=x.device)
+    p = L.GemvGroupedParams()
+    p.dtype, p.M, p.K, p.n_groups = _dtype(x), M, K, len(ws)
+    for i, w in enumerate(ws):
+        p.n_rows[i] = w.shape[0]
+    p.ldx, p.ldw, p.ldo = x.stride(0) if M > 1 else K, ws[0].stride(0), ntot
+    p.act, p.in_act = _act(act), _act(in_act)
+    wp = (C.c_void_p * len(ws))(*[w.data_ptr() for w in ws])
+    bp = (C.c_void_p * len(ws))(*[_ptr(b) for b in bs])
+    L.check(lib.sfast_hip_gemv_grouped(_ptr(x), wp, bp, _ptr(out), C.byref(p), _stream(x)), "sfast_hip_gemv_grouped")
+    return out
+
+
 def _nhwc_strides(t):
     # logical NCHW tensor -> element strides in (n, h, w, c) order
     return (t.stride(0), t.stride(2), t.stride(3), t.stride(1))
 
 
+@_on_device
 def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dilation=1, act=None,
            res_before_act=True, x2=None, upsample2x=False, rowbias=None, variant=0, split_k=0,
            channels_last_out: Optional[bool] = None, pad_extra=0):
@@ -296,6 +376,7 @@ def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dila
     return y
 
 
+@_on_device
 def attention(q, k, v, scale: Optional[float] = None, variant=0):
     """softmax(q k^T * scale) v with q [B, Sq, H, D], k/v [B, Skv, H, D] (any b/s/h strides)."""
     _require_cuda(q, k, v)
@@ -321,6 +402,7 @@ def attention(q, k, v, scale: Optional[float] = None, variant=0):
     return out
 
 
+@_on_device
 def strided_copy(src, dst):
     """dst[...] = src[...] for equal-shape tensors of rank <= 4 and arbitrary strides."""
     _require_cuda(src, dst)
@@ -345,6 +427,7 @@ def strided_copy(src, dst):
     return dst
 
 
+@_on_device
 def timestep_embedding(timesteps, dim, flip_sin_to_cos=True, downscale_freq_shift=0.0, max_period=10000.0,
                        dtype=torch.float16):
     _require_cuda(timesteps)
@@ -358,6 +441,7 @@ def timestep_embedding(timesteps, dim, flip_sin_to_cos=True, downscale_freq_shif
     return out
 
 
+@_on_device
 def cfg_ddim_step(eps_uc, latents, coef, guidance, latents_out=None, unet_in=None):
     _require_cuda(eps_uc, latents, coef)
     lib = L.init_device()

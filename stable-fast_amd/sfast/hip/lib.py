@@ -20,6 +20,8 @@ F16, BF16, F32 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_SILU, ACT_SIGMOID, ACT_TANH = range(7)
 NHWC, NCHW = 0, 1
 MAX_WSEG = 4
+MAX_GROUPS = 32
+MAX_GEMM_GROUPS = 64
 
 EXPORTS = [
     "sfast_hip_abi_version", "sfast_hip_init", "sfast_hip_last_error", "sfast_hip_last_kernel",
@@ -27,7 +29,7 @@ EXPORTS = [
     "sfast_hip_gemm_workspace_bytes", "sfast_hip_gemm",
     "sfast_hip_conv2d_workspace_bytes", "sfast_hip_conv2d",
     "sfast_hip_attention", "sfast_hip_strided_copy", "sfast_hip_timestep_embedding",
-    "sfast_hip_cfg_ddim_step", "sfast_hip_igemm_plan", "sfast_hip_set_trace", "sfast_hip_image_postprocess", "sfast_hip_add_strided",
+    "sfast_hip_gemv_grouped", "sfast_hip_gemm_grouped", "sfast_hip_cfg_ddim_step", "sfast_hip_igemm_plan", "sfast_hip_set_trace", "sfast_hip_image_postprocess", "sfast_hip_add_strided",
 ]
 
 
@@ -63,6 +65,12 @@ class GemmParams(C.Structure):
                 ("act", C.c_int32), ("res_before_act", C.c_int32), ("alpha", C.c_float),
                 ("rows_per_batch", C.c_int32), ("ld_rowbias", C.c_int64), ("in_act", C.c_int32),
                 ("variant", C.c_int32), ("split_k", C.c_int32)]
+
+
+class GemvGroupedParams(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("M", C.c_int32), ("K", C.c_int32), ("n_groups", C.c_int32),
+                ("n_rows", C.c_int32 * MAX_GROUPS), ("ldx", C.c_int64), ("ldw", C.c_int64), ("ldo", C.c_int64),
+                ("act", C.c_int32), ("in_act", C.c_int32)]
 
 
 class ConvParams(C.Structure):
@@ -126,6 +134,10 @@ def _declare(lib):
     lib.sfast_hip_gemm_workspace_bytes.argtypes = [C.POINTER(GemmParams)]
     lib.sfast_hip_gemm.restype = C.c_int
     lib.sfast_hip_gemm.argtypes = [vp, C.POINTER(vp), vp, vp, vp, vp, C.POINTER(GemmParams), vp, sz, vp]
+    lib.sfast_hip_gemm_grouped.restype = C.c_int
+    lib.sfast_hip_gemm_grouped.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(GemmParams), C.c_int32, vp]
+    lib.sfast_hip_gemv_grouped.restype = C.c_int
+    lib.sfast_hip_gemv_grouped.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), vp, C.POINTER(GemvGroupedParams), vp]
     lib.sfast_hip_conv2d_workspace_bytes.restype = sz
     lib.sfast_hip_conv2d_workspace_bytes.argtypes = [C.POINTER(ConvParams)]
     lib.sfast_hip_conv2d.restype = C.c_int
@@ -170,18 +182,25 @@ def load():
     return _lib
 
 
-_inited = False
+_inited = set()
 
 
-def init_device():
-    """One-time kernel-attribute setup; needs a visible GPU. Call before any graph capture."""
-    global _inited
+def init_device(device=None):
+    """Kernel-attribute setup, once per device (function attributes are per device); needs a visible GPU. Call before any
+    graph capture. `device`: torch.device / index; default = the current device."""
     lib = load()
-    if not _inited:
-        rc = lib.sfast_hip_init()
-        if rc != 0:
-            raise SfastHipError(f"sfast_hip_init failed ({rc}): {last_error()}")
-        _inited = True
+    import torch
+    idx = torch.cuda.current_device() if device is None else (device.index if hasattr(device, "index") else int(device))
+    if idx is None:
+        idx = torch.cuda.current_device()
+    if idx not in _inited:
+        with _lock:
+            if idx not in _inited:
+                with torch.cuda.device(idx):
+                    rc = lib.sfast_hip_init()
+                if rc != 0:
+                    raise SfastHipError(f"sfast_hip_init failed ({rc}): {last_error()}")
+                _inited.add(idx)
     return lib
 
 

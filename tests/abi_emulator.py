@@ -139,6 +139,30 @@ class EmuLib:
         _strided(out, (p.M, p.N), (p.ldo, 1), p.dtype).copy_(o)
         return 0
 
+    def sfast_hip_gemm_grouped(self, x, segs, bias, out, ref, n_groups, stream):
+        p = _p(ref)
+        self.calls.append("gemm_grouped")
+        xin = _strided(x, (p.M, p.K), (p.ldx, 1), p.dtype)
+        for g in range(n_groups):
+            w = torch.cat([_strided(segs[g * p.n_wseg + j], (p.rows_per_seg, p.K), (p.ldw, 1), p.dtype) for j in range(p.n_wseg)], dim=0)[:p.N]
+            b = _flat(bias[g], p.N, p.dtype) if bias and bias[g] else None
+            _strided(out[g], (p.M, p.N), (p.ldo, 1), p.dtype).copy_(R.linear_ref(xin, w, b, _ACT[p.act]))
+        return 0
+
+    def sfast_hip_gemv_grouped(self, x, w, bias, out, ref, stream):
+        p = _p(ref)
+        self.calls.append("gemv_grouped")
+        xin = _strided(x, (p.M, p.K), (p.ldx, 1), p.dtype)
+        off = 0
+        for g in range(p.n_groups):
+            n = p.n_rows[g]
+            wg = _strided(w[g], (n, p.K), (p.ldw, 1), p.dtype)
+            bg = _flat(bias[g], n, p.dtype) if bias and bias[g] else None
+            o = R.linear_ref(xin, wg, bg, _ACT[p.act], None, 1.0, False, False, None, 0, _ACT[p.in_act])
+            _strided(out + off * 2, (p.M, n), (p.ldo, 1), p.dtype).copy_(o)
+            off += n
+        return 0
+
     def sfast_hip_conv2d(self, x, x2, w, bias, rowbias, z, out, ref, ws, ws_bytes, stream):
         p = _p(ref)
         self.calls.append("conv2d")

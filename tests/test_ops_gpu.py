@@ -487,3 +487,57 @@ def test_golden_ops():
     c = g["attention_d40_kv77"]
     y = torch.ops.sfast_xformers.memory_efficient_attention(d(c["q"]), d(c["k"]), d(c["v"]), None, 0.0, None, None)
     compare("golden attention", y, c["y"], 3e-3, 2e-3, kernel=last_kernel())
+
+# ---- grouped GEMV (the 22 time_emb_proj layers in one launch) ------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K,rows", [(2, 1280, [320, 320, 640, 640, 1280, 1280, 1280, 1280, 640, 320]), (1, 1280, [1280] * 22),
+                                      (16, 1280, [320] * 32), (3, 256, [8, 24, 40]), (2, 1280, [320])])
+def test_gemv_grouped_matches_per_layer_linear(dtype, M, K, rows):
+    x = rnd(M, K, dtype=dtype, seed=70)
+    ws = [rnd(n, K, dtype=dtype, seed=71 + i, scale=K ** -0.5) for i, n in enumerate(rows)]
+    bs = [rnd(n, dtype=dtype, seed=171 + i) if i % 3 else None for i, n in enumerate(rows)]
+    y = F().gemv_grouped(x, ws, bs)
+    want = torch.cat([R.linear_ref(x, w, b) for w, b in zip(ws, bs)], dim=1)
+    compare(f"gemv_grouped M={M} K={K} G={len(rows)} {dtype}", y, want, *tol(dtype), kernel=last_kernel())
+    assert "gemv_grouped" in last_kernel()
+    # bitwise equal to the per-layer GEMV path (same per-column summation order)
+    one = torch.cat([F().linear(x, w, b, variant=101) for w, b in zip(ws, bs)], dim=1)
+    assert torch.equal(y, one)
+
+
+def test_gemv_grouped_activations_and_validation():
+    x = rnd(2, 512, seed=80)
+    ws = [rnd(64, 512, seed=81, scale=0.05), rnd(128, 512, seed=82, scale=0.05)]
+    y = F().gemv_grouped(x, ws, None, act="silu", in_act="silu")
+    want = torch.cat([R.linear_ref(x, w, None, "silu", in_act="silu") for w in ws], dim=1)
+    compare("gemv_grouped silu/silu", y, want, *tol(x.dtype), kernel=last_kernel())
+    from sfast.hip.lib import SfastHipError
+    with pytest.raises(SfastHipError):
+        F().gemv_grouped(x, [ws[0]] * 33)
+
+# ---- grouped GEMM (cross-attention K/V projections of one UNet level in one launch) -------------------------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K,C_,G", [(154, 768, 320, 5), (154, 768, 1280, 6), (77, 768, 640, 5), (154, 2048, 1280, 60), (154, 2048, 640, 10),
+                                     (1232, 768, 320, 5), (50, 1024, 160, 3)])
+def test_linear_grouped_matches_per_block_linear(dtype, M, K, C_, G):
+    x = rnd(M, K, dtype=dtype, seed=90)
+    groups = [[rnd(C_, K, dtype=dtype, seed=100 + 2 * g, scale=K ** -0.5), rnd(C_, K, dtype=dtype, seed=101 + 2 * g, scale=K ** -0.5)]
+              for g in range(G)]
+    outs = F().linear_grouped(x, groups)
+    k = last_kernel()
+    assert "igemm_grouped" in k
+    for g in (0, G // 2, G - 1):
+        want = R.linear_ref(x, torch.cat(groups[g], 0))
+        compare(f"linear_grouped M={M} K={K} C={C_} g={g}/{G} {dtype}", outs[g], want, *tol(dtype), kernel=k)
+    # same arithmetic as the single-problem register pipe with the same tile
+    one = F().linear(x, groups[G - 1], variant=3 if "64x64" in k else 1, split_k=1)
+    assert torch.equal(outs[G - 1], one)
+
+
+def test_linear_grouped_bias_act_single_segment():
+    x = rnd(96, 256, seed=110)
+    ws = [[rnd(192, 256, seed=111 + g, scale=0.06)] for g in range(4)]
+    bs = [rnd(192, seed=121 + g) for g in range(4)]
+    outs = F().linear_grouped(x, ws, bs, act="relu")
+    for g in range(4):
+        compare(f"linear_grouped bias relu g={g}", outs[g], R.linear_ref(x, ws[g][0], bs[g], "relu"), *tol(x.dtype), kernel=last_kernel())
