@@ -42,6 +42,8 @@ def parse():
                     help="sd15 (the BASELINE metric) | sdxl | vae (SD VAE decode 64x64 latent -> 512x512, SURVEY 8f rank 1)")
     ap.add_argument("--images", type=int, default=1, help="images per GPU (UNet batch is 2x this: CFG)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--through-compile", action="store_true",
+                    help="also time the same step through sfast.compilers.compile() + a pipeline-shaped loop (N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-kernels", default=None, help="write the per-op timing table to this JSON file")
@@ -132,13 +134,21 @@ def roofline_from(rows):
                 algorithmic_mbytes_per_launch=dom["bytes"] / dom["launches"] / 1e6, traffic=None)
     # HBM-side bytes per launch from the PMC counters: collected in their own rocprofv3 --pmc passes over this same
     # command (tools/gpu_pmc_bench.sh: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB units) and committed under profiles/
+    # (file named by SFAST_TRAFFIC_PROFILE, else the newest profiles/rNN_pmc_traffic_by_symbol.json; its run id is stated)
     try:
+        import glob
         here = os.path.dirname(os.path.abspath(__file__))
-        with open(os.path.join(here, "profiles", "r01_pmc_traffic_by_symbol.json")) as f:
-            t = json.load(f).get(dom_name)
-        if t:
-            roof["traffic"] = t["bytes_per_launch"]
-            roof["traffic_source"] = "profiles/r01_pmc_traffic_by_symbol.json (separate --pmc passes; includes Infinity-Cache hits)"
+        path = os.environ.get("SFAST_TRAFFIC_PROFILE")
+        if not path:
+            cands = sorted(glob.glob(os.path.join(here, "profiles", "r[0-9][0-9]_pmc_traffic_by_symbol.json")))
+            path = cands[-1] if cands else None
+        if path:
+            with open(path) as f:
+                t = json.load(f).get(dom_name)
+            if t:
+                roof["traffic"] = t["bytes_per_launch"]
+                roof["traffic_source"] = (f"{os.path.relpath(path, here)} (counters from separate rocprofv3 --pmc passes over this command, not "
+                                          "re-measured in this run; FETCH_SIZE x2 + WRITE_SIZE, includes Infinity-Cache hits)")
     except (OSError, ValueError):
         pass
     fam = {}
@@ -162,7 +172,7 @@ def roofline_from(rows):
 
 
 def cpu_baseline(cfg_name, images):
-    """fp32 oracle UNet on the host cores, same CFG batch-2 forward. Bounded: 1 warm-up + 2 timed."""
+    """fp32 oracle UNet on the host cores, same CFG batch-2 forward. Bounded: 1 warm-up + 3 timed."""
     sys.path.insert(0, ROOT)
     from oracle import unet_ref as U
     torch.manual_seed(0)
@@ -178,14 +188,102 @@ def cpu_baseline(cfg_name, images):
     with torch.inference_mode():
         m(x, 981, e, added_cond_kwargs=added)
         ts = []
-        for _ in range(2):
+        for _ in range(3):
             t0 = time.perf_counter()
             m(x, 981, e, added_cond_kwargs=added)
             ts.append(time.perf_counter() - t0)
     med = sorted(ts)[len(ts) // 2]
     return dict(value=1.0 / med, unit="it/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"2 timed CFG batch-{B} fp32 UNet forwards of the oracle restatement (oracle/unet_ref.py) after 1 warm-up; "
+                sample=f"3 timed CFG batch-{B} fp32 UNet forwards of the oracle restatement (oracle/unet_ref.py) after 1 warm-up; "
                        f"median {med:.2f} s/forward; diffusers itself is not installable here")
+
+
+class _Config(dict):
+    __getattr__ = dict.get
+
+
+class _DDIMSchedulerLike:
+    """Harness stand-in with diffusers' DDIMScheduler call surface (diffusers is not installable here): SD1.5's scaled-linear
+    betas, leading spacing with steps_offset 1, eta = 0, set_alpha_to_one False. Its `step` is the eager torch arithmetic a
+    pipeline would run without trace_scheduler; compile(..., trace_scheduler=True) replaces it."""
+
+    init_noise_sigma = 1.0
+
+    def __init__(self):
+        self.config = _Config(num_train_timesteps=1000, prediction_type="epsilon", clip_sample=False, thresholding=False,
+                              steps_offset=1, timestep_spacing="leading")
+        betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = self.alphas_cumprod[0]
+        self.num_inference_steps = None
+        self.timesteps = None
+
+    def set_timesteps(self, n, device=None):
+        self.num_inference_steps = n
+        ratio = 1000 // n
+        self.timesteps = ((torch.arange(0, n) * ratio).flip(0) + 1).to(device)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def step(self, model_output, timestep, sample, eta=0.0, use_clipped_model_output=False, generator=None, variance_noise=None,
+             return_dict=True):
+        t = int(timestep)
+        prev = t - 1000 // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_p = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
+        x0 = (sample - (1 - a_t) ** 0.5 * model_output) / a_t ** 0.5
+        out = a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * model_output
+        return (out,) if not return_dict else _Config(prev_sample=out)
+
+
+class _PipelineLike:
+    """The denoise loop of diffusers' StableDiffusionPipeline.__call__ (classifier-free guidance), prompt embeddings given."""
+
+    def __init__(self, unet, scheduler, device):
+        self.unet, self.scheduler, self.vae, self.device = unet, scheduler, None, device
+
+    @torch.no_grad()
+    def denoise(self, latents, prompt_embeds, guidance_scale, timesteps):
+        for t in timesteps:
+            latent_model_input = torch.cat([latents] * 2)
+            latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
+            noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=prompt_embeds, return_dict=False)[0]
+            noise_pred_uncond, noise_pred_text = noise_pred.chunk(2)
+            noise_pred = noise_pred_uncond + guidance_scale * (noise_pred_text - noise_pred_uncond)
+            latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+        return latents
+
+
+def through_compile(args, cfg, params, dev, latents, ehs, engine_ms):
+    """The same step measured through the DROP-IN surface: a module with diffusers' parameter layout + a pipeline-shaped denoise
+    loop + `sfast.compilers.compile(pipe, config)` with enable_cuda_graph and trace_scheduler -- i.e. what a stable-fast user
+    runs (reference examples/optimize_stable_diffusion_pipeline.py:127-151), including the per-step input copies, the output
+    clone and the pipeline's own guidance arithmetic that the fused DenoiseLoop does not have."""
+    from sfast.compilers.diffusion_pipeline_compiler import CompilationConfig, compile
+    from sfast.engine.unet_spec import module_from_params
+    unet = module_from_params(cfg, params)
+    sched = _DDIMSchedulerLike()
+    pipe = _PipelineLike(unet, sched, dev)
+    config = CompilationConfig.Default()
+    config.enable_cuda_graph = True
+    config.trace_scheduler = True
+    compile(pipe, config)
+    sched.set_timesteps(50, device=dev)
+    ts = list(sched.timesteps)
+    lat = latents.clone()
+    pipe.denoise(lat, ehs, 7.5, ts[:3])  # builds + captures the plan
+    torch.cuda.synchronize()
+    steps = min(args.steps, 100)
+    seq = [ts[i % 50] for i in range(steps)]
+    t0 = time.perf_counter()
+    out = pipe.denoise(lat, ehs, 7.5, seq)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms = el / steps * 1e3
+    return {"value": steps / el, "unit": "it/s", "ms_per_step": ms, "steps": steps, "gap_vs_fused_loop": ms / engine_ms - 1.0,
+            "native_scheduler_steps": getattr(sched.step, "native_calls", 0), "outputs_finite": bool(torch.isfinite(out).all()),
+            "path": "module_from_params -> sfast.compilers.compile(enable_cuda_graph, trace_scheduler) -> pipeline-shaped CFG loop"}
 
 
 def bench_vae(args, dev, rank, world, use_dist):
@@ -334,6 +432,13 @@ def main():
 
     engine = UNet2DEngine(cfg, params)
     hw = cfg["sample_size"]
+    if world > 1:
+        # rank 0 builds (and, for shapes outside the packaged cache, times) its plan first and shares the kernel choices:
+        # every replica then runs identical kernels and nobody else spends start-up time tuning
+        from sfast.engine.replicas import share_tune_cache
+        if rank == 0:
+            engine.get_plan(2 * args.images, hw, hw, 77)
+        share_tune_cache(src=0)
     loop = DenoiseLoop(engine, images=args.images, height=hw, width=hw, ctx_len=77, guidance=7.5, num_steps=50,
                        use_graph=not args.no_graph)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -391,7 +496,7 @@ def main():
             "activation_pool_mb": loop.plan.pool.total_bytes() / 1e6,
         }
         if world > 1:
-            out["weight_broadcast"] = {"bytes": bytes_bcast, "seconds": t_bcast}
+            out["weight_broadcast"] = {"bytes": bytes_bcast, "seconds": t_bcast, "gb_per_s": bytes_bcast / max(t_bcast, 1e-9) / 1e9}
         if not args.no_roofline and world == 1:
             rows = per_op_timing(loop)
             roof, families, eager_total = roofline_from(rows)
@@ -402,6 +507,8 @@ def main():
                 os.makedirs(os.path.dirname(os.path.abspath(args.dump_kernels)), exist_ok=True)
                 with open(args.dump_kernels, "w") as f:
                     json.dump(rows, f, indent=1)
+        if args.through_compile and world == 1 and args.config == "sd15" and args.images == 1:
+            out["through_compile"] = through_compile(args, cfg, params, dev, latents, ehs, elapsed / args.steps * 1e3)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.config, args.images)
         print(json.dumps(out), flush=True)

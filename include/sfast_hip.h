@@ -26,7 +26,7 @@
  *   sfast_hip_softmax_rows  <- the VAE decoder's single-head attention (compile_vae path), between two sfast_hip_gemm calls
  *   sfast_hip_add_strided   <- ControlNet residual adds of UNet2DConditionModel.forward
  *   sfast_hip_image_postprocess <- patched VaeImageProcessor (libs/diffusers/image_processor.py:13-108)
- *   sfast_hip_timestep_embedding, sfast_hip_cfg_ddim_step
+ *   sfast_hip_timestep_embedding, sfast_hip_cfg_ddim_step, sfast_hip_linear_step
  *                          <- host-side glue of the denoise loop that the reference leaves to
  *                             diffusers / trace_scheduler (compilers/diffusion_pipeline_compiler.py:103-107)
  *
@@ -289,6 +289,15 @@ int sfast_hip_timestep_embedding(const float *timesteps /* [B] device */, void *
 int sfast_hip_cfg_ddim_step(const void *eps_uc, const void *latents, void *latents_out,
                             void *unet_in, const float *coef, float guidance, int64_t numel,
                             int32_t dtype, sfast_stream_t stream);
+
+/* ---- scheduler update in linear form: out = A*sample + B*model_output, fp32 math ---------------------------
+ * (A, B) = coef[2*idx], coef[2*idx+1] with idx = *index (device int32 / int64 scalar, clamped to [0, index_limit)) or 0 when
+ * index == NULL. Every deterministic one-step sampler update is this form -- DDIM with eta = 0 for epsilon or v prediction
+ * being the case `compile(..., trace_scheduler=True)` routes here (reference: compilers/diffusion_pipeline_compiler.py:103-107
+ * traces scheduler.step into one TorchScript graph); the coefficient table over all training timesteps is built on the host
+ * once per set_timesteps(), the timestep itself stays on the device. */
+int sfast_hip_linear_step(const void *model_output, const void *sample, void *out, const float *coef, const void *index,
+                          int32_t index_is_i64, int64_t index_limit, int64_t numel, int32_t dtype, sfast_stream_t stream);
 
 /* ---- image post-process: NCHW f16/bf16/f32 image -> NHWC uint8 or float32 ----------------------
  * replaces the reference's patched VaeImageProcessor.postprocess / pt_to_pil / pt_to_numpy

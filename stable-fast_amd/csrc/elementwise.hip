@@ -68,6 +68,21 @@ __global__ void __launch_bounds__(256) cfg_ddim_kernel(const T *__restrict__ eps
     }
 }
 
+// out = A * x + B * eps with (A, B) = coef[2 * idx], coef[2 * idx + 1]; idx read from device memory (the pipeline's timestep
+// tensor lives on the GPU: looking the coefficients up on the device keeps the denoise loop free of host syncs).
+template <typename T>
+__global__ void __launch_bounds__(256) linear_step_kernel(const T *__restrict__ eps, const T *__restrict__ x, T *__restrict__ out,
+                                                          const float *__restrict__ coef, const void *__restrict__ index,
+                                                          int index_is_i64, int64_t index_limit, int64_t numel) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= numel) return;
+    int64_t idx = 0;
+    if (index) idx = index_is_i64 ? *(const int64_t *)index : (int64_t) * (const int32_t *)index;
+    idx = idx < 0 ? 0 : (idx >= index_limit ? index_limit - 1 : idx);
+    const float a = coef[2 * idx], b = coef[2 * idx + 1];
+    out[i] = Elem<T>::from_f32(fmaf(a, Elem<T>::to_f32(x[i]), b * Elem<T>::to_f32(eps[i])));
+}
+
 template <typename T> __global__ void __launch_bounds__(256) strided_add_kernel(const CopyArgs a) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < a.total; idx += stride) {
@@ -192,6 +207,30 @@ extern "C" int sfast_hip_cfg_ddim_step(const void *eps_uc, const void *latents, 
     default: set_error("cfg_ddim_step: dtype %d", dtype); return SFAST_ERR_UNSUPPORTED;
     }
     return check_launch("cfg_ddim_step");
+}
+
+extern "C" int sfast_hip_linear_step(const void *model_output, const void *sample, void *out, const float *coef, const void *index,
+                                     int32_t index_is_i64, int64_t index_limit, int64_t numel, int32_t dtype, sfast_stream_t stream) {
+    SFAST_REQUIRE(model_output && sample && out && coef && numel > 0 && index_limit > 0, SFAST_ERR_INVALID, "linear_step: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)ceil_div64(numel, 256));
+    set_kernel_name("linear_step");
+    switch (dtype) {
+    case SFAST_F16:
+        hipLaunchKernelGGL(linear_step_kernel<f16>, grid, dim3(256), 0, st, (const f16 *)model_output, (const f16 *)sample, (f16 *)out, coef,
+                           index, index_is_i64, index_limit, numel);
+        break;
+    case SFAST_BF16:
+        hipLaunchKernelGGL(linear_step_kernel<bf16>, grid, dim3(256), 0, st, (const bf16 *)model_output, (const bf16 *)sample, (bf16 *)out, coef,
+                           index, index_is_i64, index_limit, numel);
+        break;
+    case SFAST_F32:
+        hipLaunchKernelGGL(linear_step_kernel<float>, grid, dim3(256), 0, st, (const float *)model_output, (const float *)sample, (float *)out,
+                           coef, index, index_is_i64, index_limit, numel);
+        break;
+    default: set_error("linear_step: dtype %d", dtype); return SFAST_ERR_UNSUPPORTED;
+    }
+    return check_launch("linear_step");
 }
 
 extern "C" int sfast_hip_image_postprocess(const void *image, void *out, const sfast_image_params *p, sfast_stream_t stream) {

@@ -317,6 +317,12 @@ def compile(m, config):
     if getattr(m, "vae", None) is not None:
         m.vae = compile_vae(m.vae, config)
 
+    if config.enable_jit and config.trace_scheduler and device.type == "cuda" and getattr(m, "scheduler", None) is not None:
+        # reference :103-107 wraps scheduler.scale_model_input / scheduler.step in lazy_trace; here the step of a supported
+        # scheduler family becomes one HIP kernel with the same call signature (libs/diffusers/scheduler.py)
+        from ..libs.diffusers.scheduler import patch_scheduler
+        patch_scheduler(m.scheduler)
+
     if getattr(m, "image_processor", None) is not None:
         # reference :117-122: post-processing moved onto the GPU
         from ..libs.diffusers.image_processor import patch_image_prcessor

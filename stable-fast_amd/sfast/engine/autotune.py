@@ -28,6 +28,26 @@ GEGLU_VARIANTS = (1, 3, 11, 13, 16, 18, 21, 23)
 MAX_SLAB_BYTES = 192 << 20
 
 
+PACKAGED_CACHE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_gfx950.json")
+
+
+def export_cache():
+    """Snapshot of the measured (variant, split_k) choices of this process -- what `share_tune_cache` sends to replicas."""
+    with _cache_lock:
+        return {k: list(v) for k, v in _cache.items()}
+
+
+def import_cache(entries, overwrite=False):
+    """Merge choices measured elsewhere (another rank, a file): replicas then build identical plans without timing anything."""
+    n = 0
+    with _cache_lock:
+        for k, v in (entries or {}).items():
+            if overwrite or k not in _cache:
+                _cache[k] = (int(v[0]), int(v[1]))
+                n += 1
+    return n
+
+
 def enabled():
     return os.environ.get("SFAST_AUTOTUNE", "1") not in ("0", "false", "off", "")
 
@@ -97,6 +117,8 @@ def tune_plan(plan, device, dtype_tag="f16", verbose=False):
     cache_path = os.environ.get("SFAST_TUNE_CACHE")
     with _cache_lock:
         _load_file(cache_path)
+        if os.environ.get("SFAST_TUNE_PACKAGED", "1") not in ("0", "false", "off", ""):
+            _load_file(PACKAGED_CACHE)  # choices measured on an MI355X for the SD1.5 / SDXL shapes; anything else is timed here
     devname = getattr(torch.cuda.get_device_properties(device), "gcnArchName", "gpu").split(":")[0]
     todo = {}
     for op in plan.ops:

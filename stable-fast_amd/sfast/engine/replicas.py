@@ -91,3 +91,17 @@ def gather_latents(local: torch.Tensor, dst: int = 0, group=None):
     outs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
     dist.gather(local.contiguous(), outs, dst=dst, group=group)
     return outs
+
+
+def share_tune_cache(src: int = 0, group=None) -> int:
+    """Send rank `src`'s measured kernel choices (sfast.engine.autotune) to every other rank, once, before they build their plans:
+    all replicas then run the SAME (variant, split-K) per problem -- identical arithmetic on every GPU -- and only one rank pays
+    the seconds of timing. One small object broadcast; no effect on the per-step path. Returns the number of entries received."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0
+    from . import autotune
+    box = [autotune.export_cache() if dist.get_rank(group) == src else None]
+    dist.broadcast_object_list(box, src=src, group=group)
+    if dist.get_rank(group) == src:
+        return 0
+    return autotune.import_cache(box[0], overwrite=True)

@@ -213,3 +213,37 @@ def random_vae_decoder_params(cfg: dict, seed: int = 0, dtype=torch.float16, dev
             t = t.contiguous(memory_format=torch.channels_last)
         params[name] = t
     return params
+
+
+class _Node(torch.nn.Module):
+    """Attribute container of `module_from_params`; it has no forward of its own."""
+
+    def forward(self, *args, **kwargs):
+        raise RuntimeError("this module is a bare parameter container (sfast.engine.unet_spec.module_from_params): it has no eager "
+                           "forward -- hand it to sfast.compilers.compile_unet() / UNet2DEngine.from_module()")
+
+
+def module_from_params(cfg: dict, params: Dict[str, torch.Tensor]) -> torch.nn.Module:
+    """A `torch.nn.Module` tree with diffusers' attribute / state-dict layout whose parameters ARE the tensors of `params` (no copy)
+    and whose `.config` is `cfg` -- what `compile_unet()` needs from a UNet (named parameters + config) without diffusers and
+    without an eager forward. Used to drive bare state dicts (safetensors) and the benchmark's synthetic weights through the
+    drop-in `compile()` surface."""
+    root = _Node()
+    for name, t in params.items():
+        parts = name.split(".")
+        node = root
+        for part in parts[:-1]:
+            nxt = node._modules.get(part)
+            if nxt is None:
+                nxt = _Node()
+                node.add_module(part, nxt)
+            node = nxt
+        node.register_parameter(parts[-1], torch.nn.Parameter(t, requires_grad=False))
+
+    class _Cfg(dict):
+        __getattr__ = dict.get
+
+    root.config = _Cfg(cfg)
+    first = next(iter(params.values()))
+    root.dtype = first.dtype
+    return root

@@ -454,3 +454,32 @@ def cfg_ddim_step(eps_uc, latents, coef, guidance, latents_out=None, unet_in=Non
                                      float(guidance), numel, _dtype(latents), _stream(latents))
     L.check(rc, "sfast_hip_cfg_ddim_step")
     return latents_out
+
+
+@_on_device
+def linear_step(model_output, sample, coef, index=None, out=None):
+    """out = coef[idx, 0] * sample + coef[idx, 1] * model_output (fp32 math). `coef` float32 [n, 2] on the device; `index`: None (row 0),
+    a python int (resolved on the host: no sync) or a 0-d int32 / int64 tensor on the device (read by the kernel: no sync)."""
+    _require_cuda(model_output, sample, coef)
+    lib = L.init_device()
+    if coef.dtype != torch.float32 or coef.ndim != 2 or coef.shape[1] != 2 or not coef.is_contiguous():
+        raise L.SfastHipError("linear_step: coef must be a contiguous float32 [n, 2] tensor")
+    mo = model_output.contiguous()
+    x = sample.to(mo.dtype).contiguous()
+    if out is None:
+        out = torch.empty_like(mo)
+    n = coef.shape[0]
+    cptr, iptr, i64 = coef.data_ptr(), None, 0
+    if index is not None:
+        if torch.is_tensor(index) and index.device.type == "cuda":
+            if index.dtype not in (torch.int32, torch.int64) or index.numel() != 1:
+                raise L.SfastHipError("linear_step: device index must be one int32 / int64 element")
+            iptr, i64 = index.data_ptr(), int(index.dtype == torch.int64)
+        else:
+            i = int(index)
+            if not 0 <= i < n:
+                raise L.SfastHipError(f"linear_step: index {i} outside the coefficient table [0, {n})")
+            cptr, n = cptr + 8 * i, 1
+    L.check(lib.sfast_hip_linear_step(_ptr(mo), _ptr(x), _ptr(out), cptr, iptr, i64, n, mo.numel(), _dtype(mo), _stream(mo)),
+            "sfast_hip_linear_step")
+    return out

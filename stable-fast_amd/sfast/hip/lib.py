@@ -29,7 +29,7 @@ EXPORTS = [
     "sfast_hip_gemm_workspace_bytes", "sfast_hip_gemm",
     "sfast_hip_conv2d_workspace_bytes", "sfast_hip_conv2d",
     "sfast_hip_attention", "sfast_hip_strided_copy", "sfast_hip_timestep_embedding",
-    "sfast_hip_gemv_grouped", "sfast_hip_gemm_grouped", "sfast_hip_cfg_ddim_step", "sfast_hip_igemm_plan", "sfast_hip_set_trace", "sfast_hip_image_postprocess", "sfast_hip_add_strided",
+    "sfast_hip_gemv_grouped", "sfast_hip_gemm_grouped", "sfast_hip_cfg_ddim_step", "sfast_hip_linear_step", "sfast_hip_igemm_plan", "sfast_hip_set_trace", "sfast_hip_image_postprocess", "sfast_hip_add_strided",
 ]
 
 
@@ -152,6 +152,8 @@ def _declare(lib):
     lib.sfast_hip_set_trace.argtypes = [C.c_void_p]
     lib.sfast_hip_igemm_plan.restype = C.c_int
     lib.sfast_hip_igemm_plan.argtypes = [C.c_int32] * 6 + [C.POINTER(C.c_int32 * 5)]
+    lib.sfast_hip_linear_step.restype = C.c_int
+    lib.sfast_hip_linear_step.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int64, C.c_int64, C.c_int32, vp]
     lib.sfast_hip_cfg_ddim_step.restype = C.c_int
     lib.sfast_hip_cfg_ddim_step.argtypes = [vp, vp, vp, vp, vp, C.c_float, C.c_int64, C.c_int32, vp]
 

@@ -218,6 +218,7 @@ class EmuLib:
 
     def sfast_hip_cfg_ddim_step(self, eps_uc, lat, lat_out, unet_in, coef, g, numel, dtype, stream):
         self.calls.append("cfg_ddim_step")
+        g = float(getattr(g, "value", g))
         e = _flat(eps_uc, 2 * numel, dtype)
         x = _flat(lat, numel, dtype)
         c = _flat(coef, 4, L.F32)

@@ -175,3 +175,67 @@ def test_bench_contract_defaults_and_self_launch(monkeypatch):
     assert cmd[-4:] == ["--gpus", "4", "--steps", "7"] and cmd[-5].endswith("bench.py")
     # a free port is picked when none is given
     assert int(bench.torchrun_argv(2, [])[bench.torchrun_argv(2, []).index("--master-port") + 1]) > 0
+
+
+def _loop_worker(rank, world, port, q):
+    """Every rank: tiny UNet engine on the ABI emulator, weights broadcast from rank 0, its own image (seed 1234 + rank) through
+    three fused CFG + DDIM iterations of DenoiseLoop -- the per-GPU loop of bench.py --gpus N, on CPU."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from abi_emulator import EmuLib
+        from oracle import unet_ref as U
+        from sfast.engine import UNet2DEngine, autotune
+        from sfast.engine.denoise import DenoiseLoop
+        from sfast.engine.replicas import broadcast_parameters, gather_latents, share_tune_cache
+        cfg = U.tiny_config()
+        m = U.build(cfg, seed=50 + rank, dtype=torch.float16)  # different weights per rank until the broadcast
+        params = {k: (v.data.contiguous(memory_format=torch.channels_last) if v.ndim == 4 else v.data) for k, v in m.named_parameters()}
+        broadcast_parameters(params, src=0)
+        if rank == 0:
+            autotune.import_cache({"gfx950|f16|gemm|1x2x3|(0, 0, 1)": [3, 1]})
+        got = share_tune_cache(src=0)
+        eng = UNet2DEngine(m.config, params, device=torch.device("cpu"), dtype=torch.float16, _lib=EmuLib())
+        loop = DenoiseLoop(eng, images=1, height=16, width=16, ctx_len=20, guidance=7.5, num_steps=50, use_graph=False)
+        g = torch.Generator().manual_seed(1234 + rank)
+        lat = torch.randn(1, 4, 16, 16, generator=g).half()
+        ehs = torch.randn(2, 20, cfg["cross_attention_dim"], generator=g).half()
+        loop.set_inputs(lat, ehs)
+        for i in range(3):
+            loop.step(i)
+        outs = gather_latents(loop.latents.float(), dst=0)
+        q.put((rank, got, [o.clone() for o in outs] if rank == 0 else None, autotune.export_cache().get("gfx950|f16|gemm|1x2x3|(0, 0, 1)")))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_denoise_loop_replicas_gloo_world2(built_lib):
+    """Rank r's latents after three fused steps == a single-process run with rank 0's weights and seed 1234 + r."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loop_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1][1] >= 1 and res[1][3] == [3, 1]  # rank 1 received rank 0's kernel choices
+    from abi_emulator import EmuLib
+    from oracle import unet_ref as U
+    from oracle.ops_ref import cfg_ddim_ref, ddim_schedule
+    from sfast.engine import UNet2DEngine
+    cfg = U.tiny_config()
+    m = U.build(cfg, seed=50, dtype=torch.float16)
+    eng = UNet2DEngine.from_module(m, _lib=EmuLib())
+    ts, coefs = ddim_schedule(50)
+    for r in range(2):
+        g = torch.Generator().manual_seed(1234 + r)
+        lat = torch.randn(1, 4, 16, 16, generator=g).half()
+        ehs = torch.randn(2, 20, cfg["cross_attention_dim"], generator=g).half()
+        for i in range(3):
+            eps = eng.forward(torch.cat([lat, lat]), float(ts[i]), ehs)
+            c32 = torch.tensor(coefs[i], dtype=torch.float32).tolist()  # the loop keeps its coefficient table in float32
+            lat = cfg_ddim_ref(eps.flatten(), lat.flatten(), c32, 7.5).to(torch.float16).reshape(lat.shape)
+        assert torch.equal(res[0][2][r], lat.float()), r

@@ -124,7 +124,9 @@ def test_sd15_unet_parity_and_graph(sd15):
     g2.replay()
     torch.cuda.synchronize()
     assert torch.equal(r3, y) and torch.equal(plan.static_out, y)
-    assert sum(op.lane != 0 for op in plan.ops) == 24 + 1 + 16  # temb MLP + 22 projections + sinusoid, 16 text K/V GEMMs
+    # side lanes: sinusoid + time MLP (2) + ONE grouped GEMV over the 22 projections + one grouped K/V GEMM per level width (3)
+    assert sum(op.lane != 0 for op in plan.ops) == 1 + 2 + 1 + 3
+    log_value("sd15 B=2 plan", launches=len(plan.ops))
 
     # batch independence: every op is per-sample, so B=1 must reproduce row 0 of the B=2 run
     y1 = eng.forward(sample[:1], 981, ehs[:1])
@@ -337,3 +339,103 @@ def test_controlnet_engine_and_compiled_chain():
     assert not cnet.forward._warned and not unet.forward._warned
     d2, m2 = cnet(sample, 444, encoder_hidden_states=ehs, controlnet_cond=cond, conditioning_scale=0.5, return_dict=False)
     assert rel_l2(m2.float(), 0.5 * wm) < 4e-3
+
+
+# ---- trace_scheduler: the scheduler update as one HIP kernel behind diffusers' step() signature -------------------------
+class _DDIMLike:
+    """diffusers DDIMScheduler call surface (public semantics): eager reference for the native step."""
+    init_noise_sigma = 1.0
+
+    def __init__(self, prediction_type="epsilon"):
+        self.config = types.SimpleNamespace(num_train_timesteps=1000, prediction_type=prediction_type, clip_sample=False,
+                                            thresholding=False, steps_offset=1)
+        betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float64) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = self.alphas_cumprod[0]
+        self.num_inference_steps = None
+
+    def set_timesteps(self, n, device=None):
+        self.num_inference_steps = n
+        self.timesteps = ((torch.arange(0, n) * (1000 // n)).flip(0) + 1).to(device)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def step(self, model_output, timestep, sample, eta=0.0, use_clipped_model_output=False, generator=None, variance_noise=None,
+             return_dict=True):
+        t = int(timestep)
+        prev = t - 1000 // self.num_inference_steps
+        a_t = float(self.alphas_cumprod[t])
+        a_p = float(self.alphas_cumprod[prev]) if prev >= 0 else float(self.final_alpha_cumprod)
+        mo, x = model_output.double(), sample.double()
+        if self.config.prediction_type == "v_prediction":
+            x0 = a_t ** 0.5 * x - (1 - a_t) ** 0.5 * mo
+            eps = a_t ** 0.5 * mo + (1 - a_t) ** 0.5 * x
+        else:
+            x0 = (x - (1 - a_t) ** 0.5 * mo) / a_t ** 0.5
+            eps = mo
+        out = (a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * eps).to(sample.dtype)
+        return (out,) if not return_dict else types.SimpleNamespace(prev_sample=out)
+
+
+@pytest.mark.parametrize("pred", ["epsilon", "v_prediction"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_native_scheduler_step_matches_ddim(pred, dtype):
+    from sfast.libs.diffusers.scheduler import NativeDDIMStep, patch_scheduler
+    ref, s = _DDIMLike(pred), _DDIMLike(pred)
+    assert patch_scheduler(s) and isinstance(s.step, NativeDDIMStep) and s.step.__self__ is s
+    for sc in (ref, s):
+        sc.set_timesteps(50, device=DEV)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 4, 64, 64, generator=g).to(DEV, dtype)
+    e = torch.randn(2, 4, 64, 64, generator=g).to(DEV, dtype)
+    for i in (0, 17, 49):  # first step, a middle one, the last one (prev timestep < 0 -> final_alpha_cumprod)
+        t = s.timesteps[i]  # 0-d int64 CUDA tensor, read by the kernel: no host sync
+        got = s.step(e, t, x, return_dict=False)[0]
+        want = ref.step(e, t, x, return_dict=False)[0]
+        compare(f"native ddim step {pred} {dtype} i={i}", got, want, 2e-3 if dtype == torch.float16 else 1e-5, 1e-3 if dtype == torch.float16 else 1e-5)
+        got_int = s.step(e, int(t), x).prev_sample  # python-int timestep: resolved on the host
+        assert torch.equal(got_int, got)
+    assert s.step.native_calls == 6
+    # anything outside the deterministic linear form keeps the original method
+    out = s.step(e, int(s.timesteps[3]), x, eta=0.5, return_dict=False)[0]
+    assert s.step.native_calls == 6 and torch.isfinite(out).all()
+
+
+def test_compile_with_trace_scheduler_patches_the_step():
+    from sfast.compilers.diffusion_pipeline_compiler import CompilationConfig, compile
+    from sfast.libs.diffusers.scheduler import NativeDDIMStep
+    cfg = U.tiny_config()
+    pipe = MiniPipeline(U.build(cfg, seed=11, dtype=torch.float16, device=DEV))
+    pipe.scheduler = _DDIMLike()
+    config = CompilationConfig.Default()
+    config.enable_cuda_graph = True
+    config.trace_scheduler = True
+    compile(pipe, config)
+    assert isinstance(pipe.scheduler.step, NativeDDIMStep)
+    # a scheduler of an unknown family is left alone
+    other = types.SimpleNamespace(step=lambda *a, **k: None, config=types.SimpleNamespace())
+    pipe2 = MiniPipeline(U.build(cfg, seed=11, dtype=torch.float16, device=DEV))
+    pipe2.scheduler = other
+    keep = other.step
+    compile(pipe2, config)
+    assert other.step is keep
+
+
+def test_module_from_params_drives_compile_unet():
+    """Bare state dict -> parameter-container module -> compile_unet(): same output as the engine built from the oracle module."""
+    from sfast.compilers.diffusion_pipeline_compiler import CompilationConfig, compile_unet
+    from sfast.engine.unet_spec import module_from_params
+    cfg = U.tiny_config()
+    m = U.build(cfg, seed=13, dtype=torch.float16, device=DEV)
+    params = {k: v.detach().clone() for k, v in m.named_parameters()}
+    shell = module_from_params(dict(cfg), params)
+    config = CompilationConfig.Default()
+    config.enable_cuda_graph = True
+    shell = compile_unet(shell, config)
+    sample, ehs = _inputs(cfg, 2, seed=4, S=40)
+    got = shell(sample, 321, encoder_hidden_states=ehs, return_dict=False)[0]
+    want = _engine(m).forward(sample, 321, ehs)
+    assert torch.equal(got, want)
+    with pytest.raises(RuntimeError):
+        shell.conv_in(sample)
