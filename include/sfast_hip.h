@@ -161,15 +161,16 @@ int sfast_hip_gemm(const void *x, const void *const *w_segs, const void *bias,
                    const sfast_gemm_params *p, void *workspace, size_t workspace_bytes,
                    sfast_stream_t stream);
 
-/* ---- grouped GEMM: n_groups problems of identical shape that share the activation operand -------------
- * out_g[M,N] = act(x[M,K] . W_g[N,K]^T + bias_g),  g = 0 .. n_groups-1  (<= SFAST_MAX_GEMM_GROUPS), one launch.
- * The cross-attention K/V projections of all transformer blocks of one UNet level read the same text context
- * (one sfast::cublas_lowp_linear per to_k / to_v in the reference, csrc/operators/cublas/cublas_gemm.cpp:798-860);
- * p describes ONE problem (M, N, K, ldx, ldw, ldo, n_wseg <= 2 stacked segments of rows_per_seg rows, act; no residual /
- * rowbias / geglu / split-K). `w_segs` is a HOST array of n_groups * n_wseg DEVICE pointers (group-major), `bias` a host
- * array of n_groups device pointers or NULL, `out` a host array of n_groups device pointers. K % 8 == 0, N % 4 == 0. */
+/* ---- grouped GEMM: n_groups problems of identical shape in one launch ----------------------------------------
+ * out_g[M,N] = act(x_g[M,K] . W_g[N,K]^T + bias_g),  g = 0 .. n_groups-1  (<= SFAST_MAX_GEMM_GROUPS).
+ * Two callers: (1) the cross-attention K/V projections of all transformer blocks of one UNet level, which read the SAME text
+ * context (every x_g the same pointer; one sfast::cublas_lowp_linear per to_k / to_v in the reference,
+ * csrc/operators/cublas/cublas_gemm.cpp:798-860); (2) sfast::cublas_lowp_bmm / _baddbmm / batched _matmul (cublas_gemm.h:30-38):
+ * one group per batch element. p describes ONE problem (M, N, K, ldx, ldw, ldo, n_wseg <= 2 stacked segments of rows_per_seg
+ * rows, act; no residual / rowbias / geglu / split-K). `x`, `bias` (or NULL) and `out` are HOST arrays of n_groups DEVICE
+ * pointers, `w_segs` a host array of n_groups * n_wseg device pointers (group-major). K % 8 == 0, N % 4 == 0. */
 #define SFAST_MAX_GEMM_GROUPS 64
-int sfast_hip_gemm_grouped(const void *x, const void *const *w_segs, const void *const *bias, void *const *out,
+int sfast_hip_gemm_grouped(const void *const *x, const void *const *w_segs, const void *const *bias, void *const *out,
                            const sfast_gemm_params *p, int32_t n_groups, sfast_stream_t stream);
 
 /* ---- grouped GEMV: n_groups independent weight matrices W_g[n_rows[g], K] applied to ONE small input ----

@@ -241,7 +241,7 @@ extern "C" int sfast_hip_gemm(const void *x, const void *const *w_segs, const vo
     return small_gemm_naive(a, p->dtype, st);
 }
 
-extern "C" int sfast_hip_gemm_grouped(const void *x, const void *const *w_segs, const void *const *bias, void *const *out,
+extern "C" int sfast_hip_gemm_grouped(const void *const *x, const void *const *w_segs, const void *const *bias, void *const *out,
                                       const sfast_gemm_params *p, int32_t n_groups, sfast_stream_t stream) {
     SFAST_REQUIRE(p && x && w_segs && out, SFAST_ERR_INVALID, "gemm_grouped: null argument");
     SFAST_REQUIRE(n_groups >= 1 && n_groups <= SFAST_MAX_GEMM_GROUPS, SFAST_ERR_INVALID, "gemm_grouped: n_groups=%d (1..%d)", n_groups,
@@ -253,10 +253,10 @@ extern "C" int sfast_hip_gemm_grouped(const void *x, const void *const *w_segs, 
                   "gemm_grouped: geglu / split-K / rowbias / in_act are not available in grouped launches");
     SFAST_REQUIRE(is_half(p->dtype), SFAST_ERR_UNSUPPORTED, "gemm_grouped: dtype %d", p->dtype);
     SFAST_REQUIRE(p->ldx >= p->K && p->ldw >= p->K && p->ldo >= p->N, SFAST_ERR_INVALID, "gemm_grouped: bad leading dims");
-    bool ok = p->K % 8 == 0 && p->ldx % 8 == 0 && p->ldw % 8 == 0 && aligned16(x) && p->N % 4 == 0 && p->ldo % 4 == 0;
+    bool ok = p->K % 8 == 0 && p->ldx % 8 == 0 && p->ldw % 8 == 0 && p->N % 4 == 0 && p->ldo % 4 == 0;
     for (int i = 0; i < n_groups; ++i) {
-        SFAST_REQUIRE(out[i], SFAST_ERR_INVALID, "gemm_grouped: null output %d", i);
-        ok = ok && aligned8(out[i]) && (!bias || !bias[i] || aligned8(bias[i]));
+        SFAST_REQUIRE(out[i] && x[i], SFAST_ERR_INVALID, "gemm_grouped: null input / output %d", i);
+        ok = ok && aligned16(x[i]) && aligned8(out[i]) && (!bias || !bias[i] || aligned8(bias[i]));
         for (int j = 0; j < p->n_wseg; ++j) {
             SFAST_REQUIRE(w_segs[i * p->n_wseg + j], SFAST_ERR_INVALID, "gemm_grouped: null weight %d/%d", i, j);
             ok = ok && aligned16(w_segs[i * p->n_wseg + j]);
@@ -264,7 +264,7 @@ extern "C" int sfast_hip_gemm_grouped(const void *x, const void *const *w_segs, 
     }
     SFAST_REQUIRE(ok, SFAST_ERR_UNSUPPORTED, "gemm_grouped: operands must be 16-byte aligned rows (K, ldx, ldw % 8, N, ldo % 4)");
     IgemmArgs a{};
-    a.x = x;
+    a.x = x[0];
     a.x2 = nullptr;
     a.rowbias = nullptr;
     a.res = nullptr;
@@ -281,7 +281,7 @@ extern "C" int sfast_hip_gemm_grouped(const void *x, const void *const *w_segs, 
     a.act = p->act;
     a.res_before_act = 0;
     a.alpha = 1.0f;
-    return igemm_run_grouped(a, p->dtype, n_groups, w_segs, p->n_wseg, bias, out, (hipStream_t)stream);
+    return igemm_run_grouped(a, p->dtype, n_groups, x, w_segs, p->n_wseg, bias, out, (hipStream_t)stream);
 }
 
 extern "C" size_t sfast_hip_conv2d_workspace_bytes(const sfast_conv_params *p) {

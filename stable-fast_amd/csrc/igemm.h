@@ -30,7 +30,7 @@ void igemm_plan_query(int M, int N, int K, bool geglu, int variant, int split, b
 size_t igemm_workspace_bytes(int M, int N, int K, bool geglu, int variant, int split, bool glds_ok);
 bool igemm_glds_eligible(const IgemmArgs &a, int mode);
 // grouped launch (register-staged pipe): n_groups problems of identical [M, N, K] sharing x (api: sfast_hip_gemm_grouped)
-int igemm_run_grouped(IgemmArgs &a, int dtype, int n_groups, const void *const *w_segs, int n_wseg, const void *const *bias,
-                      void *const *out, hipStream_t st);
+int igemm_run_grouped(IgemmArgs &a, int dtype, int n_groups, const void *const *xs, const void *const *w_segs, int n_wseg,
+                      const void *const *bias, void *const *out, hipStream_t st);
 
 }  // namespace sfast

@@ -270,6 +270,7 @@ __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, 2 * 
 // (libs/xformers + diffusers Attention.to_k / to_v; one cublas_lowp_linear each in the reference). Weight and output
 // pointers of the group travel in the kernel-argument block; everything else is the plain kernel.
 struct IgemmGroupTab {
+    const void *x[SFAST_MAX_GEMM_GROUPS];
     const void *w0[SFAST_MAX_GEMM_GROUPS];
     const void *w1[SFAST_MAX_GEMM_GROUPS];
     const void *bias[SFAST_MAX_GEMM_GROUPS];
@@ -280,6 +281,7 @@ __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, 2 * 
     igemm_grouped_kernel(const IgemmArgs a, const IgemmGroupTab g) {
     IgemmArgs b = a;
     const int z = blockIdx.z;
+    b.x = g.x[z];
     b.w[0] = g.w0[z];
     b.w[1] = g.w1[z];
     b.w[2] = g.w1[z];
@@ -604,12 +606,13 @@ int igemm_grouped_init() {
     return rc;
 }
 
-// n_groups problems of identical [M, N, K] sharing x; per group up to two stacked weight segments, a bias and an output.
-int igemm_run_grouped(IgemmArgs &a, int dtype, int n_groups, const void *const *w_segs, int n_wseg, const void *const *bias,
-                      void *const *out, hipStream_t st) {
+// n_groups problems of identical [M, N, K]; per group an activation pointer (usually shared), up to two stacked weight segments, a bias and an output.
+int igemm_run_grouped(IgemmArgs &a, int dtype, int n_groups, const void *const *xs, const void *const *w_segs, int n_wseg,
+                      const void *const *bias, void *const *out, hipStream_t st) {
     IgemmGroupTab g{};
     for (int i = 0; i < SFAST_MAX_GEMM_GROUPS; ++i) {
         const int j = i < n_groups ? i : 0;
+        g.x[i] = xs[j];
         g.w0[i] = w_segs[j * n_wseg];
         g.w1[i] = w_segs[j * n_wseg + (n_wseg > 1 ? 1 : 0)];
         g.bias[i] = bias ? bias[j] : nullptr;

@@ -899,11 +899,11 @@ class UNet2DEngine:
                 n = len(grp)
                 wp = (C.c_void_p * (2 * n))(*[w.data_ptr() for r in grp for w in (r[1], r[2])])
                 op = (C.c_void_p * n)(*[r[3].data_ptr() for r in grp])
-                xp = ctx.data_ptr()
-                plan.keep += [p, wp, op]
+                xp = (C.c_void_p * n)(*([ctx.data_ptr()] * n))
+                plan.keep += [p, wp, op, xp]
                 name = f"attn2.to_kv[C={Cc},x{n}]"
 
-                def launch(stream, p=p, wp=wp, op=op, n=n, name=name):
+                def launch(stream, p=p, wp=wp, op=op, xp=xp, n=n, name=name):
                     L.check(lib.sfast_hip_gemm_grouped(xp, wp, None, op, C.byref(p), n, stream), name)
 
                 self._add(plan, "linear", name, 2.0 * M * 2 * Cc * K * n, (M * K + n * (2 * Cc * K + M * 2 * Cc)) * self.esize, launch,

@@ -250,31 +250,40 @@ def linear(x, weight, bias=None, *, act=None, residual=None, alpha=1.0, res_befo
 
 @_on_device
 def linear_grouped(x, weight_groups, biases=None, act=None):
-    """[act(x @ cat(W_g)^T + b_g) for g]: every group is a list of <= 2 equally sized [n, K] weights stacked along N; all groups
-    have the same shape and share `x` ([M, K]). ONE launch (sfast_hip_gemm_grouped). Returns a list of [M, N] tensors."""
+    """[act(x_g @ cat(W_g)^T + b_g) for g]: every group is a list of <= 2 equally sized [n, K] weights stacked along N; all groups
+    have the same shape. `x`: one [M, K] tensor shared by all groups, or a list of per-group [M, K] tensors. Launches of up to
+    64 groups each (sfast_hip_gemm_grouped). Returns a list of [M, N] tensors."""
     groups = [list(g) if isinstance(g, (list, tuple)) else [g] for g in weight_groups]
     flat = [w for g in groups for w in g]
-    _require_cuda(x, *flat)
+    xs = list(x) if isinstance(x, (list, tuple)) else [x] * len(groups)
+    _require_cuda(*xs, *flat)
     lib = L.init_device()
-    x2d = x.reshape(-1, x.shape[-1])
-    if x2d.stride(-1) != 1:
-        x2d = x2d.contiguous()
-    M, K = x2d.shape
+    xs2 = []
+    for t in xs:
+        t2 = t.reshape(-1, t.shape[-1])
+        xs2.append(t2 if t2.stride(-1) == 1 and (t2.shape[0] == 1 or t2.stride(0) == xs[0].reshape(-1, xs[0].shape[-1]).stride(0)) else t2.contiguous())
+    if any(t.stride(0) != xs2[0].stride(0) for t in xs2 if t.shape[0] > 1):
+        xs2 = [t.contiguous() for t in xs2]
+    M, K = xs2[0].shape
     nseg, rows = len(groups[0]), groups[0][0].shape[0]
     flat = [w.contiguous() for w in flat]
     N = nseg * rows
-    outs = [torch.empty((M, N), dtype=x.dtype, device=x.device) for _ in groups]
+    outs = [torch.empty((M, N), dtype=xs2[0].dtype, device=xs2[0].device) for _ in groups]
     bs = None
     if biases is not None:
-        bs = [None if b is None else b.to(x.dtype).contiguous() for b in biases]
+        bs = [None if b is None else b.to(xs2[0].dtype).contiguous() for b in biases]
     p = L.GemmParams()
-    p.dtype, p.M, p.N, p.K = _dtype(x), M, N, K
-    p.ldx, p.ldw, p.ldo, p.ldr = x2d.stride(0) if M > 1 else K, K, N, 0
+    p.dtype, p.M, p.N, p.K = _dtype(xs2[0]), M, N, K
+    p.ldx, p.ldw, p.ldo, p.ldr = xs2[0].stride(0) if M > 1 else K, K, N, 0
     p.n_wseg, p.rows_per_seg, p.act, p.alpha = nseg, rows, _act(act), 1.0
-    wp = (C.c_void_p * len(flat))(*[w.data_ptr() for w in flat])
-    op = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
-    bp = (C.c_void_p * len(outs))(*[_ptr(b) for b in bs]) if bs is not None else None
-    L.check(lib.sfast_hip_gemm_grouped(_ptr(x2d), wp, bp, op, C.byref(p), len(groups), _stream(x)), "sfast_hip_gemm_grouped")
+    for g0 in range(0, len(groups), L.MAX_GEMM_GROUPS):
+        g1 = min(len(groups), g0 + L.MAX_GEMM_GROUPS)
+        n = g1 - g0
+        xp = (C.c_void_p * n)(*[t.data_ptr() for t in xs2[g0:g1]])
+        wp = (C.c_void_p * (n * nseg))(*[w.data_ptr() for w in flat[g0 * nseg:g1 * nseg]])
+        op = (C.c_void_p * n)(*[o.data_ptr() for o in outs[g0:g1]])
+        bp = (C.c_void_p * n)(*[_ptr(b) for b in bs[g0:g1]]) if bs is not None else None
+        L.check(lib.sfast_hip_gemm_grouped(xp, wp, bp, op, C.byref(p), n, _stream(xs2[0])), "sfast_hip_gemm_grouped")
     return outs
 
 

@@ -135,7 +135,7 @@ def _declare(lib):
     lib.sfast_hip_gemm.restype = C.c_int
     lib.sfast_hip_gemm.argtypes = [vp, C.POINTER(vp), vp, vp, vp, vp, C.POINTER(GemmParams), vp, sz, vp]
     lib.sfast_hip_gemm_grouped.restype = C.c_int
-    lib.sfast_hip_gemm_grouped.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(GemmParams), C.c_int32, vp]
+    lib.sfast_hip_gemm_grouped.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(GemmParams), C.c_int32, vp]
     lib.sfast_hip_gemv_grouped.restype = C.c_int
     lib.sfast_hip_gemv_grouped.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), vp, C.POINTER(GemvGroupedParams), vp]
     lib.sfast_hip_conv2d_workspace_bytes.restype = sz

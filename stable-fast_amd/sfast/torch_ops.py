@@ -145,7 +145,14 @@ def cublas_lowp_addmm_activation(self, mat1, mat2, beta=1, alpha=1, use_gelu=Fal
 def cublas_lowp_bmm(self, batch2):
     if self.ndim != 3 or batch2.ndim != 3 or self.shape[0] != batch2.shape[0]:
         raise RuntimeError("cublas_lowp_bmm: expected [B, M, K] x [B, K, N]")
-    outs = [F.linear(self[b], _as_weight(batch2[b])) for b in range(self.shape[0])]
+    B, M, K = self.shape
+    N = batch2.shape[2]
+    if K % 8 == 0 and N % 4 == 0 and self.dtype in (torch.float16, torch.bfloat16):
+        # one grouped launch per 64 batch elements: group b = (self[b], batch2[b]^T), outputs are rows of ONE [B, M, N] tensor
+        w = batch2.transpose(1, 2).contiguous()  # [B, N, K]: the K-contiguous operand layout of the GEMM kernels
+        outs = F.linear_grouped([self[b] for b in range(B)], [[w[b]] for b in range(B)])
+        return torch.stack(outs, dim=0)
+    outs = [F.linear(self[b], _as_weight(batch2[b])) for b in range(B)]
     return torch.stack(outs, dim=0)
 
 

@@ -142,8 +142,8 @@ class EmuLib:
     def sfast_hip_gemm_grouped(self, x, segs, bias, out, ref, n_groups, stream):
         p = _p(ref)
         self.calls.append("gemm_grouped")
-        xin = _strided(x, (p.M, p.K), (p.ldx, 1), p.dtype)
         for g in range(n_groups):
+            xin = _strided(x[g], (p.M, p.K), (p.ldx, 1), p.dtype)
             w = torch.cat([_strided(segs[g * p.n_wseg + j], (p.rows_per_seg, p.K), (p.ldw, 1), p.dtype) for j in range(p.n_wseg)], dim=0)[:p.N]
             b = _flat(bias[g], p.N, p.dtype) if bias and bias[g] else None
             _strided(out[g], (p.M, p.N), (p.ldo, 1), p.dtype).copy_(R.linear_ref(xin, w, b, _ACT[p.act]))

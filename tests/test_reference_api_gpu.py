@@ -146,3 +146,36 @@ def test_make_dynamic_graphed_callable_caches_per_signature():
         torch.testing.assert_close(g(a * 2), lin(a * 2))
         torch.testing.assert_close(g(b), lin(b))
     assert len(g._cached) == 2 and g.__self__ is lin
+
+
+# ---- sfast_triton::_convolution (reference triton/torch_ops.py:258-296; disabled in its default pipeline) ----------
+@pytest.mark.parametrize("shape", [((2, 320, 32, 32), (640, 320, 3, 3), 1, 1), ((1, 64, 17, 23), (32, 64, 3, 3), 2, 1),
+                                   ((2, 128, 16, 16), (128, 128, 1, 1), 1, 0), ((1, 4, 64, 64), (320, 4, 3, 3), 1, 1)])
+@pytest.mark.parametrize("cl", [False, True])
+def test_triton_convolution_op(shape, cl):
+    from oracle.ops_ref import conv2d_ref
+    xs, ws, stride, pad = shape
+    with torch.no_grad():
+        x = torch.randn(*xs, device="cuda", dtype=torch.float16)
+        w = torch.randn(*ws, device="cuda", dtype=torch.float16) * (ws[1] * ws[2] * ws[3]) ** -0.5
+        b = torch.randn(ws[0], device="cuda", dtype=torch.float16)
+        if cl:
+            x, w = x.contiguous(memory_format=torch.channels_last), w.contiguous(memory_format=torch.channels_last)
+        y = torch.ops.sfast_triton._convolution(x, w, b, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1, False, False, True, True)
+        want = conv2d_ref(x, w, b, None, 1.0, stride, pad, 1)
+        torch.testing.assert_close(y.float(), want, rtol=2e-3, atol=3e-3)
+        with pytest.raises(RuntimeError):
+            torch.ops.sfast_triton._convolution(x, w, b, [1, 1], [1, 1], [1, 1], True, [0, 0], 1, False, False, True, True)
+
+
+@pytest.mark.parametrize("B", [3, 70])
+def test_bmm_is_one_grouped_launch_per_64_batches(B):
+    from sfast.hip import lib
+    a = torch.randn(B, 48, 64, device="cuda", dtype=torch.float16)
+    b = torch.randn(B, 64, 40, device="cuda", dtype=torch.float16)
+    got = torch.ops.sfast.cublas_lowp_bmm(a, b)
+    assert "igemm_grouped" in lib.last_kernel()
+    torch.testing.assert_close(got, torch.bmm(a, b), rtol=2e-2, atol=2e-2)
+    c = torch.randn(B, 48, 40, device="cuda", dtype=torch.float16)
+    torch.testing.assert_close(torch.ops.sfast.cublas_lowp_baddbmm(c, a, b, 0.5, 2.0), torch.baddbmm(c, a, b, beta=0.5, alpha=2.0),
+                               rtol=2e-2, atol=4e-2)
