@@ -87,9 +87,10 @@ _IGEMM_WAVES = {("128x128", False): (2, 2), ("128x160", False): (4, 1), ("64x64"
 
 def kernel_symbol(variant):
     """Device symbol (as rocprofv3 / profiles/*.csv print it) of a library kernel-variant string; split-K launches
-    of one tile shape share a symbol, so the split factor is dropped."""
+    of one tile shape share a symbol, so the split factor is dropped. A trailing "+staged" / "+gnstats" marks the
+    instantiation with LDS-staged stores (last template argument)."""
     import re
-    m = re.match(r"igemm_(conv|lin)_(f16|bf16)(_geglu)?\[(\d+x\d+),split=\d+,(reg|dma(\d)|ws(\d))\]", variant)
+    m = re.match(r"igemm_(conv|lin)_(f16|bf16)(_geglu)?\[(\d+x\d+),split=\d+,(reg|dma(\d)|ws(\d))\](\+staged|\+gnstats)?", variant)
     if not m:
         ma = re.match(r"attn_fwd\[D=(\d+),BQ=(\d+)\]", variant)
         if ma:  # attn_fwd_kernel<T, D, NW, TRACE = 0>: one wave per 32 queries
@@ -100,11 +101,13 @@ def kernel_symbol(variant):
     geglu = m.group(3) is not None
     bm, bn = m.group(4).split("x")
     wm, wn = _IGEMM_WAVES[(m.group(4), geglu)]
+    staged = int(m.group(8) is not None)
     if m.group(5) == "reg":
-        return f"_ZN5sfast12igemm_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi{mode}ELb{int(geglu)}EEEvNS_9IgemmArgsE"
+        return f"_ZN5sfast12igemm_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi{mode}ELb{int(geglu)}ELb{staged}EEEvNS_9IgemmArgsE"
     if m.group(5).startswith("ws"):
-        return f"_ZN5sfast20igemm_glds_ws_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi4ELi{m.group(7)}ELi{mode}ELb{int(geglu)}EEEvNS_9IgemmArgsE"
-    return f"_ZN5sfast17igemm_glds_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi{m.group(6)}ELi{mode}ELb{int(geglu)}ELi0EEEvNS_9IgemmArgsE"
+        return (f"_ZN5sfast20igemm_glds_ws_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi4ELi{m.group(7)}ELi{mode}ELb{int(geglu)}ELb{staged}EEE"
+                "vNS_9IgemmArgsE")
+    return f"_ZN5sfast17igemm_glds_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi{m.group(6)}ELi{mode}ELb{int(geglu)}ELi0ELb0EEEvNS_9IgemmArgsE"
 
 
 def roofline_from(rows):

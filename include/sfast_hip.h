@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define SFAST_HIP_ABI_VERSION 2
+#define SFAST_HIP_ABI_VERSION 3
 
 typedef void *sfast_stream_t; /* hipStream_t */
 
@@ -231,6 +231,50 @@ size_t sfast_hip_conv2d_workspace_bytes(const sfast_conv_params *p);
 int sfast_hip_conv2d(const void *x, const void *x2, const void *w, const void *bias,
                      const void *rowbias, const void *z, void *out, const sfast_conv_params *p,
                      void *workspace, size_t workspace_bytes, sfast_stream_t stream);
+
+/* ---- epilogue extensions of the GEMM / conv families (sfast_hip_gemm_ex, sfast_hip_conv2d_ex) --------------------------
+ * out_scale : v = out_scale * acc + bias + ...  (0 is read as 1). The VAE's single-head attention scales q.k^T BEFORE the f16
+ *             store this way (diffusers applies the scale inside the fp32 product; unscaled f16 logits can overflow).
+ * gn_unit / gn_rows_per_sample + the `gn_stats` pointer: the epilogue additionally reduces its output tile to GroupNorm partial
+ *             statistics -- one float2 {mean, M2} per (row block, tile_n, unit slot), sfast_gn_stats_layout -- so that the
+ *             GroupNorm that consumes this tensor is ONE normalisation pass (sfast_hip_group_norm_apply) instead of a statistics
+ *             kernel plus a normalisation kernel (reference: triton/ops/group_norm.py:111-165 + :272-349, two launches).
+ *             gn_unit = channels per statistics unit: >= 8, a divisor of every consumer's C/G (and of the channel offset at
+ *             which the tensor sits inside a virtual concat); gn_rows_per_sample = H*W of the output. The records of one tensor
+ *             can serve several consumers (e.g. a skip connection normalised alone and again inside a concat).            */
+typedef struct {
+    float out_scale;
+    int32_t gn_unit;
+    int32_t gn_rows_per_sample;
+    int32_t reserved;
+} sfast_epilogue_ext;
+
+typedef struct {
+    int32_t rb_rows; /* rows per row block (a tile's BM, or the rows a split-K reduce workgroup owns) */
+    int32_t n_rb;    /* row blocks over all samples: rb_rows * n_rb == M */
+    int32_t bno;     /* output columns per tile_n */
+    int32_t tiles_n;
+    int32_t slots;   /* records per (row block, tile_n) */
+    int32_t unit;
+} sfast_gn_stats_layout; /* buffer: n_rb * tiles_n * slots float2 */
+
+/* host-only: the layout the (variant, split_k) choice carried by p would write; SFAST_ERR_UNSUPPORTED when that kernel cannot */
+int sfast_hip_gemm_stats_layout(const sfast_gemm_params *p, const sfast_epilogue_ext *ext, sfast_gn_stats_layout *out);
+int sfast_hip_conv2d_stats_layout(const sfast_conv_params *p, const sfast_epilogue_ext *ext, sfast_gn_stats_layout *out);
+
+int sfast_hip_gemm_ex(const void *x, const void *const *w_segs, const void *bias, const void *rowbias, const void *residual,
+                      void *out, const sfast_gemm_params *p, const sfast_epilogue_ext *ext /* or NULL */,
+                      void *gn_stats /* or NULL */, void *workspace, size_t workspace_bytes, sfast_stream_t stream);
+int sfast_hip_conv2d_ex(const void *x, const void *x2, const void *w, const void *bias, const void *rowbias, const void *z,
+                        void *out, const sfast_conv_params *p, const sfast_epilogue_ext *ext /* or NULL */,
+                        void *gn_stats /* or NULL */, void *workspace, size_t workspace_bytes, sfast_stream_t stream);
+
+/* GroupNorm(+SiLU) of an NHWC tensor (optionally a virtual concat x | x2) whose statistics were left behind by the kernels that
+ * produced x (stats1 / l1) and x2 (stats2 / l2): one pass, x read once. Records of different row blocks are merged with the
+ * pairwise variance update in a fixed order (bitwise reproducible). Same arithmetic contract as sfast_hip_group_norm. */
+int sfast_hip_group_norm_apply(const void *x, const void *x2, const void *gamma, const void *beta, void *y,
+                               const sfast_gn_params *p, const void *stats1, const sfast_gn_stats_layout *l1,
+                               const void *stats2, const sfast_gn_stats_layout *l2, sfast_stream_t stream);
 
 /* ---- scaled-dot-product attention: out = softmax(q k^T * scale) v -------------------------
  * q [B,Sq,H,D], k/v [B,Skv,H,D], out [B,Sq,H,D]; element strides (b, s, h), d stride 1.       */

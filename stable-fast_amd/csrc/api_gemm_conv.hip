@@ -184,13 +184,40 @@ extern "C" size_t sfast_hip_gemm_workspace_bytes(const sfast_gemm_params *p) {
     return igemm_workspace_bytes(p->M, p->N, p->K, p->geglu != 0, p->variant < 100 ? p->variant : 0, p->split_k, true);
 }
 
+static float ext_scale(const sfast_epilogue_ext *ext) { return (ext && ext->out_scale != 0.0f) ? ext->out_scale : 1.0f; }
+
 extern "C" int sfast_hip_gemm(const void *x, const void *const *w_segs, const void *bias, const void *rowbias,
                               const void *residual, void *out, const sfast_gemm_params *p, void *workspace,
                               size_t workspace_bytes, sfast_stream_t stream) {
+    return sfast_hip_gemm_ex(x, w_segs, bias, rowbias, residual, out, p, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int sfast_hip_gemm_stats_layout(const sfast_gemm_params *p, const sfast_epilogue_ext *ext, sfast_gn_stats_layout *out) {
+    SFAST_REQUIRE(p && ext && out, SFAST_ERR_INVALID, "gemm_stats_layout: null argument");
+    StatsLayout l{};
+    const bool igemm = is_half(p->dtype) && p->K % 8 == 0 && !(p->M <= 16 && p->variant == 0) && p->variant < 100 && p->N % 8 == 0 && p->ldo % 8 == 0;
+    if (!igemm || !igemm_stats_layout(p->M, p->N, p->K, p->geglu != 0, p->variant, p->split_k, true, ext->gn_unit, ext->gn_rows_per_sample, l)) {
+        set_error("gemm_stats_layout: this problem / kernel choice cannot emit GroupNorm statistics");
+        return SFAST_ERR_UNSUPPORTED;
+    }
+    out->rb_rows = l.rb_rows;
+    out->n_rb = l.n_rb;
+    out->bno = l.bno;
+    out->tiles_n = l.tiles_n;
+    out->slots = l.slots;
+    out->unit = ext->gn_unit;
+    return SFAST_OK;
+}
+
+extern "C" int sfast_hip_gemm_ex(const void *x, const void *const *w_segs, const void *bias, const void *rowbias,
+                                 const void *residual, void *out, const sfast_gemm_params *p, const sfast_epilogue_ext *ext,
+                                 void *gn_stats, void *workspace, size_t workspace_bytes, sfast_stream_t stream) {
     int rc = validate_gemm(x, w_segs, out, p);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const GemmRoute route = gemm_route(x, w_segs, bias, rowbias, residual, out, p);
+    SFAST_REQUIRE(!gn_stats || (ext && route.kind == GemmRoute::IGEMM), SFAST_ERR_UNSUPPORTED,
+                  "gemm: GroupNorm statistics are emitted by the MFMA path only (and need an sfast_epilogue_ext)");
     if (route.kind == GemmRoute::IGEMM) {
         IgemmArgs a{};
         a.x = x;
@@ -213,6 +240,10 @@ extern "C" int sfast_hip_gemm(const void *x, const void *const *w_segs, const vo
         a.act = p->act;
         a.res_before_act = p->res_before_act;
         a.alpha = p->alpha;
+        a.out_scale = ext_scale(ext);
+        a.gn_stats = (float *)gn_stats;
+        a.gn_unit = ext ? ext->gn_unit : 0;
+        a.gn_rows_per_sample = ext ? ext->gn_rows_per_sample : 0;
         return igemm_run(a, p->dtype, 0, p->geglu != 0, p->variant < 100 ? p->variant : 0, p->split_k, workspace, workspace_bytes, st);
     }
     SmallGemmArgs a{};
@@ -237,6 +268,7 @@ extern "C" int sfast_hip_gemm(const void *x, const void *const *w_segs, const vo
     a.res_before_act = p->res_before_act;
     a.in_act = p->in_act;
     a.alpha = p->alpha;
+    a.out_scale = ext_scale(ext);
     if (route.kind == GemmRoute::GEMV) return small_gemv(a, p->dtype, st);
     return small_gemm_naive(a, p->dtype, st);
 }
@@ -298,6 +330,35 @@ extern "C" size_t sfast_hip_conv2d_workspace_bytes(const sfast_conv_params *p) {
 extern "C" int sfast_hip_conv2d(const void *x, const void *x2, const void *w, const void *bias, const void *rowbias,
                                 const void *z, void *out, const sfast_conv_params *p, void *workspace,
                                 size_t workspace_bytes, sfast_stream_t stream) {
+    return sfast_hip_conv2d_ex(x, x2, w, bias, rowbias, z, out, p, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int sfast_hip_conv2d_stats_layout(const sfast_conv_params *p, const sfast_epilogue_ext *ext, sfast_gn_stats_layout *out) {
+    SFAST_REQUIRE(p && ext && out, SFAST_ERR_INVALID, "conv2d_stats_layout: null argument");
+    const ConvGeom g = conv_geom(p, nullptr);
+    const int64_t M = (int64_t)p->B * g.Ho * g.Wo;
+    const int K = p->KH * p->KW * p->Cin;
+    const int C2 = p->Cin - p->C1;
+    const bool igemm = is_half(p->dtype) && p->Cout >= 16 && p->Cout % 8 == 0 && M > 0 && M <= INT32_MAX && K % 8 == 0 && p->C1 % 8 == 0 &&
+                       C2 % 8 == 0 && g.out_dense && g.ldo % 8 == 0 && p->variant < 100;
+    const bool glds_ok = !p->upsample2x && p->C1 % 64 == 0 && C2 % 64 == 0 && p->KH * p->KW <= 32;
+    StatsLayout l{};
+    if (!igemm || !igemm_stats_layout((int)M, p->Cout, K, false, p->variant, p->split_k, glds_ok, ext->gn_unit, ext->gn_rows_per_sample, l)) {
+        set_error("conv2d_stats_layout: this problem / kernel choice cannot emit GroupNorm statistics");
+        return SFAST_ERR_UNSUPPORTED;
+    }
+    out->rb_rows = l.rb_rows;
+    out->n_rb = l.n_rb;
+    out->bno = l.bno;
+    out->tiles_n = l.tiles_n;
+    out->slots = l.slots;
+    out->unit = ext->gn_unit;
+    return SFAST_OK;
+}
+
+extern "C" int sfast_hip_conv2d_ex(const void *x, const void *x2, const void *w, const void *bias, const void *rowbias,
+                                   const void *z, void *out, const sfast_conv_params *p, const sfast_epilogue_ext *ext, void *gn_stats,
+                                   void *workspace, size_t workspace_bytes, sfast_stream_t stream) {
     int rc = validate_conv(x, x2, w, out, p);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -307,6 +368,8 @@ extern "C" int sfast_hip_conv2d(const void *x, const void *x2, const void *w, co
     SFAST_REQUIRE(M64 <= INT32_MAX, SFAST_ERR_UNSUPPORTED, "conv2d: too many output pixels");
     bool fold = false;
     const ConvKind kind = conv_route(x, x2, w, bias, rowbias, z, out, p, g, fold);
+    SFAST_REQUIRE(!gn_stats || (ext && kind == CONV_IGEMM), SFAST_ERR_UNSUPPORTED,
+                  "conv2d: GroupNorm statistics are emitted by the MFMA path only (and need an sfast_epilogue_ext)");
     if (kind == CONV_IGEMM) {
         IgemmArgs a{};
         a.x = x;
@@ -344,10 +407,15 @@ extern "C" int sfast_hip_conv2d(const void *x, const void *x2, const void *w, co
         a.dil_h = p->dil_h;
         a.dil_w = p->dil_w;
         a.ups = p->upsample2x;
+        a.out_scale = ext_scale(ext);
+        a.gn_stats = (float *)gn_stats;
+        a.gn_unit = ext ? ext->gn_unit : 0;
+        a.gn_rows_per_sample = ext ? ext->gn_rows_per_sample : 0;
         return igemm_run(a, p->dtype, 1, false, p->variant < 100 ? p->variant : 0, p->split_k, workspace, workspace_bytes, st);
     }
     SmallConvArgs a{};
     fill_small_conv(a, x, x2, w, bias, rowbias, z, out, p, g);
+    a.out_scale = ext_scale(ext);
     if (kind == CONV_SMALL_N) return small_conv_n(a, p->dtype, st);
     if (kind == CONV_SMALL_C) return small_conv_c(a, p->dtype, st);
     return small_conv_naive(a, p->dtype, st);

@@ -19,12 +19,29 @@ struct IgemmArgs {
     int H, W, C1, C2, Ho, Wo, KH, KW, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, ups;
     int tiles_m, tiles_n, ktiles, ktiles_per_split, splits;
     unsigned long long *trace;  // profiling: per-workgroup phase timestamps (8 slots each); nullptr in production
+    // ---- epilogue extensions (sfast_epilogue_ext) -----------------------------------------------------------
+    float out_scale;   // v = out_scale * acc + bias + ...   (1 = plain)
+    int stage_out;     // 1: the finished tile is staged in LDS and leaves as whole 16-byte row segments
+    float *gn_stats;   // GroupNorm partial statistics of the output (float2 {mean, M2} per tile slot), or nullptr
+    int gn_unit;       // channels per statistics unit (divides every consumer's channels-per-group)
+    int gn_slots;      // unit slots per tile_n (host: stats_slots(BNO, unit))
+    int gn_rows_per_sample;  // host-side validation only
 };
+
+// statistics slots a tile of `bno` output columns can overlap: units are `unit` channels wide, tile origins multiples of bno
+static inline int stats_slots(int bno, int unit) { return (bno - 1) / unit + 2; }
 
 // mode: 0 = linear (x row m at x + m*ldx), 1 = conv (implicit im2col over dense NHWC x / x2).
 // Fills the plan fields of `a` (tiles, split) and launches on `st`.
 int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int split, void *ws, size_t ws_bytes,
               hipStream_t st);
+// GroupNorm-statistics layout the epilogue of this problem would write (tile rows, tile columns, slots per tile_n, tiles_n,
+// float2 records in total); returns false when the chosen kernel cannot emit them
+struct StatsLayout {
+    int rb_rows, bno, slots, tiles_n, n_rb;
+};
+bool igemm_stats_layout(int M, int N, int K, bool geglu, int variant, int split, bool glds_ok, int unit, int rows_per_sample,
+                        StatsLayout &out);
 // glds_ok: whether the LDS-DMA pipe may be chosen for this problem (see igemm_glds_eligible)
 void igemm_plan_query(int M, int N, int K, bool geglu, int variant, int split, bool glds_ok, int out[5]);
 size_t igemm_workspace_bytes(int M, int N, int K, bool geglu, int variant, int split, bool glds_ok);

@@ -36,7 +36,7 @@ namespace sfast {
 
 
 // MODE 0: linear (row m -> x + m*ldx). MODE 1: conv (implicit im2col, NHWC).
-template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GEGLU>
+template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GEGLU, bool STAGED = false>
 __device__ __forceinline__ void igemm_body(const IgemmArgs &a) {
     using vec8 = typename Elem<T>::vec8;
     constexpr int NT = WM * WN * 64;
@@ -253,16 +253,14 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs &a) {
 
     // ---- epilogue: batched operand loads, fp32 math, 8-byte stores (igemm_device.h) -------------------------
     trace_mark(a, 4);
-    if constexpr (!EPI_EARLY)
-        epilogue_late<T, FN, FM>(a, acc, m0 + wm * (FM * 32), n0 + wn * WNB, l31, hi, blockIdx.y);
-    else
-        epilogue_finish<T, FN, FM, GEGLU>(a, acc, epi, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi, blockIdx.y);
+    run_epilogue<T, BM, BNO, FN, FM, GEGLU, EPI_EARLY, NT, STAGED>(a, acc, epi, smem, m0, n0, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi,
+                                                             tid, blockIdx.y);
     trace_finish(a);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GEGLU>
+template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GEGLU, bool STAGED = false>
 __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, 2 * (BM + BN) * 128)) igemm_kernel(const IgemmArgs a) {
-    igemm_body<T, BM, BN, WM, WN, MODE, GEGLU>(a);
+    igemm_body<T, BM, BN, WM, WN, MODE, GEGLU, STAGED>(a);
 }
 
 // Grouped launch: blockIdx.z selects one of up to SFAST_MAX_GEMM_GROUPS independent problems of identical shape that share the
@@ -359,7 +357,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const IgemmArgs a) {
     } else {
         const bool res_now = a.res_before_act || a.act == SFAST_ACT_NONE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = v[i] + b0[i] + b1[i] + (res_now ? r[i] * a.alpha : -0.0f);
+        for (int i = 0; i < 4; ++i) o[i] = fmaf(v[i], a.out_scale, b0[i]) + b1[i] + (res_now ? r[i] * a.alpha : -0.0f);
         if (a.act != SFAST_ACT_NONE) {
             f32x4 ov = {o[0], o[1], o[2], o[3]};
 #pragma unroll 1
@@ -371,6 +369,127 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const IgemmArgs a) {
         }
     }
     *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = pack4<T>(o[0], o[1], o[2], o[3]);
+}
+
+// Split-K reduce + epilogue + GroupNorm partial statistics: a workgroup owns R = TY*RT complete output rows, thread (c, ty) the
+// 8-channel chunk column c of rows ty, ty+TY, ... -- the row block is one statistics tile (tile_n = 1, bno = N) in the record layout
+// of flush_staged_tile (igemm_device.h). Shifts: the slot's first element in the block's row 0, shared through LDS.
+template <typename T, int RT>
+__global__ void __launch_bounds__(512) splitk_reduce_rows_kernel(const IgemmArgs a, int TY) {
+    extern __shared__ __attribute__((aligned(16))) char rsm[];
+    typedef const u32x4 __attribute__((address_space(1))) * g4_ptr;
+    const g4_ptr zero = (g4_ptr)(const void *)g_zero16;
+    const int CPR = a.N / 8;
+    const int tid = threadIdx.x;
+    const int c = tid % CPR, ty = tid / CPR;
+    const bool active = ty < TY;
+    const int R = TY * RT;
+    const int row0 = blockIdx.x * R;
+    const int n = c * 8;
+    T *row0v = reinterpret_cast<T *>(rsm);                              // [N] the block's row 0 (shifts)
+    float *red = reinterpret_cast<float *>(rsm + ((a.N * 2 + 15) / 16) * 16);  // [TY*CPR][4]
+    const BatchOfRow batch_of(a);
+    u32x4 outv[RT];
+    const u32x4 vb = *(a.bias ? (g4_ptr)(const void *)((const T *)a.bias + n) : zero);
+    float b0[8];
+    unpack8<T>(vb, b0);
+#pragma unroll
+    for (int k = 0; k < RT; ++k) {
+        const int m = row0 + ty + k * TY;
+        outv[k] = u32x4{0u, 0u, 0u, 0u};
+        if (!active || m >= a.M) continue;
+        const int bi = a.rowbias ? batch_of(m) : 0;
+        const u32x4 vb2 = *(a.rowbias ? (g4_ptr)(const void *)((const T *)a.rowbias + (int64_t)bi * a.ld_rowbias + n) : zero);
+        const u32x4 vr = *(a.res ? (g4_ptr)(const void *)((const T *)a.res + (int64_t)m * a.ldr + n) : zero);
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float *p0 = a.partial + (int64_t)m * a.N + n;
+        const int64_t zstride = (int64_t)a.M * a.N;
+        for (int z = 0; z < a.splits; ++z) {  // summation order z = 0, 1, 2, ...
+            const f32x4 t0 = *reinterpret_cast<const f32x4 *>(p0 + z * zstride), t1 = *reinterpret_cast<const f32x4 *>(p0 + z * zstride + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] += t0[i];
+                v[4 + i] += t1[i];
+            }
+        }
+        float b1[8], r[8];
+        unpack8<T>(vb2, b1);
+        unpack8<T>(vr, r);
+        const bool res_now = a.res_before_act || a.act == SFAST_ACT_NONE;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaf(v[i], a.out_scale, b0[i]) + b1[i] + (res_now ? r[i] * a.alpha : -0.0f);
+        if (a.act != SFAST_ACT_NONE) {
+#pragma unroll 1
+            for (int i = 0; i < 8; ++i) v[i] = apply_act(v[i], a.act);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += res_now ? -0.0f : r[i] * a.alpha;
+        }
+        outv[k] = pack8<T>(v);
+        *reinterpret_cast<u32x4 *>((T *)a.out + (int64_t)m * a.ldo + n) = outv[k];
+        if (ty == 0 && k == 0) *reinterpret_cast<u32x4 *>(row0v + n) = outv[k];
+    }
+    __syncthreads();
+    const int unit = a.gn_unit;
+    const int U0 = n / unit;
+    const int nb = min(8, (U0 + 1) * unit - n);
+    float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+    if (active) {
+        const float sha = (float)row0v[U0 * unit], shb = nb < 8 ? (float)row0v[(U0 + 1) * unit] : 0.f;
+#pragma unroll
+        for (int k = 0; k < RT; ++k) {
+            if (row0 + ty + k * TY >= a.M) continue;
+            float f[8];
+            unpack8<T>(outv[k], f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i < nb) {
+                    const float d = f[i] - sha;
+                    s1a += d;
+                    s2a = fmaf(d, d, s2a);
+                } else {
+                    const float d = f[i] - shb;
+                    s1b += d;
+                    s2b = fmaf(d, d, s2b);
+                }
+            }
+        }
+        *reinterpret_cast<f32x4 *>(red + tid * 4) = f32x4{s1a, s2a, s1b, s2b};
+    }
+    __syncthreads();
+    for (int j = tid; j < a.gn_slots; j += blockDim.x) {
+        const int lo = j * unit, hi_ = min(a.N, lo + unit);
+        float mean = 0.f, m2 = 0.f;
+        if (hi_ > lo) {
+            const float sh = (float)row0v[lo];
+            float s1 = 0.f, s2 = 0.f;
+            for (int cc = lo >> 3; cc <= (hi_ - 1) >> 3; ++cc) {
+                const int part = ((cc * 8) / unit == j) ? 0 : 2;
+                for (int t = 0; t < TY; ++t) {
+                    const float *q = red + (t * CPR + cc) * 4 + part;
+                    s1 += q[0];
+                    s2 += q[1];
+                }
+            }
+            const float cnt = (float)(hi_ - lo) * (float)min(R, a.M - row0);
+            mean = sh + s1 / cnt;
+            m2 = fmaxf(s2 - s1 * s1 / cnt, 0.f);
+        }
+        float *o = a.gn_stats + ((int64_t)blockIdx.x * a.gn_slots + j) * 2;
+        o[0] = mean;
+        o[1] = m2;
+    }
+}
+
+// rows per workgroup of the statistics-emitting reduce: TY row phases x RT rows per thread
+static void reduce_rows_geometry(int M, int N, int rows_per_sample, int &TY, int &RT) {
+    const int CPR = N / 8;
+    TY = 1;
+    while (TY < 8 && CPR * TY * 2 <= 512) TY *= 2;
+    RT = 1;
+    while (RT < 4 && M / (TY * RT * 2) >= 256) RT *= 2;
+    while (TY * RT > 1 && rows_per_sample % (TY * RT) != 0) {
+        if (RT > 1) RT /= 2; else TY /= 2;
+    }
 }
 
 // ---- host side: variants, heuristics, launch -------------------------------------------------------
@@ -402,18 +521,18 @@ int igemm_glds_ws_launch(const IgemmArgs &a, int dtype, int mode, bool geglu, in
 int igemm_glds_init();                                                                               // igemm_glds.hip
 int igemm_glds_launch(const IgemmArgs &a, int dtype, int mode, bool geglu, int BM, int BN, int NS, hipStream_t st);  // igemm_glds.hip
 
-template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GEGLU>
+template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GEGLU, bool STAGED = false>
 static int launch_one(const IgemmArgs &a, hipStream_t st) {
     constexpr int smem = 2 * (BM + BN) * 128;
-    auto kern = igemm_kernel<T, BM, BN, WM, WN, MODE, GEGLU>;
+    auto kern = igemm_kernel<T, BM, BN, WM, WN, MODE, GEGLU, STAGED>;
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n, a.splits), dim3(WM * WN * 64), smem, st, a);
     return check_launch("igemm");
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GEGLU>
+template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GEGLU, bool STAGED = false>
 static int set_attr_one() {
     constexpr int smem = 2 * (BM + BN) * 128;
-    auto kern = igemm_kernel<T, BM, BN, WM, WN, MODE, GEGLU>;
+    auto kern = igemm_kernel<T, BM, BN, WM, WN, MODE, GEGLU, STAGED>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) {
@@ -435,12 +554,14 @@ static int set_attr_one() {
     OP(T, 64, 128, 2, 2, 0, true)
 
 static int g_pipe_pref = -1;  // -1 auto, 0 force register pipe, 1 force LDS-DMA pipe (SFAST_IGEMM_PIPE)
+static int g_stage_pref = 0;  // 1: stage every eligible output tile through LDS (SFAST_STAGE_OUT=1), not only those that emit statistics
 
 int igemm_grouped_init();
 int igemm_init() {
     int rc = 0;
-#define INIT_OP(T, BM, BN, WM, WN, MODE, G) \
-    if (!rc) rc = set_attr_one<T, BM, BN, WM, WN, MODE, G>();
+#define INIT_OP(T, BM, BN, WM, WN, MODE, G)                  \
+    if (!rc) rc = set_attr_one<T, BM, BN, WM, WN, MODE, G>(); \
+    if (!rc && !G) rc = set_attr_one<T, BM, BN, WM, WN, MODE, false, true>();
     SFAST_FOR_VARIANTS(f16, 0, INIT_OP)
     SFAST_FOR_VARIANTS(f16, 1, INIT_OP)
     SFAST_FOR_VARIANTS(bf16, 0, INIT_OP)
@@ -451,6 +572,8 @@ int igemm_init() {
     if (!rc) rc = igemm_grouped_init();
     if (!rc) rc = igemm_glds_init();
     if (!rc) rc = igemm_glds_ws_init();
+    const char *so = getenv("SFAST_STAGE_OUT");
+    g_stage_pref = (so && so[0] == '1') ? 1 : 0;
     const char *e = getenv("SFAST_IGEMM_PIPE");
     if (e && e[0] == 'r') g_pipe_pref = 0;
     if (e && e[0] == 'g') g_pipe_pref = 1;
@@ -459,9 +582,13 @@ int igemm_init() {
 
 template <typename T, int MODE>
 static int dispatch_variant(const IgemmArgs &a, const Variant &v, bool geglu, hipStream_t st) {
-#define LAUNCH_OP(TT, BM_, BN_, WM_, WN_, MODE_, G_)                                   \
-    if (v.BM == BM_ && v.BN == BN_ && v.WM == WM_ && v.WN == WN_ && geglu == G_)      \
-        return launch_one<TT, BM_, BN_, WM_, WN_, MODE_, G_>(a, st);
+#define LAUNCH_OP(TT, BM_, BN_, WM_, WN_, MODE_, G_)                                                    \
+    if (v.BM == BM_ && v.BN == BN_ && v.WM == WM_ && v.WN == WN_ && geglu == G_) {                     \
+        if constexpr (!G_) {                                                                           \
+            if (a.stage_out) return launch_one<TT, BM_, BN_, WM_, WN_, MODE_, false, true>(a, st);     \
+        }                                                                                              \
+        return launch_one<TT, BM_, BN_, WM_, WN_, MODE_, G_>(a, st);                                   \
+    }
     if (!geglu) {
         SFAST_FOR_VARIANTS(T, MODE, LAUNCH_OP)
     } else {
@@ -486,6 +613,19 @@ struct IgemmPlan {
 // and is modelled by its own rate. The 16x16 / 8x8 UNet levels (M <= 512, K up to 23k) are
 // weight-streaming bound and want as many K-splits as it takes to put ~2 workgroups on every CU;
 // measured optima cluster at 480..640 workgroups.
+// Staged-store / statistics kernels exist for the register pipe and the wave-specialised pipe; a forced LDS-DMA ring variant
+// is replaced by the same tile shape in one of those (ring depth is a latency knob, the arithmetic is identical).
+static int staged_variant(int id) {
+    switch (id) {
+    case 11: case 16: return 21;
+    case 12: case 17: return 22;
+    case 13: case 18: return 23;
+    case 14: return 4;
+    case 15: return 5;
+    default: return id;
+    }
+}
+
 static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, int force_split, bool glds_ok) {
     const Variant *vs = geglu ? kGegluVariants : kVariants;
     const int nv = geglu ? (int)(sizeof(kGegluVariants) / sizeof(Variant)) : (int)(sizeof(kVariants) / sizeof(Variant));
@@ -564,6 +704,31 @@ static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, 
     return best;
 }
 
+bool igemm_stats_layout(int M, int N, int K, bool geglu, int variant, int split, bool glds_ok, int unit, int rows_per_sample,
+                        StatsLayout &out) {
+    if (geglu || unit < 8 || rows_per_sample <= 0 || M % rows_per_sample != 0 || N % 8 != 0) return false;
+    IgemmPlan p = igemm_plan(M, N, K, geglu, variant, split, glds_ok);
+    if (p.v.pipe == 1 && p.splits == 1) p = igemm_plan(M, N, K, geglu, staged_variant(p.v.id), p.splits, glds_ok);
+    if (p.splits == 1) {
+        if (rows_per_sample % p.v.BM != 0) return false;
+        out.rb_rows = p.v.BM;
+        out.bno = p.v.BN;
+        out.slots = stats_slots(p.v.BN, unit);
+        out.tiles_n = p.tiles_n;
+        out.n_rb = M / p.v.BM;
+        return true;
+    }
+    if (N / 8 > 512 || N * 2 + 16 + 512 * 16 > 64 * 1024) return false;
+    int ty, rt;
+    reduce_rows_geometry(M, N, rows_per_sample, ty, rt);
+    out.rb_rows = ty * rt;
+    out.bno = N;
+    out.slots = ceil_div(N, unit);
+    out.tiles_n = 1;
+    out.n_rb = M / (ty * rt);
+    return true;
+}
+
 void igemm_plan_query(int M, int N, int K, bool geglu, int variant, int split, bool glds_ok, int out[5]) {
     IgemmPlan p = igemm_plan(M, N, K, geglu, variant, split, glds_ok);
     out[0] = p.v.BM;
@@ -629,6 +794,9 @@ int igemm_run_grouped(IgemmArgs &a, int dtype, int n_groups, const void *const *
     a.splits = 1;
     a.partial = nullptr;
     a.trace = nullptr;
+    a.out_scale = 1.0f;
+    a.stage_out = 0;
+    a.gn_stats = nullptr;
     set_kernel_name("igemm_grouped_%s[%dx%d,G=%d,reg]", dtype == SFAST_F16 ? "f16" : "bf16", BM, BN, n_groups);
     const dim3 grid(a.tiles_m * a.tiles_n, 1, n_groups);
 #define GROUPED_LAUNCH(T, BM_, BN_) \
@@ -647,6 +815,8 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
               hipStream_t st) {
     const bool glds_ok = igemm_glds_eligible(a, mode);
     IgemmPlan p = igemm_plan(a.M, a.N, a.K, geglu, variant, split, glds_ok);
+    const bool want_staged = !geglu && (a.gn_stats != nullptr || g_stage_pref > 0);
+    if (want_staged && p.v.pipe == 1 && p.splits == 1) p = igemm_plan(a.M, a.N, a.K, geglu, staged_variant(p.v.id), p.splits, glds_ok);
     a.tiles_m = p.tiles_m;
     a.tiles_n = p.tiles_n;
     a.ktiles = p.ktiles;
@@ -654,6 +824,25 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
     a.splits = p.splits;
     a.partial = nullptr;
     a.trace = g_igemm_trace;
+    if (a.out_scale == 0.f) a.out_scale = 1.0f;
+    // staged (LDS -> 16-byte row segments) stores need 16-byte aligned output rows; statistics additionally whole tiles per sample
+    const int bno_sel = geglu ? p.v.BN / 2 : p.v.BN;
+    const bool stage_ok = a.N % 8 == 0 && a.ldo % 8 == 0 && aligned16(a.out);
+    int red_ty = 0, red_rt = 0;
+    if (a.gn_stats) {
+        SFAST_REQUIRE(!geglu && stage_ok && a.gn_unit >= 8 && a.gn_rows_per_sample > 0 && a.M % a.gn_rows_per_sample == 0, SFAST_ERR_UNSUPPORTED,
+                      "igemm: GroupNorm statistics need a non-GEGLU problem with 16-byte aligned output rows and unit >= 8");
+        if (p.splits == 1) {
+            SFAST_REQUIRE(a.gn_rows_per_sample % p.v.BM == 0, SFAST_ERR_UNSUPPORTED, "igemm: %d rows per sample do not tile by BM=%d",
+                          a.gn_rows_per_sample, p.v.BM);
+            a.gn_slots = stats_slots(bno_sel, a.gn_unit);
+        } else {
+            SFAST_REQUIRE(a.N / 8 <= 512 && a.N * 2 + 16 + 512 * 16 <= 64 * 1024, SFAST_ERR_UNSUPPORTED, "igemm: N=%d too wide for the statistics reduce", a.N);
+            reduce_rows_geometry(a.M, a.N, a.gn_rows_per_sample, red_ty, red_rt);
+            a.gn_slots = ceil_div(a.N, a.gn_unit);
+        }
+    }
+    a.stage_out = (p.splits == 1 && !geglu && stage_ok && (a.gn_stats != nullptr || g_stage_pref > 0)) ? 1 : 0;
     if (p.splits > 1) {
         const size_t need = (size_t)p.splits * a.M * (geglu ? 2 * (size_t)a.N : (size_t)a.N) * sizeof(float);
         SFAST_REQUIRE(ws && ws_bytes >= need, SFAST_ERR_WORKSPACE, "igemm: workspace %zu < %zu", ws_bytes, need);
@@ -661,8 +850,8 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
     }
     char pipe[8];
     snprintf(pipe, sizeof(pipe), p.v.pipe == 2 ? "ws%d" : p.v.pipe ? "dma%d" : "reg", p.v.ns);
-    set_kernel_name("igemm_%s_%s%s[%dx%d,split=%d,%s]", mode ? "conv" : "lin", dtype == SFAST_F16 ? "f16" : "bf16",
-                    geglu ? "_geglu" : "", p.v.BM, p.v.BN, p.splits, pipe);
+    set_kernel_name("igemm_%s_%s%s[%dx%d,split=%d,%s]%s", mode ? "conv" : "lin", dtype == SFAST_F16 ? "f16" : "bf16",
+                    geglu ? "_geglu" : "", p.v.BM, p.v.BN, p.splits, pipe, a.gn_stats ? "+gnstats" : (a.stage_out ? "+staged" : ""));
     int rc;
     if (p.v.pipe == 2)
         rc = igemm_glds_ws_launch(a, dtype, mode, geglu, p.v.BM, p.v.BN, p.v.ns, st);
@@ -673,6 +862,19 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
     else
         rc = mode ? dispatch_variant<bf16, 1>(a, p.v, geglu, st) : dispatch_variant<bf16, 0>(a, p.v, geglu, st);
     if (rc) return rc;
+    if (p.splits > 1 && a.gn_stats) {
+        const int R = red_ty * red_rt, CPR = a.N / 8;
+        const dim3 grid((unsigned)ceil_div(a.M, R)), block((unsigned)(((CPR * red_ty + 63) / 64) * 64));
+        const size_t smem = (size_t)((a.N * 2 + 15) / 16) * 16 + (size_t)block.x * 16;
+#define RR_LAUNCH(T, RT_) hipLaunchKernelGGL((splitk_reduce_rows_kernel<T, RT_>), grid, block, smem, st, a, red_ty)
+        if (dtype == SFAST_F16) {
+            if (red_rt == 4) RR_LAUNCH(f16, 4); else if (red_rt == 2) RR_LAUNCH(f16, 2); else RR_LAUNCH(f16, 1);
+        } else {
+            if (red_rt == 4) RR_LAUNCH(bf16, 4); else if (red_rt == 2) RR_LAUNCH(bf16, 2); else RR_LAUNCH(bf16, 1);
+        }
+#undef RR_LAUNCH
+        return check_launch("splitk_reduce_rows");
+    }
     if (p.splits > 1) {
         const int64_t total = (int64_t)a.M * (a.N / 4);
         const dim3 grid((unsigned)ceil_div64(total, 256));

@@ -214,11 +214,29 @@ __device__ __forceinline__ void store_partial(const IgemmArgs &a, f32x16 (&acc)[
     }
 }
 
-// Pass 1 over one 32x32 fragment: acc += bias + row-bias (+ residual when it belongs before the activation, or when
-// there is no activation and the order is moot). Without an activation the fragment is finished and stored here.
-template <typename T>
-__device__ __forceinline__ void fragment_pass1(const IgemmArgs &a, f32x16 &acc, const u32x2 (&vb)[4], const u32x2 (&vb2)[4],
-                                               const u32x2 (&vr)[4], bool mok, int m, int nfrag, int hi) {
+// ---- where a finished group of 4 output values goes ------------------------------------------------------------
+// STAGED = false: straight to global memory (8 bytes per lane, one row per lane: 32 row segments per store instruction).
+// STAGED = true : into an LDS image of the output tile (row stride BNO*2 + 8 bytes: the 16 lanes of a ds_write_b64 group hit
+//                 16 different 8-byte bank pairs); flush_staged_tile() then writes whole 16-byte chunks of contiguous row
+//                 segments and, on request, reduces the tile to GroupNorm partial statistics on the way out.
+struct StageCtx {
+    char *lds;
+    int m0, n0, ldr;
+};
+template <typename T, bool STAGED>
+__device__ __forceinline__ void put4(const IgemmArgs &a, const StageCtx &sc, int m, int n, bool ok, u32x2 v) {
+    if constexpr (STAGED) {
+        *reinterpret_cast<u32x2 *>(sc.lds + (m - sc.m0) * sc.ldr + (n - sc.n0) * 2) = v;
+    } else {
+        if (ok) *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = v;
+    }
+}
+
+// Pass 1 over one 32x32 fragment: acc = out_scale*acc + bias + row-bias (+ residual when it belongs before the activation, or
+// when there is no activation and the order is moot). Without an activation the fragment is finished and stored here.
+template <typename T, bool STAGED>
+__device__ __forceinline__ void fragment_pass1(const IgemmArgs &a, const StageCtx &sc, f32x16 &acc, const u32x2 (&vb)[4],
+                                               const u32x2 (&vb2)[4], const u32x2 (&vr)[4], bool mok, int m, int nfrag, int hi) {
     const bool res_now = a.res_before_act || a.act == SFAST_ACT_NONE;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -227,20 +245,20 @@ __device__ __forceinline__ void fragment_pass1(const IgemmArgs &a, f32x16 &acc, 
         unpack4<T>(vb2[g], b1);
         unpack4<T>(vr[g], r);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[4 * g + i] = acc[4 * g + i] + b0[i] + b1[i] + (res_now ? r[i] * a.alpha : -0.0f);
+        for (int i = 0; i < 4; ++i) acc[4 * g + i] = fmaf(acc[4 * g + i], a.out_scale, b0[i]) + b1[i] + (res_now ? r[i] * a.alpha : -0.0f);
     }
     if (a.act == SFAST_ACT_NONE) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = nfrag + 8 * g + 4 * hi;
-            if (mok && n < a.N)
-                *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = pack4<T>(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+            put4<T, STAGED>(a, sc, m, n, mok && n < a.N, pack4<T>(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]));
         }
     }
 }
 // Pass 2 (only with an activation): add the residual that belongs after it, store.
-template <typename T>
-__device__ __forceinline__ void fragment_pass2(const IgemmArgs &a, const f32x16 &acc, const u32x2 (&vr)[4], bool mok, int m, int nfrag, int hi) {
+template <typename T, bool STAGED>
+__device__ __forceinline__ void fragment_pass2(const IgemmArgs &a, const StageCtx &sc, const f32x16 &acc, const u32x2 (&vr)[4], bool mok, int m,
+                                               int nfrag, int hi) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         float r[4];
@@ -249,15 +267,16 @@ __device__ __forceinline__ void fragment_pass2(const IgemmArgs &a, const f32x16 
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = acc[4 * g + i] + (a.res_before_act ? -0.0f : r[i] * a.alpha);
-        if (mok && n < a.N) *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+        put4<T, STAGED>(a, sc, m, n, mok && n < a.N, pack4<T>(v[0], v[1], v[2], v[3]));
     }
 }
 
 // Activation tail (only when a.act != NONE): one switch over the tile, then the residual that belongs AFTER the
 // activation is fetched again, one fragment ahead, and the tile is stored. Re-fetching instead of keeping the
 // prefetched residual live across the switch keeps the register peak of this rare path out of the kernel's budget.
-template <typename T, int FN, int FM>
-__device__ __forceinline__ void epilogue_act_tail(const IgemmArgs &a, f32x16 (&acc)[FN][FM], int mbase, int nbase, int l31, int hi) {
+template <typename T, int FN, int FM, bool STAGED>
+__device__ __forceinline__ void epilogue_act_tail(const IgemmArgs &a, const StageCtx &sc, f32x16 (&acc)[FN][FM], int mbase, int nbase, int l31,
+                                                  int hi) {
     typedef const u32x2 __attribute__((address_space(1))) * g2_ptr;
     const g2_ptr zero = (g2_ptr)(const void *)g_zero16;
     apply_act_tile<FN, FM, FN>(acc, a.act);
@@ -279,13 +298,14 @@ __device__ __forceinline__ void epilogue_act_tail(const IgemmArgs &a, f32x16 (&a
         const int fm = f / FN, fh = f % FN;
         if (f + 1 < FN * FM) fetch(f + 1, (f + 1) & 1);
         const int m = mbase + fm * 32 + l31;
-        fragment_pass2<T>(a, acc[fh][fm], vr[f & 1], m < a.M, m, nbase + fh * 32, hi);
+        fragment_pass2<T, STAGED>(a, sc, acc[fh][fm], vr[f & 1], m < a.M, m, nbase + fh * 32, hi);
     }
 }
 
-template <typename T, int FN, int FM, bool GEGLU>
-__device__ __forceinline__ void epilogue_finish(const IgemmArgs &a, f32x16 (&acc)[FN][FM], const EpiOperands<(GEGLU ? FN / 2 : FN), FM> &e,
-                                                int mbase, int nbase, int l31, int hi, int split_idx) {
+template <typename T, int FN, int FM, bool GEGLU, bool STAGED>
+__device__ __forceinline__ void epilogue_finish(const IgemmArgs &a, const StageCtx &sc, f32x16 (&acc)[FN][FM],
+                                                const EpiOperands<(GEGLU ? FN / 2 : FN), FM> &e, int mbase, int nbase, int l31, int hi,
+                                                int split_idx) {
     if (a.splits > 1) {
         store_partial<FN, FM, GEGLU>(a, acc, mbase, nbase, l31, hi, split_idx);
         return;
@@ -311,15 +331,15 @@ __device__ __forceinline__ void epilogue_finish(const IgemmArgs &a, f32x16 (&acc
                         const float gt = acc[fh + o][fm][4 * g + i] + b1[i];
                         v[i] = h * act_gelu_erf(gt);
                     }
-                    if (mok && n < a.N) *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+                    put4<T, STAGED>(a, sc, m, n, mok && n < a.N, pack4<T>(v[0], v[1], v[2], v[3]));
                 }
             } else {
-                fragment_pass1<T>(a, acc[fh][fm], e.vb[fh], e.vb2[fm][fh], e.vr[fm][fh], mok, m, nbase + fh * 32, hi);
+                fragment_pass1<T, STAGED>(a, sc, acc[fh][fm], e.vb[fh], e.vb2[fm][fh], e.vr[fm][fh], mok, m, nbase + fh * 32, hi);
             }
         }
     }
     if constexpr (!GEGLU) {
-        if (a.act != SFAST_ACT_NONE) epilogue_act_tail<T, FN, FM>(a, acc, mbase, nbase, l31, hi);
+        if (a.act != SFAST_ACT_NONE) epilogue_act_tail<T, FN, FM, STAGED>(a, sc, acc, mbase, nbase, l31, hi);
     }
 }
 
@@ -327,9 +347,9 @@ __device__ __forceinline__ void epilogue_finish(const IgemmArgs &a, f32x16 (&acc
 // fragment AHEAD of the one being finished (12 vectors each), which keeps the epilogue inside the register budget
 // of two waves per SIMD while still overlapping every operand round trip but the first with math and stores.
 // (Program order = load(f+1), store(f): legal for in-place residuals because fragments never overlap.)
-template <typename T, int FN, int FM>
-__device__ __forceinline__ void epilogue_late(const IgemmArgs &a, f32x16 (&acc)[FN][FM], int mbase, int nbase, int l31, int hi,
-                                              int split_idx) {
+template <typename T, int FN, int FM, bool STAGED>
+__device__ __forceinline__ void epilogue_late(const IgemmArgs &a, const StageCtx &sc, f32x16 (&acc)[FN][FM], int mbase, int nbase, int l31,
+                                              int hi, int split_idx) {
     typedef const u32x2 __attribute__((address_space(1))) * g2_ptr;
     const g2_ptr zero = (g2_ptr)(const void *)g_zero16;
     if (a.splits > 1) {
@@ -360,9 +380,123 @@ __device__ __forceinline__ void epilogue_late(const IgemmArgs &a, f32x16 (&acc)[
         const int fm = f / FN, fh = f % FN;
         if (f + 1 < FN * FM) fetch(f + 1, (f + 1) & 1);
         const int m = mbase + fm * 32 + l31;
-        fragment_pass1<T>(a, acc[fh][fm], vb[f & 1], vb2[f & 1], vr[f & 1], m < a.M, m, nbase + fh * 32, hi);
+        fragment_pass1<T, STAGED>(a, sc, acc[fh][fm], vb[f & 1], vb2[f & 1], vr[f & 1], m < a.M, m, nbase + fh * 32, hi);
     }
-    if (a.act != SFAST_ACT_NONE) epilogue_act_tail<T, FN, FM>(a, acc, mbase, nbase, l31, hi);
+    if (a.act != SFAST_ACT_NONE) epilogue_act_tail<T, FN, FM, STAGED>(a, sc, acc, mbase, nbase, l31, hi);
+}
+
+// ---- staged tile -> global memory (+ GroupNorm partial statistics) ------------------------------------------------
+// Thread t of the NTC consumer threads owns chunk column t % (BNO/8) (8 output channels = 16 bytes) of rows t / (BNO/8) + k*RPP:
+// 16 consecutive lanes write 256 contiguous bytes of one output row. On request the same pass reduces the tile to the
+// statistics the consuming GroupNorm needs, so that it becomes ONE normalisation pass instead of a statistics pass plus a
+// normalisation pass (the reference's Triton GroupNorm is that two-kernel form, triton/ops/group_norm.py:111-165 + :272-349):
+//   a statistics UNIT is `gn_unit` consecutive channels (a divisor of every consumer's channels-per-group); a tile emits one
+//   {mean, M2} record per unit SLOT it overlaps (a unit cut by the tile's column range yields one record in each tile),
+//   sums are shifted by the slot's first element in tile row 0 (exactly additive within the tile), order of summation fixed.
+// The consumer merges records of different tiles with Chan's parallel-variance formula (norm.hip: gn_nhwc_apply_pre_kernel).
+template <typename T, int BM, int BNO, int NTC>
+__device__ __forceinline__ void flush_staged_tile(const IgemmArgs &a, char *lds, int m0, int n0, int ctid) {
+    constexpr int CPR = BNO / 8, LDR = BNO * 2 + 8, RPP = NTC / CPR, NTF = RPP * CPR;
+    constexpr int SCR = ((BM * LDR + 15) / 16) * 16;  // float4 per flush thread: {s1, s2} of the chunk's two unit parts
+    __syncthreads();                                  // every fragment of the tile is in LDS
+    const bool stats = a.gn_stats != nullptr;
+    const int c = ctid % CPR, rp = ctid / CPR;
+    const int n = n0 + c * 8;
+    const int unit = stats ? a.gn_unit : 8;
+    const int U0 = n / unit;                                  // unit of the chunk's first channel
+    const int nb = min(8, (U0 + 1) * unit - n);               // channels of the chunk inside U0; the rest belong to U0 + 1
+    float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+    if (ctid < NTF && n < a.N) {
+        float sha = 0.f, shb = 0.f;
+        if (stats) {
+            const int ca = max(n0, U0 * unit) - n0, cb = (U0 + 1) * unit - n0;  // first in-tile channel of either unit slot
+            sha = (float)*reinterpret_cast<const T *>(lds + ca * 2);
+            shb = nb < 8 ? (float)*reinterpret_cast<const T *>(lds + cb * 2) : 0.f;
+        }
+        const char *src = lds + rp * LDR + c * 16;
+        T *dst = (T *)a.out + (int64_t)(m0 + rp) * a.ldo + n;
+        const int64_t dstep = (int64_t)RPP * a.ldo;
+#pragma unroll 4
+        for (int r = rp; r < BM; r += RPP) {
+            if (m0 + r < a.M) {
+                const u32x2 lo = *reinterpret_cast<const u32x2 *>(src), hi2 = *reinterpret_cast<const u32x2 *>(src + 8);
+                const u32x4 v = {lo[0], lo[1], hi2[0], hi2[1]};
+                *reinterpret_cast<u32x4 *>(dst) = v;
+                if (stats) {
+                    float f[8];
+                    unpack8<T>(v, f);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        if (i < nb) {
+                            const float d = f[i] - sha;
+                            s1a += d;
+                            s2a = fmaf(d, d, s2a);
+                        } else {
+                            const float d = f[i] - shb;
+                            s1b += d;
+                            s2b = fmaf(d, d, s2b);
+                        }
+                    }
+                }
+            }
+            src += RPP * LDR;
+            dst += dstep;
+        }
+    }
+    if (!stats) return;
+    float *red = reinterpret_cast<float *>(lds + SCR);
+    if (ctid < NTF) *reinterpret_cast<f32x4 *>(red + ctid * 4) = f32x4{s1a, s2a, s1b, s2b};
+    __syncthreads();
+    // slot j of this tile <-> unit n0/unit + j; fixed summation order: chunk columns ascending, row phases ascending
+    const int ufirst = n0 / unit;
+    const int nend = min(n0 + BNO, a.N);
+    if (ctid < a.gn_slots) {
+        const int U = ufirst + ctid;
+        const int lo = max(n0, U * unit), hi_ = min(nend, (U + 1) * unit);
+        float mean = 0.f, m2 = 0.f;
+        if (hi_ > lo) {
+            const float sh = (float)*reinterpret_cast<const T *>(lds + (lo - n0) * 2);
+            float s1 = 0.f, s2 = 0.f;
+            for (int cc = (lo - n0) >> 3; cc <= (hi_ - 1 - n0) >> 3; ++cc) {
+                const int part = ((n0 + cc * 8) / unit == U) ? 0 : 2;
+                for (int j = 0; j < RPP; ++j) {
+                    const float *q = red + (j * CPR + cc) * 4 + part;
+                    s1 += q[0];
+                    s2 += q[1];
+                }
+            }
+            const float cnt = (float)(hi_ - lo) * (float)min(BM, a.M - m0);
+            mean = sh + s1 / cnt;
+            m2 = fmaxf(s2 - s1 * s1 / cnt, 0.f);
+        }
+        const int tile_m = m0 / BM, tile_n = n0 / BNO;
+        float *o = a.gn_stats + (((int64_t)tile_m * a.tiles_n + tile_n) * a.gn_slots + ctid) * 2;
+        o[0] = mean;
+        o[1] = m2;
+    }
+}
+
+// One entry for the three kernel files: split-K slab store, or the fused epilogue with direct (STAGED = false) or staged stores.
+// STAGED is a KERNEL template parameter (separate instantiations, chosen on the host from IgemmArgs::stage_out): with both store
+// paths in one kernel the 128-wide tiles ran out of their 256 registers and spilled.
+template <typename T, int BM, int BNO, int FN, int FM, bool GEGLU, bool EPI_EARLY, int NTC, bool STAGED>
+__device__ __forceinline__ void run_epilogue(const IgemmArgs &a, f32x16 (&acc)[FN][FM],
+                                             const EpiOperands<(EPI_EARLY ? (GEGLU ? FN / 2 : FN) : 1), (EPI_EARLY ? FM : 1)> &epi, char *smem,
+                                             int m0, int n0, int mbase, int nbase, int l31, int hi, int ctid, int split_idx) {
+    StageCtx sc{smem, m0, n0, BNO * 2 + 8};
+    if constexpr (STAGED) {
+        __syncthreads();  // LDS ring is free: every wave is past its last fragment read and its last LDS-DMA has landed
+        if constexpr (EPI_EARLY)
+            epilogue_finish<T, FN, FM, GEGLU, true>(a, sc, acc, epi, mbase, nbase, l31, hi, split_idx);
+        else
+            epilogue_late<T, FN, FM, true>(a, sc, acc, mbase, nbase, l31, hi, split_idx);
+        flush_staged_tile<T, BM, BNO, NTC>(a, smem, m0, n0, ctid);
+    } else {
+        if constexpr (EPI_EARLY)
+            epilogue_finish<T, FN, FM, GEGLU, false>(a, sc, acc, epi, mbase, nbase, l31, hi, split_idx);
+        else
+            epilogue_late<T, FN, FM, false>(a, sc, acc, mbase, nbase, l31, hi, split_idx);
+    }
 }
 
 }  // namespace sfast

@@ -38,7 +38,7 @@ typedef __attribute__((address_space(3))) void *glds_dst_t;
 
 // EXP != 0: profiling experiments (tools/trace_igemm.py, only instantiated for two tiles): bit0 no MFMAs, bit1 no
 // fragment reads, bit2 no in-loop LDS-DMA requests, bit3 no per-tile barrier. Results are garbage.
-template <typename T, int BM, int BN, int WM, int WN, int NS, int MODE, bool GEGLU, int EXP = 0>
+template <typename T, int BM, int BN, int WM, int WN, int NS, int MODE, bool GEGLU, int EXP = 0, bool STAGED = false>
 __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, NS *(BM + BN) * 128)) igemm_glds_kernel(const IgemmArgs a) {
     using vec8 = typename Elem<T>::vec8;
     constexpr int NT = WM * WN * 64;
@@ -298,10 +298,8 @@ __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, NS *
 
     // ---- epilogue: batched operand loads, fp32 math, 8-byte stores (igemm_device.h) -------------------------
     trace_mark(a, 4);
-    if constexpr (!EPI_EARLY)
-        epilogue_late<T, FN, FM>(a, acc, m0 + wm * (FM * 32), n0 + wn * WNB, l31, hi, blockIdx.y);
-    else
-        epilogue_finish<T, FN, FM, GEGLU>(a, acc, epi, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi, blockIdx.y);
+    run_epilogue<T, BM, BNO, FN, FM, GEGLU, EPI_EARLY, NT, STAGED>(a, acc, epi, smem, m0, n0, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi,
+                                                             tid, blockIdx.y);
     trace_finish(a);
 }
 

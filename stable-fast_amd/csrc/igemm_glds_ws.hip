@@ -25,7 +25,7 @@ template <int N> __device__ __forceinline__ void ws_wait_vmcnt() {
 typedef const u32x4 __attribute__((address_space(1))) * ws_src_t;
 typedef __attribute__((address_space(3))) void *ws_dst_t;
 
-template <typename T, int BM, int BN, int WM, int WN, int PW, int NS, int MODE, bool GEGLU>
+template <typename T, int BM, int BN, int WM, int WN, int PW, int NS, int MODE, bool GEGLU, bool STAGED = false>
 __global__ void __launch_bounds__((WM * WN + PW) * 64, igemm_min_waves((WM * WN + PW) * 64, NS *(BM + BN) * 128))
     igemm_glds_ws_kernel(const IgemmArgs a) {
     using vec8 = typename Elem<T>::vec8;
@@ -254,10 +254,8 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, igemm_min_waves((WM * WN 
     }
 
     trace_mark(a, 4);
-    if constexpr (!EPI_EARLY)
-        epilogue_late<T, FN, FM>(a, acc, m0 + wm * (FM * 32), n0 + wn * WNB, l31, hi, blockIdx.y);
-    else
-        epilogue_finish<T, FN, FM, GEGLU>(a, acc, epi, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi, blockIdx.y);
+    run_epilogue<T, BM, BNO, FN, FM, GEGLU, EPI_EARLY, NC, STAGED>(a, acc, epi, smem, m0, n0, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi,
+                                                             tid, blockIdx.y);
     trace_finish(a);
 }
 
@@ -272,10 +270,10 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, igemm_min_waves((WM * WN 
     OP(T, 128, 128, 2, 2, 4, 4, 0, true)   \
     OP(T, 64, 128, 2, 2, 4, 3, 0, true)
 
-template <typename T, int BM, int BN, int WM, int WN, int PW, int NS, int MODE, bool GEGLU>
+template <typename T, int BM, int BN, int WM, int WN, int PW, int NS, int MODE, bool GEGLU, bool STAGED = false>
 static int ws_set_attr() {
     constexpr int smem = NS * (BM + BN) * 128;
-    auto kern = igemm_glds_ws_kernel<T, BM, BN, WM, WN, PW, NS, MODE, GEGLU>;
+    auto kern = igemm_glds_ws_kernel<T, BM, BN, WM, WN, PW, NS, MODE, GEGLU, STAGED>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) {
         set_error("hipFuncSetAttribute(igemm_glds_ws %dx%dx%d): %s", BM, BN, NS, hipGetErrorString(e));
@@ -286,8 +284,9 @@ static int ws_set_attr() {
 
 int igemm_glds_ws_init() {
     int rc = 0;
-#define INIT_OP(T, BM, BN, WM, WN, PW, NS, MODE, G) \
-    if (!rc) rc = ws_set_attr<T, BM, BN, WM, WN, PW, NS, MODE, G>();
+#define INIT_OP(T, BM, BN, WM, WN, PW, NS, MODE, G)                  \
+    if (!rc) rc = ws_set_attr<T, BM, BN, WM, WN, PW, NS, MODE, G>(); \
+    if (!rc && !G) rc = ws_set_attr<T, BM, BN, WM, WN, PW, NS, MODE, false, true>();
     SFAST_FOR_WS_VARIANTS(f16, 0, INIT_OP)
     SFAST_FOR_WS_VARIANTS(f16, 1, INIT_OP)
     SFAST_FOR_WS_VARIANTS(bf16, 0, INIT_OP)
@@ -304,6 +303,13 @@ template <typename T, int MODE>
 static int ws_dispatch(const IgemmArgs &a, int BM_, int BN_, int NS_, bool geglu, hipStream_t st) {
 #define LAUNCH_OP(TT, BM, BN, WM, WN, PW, NS, MODE_, G_)                                                                       \
     if (BM_ == BM && BN_ == BN && NS_ == NS && geglu == G_) {                                                                  \
+        if constexpr (!G_) {                                                                                                   \
+            if (a.stage_out) {                                                                                                 \
+                auto ks = igemm_glds_ws_kernel<TT, BM, BN, WM, WN, PW, NS, MODE_, false, true>;                                \
+                hipLaunchKernelGGL(ks, dim3(a.tiles_m *a.tiles_n, a.splits), dim3((WM * WN + PW) * 64), NS *(BM + BN) * 128, st, a); \
+                return check_launch("igemm_glds_ws_staged");                                                                   \
+            }                                                                                                                  \
+        }                                                                                                                      \
         auto kern = igemm_glds_ws_kernel<TT, BM, BN, WM, WN, PW, NS, MODE_, G_>;                                               \
         hipLaunchKernelGGL(kern, dim3(a.tiles_m *a.tiles_n, a.splits), dim3((WM * WN + PW) * 64), NS *(BM + BN) * 128, st, a); \
         return check_launch("igemm_glds_ws");                                                                                  \

@@ -145,18 +145,88 @@ __global__ void gn_nhwc_stats_kernel(const T *__restrict__ x, const T *__restric
 }
 
 template <typename T, bool SILU>
+__device__ __forceinline__ void gn_apply_rows(const T *__restrict__ x, const T *__restrict__ x2, const T *__restrict__ gamma,
+                                              const T *__restrict__ beta, T *__restrict__ y, const GnGeom &g, int rows_per_block,
+                                              const float *mean, const float *rstd, u32x4 ga_raw, u32x4 be_raw);
+
+// Statistics handed over by the PRODUCERS of the tensor (igemm_device.h flush_staged_tile / splitk_reduce_rows_kernel): per
+// concat source one array of {mean, M2} records indexed [sample][row block][tile_n][slot].
+struct GnPre {
+    const float *p[2];
+    int rb_rows[2], n_rb[2], bno[2], tiles_n[2], slots[2], unit[2], nch[2], coff[2];
+};
+
+// Chan et al. pairwise update: (n, mean, M2) <- (n, mean, M2) (+) (ni, mi, M2i)
+__device__ __forceinline__ void chan_merge(float &n, float &mean, float &m2, float ni, float mi, float m2i) {
+    if (ni <= 0.f) return;
+    const float nn = n + ni;
+    const float d = mi - mean;
+    const float f = ni / nn;
+    mean = fmaf(d, f, mean);
+    m2 = m2 + m2i + d * d * n * f;
+    n = nn;
+}
+
+template <typename T, bool SILU, bool PRE>
 __global__ void gn_nhwc_apply_kernel(const T *__restrict__ x, const T *__restrict__ x2,
                                      const T *__restrict__ gamma, const T *__restrict__ beta,
                                      T *__restrict__ y, const float *__restrict__ partial, GnGeom g,
-                                     int rows_per_block, int nsplit, float eps) {
+                                     int rows_per_block, int nsplit, float eps, const GnPre pre) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *mean = smem;               // [G]
     float *rstd = smem + g.G;         // [G]
-    float *tmp = smem + 2 * g.G;      // [G][8][2]
+    float *tmp = smem + 2 * g.G;      // [G][8][2]  (PRE: [G][8][3])
     const int NT = g.TXB * g.TY;
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     constexpr int RS = 8;
+    if constexpr (PRE) {
+        // gamma / beta of the first channel pass go out first, as below
+        const int tx0 = tid % g.TXB;
+        const bool pre_ok = tx0 < g.CX && tid < g.TXB * g.TY;
+        u32x4 ga_raw = {0u, 0u, 0u, 0u}, be_raw = {0u, 0u, 0u, 0u};
+        if (pre_ok && gamma) ga_raw = *reinterpret_cast<const u32x4 *>(gamma + tx0 * 8);
+        if (pre_ok && beta) be_raw = *reinterpret_cast<const u32x4 *>(beta + tx0 * 8);
+        // merge the producers' records: thread (group, k) takes row blocks k, k+8, ... of every unit slot of its group in
+        // ascending channel order, then the eight lanes of a group are merged in order -> fixed order, bitwise reproducible
+        if (tid < g.G * RS) {
+            const int grp = tid / RS, k = tid % RS;
+            float n = 0.f, mu = 0.f, m2 = 0.f;
+            int c = grp * g.cpg;
+            const int cend = c + g.cpg;
+            while (c < cend) {
+                const int s = c < g.C1 ? 0 : 1;
+                const int cl = c - pre.coff[s];
+                const int Ul = cl / pre.unit[s];
+                const int uend = min((Ul + 1) * pre.unit[s], pre.nch[s]);
+                for (int tn = cl / pre.bno[s]; tn <= (uend - 1) / pre.bno[s]; ++tn) {
+                    const int j = Ul - (tn * pre.bno[s]) / pre.unit[s];
+                    const int lo = max(tn * pre.bno[s], cl), hi = min((tn + 1) * pre.bno[s], uend);
+                    const float cnt = (float)(hi - lo) * (float)pre.rb_rows[s];
+                    for (int rb = k; rb < pre.n_rb[s]; rb += RS) {
+                        const float2 v = *reinterpret_cast<const float2 *>(
+                            pre.p[s] + ((((int64_t)b * pre.n_rb[s] + rb) * pre.tiles_n[s] + tn) * pre.slots[s] + j) * 2);
+                        chan_merge(n, mu, m2, cnt, v.x, v.y);
+                    }
+                }
+                c = uend + pre.coff[s];
+            }
+            tmp[tid * 3] = n;
+            tmp[tid * 3 + 1] = mu;
+            tmp[tid * 3 + 2] = m2;
+        }
+        __syncthreads();
+        if (tid < g.G) {
+            float n = 0.f, mu = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < RS; ++j) chan_merge(n, mu, m2, tmp[(tid * RS + j) * 3], tmp[(tid * RS + j) * 3 + 1], tmp[(tid * RS + j) * 3 + 2]);
+            mean[tid] = mu;
+            rstd[tid] = rsqrtf(fmaxf(m2 / n, 0.f) + eps);  // biased variance (group_norm.py:48)
+        }
+        __syncthreads();
+        gn_apply_rows<T, SILU>(x, x2, gamma, beta, y, g, rows_per_block, mean, rstd, ga_raw, be_raw);
+        return;
+    }
     // requests that do not depend on the statistics go out first (shift value, this thread's gamma / beta vectors of
     // the first channel pass): their round trips overlap the partial-sum reduction instead of following it
     const float sh_early = (tid < g.G) ? (float)*gn_src(x, x2, g, b, 0, tid * g.cpg) : 0.f;
@@ -206,6 +276,16 @@ __global__ void gn_nhwc_apply_kernel(const T *__restrict__ x, const T *__restric
     }
     __syncthreads();
 
+    gn_apply_rows<T, SILU>(x, x2, gamma, beta, y, g, rows_per_block, mean, rstd, ga_raw, be_raw);
+}
+
+template <typename T, bool SILU>
+__device__ __forceinline__ void gn_apply_rows(const T *__restrict__ x, const T *__restrict__ x2, const T *__restrict__ gamma,
+                                              const T *__restrict__ beta, T *__restrict__ y, const GnGeom &g, int rows_per_block,
+                                              const float *mean, const float *rstd, u32x4 ga_raw, u32x4 be_raw) {
+    const int NT = g.TXB * g.TY;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
     const int tx = tid % g.TXB, ty = tid / g.TXB;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(g.HW, r0 + rows_per_block);
@@ -618,16 +698,35 @@ static int gn_launch_fast(const void *x, const void *x2, const void *gamma, cons
     const size_t smem_stats = (size_t)(NT * 4 + g.G * 2) * sizeof(float);
     hipLaunchKernelGGL(gn_nhwc_stats_kernel<T>, dim3(pl.nsplit, p->N), dim3(threads), smem_stats, st,
                        (const T *)x, (const T *)x2, ws, g, pl.rows_stats, pl.nsplit);
-    const size_t smem_apply = (size_t)(2 * g.G + g.G * 16) * sizeof(float);
+    const size_t smem_apply = (size_t)(2 * g.G + g.G * 24) * sizeof(float);
+    const GnPre none{};
     if (p->act == SFAST_ACT_SILU)
-        hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, true>), dim3(pl.napply, p->N), dim3(threads), smem_apply,
+        hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, true, false>), dim3(pl.napply, p->N), dim3(threads), smem_apply,
                            st, (const T *)x, (const T *)x2, (const T *)gamma, (const T *)beta, (T *)y, ws, g,
-                           pl.rows_apply, pl.nsplit, p->eps);
+                           pl.rows_apply, pl.nsplit, p->eps, none);
     else
-        hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, false>), dim3(pl.napply, p->N), dim3(threads), smem_apply,
+        hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, false, false>), dim3(pl.napply, p->N), dim3(threads), smem_apply,
                            st, (const T *)x, (const T *)x2, (const T *)gamma, (const T *)beta, (T *)y, ws, g,
-                           pl.rows_apply, pl.nsplit, p->eps);
+                           pl.rows_apply, pl.nsplit, p->eps, none);
     return check_launch("group_norm_nhwc");
+}
+
+// one normalisation pass over statistics the producers left behind
+template <typename T>
+static int gn_launch_pre(const void *x, const void *x2, const void *gamma, const void *beta, void *y, const sfast_gn_params *p,
+                         const GnPlan &pl, const GnPre &pre, hipStream_t st) {
+    const GnGeom &g = pl.g;
+    const int NT = g.TXB * g.TY;
+    int threads = ((NT + 63) / 64) * 64;
+    if (threads < g.G * 8) threads = ((g.G * 8 + 63) / 64) * 64;
+    const size_t smem_apply = (size_t)(2 * g.G + g.G * 24) * sizeof(float);
+    if (p->act == SFAST_ACT_SILU)
+        hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, true, true>), dim3(pl.napply, p->N), dim3(threads), smem_apply, st, (const T *)x,
+                           (const T *)x2, (const T *)gamma, (const T *)beta, (T *)y, (const float *)nullptr, g, pl.rows_apply, 0, p->eps, pre);
+    else
+        hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, false, true>), dim3(pl.napply, p->N), dim3(threads), smem_apply, st, (const T *)x,
+                           (const T *)x2, (const T *)gamma, (const T *)beta, (T *)y, (const float *)nullptr, g, pl.rows_apply, 0, p->eps, pre);
+    return check_launch("group_norm_apply");
 }
 
 template <typename T>
@@ -767,6 +866,45 @@ extern "C" int sfast_hip_group_norm(const void *x, const void *x2, const void *g
     }
     set_error("group_norm: bad dtype %d", p->dtype);
     return SFAST_ERR_UNSUPPORTED;
+}
+
+extern "C" int sfast_hip_group_norm_apply(const void *x, const void *x2, const void *gamma, const void *beta, void *y,
+                                          const sfast_gn_params *p, const void *stats1, const sfast_gn_stats_layout *l1,
+                                          const void *stats2, const sfast_gn_stats_layout *l2, sfast_stream_t stream) {
+    SFAST_REQUIRE(p && x && y && stats1 && l1, SFAST_ERR_INVALID, "group_norm_apply: null argument");
+    SFAST_REQUIRE(p->N > 0 && p->C > 0 && p->HW > 0 && p->G > 0 && p->C % p->G == 0, SFAST_ERR_INVALID,
+                  "group_norm_apply: bad shape N=%d C=%d HW=%d G=%d", p->N, p->C, p->HW, p->G);
+    SFAST_REQUIRE(p->act == SFAST_ACT_NONE || p->act == SFAST_ACT_SILU, SFAST_ERR_UNSUPPORTED, "group_norm_apply: act %d unsupported", p->act);
+    SFAST_REQUIRE(p->C1 > 0 && p->C1 <= p->C && (p->C1 == p->C || (x2 && stats2 && l2)), SFAST_ERR_INVALID,
+                  "group_norm_apply: a concat input needs x2 and its statistics");
+    GnPlan pl = gn_plan(p);
+    const bool ptr_ok = aligned16(x) && aligned16(y) && (p->C1 == p->C || aligned16(x2)) && (!gamma || aligned16(gamma)) && (!beta || aligned16(beta));
+    SFAST_REQUIRE(pl.fast && ptr_ok && p->layout == SFAST_NHWC, SFAST_ERR_UNSUPPORTED,
+                  "group_norm_apply: needs the NHWC fast path (f16/bf16, C and C1 multiples of 8, 16-byte aligned)");
+    const int cpg = p->C / p->G;
+    GnPre pre{};
+    const sfast_gn_stats_layout *ls[2] = {l1, p->C1 == p->C ? l1 : l2};
+    const void *ps[2] = {stats1, p->C1 == p->C ? stats1 : stats2};
+    const int nch[2] = {p->C1, p->C - p->C1}, coff[2] = {0, p->C1};
+    for (int s = 0; s < 2; ++s) {
+        const sfast_gn_stats_layout *l = ls[s];
+        SFAST_REQUIRE(l->unit > 0 && cpg % l->unit == 0 && coff[s] % l->unit == 0 && l->rb_rows > 0 && l->n_rb > 0 && l->bno > 0 &&
+                          l->tiles_n > 0 && l->slots > 0 && (int64_t)l->rb_rows * l->n_rb == (int64_t)p->N * p->HW && l->n_rb % p->N == 0,
+                      SFAST_ERR_INVALID, "group_norm_apply: statistics layout %d does not tile this tensor (unit %d, C/G %d)", s, l->unit, cpg);
+        pre.p[s] = (const float *)ps[s];
+        pre.rb_rows[s] = l->rb_rows;
+        pre.n_rb[s] = l->n_rb / p->N;
+        pre.bno[s] = l->bno;
+        pre.tiles_n[s] = l->tiles_n;
+        pre.slots[s] = l->slots;
+        pre.unit[s] = l->unit;
+        pre.nch[s] = nch[s] > 0 ? nch[s] : 1;
+        pre.coff[s] = coff[s];
+    }
+    set_kernel_name("gn_apply[TXB=%d,TY=%d,apply=%d]", pl.g.TXB, pl.g.TY, pl.napply);
+    hipStream_t st = (hipStream_t)stream;
+    if (p->dtype == SFAST_F16) return gn_launch_pre<f16>(x, x2, gamma, beta, y, p, pl, pre, st);
+    return gn_launch_pre<bf16>(x, x2, gamma, beta, y, p, pl, pre, st);
 }
 
 template <typename T>

@@ -14,6 +14,7 @@ struct SmallGemmArgs {
     int rows_per_seg, rows_per_batch;
     int geglu, act, res_before_act, in_act;
     float alpha;
+    float out_scale;  // accumulator scale (sfast_epilogue_ext); the launchers map 0 to 1
 };
 
 struct SmallConvArgs {
@@ -25,6 +26,7 @@ struct SmallConvArgs {
     int64_t ld_rowbias;
     int act, res_before_act;
     float alpha;
+    float out_scale;
 };
 
 int small_gemv(const SmallGemmArgs &a, int dtype, hipStream_t st);        // M <= 16, K % 8 == 0, aligned

@@ -14,7 +14,9 @@ namespace sfast {
 template <typename T>
 __device__ __forceinline__ void small_epilogue(const SmallGemmArgs &a, int m, int n, float v, float g) {
     // v (and g for geglu) are raw accumulators of output (m, n)
+    v *= a.out_scale;
     if (a.geglu) {
+        g *= a.out_scale;
         if (a.bias) {
             v += Elem<T>::to_f32(((const T *)a.bias)[n]);
             g += Elem<T>::to_f32(((const T *)a.bias)[a.N + n]);
@@ -188,6 +190,7 @@ __global__ void __launch_bounds__(256) gemm_naive_kernel(const SmallGemmArgs a) 
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void conv_store(const SmallConvArgs &a, int b, int ho, int wo, int co, float v) {
+    v *= a.out_scale;
     if (a.bias) v += Elem<T>::to_f32(((const T *)a.bias)[co]);
     if (a.rowbias) v += Elem<T>::to_f32(((const T *)a.rowbias)[(int64_t)b * a.ld_rowbias + co]);
     float r = 0.f;
@@ -215,7 +218,7 @@ __device__ __forceinline__ void conv_store8(const SmallConvArgs &a, int b, int h
     unpack8<T>(vz, fz);
     const bool res_now = a.res_before_act || a.act == SFAST_ACT_NONE;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = acc[e] + fb[e] + frb[e] + (res_now ? a.alpha * fz[e] : -0.0f);
+    for (int e = 0; e < 8; ++e) v[e] = fmaf(acc[e], a.out_scale, fb[e]) + frb[e] + (res_now ? a.alpha * fz[e] : -0.0f);
     if (a.act != SFAST_ACT_NONE) {
         f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
 #pragma unroll 1

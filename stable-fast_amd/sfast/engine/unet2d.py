@@ -57,12 +57,16 @@ class _Pool:
         self.device, self.dtype = device, dtype
         self.free = defaultdict(list)
         self.all = []
+        self.writer = None  # the plan's buffer -> producer map (UNetPlan.writer), kept consistent with buffer recycling
 
     def get(self, numel):
         numel = int(numel)
         lst = self.free[numel]
         if lst:
-            return lst.pop()
+            t = lst.pop()
+            if self.writer is not None:
+                self.writer.pop(id(t), None)  # recycled: whatever its last producer knew about it is void
+            return t
         t = torch.empty(numel, dtype=self.dtype, device=self.device)
         self.all.append(t)
         return t
@@ -103,6 +107,9 @@ class UNetPlan:
         self.pool = None
         self.keep = []  # ctypes objects / tensors that must outlive the launches
         self.kv_requests = []  # (name, Wk, Wv, kv buffer, C) of every cross-attention block, grouped at the end of build_plan
+        self.writer = {}       # id(buffer) -> producer record of the op that last wrote the whole buffer (GroupNorm statistics hand-over)
+        self.gn_candidates = []
+        self.gn_fused = 0      # GroupNorms that run as ONE normalisation pass over statistics their producers emit
 
     def run(self, stream_ptr):
         """Serial execution in program order on one stream (eager mode, tuning, per-op timing)."""
@@ -404,11 +411,20 @@ class UNet2DEngine:
         xp, x2p, gp, bp, yp = x.data_ptr(), (x2.data_ptr() if x2 is not None else None), gamma.data_ptr(), beta.data_ptr(), y.data_ptr()
         ws = plan.ws
         plan.keep.append(p)
+        pre = [None]  # set by _fuse_gn_statistics: (stats1 ptr, layout1, stats2 ptr, layout2)
 
-        def launch(stream, p=p):
+        def launch(stream, p=p, pre=pre):
+            if pre[0] is not None:
+                s1, l1, s2, l2 = pre[0]
+                L.check(lib.sfast_hip_group_norm_apply(xp, x2p, gp, bp, yp, C.byref(p), s1, C.byref(l1), s2, C.byref(l2) if l2 is not None else None,
+                                                       stream), name)
+                return
             L.check(lib.sfast_hip_group_norm(xp, x2p, gp, bp, yp, C.byref(p), ws[0].data_ptr() if ws[0] is not None else None, ws[1], stream), name)
 
         self._add(plan, "gn_silu" if silu else "gn", name, 0.0, (2.0 * N * HW * Ctot + 2 * Ctot) * self.esize, launch)
+        plan.gn_candidates.append(dict(name=name, p=p, pre=pre, xw=plan.writer.get(id(x)), x2w=plan.writer.get(id(x2)) if x2 is not None else None,
+                                       concat=x2 is not None, HW=HW))
+        plan.writer.pop(id(y), None)
 
     def _op_ln(self, plan, name, x, y, M, N, prefix):
         lib = self.lib
@@ -416,6 +432,7 @@ class UNet2DEngine:
         p = L.LnParams(self.dt, M, N, 1e-5)
         xp, gp, bp, yp = x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr()
         plan.keep.append(p)
+        plan.writer.pop(id(y), None)
 
         def launch(stream, p=p):
             L.check(lib.sfast_hip_layer_norm(xp, gp, bp, yp, C.byref(p), stream), name)
@@ -440,13 +457,21 @@ class UNet2DEngine:
         rp = residual.data_ptr() if residual is not None else None
         op = out.data_ptr() + out_offset * self.esize
         ws = plan.ws if lane == LANE_MAIN else plan.ws_side
-        plan.keep += [p, segs]
+        ext = L.EpilogueExt()
+        stats = [None]  # device buffer of GroupNorm partial statistics once a consumer asks for them (_fuse_gn_statistics)
+        plan.keep += [p, segs, ext]
 
-        def launch(stream, p=p, segs=segs):
-            L.check(lib.sfast_hip_gemm(xp, segs, bp, None, rp, op, C.byref(p), ws[0].data_ptr() if ws[0] is not None else None, ws[1], stream), name)
+        def launch(stream, p=p, segs=segs, ext=ext, stats=stats):
+            L.check(lib.sfast_hip_gemm_ex(xp, segs, bp, None, rp, op, C.byref(p), C.byref(ext), stats[0].data_ptr() if stats[0] is not None else None,
+                                          ws[0].data_ptr() if ws[0] is not None else None, ws[1], stream), name)
 
         def launch_with(stream, ws_ptr, ws_bytes, p=p, segs=segs):
             return lib.sfast_hip_gemm(xp, segs, bp, None, rp, op, C.byref(p), ws_ptr, ws_bytes, stream)
+
+        if out_offset == 0 and ldo == N and lane == LANE_MAIN:
+            plan.writer[id(out)] = dict(name=name, p=p, ext=ext, stats=stats, conv=False, lane=lane)
+        else:
+            plan.writer.pop(id(out), None)
 
         wrows = (2 * N if geglu else N)
         flops = 2.0 * M * wrows * K
@@ -506,13 +531,21 @@ class UNet2DEngine:
         zp = z.data_ptr() if z is not None else None
         op = out.data_ptr()
         ws = plan.ws
-        plan.keep.append(p)
+        ext = L.EpilogueExt()
+        stats = [None]
+        plan.keep += [p, ext]
 
-        def launch(stream, p=p):
-            L.check(lib.sfast_hip_conv2d(xp, x2p, wp, bp, rbp, zp, op, C.byref(p), ws[0].data_ptr() if ws[0] is not None else None, ws[1], stream), name)
+        def launch(stream, p=p, ext=ext, stats=stats):
+            L.check(lib.sfast_hip_conv2d_ex(xp, x2p, wp, bp, rbp, zp, op, C.byref(p), C.byref(ext), stats[0].data_ptr() if stats[0] is not None else None,
+                                            ws[0].data_ptr() if ws[0] is not None else None, ws[1], stream), name)
 
         def launch_with(stream, ws_ptr, ws_bytes, p=p):
             return lib.sfast_hip_conv2d(xp, x2p, wp, bp, rbp, zp, op, C.byref(p), ws_ptr, ws_bytes, stream)
+
+        if os_ is None:
+            plan.writer[id(out)] = dict(name=name, p=p, ext=ext, stats=stats, conv=True, lane=LANE_MAIN)
+        else:
+            plan.writer.pop(id(out), None)
 
         M = B * Ho * Wo
         flops = 2.0 * M * Cout * Cin * k * k
@@ -531,6 +564,7 @@ class UNet2DEngine:
         ap.dst_strides = (C.c_int64 * 4)(Hh * Ww * Cc, Ww * Cc, Cc, 1)
         plan.keep.append(ap)
         sp, dp = src_nchw.data_ptr(), dst_nhwc.data_ptr()
+        plan.writer.pop(id(dst_nhwc), None)  # modified in place: statistics of its producer no longer describe it
         self._add(plan, "misc", name, 0.0, 3.0 * B * Cc * Hh * Ww * self.esize,
                   lambda s, ap=ap: L.check(lib.sfast_hip_add_strided(sp, dp, C.byref(ap), s), name))
 
@@ -549,6 +583,7 @@ class UNet2DEngine:
         vp = v.data_ptr() + v_off * self.esize
         op = out.data_ptr()
         plan.keep.append(p)
+        plan.writer.pop(id(out), None)
 
         def launch(stream, p=p):
             L.check(lib.sfast_hip_attention(qp, kp, vp, op, C.byref(p), stream), name)
@@ -677,6 +712,7 @@ class UNet2DEngine:
         dev, dt = self.device, self.dtype
         plan = UNetPlan(self, B, H, W, S_ctx)
         pool = plan.pool = _Pool(dev, dt)
+        pool.writer = plan.writer
         # static inputs / output
         sample = torch.zeros((B, self.in_ch, H, W), dtype=dt, device=dev)
         tbuf = torch.zeros((B,), dtype=torch.float32, device=dev)
@@ -910,6 +946,57 @@ class UNet2DEngine:
                           lane=LANE_KV)
         plan.ops = new_ops + saved
 
+    def _fuse_gn_statistics(self, plan):
+        """GroupNorm as ONE pass: every large GroupNorm whose input tensor(s) were written by MFMA GEMM / conv launches gets its
+        statistics from those launches' epilogues (sfast_epilogue_ext / sfast_hip_group_norm_apply) instead of running its own
+        statistics kernel. Runs after autotuning: the record layout follows the tile shape that was chosen for the producer."""
+        import os
+        if os.environ.get("SFAST_GN_FUSE", "1") in ("0", "false", "off", ""):
+            return
+        import math
+        lib = self.lib
+        # one statistics unit for the whole plan: the widest channel count that divides every GroupNorm's channels-per-group and
+        # every concat boundary (SD / SDXL: 320 / 32 = 10), so that the records of a tensor serve all of its consumers
+        unit = 0
+        for c in plan.gn_candidates:
+            unit = math.gcd(unit, c["p"].C // c["p"].G)
+            if c["concat"]:
+                unit = math.gcd(unit, c["p"].C1)
+        if unit < 8 or not hasattr(lib, "sfast_hip_group_norm_apply"):
+            return
+        for c in plan.gn_candidates:
+            p = c["p"]
+            cpg = p.C // p.G
+            srcs = [c["xw"]] + ([c["x2w"]] if c["concat"] else [])
+            if any(w is None for w in srcs) or cpg % unit or p.C1 % unit or p.C % 8 or p.C1 % 8:
+                continue
+            if p.HW * cpg * 2 <= 32 * 1024 and p.N * p.HW * p.C * 2 <= (4 << 20):
+                continue  # the library runs these as one single-pass kernel already (norm.hip gn_small)
+            lays = []
+            for w in srcs:
+                ext = L.EpilogueExt(0.0, unit, p.HW, 0)
+                lay = L.GnStatsLayout()
+                q = lib.sfast_hip_conv2d_stats_layout if w["conv"] else lib.sfast_hip_gemm_stats_layout
+                if q(C.byref(w["p"]), C.byref(ext), C.byref(lay)) != 0:
+                    lays = None
+                    break
+                lays.append(lay)
+            if lays is None:
+                continue
+            for w, lay in zip(srcs, lays):
+                if w["stats"][0] is None:
+                    w["ext"].gn_unit, w["ext"].gn_rows_per_sample = unit, p.HW
+                    w["stats"][0] = torch.zeros(max(lay.nbytes() // 4, 2), dtype=torch.float32, device=self.device)
+                    plan.keep.append(lay)
+                elif w["ext"].gn_rows_per_sample != p.HW:
+                    lays = None
+                    break
+            if lays is None:
+                continue
+            s2 = (srcs[1]["stats"][0].data_ptr(), lays[1]) if c["concat"] else (None, None)
+            c["pre"][0] = (srcs[0]["stats"][0].data_ptr(), lays[0], s2[0], s2[1])
+            plan.gn_fused += 1
+
     def _finish_plan(self, plan):
         # measured tile / pipe / split-K selection per distinct GEMM / conv problem (cuDNN-benchmark style)
         from . import autotune
@@ -921,6 +1008,7 @@ class UNet2DEngine:
                     p = op.tune[0]
                     q = lib.sfast_hip_gemm_workspace_bytes if isinstance(p, L.GemmParams) else lib.sfast_hip_conv2d_workspace_bytes
                     self._need_ws(plan, q(C.byref(p)), op.lane)
+        self._fuse_gn_statistics(plan)
         if plan.ws[1]:
             plan.ws[0] = torch.empty(plan.ws[1], dtype=torch.uint8, device=dev)
         if plan.ws_side[1]:

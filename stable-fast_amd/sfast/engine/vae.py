@@ -168,8 +168,11 @@ class VaeDecoderEngine(UNet2DEngine):
         for b in range(B):
             base = b * S * 3 * Cc
             # S = q . k^T : x = q rows (ld 3C), "weight" rows = k rows (ld 3C)
-            self._op_gemm_raw(plan, f"{pre}.qk.{b}", qkv, base, qkv, base + Cc, 3 * Cc, scores, 0, S, S, Cc, 3 * Cc, S, kind="attn_vae")
-            self._op_softmax(plan, f"{pre}.softmax.{b}", scores, S, S, S, float(Cc) ** -0.5)
+            # logits leave the GEMM already scaled (fp32 accumulator x 1/sqrt(C) before the f16 store, sfast_epilogue_ext.out_scale):
+            # unscaled q.k^T over 512 channels can exceed f16's range on real VAE activations
+            self._op_gemm_raw(plan, f"{pre}.qk.{b}", qkv, base, qkv, base + Cc, 3 * Cc, scores, 0, S, S, Cc, 3 * Cc, S, kind="attn_vae",
+                              out_scale=float(Cc) ** -0.5)
+            self._op_softmax(plan, f"{pre}.softmax.{b}", scores, S, S, S, 1.0)
             self._op_transpose(plan, f"{pre}.vT.{b}", qkv, base + 2 * Cc, S, Cc, 3 * Cc, vt)
             # O = P . v : "weight" rows = v^T rows [C][S]
             self._op_gemm_raw(plan, f"{pre}.pv.{b}", scores, 0, vt, 0, S, o, b * S * Cc, S, Cc, S, S, Cc, kind="attn_vae")
@@ -182,7 +185,7 @@ class VaeDecoderEngine(UNet2DEngine):
         pool.put(o)
         return out
 
-    def _op_gemm_raw(self, plan, name, x, x_off, w, w_off, ldw, out, out_off, M, N, K, ldx, ldo, kind="linear"):
+    def _op_gemm_raw(self, plan, name, x, x_off, w, w_off, ldw, out, out_off, M, N, K, ldx, ldo, kind="linear", out_scale=1.0):
         """out[M,N] = x[M,K] . w[N,K]^T on raw (buffer, element offset, leading dimension) operands."""
         lib = self.lib
         p = L.GemmParams()
@@ -196,13 +199,16 @@ class VaeDecoderEngine(UNet2DEngine):
         xp = x.data_ptr() + x_off * self.esize
         op = out.data_ptr() + out_off * self.esize
         ws = plan.ws
-        plan.keep += [p, segs]
+        ext = L.EpilogueExt(float(out_scale), 0, 0, 0)
+        plan.keep += [p, segs, ext]
+        plan.writer.pop(id(out), None)
 
-        def launch(stream, p=p, segs=segs):
-            L.check(lib.sfast_hip_gemm(xp, segs, None, None, None, op, C.byref(p), ws[0].data_ptr() if ws[0] is not None else None, ws[1], stream), name)
+        def launch(stream, p=p, segs=segs, ext=ext):
+            L.check(lib.sfast_hip_gemm_ex(xp, segs, None, None, None, op, C.byref(p), C.byref(ext), None,
+                                          ws[0].data_ptr() if ws[0] is not None else None, ws[1], stream), name)
 
-        def launch_with(stream, ws_ptr, ws_bytes, p=p, segs=segs):
-            return lib.sfast_hip_gemm(xp, segs, None, None, None, op, C.byref(p), ws_ptr, ws_bytes, stream)
+        def launch_with(stream, ws_ptr, ws_bytes, p=p, segs=segs, ext=ext):
+            return lib.sfast_hip_gemm_ex(xp, segs, None, None, None, op, C.byref(p), C.byref(ext), None, ws_ptr, ws_bytes, stream)
 
         self._add(plan, kind, name, 2.0 * M * N * K, (M * K + N * K + M * N) * self.esize, launch, tune=(p, launch_with))
 
@@ -214,6 +220,7 @@ class VaeDecoderEngine(UNet2DEngine):
         dev, dt = self.device, self.dtype
         plan = UNetPlan(self, B, H, W, 0)
         pool = plan.pool = _Pool(dev, dt)
+        pool.writer = plan.writer
         scale = 1 << (self.n_up - 1)
         z = torch.zeros((B, self.in_ch, H, W), dtype=dt, device=dev)
         img = torch.zeros((B, self.out_ch, H * scale, W * scale), dtype=dt, device=dev)
@@ -320,6 +327,7 @@ class VaeEncoderEngine(VaeDecoderEngine):
             raise UnsupportedVae(f"image {H}x{W} not divisible by {1 << n_ds}")
         plan = UNetPlan(self, B, H, W, 0)
         pool = plan.pool = _Pool(dev, dt)
+        pool.writer = plan.writer
         img = torch.zeros((B, self.in_ch, H, W), dtype=dt, device=dev)
         out = torch.zeros((B, self.out_ch, H >> n_ds, W >> n_ds), dtype=dt, device=dev)
         plan.static_in = {"sample": img}

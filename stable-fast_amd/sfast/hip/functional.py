@@ -124,6 +124,24 @@ def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, act=None, x2=Non
 
 
 @_on_device
+def group_norm_apply(x, num_groups, weight, bias, eps, act, stats1, lay1, x2=None, stats2=None, lay2=None):
+    """GroupNorm(+SiLU) of a channels_last tensor (optionally a virtual concat x | x2) from producer-emitted statistics."""
+    _require_cuda(x, weight, bias, x2, stats1, stats2)
+    lib = L.init_device()
+    if not x.is_contiguous(memory_format=torch.channels_last) or (x2 is not None and not x2.is_contiguous(memory_format=torch.channels_last)):
+        raise L.SfastHipError("group_norm_apply: channels_last inputs required")
+    N, C1, H, W = x.shape
+    Ctot = C1 + (x2.shape[1] if x2 is not None else 0)
+    y = torch.empty((N, Ctot, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    p = L.GnParams(_dtype(x), L.NHWC, N, Ctot, H * W, int(num_groups), C1, _act(act), float(eps))
+    w = weight.to(x.dtype).contiguous() if weight is not None else None
+    b = bias.to(x.dtype).contiguous() if bias is not None else None
+    L.check(lib.sfast_hip_group_norm_apply(_ptr(x), _ptr(x2), _ptr(w), _ptr(b), _ptr(y), C.byref(p), _ptr(stats1), C.byref(lay1), _ptr(stats2),
+                                           C.byref(lay2) if lay2 is not None else None, _stream(x)), "sfast_hip_group_norm_apply")
+    return y
+
+
+@_on_device
 def layer_norm(x, normalized_shape: Sequence[int], weight=None, bias=None, eps=1e-5):
     _require_cuda(x, weight, bias)
     lib = L.init_device()
@@ -177,7 +195,8 @@ def softmax_rows(x, scale=1.0, out=None):
 
 @_on_device
 def linear(x, weight, bias=None, *, act=None, residual=None, alpha=1.0, res_before_act=False,
-           geglu=False, rowbias=None, rows_per_batch=0, in_act=None, variant=0, split_k=0, out=None):
+           geglu=False, rowbias=None, rows_per_batch=0, in_act=None, variant=0, split_k=0, out=None, out_scale=1.0, gn_unit=0,
+           rows_per_sample=0):
     """out[..., N] = epilogue(x[..., K] @ W[N, K]^T). `weight` may be a list of <= 4 equally sized
     [n_i, K] tensors stacked along N (e.g. live to_q / to_k / to_v weights)."""
     ws_list = list(weight) if isinstance(weight, (list, tuple)) else [weight]
@@ -242,10 +261,19 @@ def linear(x, weight, bias=None, *, act=None, residual=None, alpha=1.0, res_befo
     segs = (C.c_void_p * len(ws_list))(*[w.data_ptr() for w in ws_list])
     nb = lib.sfast_hip_gemm_workspace_bytes(C.byref(p))
     wsb, nb = _ws(nb, x)
-    rc = lib.sfast_hip_gemm(_ptr(x2d), segs, _ptr(bias), _ptr(rowbias), _ptr(res2d), _ptr(out2d), C.byref(p),
-                            _ptr(wsb), nb, _stream(x))
+    ext = L.EpilogueExt(float(out_scale), int(gn_unit), int(rows_per_sample), 0)
+    stats, lay = None, None
+    if gn_unit:
+        lay = L.GnStatsLayout()
+        L.check(lib.sfast_hip_gemm_stats_layout(C.byref(p), C.byref(ext), C.byref(lay)), "sfast_hip_gemm_stats_layout")
+        stats = torch.full((lay.nbytes() // 4,), float("nan"), dtype=torch.float32, device=x.device)
+    rc = lib.sfast_hip_gemm_ex(_ptr(x2d), segs, _ptr(bias), _ptr(rowbias), _ptr(res2d), _ptr(out2d), C.byref(p), C.byref(ext), _ptr(stats),
+                               _ptr(wsb), nb, _stream(x))
     L.check(rc, "sfast_hip_gemm")
-    return out2d.reshape(*lead, N) if out is None else out
+    res = out2d.reshape(*lead, N) if out is None else out
+    if gn_unit:
+        return res, stats, lay
+    return res
 
 
 @_on_device
@@ -292,6 +320,8 @@ def gemv_grouped(x, weights, biases=None, act=None, in_act=None):
     """out[m, off_g + n] = act(in_act(x)[m] @ W_g[n] + b_g[n]) for every W_g of `weights` ([n_g, K] each, <= 32), ONE launch.
     Returns [M, sum n_g]."""
     weights = list(weights)
+    if not 1 <= len(weights) <= L.MAX_GROUPS:
+        raise L.SfastHipError(f"gemv_grouped: {len(weights)} groups (1..{L.MAX_GROUPS} per launch)")
     biases = list(biases) if biases is not None else [None] * len(weights)
     _require_cuda(x, *weights, *[b for b in biases if b is not None])
     lib = L.init_device()
@@ -324,10 +354,12 @@ def _nhwc_strides(t):
 @_on_device
 def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dilation=1, act=None,
            res_before_act=True, x2=None, upsample2x=False, rowbias=None, variant=0, split_k=0,
-           channels_last_out: Optional[bool] = None, pad_extra=0):
+           channels_last_out: Optional[bool] = None, pad_extra=0, out_scale=1.0, gn_unit=0):
     """y = act(conv2d(x, w) + bias + rowbias[b] + alpha*z) on logical NCHW tensors of any strides.
     x2: optional tensor concatenated to x along channels (virtual). upsample2x: nearest 2x first.
-    pad_extra: additional zero rows / columns at the bottom / right on top of `padding` (F.pad(x, (0, e, 0, e)))."""
+    pad_extra: additional zero rows / columns at the bottom / right on top of `padding` (F.pad(x, (0, e, 0, e))).
+    out_scale: accumulator scale (sfast_epilogue_ext). gn_unit > 0: also emit GroupNorm partial statistics of y; returns
+    (y, stats float32 tensor, GnStatsLayout) -- feed them to group_norm_apply()."""
     _require_cuda(x, weight, bias, z, x2, rowbias)
     lib = L.init_device()
     if x.ndim != 4 or weight.ndim != 4:
@@ -379,9 +411,17 @@ def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dila
     p.ld_rowbias, p.variant, p.split_k = ld_rb, int(variant), int(split_k)
     nb = lib.sfast_hip_conv2d_workspace_bytes(C.byref(p))
     wsb, nb = _ws(nb, x)
-    rc = lib.sfast_hip_conv2d(_ptr(x), _ptr(x2), _ptr(weight), _ptr(bias), _ptr(rowbias), _ptr(zz), _ptr(y),
-                              C.byref(p), _ptr(wsb), nb, _stream(x))
+    ext = L.EpilogueExt(float(out_scale), int(gn_unit), Ho * Wo, 0)
+    stats, lay = None, None
+    if gn_unit:
+        lay = L.GnStatsLayout()
+        L.check(lib.sfast_hip_conv2d_stats_layout(C.byref(p), C.byref(ext), C.byref(lay)), "sfast_hip_conv2d_stats_layout")
+        stats = torch.full((lay.nbytes() // 4,), float("nan"), dtype=torch.float32, device=x.device)
+    rc = lib.sfast_hip_conv2d_ex(_ptr(x), _ptr(x2), _ptr(weight), _ptr(bias), _ptr(rowbias), _ptr(zz), _ptr(y),
+                                 C.byref(p), C.byref(ext), _ptr(stats), _ptr(wsb), nb, _stream(x))
     L.check(rc, "sfast_hip_conv2d")
+    if gn_unit:
+        return y, stats, lay
     return y
 
 

@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "_lib", "libsfast_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # enums (include/sfast_hip.h)
 F16, BF16, F32 = 0, 1, 2
@@ -26,8 +26,9 @@ MAX_GEMM_GROUPS = 64
 EXPORTS = [
     "sfast_hip_abi_version", "sfast_hip_init", "sfast_hip_last_error", "sfast_hip_last_kernel",
     "sfast_hip_group_norm_workspace_bytes", "sfast_hip_group_norm", "sfast_hip_layer_norm", "sfast_hip_softmax_rows",
-    "sfast_hip_gemm_workspace_bytes", "sfast_hip_gemm",
-    "sfast_hip_conv2d_workspace_bytes", "sfast_hip_conv2d",
+    "sfast_hip_gemm_workspace_bytes", "sfast_hip_gemm", "sfast_hip_gemm_ex", "sfast_hip_gemm_stats_layout",
+    "sfast_hip_conv2d_workspace_bytes", "sfast_hip_conv2d", "sfast_hip_conv2d_ex", "sfast_hip_conv2d_stats_layout",
+    "sfast_hip_group_norm_apply",
     "sfast_hip_attention", "sfast_hip_strided_copy", "sfast_hip_timestep_embedding",
     "sfast_hip_gemv_grouped", "sfast_hip_gemm_grouped", "sfast_hip_cfg_ddim_step", "sfast_hip_linear_step", "sfast_hip_igemm_plan", "sfast_hip_set_trace", "sfast_hip_image_postprocess", "sfast_hip_add_strided",
 ]
@@ -65,6 +66,18 @@ class GemmParams(C.Structure):
                 ("act", C.c_int32), ("res_before_act", C.c_int32), ("alpha", C.c_float),
                 ("rows_per_batch", C.c_int32), ("ld_rowbias", C.c_int64), ("in_act", C.c_int32),
                 ("variant", C.c_int32), ("split_k", C.c_int32)]
+
+
+class EpilogueExt(C.Structure):
+    _fields_ = [("out_scale", C.c_float), ("gn_unit", C.c_int32), ("gn_rows_per_sample", C.c_int32), ("reserved", C.c_int32)]
+
+
+class GnStatsLayout(C.Structure):
+    _fields_ = [("rb_rows", C.c_int32), ("n_rb", C.c_int32), ("bno", C.c_int32), ("tiles_n", C.c_int32), ("slots", C.c_int32),
+                ("unit", C.c_int32)]
+
+    def nbytes(self):
+        return int(self.n_rb) * int(self.tiles_n) * int(self.slots) * 8
 
 
 class GemvGroupedParams(C.Structure):
@@ -134,6 +147,17 @@ def _declare(lib):
     lib.sfast_hip_gemm_workspace_bytes.argtypes = [C.POINTER(GemmParams)]
     lib.sfast_hip_gemm.restype = C.c_int
     lib.sfast_hip_gemm.argtypes = [vp, C.POINTER(vp), vp, vp, vp, vp, C.POINTER(GemmParams), vp, sz, vp]
+    lib.sfast_hip_gemm_ex.restype = C.c_int
+    lib.sfast_hip_gemm_ex.argtypes = [vp, C.POINTER(vp), vp, vp, vp, vp, C.POINTER(GemmParams), C.POINTER(EpilogueExt), vp, vp, sz, vp]
+    lib.sfast_hip_conv2d_ex.restype = C.c_int
+    lib.sfast_hip_conv2d_ex.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(ConvParams), C.POINTER(EpilogueExt), vp, vp, sz, vp]
+    lib.sfast_hip_gemm_stats_layout.restype = C.c_int
+    lib.sfast_hip_gemm_stats_layout.argtypes = [C.POINTER(GemmParams), C.POINTER(EpilogueExt), C.POINTER(GnStatsLayout)]
+    lib.sfast_hip_conv2d_stats_layout.restype = C.c_int
+    lib.sfast_hip_conv2d_stats_layout.argtypes = [C.POINTER(ConvParams), C.POINTER(EpilogueExt), C.POINTER(GnStatsLayout)]
+    lib.sfast_hip_group_norm_apply.restype = C.c_int
+    lib.sfast_hip_group_norm_apply.argtypes = [vp, vp, vp, vp, vp, C.POINTER(GnParams), vp, C.POINTER(GnStatsLayout), vp,
+                                               C.POINTER(GnStatsLayout), vp]
     lib.sfast_hip_gemm_grouped.restype = C.c_int
     lib.sfast_hip_gemm_grouped.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(GemmParams), C.c_int32, vp]
     lib.sfast_hip_gemv_grouped.restype = C.c_int

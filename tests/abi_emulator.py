@@ -65,6 +65,12 @@ class EmuLib:
     def sfast_hip_conv2d_workspace_bytes(self, ref):
         return self.real.sfast_hip_conv2d_workspace_bytes(ref)
 
+    def sfast_hip_gemm_stats_layout(self, p, ext, out):
+        return self.real.sfast_hip_gemm_stats_layout(p, ext, out)
+
+    def sfast_hip_conv2d_stats_layout(self, p, ext, out):
+        return self.real.sfast_hip_conv2d_stats_layout(p, ext, out)
+
     def sfast_hip_last_error(self):
         return self.err
 
@@ -137,6 +143,110 @@ class EmuLib:
         o = R.linear_ref(xin, w, b, _ACT[p.act], r, p.alpha, bool(p.res_before_act), bool(p.geglu), rb, p.rows_per_batch,
                          _ACT[p.in_act])
         _strided(out, (p.M, p.N), (p.ldo, 1), p.dtype).copy_(o)
+        return 0
+
+    # ---- epilogue extensions: out_scale + GroupNorm partial statistics in the layout the real library reports ------------
+    def _emit_stats(self, out2d, lay, stats_ptr):
+        """out2d: [M, N] view of the op's (rounded) output. Writes one {mean, M2} float2 per (row block, tile_n, slot)."""
+        M, N = out2d.shape
+        R, bno, S, tn_n, u = lay.rb_rows, lay.bno, lay.slots, lay.tiles_n, lay.unit
+        assert R * lay.n_rb == M
+        rec = _flat(stats_ptr, lay.n_rb * tn_n * S * 2, L.F32).reshape(lay.n_rb, tn_n, S, 2)
+        rec.fill_(float("nan"))  # slots a tile does not overlap are never read by a correct consumer
+        o = out2d.float()
+        for rb in range(lay.n_rb):
+            blk = o[rb * R:(rb + 1) * R]
+            for tn in range(tn_n):
+                for j in range(S):
+                    U = (tn * bno) // u + j
+                    lo, hi = max(tn * bno, U * u), min(min((tn + 1) * bno, N), (U + 1) * u)
+                    if hi > lo:
+                        v = blk[:, lo:hi]
+                        m = v.mean()
+                        rec[rb, tn, j, 0] = m
+                        rec[rb, tn, j, 1] = ((v - m) ** 2).sum()
+
+    def sfast_hip_gemm_ex(self, x, segs, bias, rowbias, res, out, ref, ext_ref, stats, ws, ws_bytes, stream):
+        ext = _p(ext_ref) if ext_ref is not None else None
+        p0 = _p(ref)
+        if ext is not None and ext.out_scale not in (0.0, 1.0):
+            # scale folded into the activation operand in fp32 (only the bias-free, residual-free form is used that way)
+            assert not bias and not res and not rowbias and not p0.geglu
+            xin = _strided(x, (p0.M, p0.K), (p0.ldx, 1), p0.dtype)
+            w = torch.cat([_strided(segs[i], (p0.rows_per_seg, p0.K), (p0.ldw, 1), p0.dtype) for i in range(p0.n_wseg)], dim=0)[:p0.N]
+            o = R.act_ref((xin.float() @ w.float().t()) * ext.out_scale, _ACT[p0.act])
+            _strided(out, (p0.M, p0.N), (p0.ldo, 1), p0.dtype).copy_(o)
+            self.calls.append("gemm")
+            return 0
+        rc = self.sfast_hip_gemm(x, segs, bias, rowbias, res, out, ref, ws, ws_bytes, stream)
+        if stats:
+            p = _p(ref)
+            lay = L.GnStatsLayout()
+            assert self.real.sfast_hip_gemm_stats_layout(ref, ext_ref, C.byref(lay)) == 0
+            self._emit_stats(_strided(out, (p.M, p.N), (p.ldo, 1), p.dtype), lay, stats)
+            self.calls.append("gn_stats")
+        return rc
+
+    def sfast_hip_conv2d_ex(self, x, x2, w, bias, rowbias, z, out, ref, ext_ref, stats, ws, ws_bytes, stream):
+        ext = _p(ext_ref) if ext_ref is not None else None
+        assert ext is None or ext.out_scale in (0.0, 1.0)
+        rc = self.sfast_hip_conv2d(x, x2, w, bias, rowbias, z, out, ref, ws, ws_bytes, stream)
+        if stats:
+            p = _p(ref)
+            lay = L.GnStatsLayout()
+            assert self.real.sfast_hip_conv2d_stats_layout(ref, ext_ref, C.byref(lay)) == 0
+            M = lay.rb_rows * lay.n_rb
+            self._emit_stats(_strided(out, (M, p.Cout), (p.os[2], 1), p.dtype), lay, stats)
+            self.calls.append("gn_stats")
+        return rc
+
+    def sfast_hip_group_norm_apply(self, x, x2, gamma, beta, y, ref, s1, l1_ref, s2, l2_ref, stream):
+        """Uses ONLY the handed-over records for the statistics (a planner that wires a stale or foreign buffer shows up as a
+        wrong result), merged with the pairwise update like the kernel."""
+        p = _p(ref)
+        self.calls.append("group_norm_apply")
+        C1, C2 = p.C1, p.C - p.C1
+        cpg = p.C // p.G
+        xa = _flat(x, p.N * p.HW * C1, p.dtype).reshape(p.N, p.HW, C1).float()
+        if C2:
+            xa = torch.cat([xa, _flat(x2, p.N * p.HW * C2, p.dtype).reshape(p.N, p.HW, C2).float()], dim=2)
+        srcs = [(s1, _p(l1_ref), 0, C1)]
+        if C2:
+            srcs.append((s2, _p(l2_ref), C1, C2))
+        cnt = torch.zeros(p.N, p.G, dtype=torch.float64)
+        acc1 = torch.zeros(p.N, p.G, dtype=torch.float64)
+        recs = []
+        for sp, lay, coff, nch in srcs:
+            assert cpg % lay.unit == 0 and coff % lay.unit == 0 and lay.rb_rows * lay.n_rb == p.N * p.HW
+            per = lay.n_rb // p.N
+            rec = _flat(sp, lay.n_rb * lay.tiles_n * lay.slots * 2, L.F32).reshape(p.N, per, lay.tiles_n, lay.slots, 2).double()
+            for tn in range(lay.tiles_n):
+                for j in range(lay.slots):
+                    U = (tn * lay.bno) // lay.unit + j
+                    lo, hi = max(tn * lay.bno, U * lay.unit), min(min((tn + 1) * lay.bno, nch), (U + 1) * lay.unit)
+                    if hi <= lo:
+                        continue
+                    g = (coff + lo) // cpg
+                    n_i = float((hi - lo) * lay.rb_rows)
+                    recs.append((g, n_i, rec[:, :, tn, j, 0], rec[:, :, tn, j, 1]))
+                    cnt[:, g] += n_i * per
+                    acc1[:, g] += n_i * rec[:, :, tn, j, 0].sum(dim=1)
+        assert torch.all(cnt == p.HW * cpg), "statistics records do not cover every group exactly once"
+        mean = acc1 / cnt
+        m2 = torch.zeros_like(mean)
+        for g, n_i, mi, m2i in recs:
+            m2[:, g] += m2i.sum(dim=1) + (n_i * (mi - mean[:, g:g + 1]) ** 2).sum(dim=1)
+        rstd = 1.0 / torch.sqrt(m2 / cnt + p.eps)
+        xg = xa.reshape(p.N, p.HW, p.G, cpg).double()
+        yv = (xg - mean[:, None, :, None]) * rstd[:, None, :, None]
+        yv = yv.reshape(p.N, p.HW, p.C).float()
+        if gamma:
+            yv = yv * _flat(gamma, p.C, p.dtype).float()
+        if beta:
+            yv = yv + _flat(beta, p.C, p.dtype).float()
+        if p.act == L.ACT_SILU:
+            yv = torch.nn.functional.silu(yv)
+        _flat(y, p.N * p.HW * p.C, p.dtype).reshape(p.N, p.HW, p.C).copy_(yv)
         return 0
 
     def sfast_hip_gemm_grouped(self, x, segs, bias, out, ref, n_groups, stream):

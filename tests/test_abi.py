@@ -30,11 +30,14 @@ def test_ctypes_structs_match_the_c_header(built_lib):
     from sfast.hip import lib as L
     structs = {"sfast_gn_params": L.GnParams, "sfast_ln_params": L.LnParams, "sfast_gemm_params": L.GemmParams,
                "sfast_conv_params": L.ConvParams, "sfast_attn_params": L.AttnParams, "sfast_copy_params": L.CopyParams,
-               "sfast_temb_params": L.TembParams, "sfast_softmax_params": L.SoftmaxParams, "sfast_image_params": L.ImageParams, "sfast_add_params": L.AddParams}
+               "sfast_temb_params": L.TembParams, "sfast_softmax_params": L.SoftmaxParams, "sfast_image_params": L.ImageParams, "sfast_add_params": L.AddParams,
+               "sfast_gemv_grouped_params": L.GemvGroupedParams, "sfast_epilogue_ext": L.EpilogueExt, "sfast_gn_stats_layout": L.GnStatsLayout}
     body = "".join(f'printf("%zu\\n", sizeof({n}));' for n in structs)
     probes = [("sfast_gemm_params", "ld_rowbias"), ("sfast_gemm_params", "split_k"), ("sfast_conv_params", "xs"),
               ("sfast_conv_params", "ld_rowbias"), ("sfast_conv_params", "pad_w_extra"), ("sfast_attn_params", "scale"), ("sfast_copy_params", "dst_strides"),
-              ("sfast_softmax_params", "ldx"), ("sfast_softmax_params", "scale"), ("sfast_image_params", "to_uint8"), ("sfast_add_params", "dst_strides")]
+              ("sfast_softmax_params", "ldx"), ("sfast_softmax_params", "scale"), ("sfast_image_params", "to_uint8"), ("sfast_add_params", "dst_strides"),
+              ("sfast_gemv_grouped_params", "ldx"), ("sfast_gemv_grouped_params", "in_act"), ("sfast_epilogue_ext", "gn_rows_per_sample"),
+              ("sfast_gn_stats_layout", "unit")]
     body += "".join(f'printf("%zu\\n", offsetof({s}, {f}));' for s, f in probes)
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "abi.c")
@@ -133,7 +136,8 @@ def test_bench_kernel_symbols_name_real_device_kernels(built_lib):
                 "igemm_conv_f16[128x128,split=1,ws4]", "igemm_conv_f16[128x128,split=12,reg]", "igemm_conv_f16[128x160,split=2,reg]",
                 "igemm_conv_f16[128x160,split=4,ws4]", "igemm_conv_f16[64x64,split=3,ws4]", "igemm_lin_f16[128x128,split=1,dma2]",
                 "igemm_lin_f16[128x128,split=4,ws4]", "igemm_lin_f16[64x64,split=1,reg]", "igemm_lin_f16[64x64,split=6,ws4]",
-                "igemm_lin_f16_geglu[128x128,split=1,dma2]", "igemm_lin_f16_geglu[64x128,split=1,ws3]", "igemm_lin_bf16[64x64,split=1,ws4]"]
+                "igemm_lin_f16_geglu[128x128,split=1,dma2]", "igemm_lin_f16_geglu[64x128,split=1,ws3]", "igemm_lin_bf16[64x64,split=1,ws4]",
+                "igemm_conv_f16[128x128,split=1,ws4]+gnstats", "igemm_lin_f16[64x64,split=1,reg]+gnstats", "igemm_conv_f16[128x160,split=1,ws4]+staged"]
     for v in variants:
         sym = bench.kernel_symbol(v)
         assert sym.startswith("_ZN5sfast"), (v, sym)

@@ -235,3 +235,38 @@ def test_controlnet_engine_on_the_emulator(built_lib):
     assert rel_l2(y, want) < 4e-3
     with pytest.raises(UnsupportedUNet):
         ControlNetEngine.from_module(m16, _lib=EmuLib())  # a UNet is not a ControlNet
+
+
+def test_groupnorm_statistics_come_from_the_producers(built_lib):
+    """Large GroupNorms run as ONE normalisation pass over partial statistics emitted by the epilogues of the GEMM / conv launches
+    that wrote their input (sfast_epilogue_ext -> sfast_hip_group_norm_apply). The emulator writes / reads the records in the
+    layout the REAL library reports for the chosen tiles and uses nothing but those records for the statistics, so a stale or
+    mis-wired buffer (recycled activation, concat offset, in-place ControlNet add) breaks parity with the oracle."""
+    cfg = U.tiny_config(sample_size=64, block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                        up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), attention_head_dim=8, norm_num_groups=32)
+    m = U.build(cfg, seed=21, dtype=torch.float16)
+    emu = EmuLib()
+    eng = UNet2DEngine.from_module(m, _lib=emu)
+    g = torch.Generator().manual_seed(22)
+    sample = torch.randn(1, 4, 64, 64, generator=g).half()
+    ehs = torch.randn(1, 20, cfg["cross_attention_dim"], generator=g).half()
+    y = eng.forward(sample, 500, ehs)
+    plan = eng.get_plan(1, 64, 64, 20)
+    assert plan.gn_fused >= 5, plan.gn_fused
+    assert emu.calls.count("group_norm_apply") == plan.gn_fused and emu.calls.count("gn_stats") >= plan.gn_fused // 2
+    with torch.no_grad():
+        want = m.float()(sample.float(), 500, ehs.float()).sample
+    err = float((y.float() - want).norm() / want.norm())
+    assert err < 4e-3, err
+    # with ControlNet residuals the skip tensors are modified in place AFTER their producers ran: those GroupNorms must fall back
+    skips = [torch.randn(1, c, h, h, generator=g).half() * 0.1 for c, h in ((320, 64), (320, 64), (320, 32), (640, 32))]
+    mid = torch.randn(1, 640, 32, 32, generator=g).half() * 0.1
+    emu.calls.clear()
+    y2 = eng.forward(sample, 500, ehs, down_block_additional_residuals=skips, mid_block_additional_residual=mid)
+    with torch.no_grad():
+        want2 = m(sample.float(), 500, ehs.float(), down_block_additional_residuals=[s.float() for s in skips],
+                  mid_block_additional_residual=mid.float()).sample
+    err2 = float((y2.float() - want2).norm() / want2.norm())
+    assert err2 < 4e-3, err2
+    plan2 = eng.get_plan(1, 64, 64, 20, True)
+    assert 0 < plan2.gn_fused < plan.gn_fused

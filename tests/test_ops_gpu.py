@@ -541,3 +541,104 @@ def test_linear_grouped_bias_act_single_segment():
     outs = F().linear_grouped(x, ws, bs, act="relu")
     for g in range(4):
         compare(f"linear_grouped bias relu g={g}", outs[g], R.linear_ref(x, ws[g][0], bs[g], "relu"), *tol(x.dtype), kernel=last_kernel())
+
+
+# ---- GroupNorm statistics emitted by the producing GEMM / conv epilogue -> one-pass GroupNorm --------------------------------
+def _stats_reference(y_nhwc_2d, lay):
+    """{mean, M2} records of a [M, N] output in the layout the library reported."""
+    import numpy as np
+    M, N = y_nhwc_2d.shape
+    o = y_nhwc_2d.double().cpu()
+    rec = np.full((lay.n_rb, lay.tiles_n, lay.slots, 2), np.nan)
+    for rb in range(lay.n_rb):
+        blk = o[rb * lay.rb_rows:(rb + 1) * lay.rb_rows]
+        for tn in range(lay.tiles_n):
+            for j in range(lay.slots):
+                U = (tn * lay.bno) // lay.unit + j
+                lo, hi = max(tn * lay.bno, U * lay.unit), min(min((tn + 1) * lay.bno, N), (U + 1) * lay.unit)
+                if hi > lo:
+                    v = blk[:, lo:hi]
+                    rec[rb, tn, j, 0] = float(v.mean())
+                    rec[rb, tn, j, 1] = float(((v - v.mean()) ** 2).sum())
+    return rec
+
+
+@pytest.mark.parametrize("variant,split", [(0, 0), (1, 1), (2, 1), (3, 1), (5, 1), (11, 1), (12, 1), (13, 1), (21, 1), (22, 1), (23, 1), (21, 4), (23, 6), (3, 3)])
+@pytest.mark.parametrize("cin,cout,hw,unit", [(320, 320, 32, 10), (640, 1280, 16, 20)])
+def test_conv_epilogue_emits_groupnorm_statistics(variant, split, cin, cout, hw, unit):
+    import numpy as np
+    x = rnd(2, cin, hw, hw, seed=200, shift=0.5).contiguous(memory_format=torch.channels_last)
+    w = rnd(cout, cin, 3, 3, seed=201, scale=(9 * cin) ** -0.5).contiguous(memory_format=torch.channels_last)
+    b = rnd(cout, seed=202, shift=2.0)
+    z = rnd(2, cout, hw, hw, seed=203).contiguous(memory_format=torch.channels_last)
+    try:
+        y, stats, lay = F().conv2d(x, w, b, z=z, padding=1, variant=variant, split_k=split, gn_unit=unit)
+    except Exception as e:  # a tile that does not divide H*W cannot emit statistics: the library says so instead of guessing
+        assert (hw * hw) % {1: 128, 2: 128, 5: 256, 11: 128, 12: 128, 21: 128, 22: 128}.get(variant, 64) != 0 or "statistics" in str(e), e
+        pytest.skip(f"variant {variant}: {e}")
+    k = last_kernel()
+    assert "+gnstats" in k
+    plain = F().conv2d(x, w, b, z=z, padding=1, variant=variant, split_k=split)
+    assert torch.equal(y, plain), k  # staged stores / the statistics reduce change nothing in the output
+    want = _stats_reference(y.permute(0, 2, 3, 1).reshape(-1, cout), lay)
+    got = stats.double().cpu().numpy().reshape(want.shape)
+    used = ~np.isnan(want)
+    assert np.allclose(got[..., 0][used[..., 0]], want[..., 0][used[..., 0]], rtol=1e-4, atol=1e-4), k
+    assert np.allclose(got[..., 1][used[..., 1]], want[..., 1][used[..., 1]], rtol=2e-3, atol=1e-2), k
+    # ... and the one-pass GroupNorm over them equals the oracle (and the library's own two-pass GroupNorm to rounding)
+    G = 32
+    gam, bet = rnd(cout, seed=204, shift=1.0, scale=0.2), rnd(cout, seed=205, scale=0.2)
+    yn = F().group_norm_apply(y, G, gam, bet, 1e-5, "silu", stats, lay)
+    compare(f"gn_apply conv {cin}->{cout}@{hw} v{variant} s{split}", yn, R.group_norm_ref(y, G, gam, bet, 1e-5, True), *tol(y.dtype, 2.0), kernel=k)
+
+
+@pytest.mark.parametrize("M,N,K,hw,unit", [(8192, 320, 320, 4096, 10), (2048, 640, 2560, 1024, 10), (512, 1280, 1280, 256, 20)])
+@pytest.mark.parametrize("variant", [0, 3, 13, 23, 1, 21])
+def test_gemm_epilogue_statistics_and_concat_groupnorm(M, N, K, hw, unit, variant):
+    """proj_out-style GEMM + residual emits statistics; consumed alone (C/G = N/32) and as the second half of a virtual concat."""
+    x = rnd(M, K, seed=210)
+    w = rnd(N, K, seed=211, scale=K ** -0.5)
+    b = rnd(N, seed=212)
+    res = rnd(M, N, seed=213, shift=-1.0)
+    try:
+        y, stats, lay = F().linear(x, w, b, residual=res, variant=variant, split_k=1, gn_unit=unit, rows_per_sample=hw)
+    except Exception as e:
+        pytest.skip(str(e))
+    k = last_kernel()
+    assert torch.equal(y, F().linear(x, w, b, residual=res, variant=variant, split_k=1))
+    B = M // hw
+    side = int(hw ** 0.5)
+    y4 = y.reshape(B, side, side, N).permute(0, 3, 1, 2)  # channels_last view
+    gam, bet = rnd(N, seed=214, shift=1.0, scale=0.1), rnd(N, seed=215)
+    yn = F().group_norm_apply(y4, 32, gam, bet, 1e-6, None, stats, lay)
+    compare(f"gn_apply gemm {M}x{N}x{K} v{variant}", yn, R.group_norm_ref(y4, 32, gam, bet, 1e-6, False), *tol(y.dtype, 2.0), kernel=k)
+    # concat [first | y]: the first source's statistics come from a conv launch
+    c1 = 2 * N
+    xa = rnd(B, N, side, side, seed=216).contiguous(memory_format=torch.channels_last)
+    wa = rnd(c1, N, 1, 1, seed=217, scale=N ** -0.5).contiguous(memory_format=torch.channels_last)
+    first, st1, lay1 = F().conv2d(xa, wa, None, gn_unit=unit)
+    g2, b2 = rnd(c1 + N, seed=218, shift=1.0, scale=0.1), rnd(c1 + N, seed=219)
+    yc = F().group_norm_apply(first, 32, g2, b2, 1e-5, "silu", st1, lay1, x2=y4, stats2=stats, lay2=lay)
+    want = R.group_norm_ref(torch.cat([first, y4], 1), 32, g2, b2, 1e-5, True)
+    compare(f"gn_apply concat {c1}+{N}@{side} v{variant}", yc, want, *tol(y.dtype, 2.0), kernel=last_kernel())
+
+
+def test_groupnorm_statistics_survive_a_large_offset():
+    """mean >> std: shifted sums inside a tile + pairwise merges across tiles keep the variance (a raw sum / sum-of-squares would not)."""
+    x = rnd(1, 320, 64, 64, seed=220, scale=0.05).contiguous(memory_format=torch.channels_last)
+    w = torch.zeros(320, 320, 1, 1, device=DEV, dtype=torch.float16)
+    w[torch.arange(320), torch.arange(320), 0, 0] = 1.0
+    w = w.contiguous(memory_format=torch.channels_last)
+    b = torch.full((320,), 60.0, device=DEV, dtype=torch.float16)
+    y, stats, lay = F().conv2d(x, w, b, gn_unit=10)
+    yn = F().group_norm_apply(y, 32, None, None, 1e-5, None, stats, lay)
+    compare("gn_apply offset 60 / std 0.05", yn, R.group_norm_ref(y, 32, None, None, 1e-5, False), 3e-2, 2e-2, kernel=last_kernel())
+
+
+def test_out_scale_applies_before_the_output_rounding():
+    q, kk = rnd(256, 512, seed=230, scale=4.0), rnd(256, 512, seed=231, scale=4.0)
+    y = F().linear(q, kk, out_scale=512 ** -0.5)
+    want = (q.float() @ kk.float().t()) * 512 ** -0.5
+    compare("linear out_scale", y, want, *tol(y.dtype, 4.0), kernel=last_kernel())
+    assert torch.isfinite(y).all() and not torch.isfinite(F().linear(q * 8, kk * 8)).all()  # unscaled logits overflow f16 ...
+    assert torch.isfinite(F().linear(q * 8, kk * 8, out_scale=2.0 ** -10)).all()            # ... scaled in fp32 they do not

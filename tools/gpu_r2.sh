@@ -1,0 +1,44 @@
+#!/bin/bash
+# Round-2 GPU sessions. usage: tools/gpu_r2.sh <mode>   (everything lands in gpurun_out/)
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+MODE=${1:-a}
+export TMPDIR=/tmp
+export SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_cache_r2.json
+PYT="python -m pytest -q --no-header --tb=short -p no:cacheprovider --timeout=900 --maxfail=30 -m gpu"
+run() { # name, timeout, command...
+  local name=$1 to=$2; shift 2
+  echo "=== $name ===" | tee -a gpurun_out/session.log
+  local t0=$(date +%s)
+  timeout $to "$@" > gpurun_out/$name.log 2>&1
+  echo "exit=$? $(( $(date +%s) - t0 ))s $(tail -n 1 gpurun_out/$name.log | cut -c1-300)" | tee -a gpurun_out/session.log
+}
+prof() { # name, bench args...
+  local name=$1; shift
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof_$name -o bench -- python $OLDPWD/bench.py "$@" --no-cpu-baseline --no-roofline > $OLDPWD/gpurun_out/rocprof_$name.log 2>&1 )
+  echo "rocprof $name exit=$?" >> gpurun_out/session.log
+  for db in $(find gpurun_out/prof_$name -name "*.db"); do python tools/rocpd_summary.py $db --csv gpurun_out/kernel_stats_$name.csv --top 70 --step-marker cfg_ddim --steps 8 > gpurun_out/kernel_stats_$name.txt; done
+  rm -rf gpurun_out/prof_$name
+}
+rm -f gpurun_out/parity.jsonl gpurun_out/session.log gpurun_out/error_budget.jsonl
+rocminfo 2>/dev/null | grep -E "gfx|Compute Unit" | head -2 >> gpurun_out/session.log
+case $MODE in
+a)  # first session of the round: whole suite, floor probe, bench through both paths, error budget, dispatch profile
+  run t_new    900 $PYT tests/test_ops_gpu.py -k "grouped" tests/test_reference_api_gpu.py -k "grouped or convolution_op or bmm"
+  run floor    300 python tools/launch_floor.py
+  run bench    900 python bench.py --steps 30 --warmup 5 --through-compile --dump-kernels gpurun_out/kernels.json
+  run t_all   1800 $PYT tests --deselect tests/test_sdxl_gpu.py
+  run budget   600 python tools/error_budget.py --config sd15 --batch 2
+  run t_sdxl  1500 $PYT tests/test_sdxl_gpu.py
+  prof sd15 --steps 10 --warmup 2
+  ;;
+quick)
+  run t_quick  900 $PYT tests/test_ops_gpu.py tests/test_unet_gpu.py -k "${2:-not zzz}"
+  run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json --no-cpu-baseline
+  ;;
+bench)
+  run bench    900 python bench.py --steps 30 --warmup 5 --through-compile --dump-kernels gpurun_out/kernels.json
+  prof sd15 --steps 10 --warmup 2
+  ;;
+esac
+cut -c1-400 gpurun_out/session.log
