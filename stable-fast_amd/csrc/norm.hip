@@ -425,12 +425,30 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const T *__restrict__ x, c
     const int nch = N / 8;
     const T *xr = x + (int64_t)row * N;
     u32x4 cache[MAXCH];
+    // gamma / beta do not depend on the statistics: requested together with the row (for rows up to 2048 wide), so their round
+    // trip overlaps the two reductions instead of following them -- a LayerNorm launch of the UNet is a chain of exposed latencies
+    constexpr bool PRE = MAXCH <= 4;
+    u32x4 gar[PRE ? MAXCH : 1], ber[PRE ? MAXCH : 1];
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) {
+        const int ch = lane + j * 64;
+        if (ch < nch) cache[j] = *reinterpret_cast<const u32x4 *>(xr + ch * 8);
+    }
+    if constexpr (PRE) {
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) {
+            const int ch = lane + j * 64;
+            gar[j] = u32x4{0u, 0u, 0u, 0u};
+            ber[j] = u32x4{0u, 0u, 0u, 0u};
+            if (ch < nch && gamma) gar[j] = *reinterpret_cast<const u32x4 *>(gamma + ch * 8);
+            if (ch < nch && beta) ber[j] = *reinterpret_cast<const u32x4 *>(beta + ch * 8);
+        }
+    }
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < MAXCH; ++j) {
         const int ch = lane + j * 64;
         if (ch < nch) {
-            cache[j] = *reinterpret_cast<const u32x4 *>(xr + ch * 8);
             float f[8];
             unpack8<T>(cache[j], f);
 #pragma unroll
@@ -461,13 +479,15 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const T *__restrict__ x, c
             float f[8], ga[8], be[8];
             unpack8<T>(cache[j], f);
             if (gamma) {
-                unpack8<T>(*reinterpret_cast<const u32x4 *>(gamma + ch * 8), ga);
+                if constexpr (PRE) unpack8<T>(gar[j], ga);
+                else unpack8<T>(*reinterpret_cast<const u32x4 *>(gamma + ch * 8), ga);
             } else {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) ga[i] = 1.f;
             }
             if (beta) {
-                unpack8<T>(*reinterpret_cast<const u32x4 *>(beta + ch * 8), be);
+                if constexpr (PRE) unpack8<T>(ber[j], be);
+                else unpack8<T>(*reinterpret_cast<const u32x4 *>(beta + ch * 8), be);
             } else {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) be[i] = 0.f;
@@ -519,11 +539,17 @@ __global__ void __launch_bounds__(512) gn_small_kernel(const T *__restrict__ x, 
                                                        float eps) {
     extern __shared__ __attribute__((aligned(16))) uint32_t gsm[];  // [HW][cpg/2] dwords
     __shared__ float red[2][8];
+    __shared__ uint32_t gb[2][128];  // gamma / beta dwords of this group (cpg <= 256), requested before the statistics pass
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = blockIdx.x, b = blockIdx.y;
     const int dpg = cpg / 2;           // dwords per pixel of this group
     const int total = HW * dpg;
     const int c0 = grp * cpg;          // first channel of the group
+    const bool gb_lds = dpg <= 128;
+    if (gb_lds && tid < dpg) {
+        gb[0][tid] = gamma ? *reinterpret_cast<const uint32_t *>(gamma + c0 + 2 * tid) : 0u;
+        gb[1][tid] = beta ? *reinterpret_cast<const uint32_t *>(beta + c0 + 2 * tid) : 0u;
+    }
     const int C2 = C - C1;
     typedef typename Elem<T>::vec2 vec2;
     // shift = first element of the group (as in the large path)
@@ -596,12 +622,12 @@ __global__ void __launch_bounds__(512) gn_small_kernel(const T *__restrict__ x, 
         const vec2 v = __builtin_bit_cast(vec2, gsm[k]);
         float ga0 = 1.f, ga1 = 1.f, be0 = 0.f, be1 = 0.f;
         if (gamma) {
-            const vec2 g2 = __builtin_bit_cast(vec2, *reinterpret_cast<const uint32_t *>(gamma + c));
+            const vec2 g2 = __builtin_bit_cast(vec2, gb_lds ? gb[0][j] : *reinterpret_cast<const uint32_t *>(gamma + c));
             ga0 = (float)g2[0];
             ga1 = (float)g2[1];
         }
         if (beta) {
-            const vec2 b2 = __builtin_bit_cast(vec2, *reinterpret_cast<const uint32_t *>(beta + c));
+            const vec2 b2 = __builtin_bit_cast(vec2, gb_lds ? gb[1][j] : *reinterpret_cast<const uint32_t *>(beta + c));
             be0 = (float)b2[0];
             be1 = (float)b2[1];
         }

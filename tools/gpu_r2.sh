@@ -32,6 +32,15 @@ a)  # first session of the round: whole suite, floor probe, bench through both p
   run t_sdxl  1500 $PYT tests/test_sdxl_gpu.py
   prof sd15 --steps 10 --warmup 2
   ;;
+b)  # statistics hand-over: new op tests, whole-UNet tests, A/B of the fusion and of staged stores, dispatch profile
+  run t_stats  900 $PYT tests/test_ops_gpu.py -k "statistics or out_scale or gemv_grouped or layer_norm or group_norm"
+  run t_unet  1500 $PYT tests/test_unet_gpu.py tests/test_vae_gpu.py
+  run bench_fused   600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --dump-kernels gpurun_out/kernels.json
+  SFAST_GN_FUSE=0 run bench_nofuse 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  SFAST_STAGE_OUT=1 run bench_staged 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  run bench_fused2  600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  prof sd15 --steps 10 --warmup 2
+  ;;
 quick)
   run t_quick  900 $PYT tests/test_ops_gpu.py tests/test_unet_gpu.py -k "${2:-not zzz}"
   run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json --no-cpu-baseline
