@@ -92,9 +92,9 @@ def kernel_symbol(variant):
     import re
     m = re.match(r"igemm_(conv|lin)_(f16|bf16)(_geglu)?\[(\d+x\d+),split=\d+,(reg|dma(\d)|ws(\d))\](\+staged|\+gnstats)?", variant)
     if not m:
-        ma = re.match(r"attn_fwd\[D=(\d+),BQ=(\d+)\]", variant)
-        if ma:  # attn_fwd_kernel<T, D, NW, TRACE = 0>: one wave per 32 queries
-            return f"_ZN5sfast15attn_fwd_kernelIDF16_Li{ma.group(1)}ELi{int(ma.group(2)) // 32}ELi0EEEvNS_8AttnArgsE"
+        ma = re.match(r"attn_fwd\[D=(\d+),BQ=(\d+)\](\+bias)?", variant)
+        if ma:  # attn_fwd_kernel<T, D, NW, TRACE = 0, BIAS = false>: one wave per 32 queries
+            return f"_ZN5sfast15attn_fwd_kernelIDF16_Li{ma.group(1)}ELi{int(ma.group(2)) // 32}ELi0ELb{int(ma.group(3) is not None)}EEEvNS_8AttnArgsE"
         return variant.split("[")[0]
     mode = 1 if m.group(1) == "conv" else 0
     t = "DF16_" if m.group(2) == "f16" else "DF16b"

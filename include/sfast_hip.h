@@ -288,6 +288,12 @@ typedef struct {
 
 int sfast_hip_attention(const void *q, const void *k, const void *v, void *out,
                         const sfast_attn_params *p, sfast_stream_t stream);
+/* out = softmax(q k^T * scale + bias) v: the `attn_bias` argument of sfast_xformers::memory_efficient_attention
+ * (libs/xformers/xformers_attention.py:30-47) / diffusers' attention_mask. bias[b][h][q][key] in the dtype of q, key stride 1,
+ * element strides bias_strides = (b, h, q), 0 = broadcast (a key-padding mask is (Skv, 0, 0)); -inf entries mask a key.
+ * bias == NULL is sfast_hip_attention. */
+int sfast_hip_attention_bias(const void *q, const void *k, const void *v, const void *bias, const int64_t *bias_strides,
+                             void *out, const sfast_attn_params *p, sfast_stream_t stream);
 
 /* ---- strided copy (rank <= 4) ------------------------------------------------------------- */
 typedef struct {

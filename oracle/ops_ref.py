@@ -108,11 +108,16 @@ def conv2d_ref(x, weight, bias=None, z=None, alpha=1.0, stride=1, padding=0, dil
     return act_ref(v, act) + r
 
 
-def attention_ref(q, k, v, scale=None):
-    """q [B, Sq, H, D], k/v [B, Skv, H, D] -> [B, Sq, H, D]; explicit softmax form in fp32."""
+def attention_ref(q, k, v, scale=None, attn_bias=None):
+    """q [B, Sq, H, D], k/v [B, Skv, H, D] -> [B, Sq, H, D]; explicit softmax form in fp32. attn_bias: additive, broadcastable
+    to [B, H, Sq, Skv] (xformers.ops.memory_efficient_attention's tensor bias as the reference passes it through,
+    /root/reference/src/sfast/libs/xformers/xformers_attention.py:30-47)."""
     qf, kf, vf = (t.float().transpose(1, 2) for t in (q, k, v))
     s = scale if scale is not None else 1.0 / math.sqrt(q.shape[-1])
-    p = torch.softmax(qf @ kf.transpose(-1, -2) * s, dim=-1)
+    logits = qf @ kf.transpose(-1, -2) * s
+    if attn_bias is not None:
+        logits = logits + attn_bias.float()
+    p = torch.softmax(logits, dim=-1)
     return (p @ vf).transpose(1, 2).contiguous()
 
 

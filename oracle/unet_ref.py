@@ -112,14 +112,14 @@ class Attention(nn.Module):
         self.to_v = nn.Linear(ctx_dim, dim, bias=False)
         self.to_out = nn.ModuleList([nn.Linear(dim, dim), nn.Identity()])
 
-    def forward(self, x, ctx=None):
+    def forward(self, x, ctx=None, bias=None):
         ctx = x if ctx is None else ctx
         B, S, C = x.shape
         H = self.heads
         q = self.to_q(x).view(B, S, H, C // H).transpose(1, 2)
         k = self.to_k(ctx).view(B, -1, H, C // H).transpose(1, 2)
         v = self.to_v(ctx).view(B, -1, H, C // H).transpose(1, 2)
-        o = F.scaled_dot_product_attention(q, k, v)  # scale = head_dim ** -0.5
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=None if bias is None else bias[:, None].to(q.dtype))  # scale = head_dim ** -0.5
         return self.to_out[0](o.transpose(1, 2).reshape(B, S, C))
 
 
@@ -153,8 +153,11 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, x, ctx):
+        cross_bias = None
+        if isinstance(ctx, tuple):  # (encoder_hidden_states, additive cross-attention bias [B, 1, S_ctx])
+            ctx, cross_bias = ctx
         x = self.attn1(self.norm1(x)) + x
-        x = self.attn2(self.norm2(x), ctx) + x
+        x = self.attn2(self.norm2(x), ctx, cross_bias) + x
         return self.ff(self.norm3(x)) + x
 
 
@@ -325,9 +328,16 @@ class UNet2DConditionModel(nn.Module):
         return self.conv_in.weight.device
 
     def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, return_dict=True,
-                down_block_additional_residuals=None, mid_block_additional_residual=None, **_):
+                down_block_additional_residuals=None, mid_block_additional_residual=None, encoder_attention_mask=None, **_):
         c = self.config
         B = sample.shape[0]
+        if encoder_attention_mask is not None:
+            # diffusers UNet2DConditionModel.forward: keep-mask [B, S] -> additive bias (1 - mask) * -10000, unsqueezed to [B, 1, S];
+            # applied to the cross-attention (attn2) of every transformer block
+            m_ = encoder_attention_mask
+            if m_.ndim == 2:
+                m_ = ((1 - m_.to(sample.dtype)) * -10000.0).unsqueeze(1)
+            encoder_hidden_states = (encoder_hidden_states, m_)
         t = timestep
         if not torch.is_tensor(t):
             t = torch.tensor([t], dtype=torch.float32, device=sample.device)

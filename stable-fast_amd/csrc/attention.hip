@@ -49,6 +49,11 @@ struct AttnArgs {
     float scale, scale_log2e;
     uint32_t kspan, vspan;      // bytes spanned by the K / V rows of one (batch, head): buffer-descriptor ranges
     unsigned long long *trace;  // profiling only (sfast_hip_set_trace): per-workgroup shader-cycle split of the tile loop
+    // additive attention bias (xformers attn_bias / diffusers attention_mask): bias[b][h][q][key], key stride 1
+    const void *bias;
+    int64_t bs[3];        // element strides (b, h, q); 0 = broadcast
+    uint32_t bspan;       // bytes spanned by the bias rows of one (batch, head)
+    float inv_scale;      // bias enters the RAW scores as bias / scale (the softmax scale is folded into the exp2 argument)
 };
 extern unsigned long long *g_igemm_trace;  // igemm_glds.hip
 
@@ -71,7 +76,7 @@ template <int D> struct AttnGeom {
 
 // TRACE = 1 (profiling instantiation, chosen while a trace buffer is set): wave 0 sums s_memtime deltas of the tile
 // phases -- record [top, phase 1, phase 2, barrier wait, whole kernel, tiles] per workgroup (tools/attn_ab.py --trace).
-template <typename T, int D, int NW, int TRACE = 0>
+template <typename T, int D, int NW, int TRACE = 0, bool BIAS = false>
 __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
     unsigned long long tr_acc[4] = {0, 0, 0, 0}, tr_t0 = 0, tr_last = 0;
     if constexpr (TRACE) tr_t0 = __builtin_amdgcn_s_memtime();
@@ -169,6 +174,32 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
         return __builtin_amdgcn_make_buffer_rsrc((void *)(((uintptr_t)hi32 << 32) | lo), 0, (int)bytes, 0x00020000);
     };
     const __amdgpu_buffer_rsrc_t ksrd = make_srd(Kp, a.kspan), vsrd = make_srd(Vp, a.vspan);
+    // additive bias: the lane that owns query row qrow reads, per 32-key block, the four 4-key groups its S^T registers hold
+    // (keys 8g + 4hi .. +3 <-> registers 4g .. 4g+3). Rows / keys outside the tensor are outside the descriptor and read 0.
+    const T *Bp = BIAS ? (const T *)a.bias + (int64_t)b * a.bs[0] + (int64_t)h * a.bs[1] : nullptr;
+    const __amdgpu_buffer_rsrc_t bsrd = make_srd(BIAS ? Bp : Kp, BIAS ? a.bspan : 0u);
+    const uint32_t brow = BIAS ? (uint32_t)(((int64_t)qrow * a.bs[2] + 4 * hi) * 2) : 0u;
+    u32x2 breg[BIAS ? 8 : 1];
+    auto load_bias = [&](int kt_) __attribute__((always_inline)) {
+        if constexpr (BIAS) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {  // j = kb * 4 + g
+                const uint32_t off = brow + (uint32_t)(kt_ * 64 + (j >> 2) * 32 + (j & 3) * 8) * 2u;
+                breg[j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(bsrd, qrow < a.Sq ? off : 0x80000000u, 0, 0));
+            }
+        }
+    };
+    auto add_bias = [&](f32x16 (&t)[2]) __attribute__((always_inline)) {
+        if constexpr (BIAS) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f[4];
+                unpack4<T>(breg[j], f);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[j >> 2][4 * (j & 3) + i] = fmaf(f[i], a.inv_scale, t[j >> 2][4 * (j & 3) + i]);
+            }
+        }
+    };
     const uint32_t ktile_bytes = (uint32_t)a.ks[1] * 128u, vtile_bytes = (uint32_t)a.vs[1] * 128u;
     uint32_t koff[KTASK], voff[VTASK][2];
 #pragma unroll
@@ -280,6 +311,8 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
             for (int kd = 0; kd < KD; ++kd) s[0][kb] = amfma32(qk_frag(smem, kb, kd), qf[kd], s[0][kb]);
         }
         read_kf(smem + STAGE);
+        load_bias(0);
+        add_bias(s[0]);
         mloc = row_max(s[0]);
         prefetch_k(kreg);  // K(3), V(1): staged by iteration 0
         prefetch_v();
@@ -322,8 +355,10 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
         }
-        const float mc = m_run * c;
+        // (a row whose keys so far are all masked with -inf has m_run = -inf: exp2(-inf * c - 0) = 0, not NaN)
+        const float mc = (BIAS && m_run == -INFINITY) ? 0.f : m_run * c;
         float rowsum = 0.f;
+        load_bias(kt + 1);  // bias of the tile whose S^T this iteration computes; added before its row max (phase 2)
 
         // V^T(kt) fragments are read during phase 1: their LDS latency runs under it instead of stalling the PV MFMAs (with
         // one or two waves per SIMD nothing else hides it -- phase 2 measured 870 cycles for 8 MFMAs before this)
@@ -365,6 +400,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- phase 2: O^T += V^T . P^T  ||  row max of S(kt+1), staging of K(kt+3) / V(kt+1) ---------------------------
+        add_bias(s[nxt]);
         float mpart[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
@@ -482,11 +518,13 @@ __global__ void __launch_bounds__(64) attn_naive_kernel(const AttnArgs a) {
         float acc = 0.f;
         for (int d = 0; d < a.D; ++d) acc = fmaf(Elem<T>::to_f32(Qp[d]), Elem<T>::to_f32(kr[d]), acc);
         acc *= a.scale;
+        if (a.bias) acc += Elem<T>::to_f32(((const T *)a.bias)[(int64_t)b * a.bs[0] + (int64_t)h * a.bs[1] + (int64_t)q * a.bs[2] + k]);
         sc[k] = acc;
         mx = fmaxf(mx, acc);
     }
     mx = wave_max(mx);
     float sum = 0.f;
+    if (mx == -INFINITY) mx = 0.f;  // fully masked row: all probabilities 0 (0/0 below -> NaN, as the reference's kernels give)
     for (int k = lane; k < a.Skv; k += 64) {
         const float p = __expf(sc[k] - mx);
         sc[k] = p;
@@ -514,11 +552,23 @@ template <typename T, int D, int NW> static int attn_set_attr() {
     return 0;
 }
 
+template <typename T, int D> static int attn_set_attr_bias() {
+    auto kern = attn_fwd_kernel<T, D, 4, 0, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       AttnGeom<D>::LDS_TOTAL);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(attn bias D=%d): %s", D, hipGetErrorString(e));
+        return SFAST_ERR_LAUNCH;
+    }
+    return 0;
+}
+
 template <typename T> static int attn_init_t() {
     int rc = 0;
 #define A_INIT(D)                                  \
     if (!rc) rc = attn_set_attr<T, D, 2>();        \
-    if (!rc) rc = attn_set_attr<T, D, 4>();
+    if (!rc) rc = attn_set_attr<T, D, 4>();        \
+    if (!rc) rc = attn_set_attr_bias<T, D>();
     A_INIT(40) A_INIT(64) A_INIT(80) A_INIT(128) A_INIT(160)
 #undef A_INIT
     return rc;
@@ -532,6 +582,11 @@ int attention_init() {
 
 template <typename T, int D>
 static int attn_launch_d(const AttnArgs &a, int nw, hipStream_t st) {
+    if (a.bias) {  // biased instantiation: four waves per workgroup
+        const dim3 gridb(ceil_div(a.Sq, 128), a.H, a.B);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 0, true>), gridb, dim3(256), AttnGeom<D>::LDS_TOTAL, st, a);
+        return check_launch("attention(bias)");
+    }
     const dim3 grid(ceil_div(a.Sq, nw * 32), a.H, a.B);
     if constexpr (std::is_same<T, f16>::value && (D == 40 || D == 64)) {
         if (a.trace != nullptr && nw == 4) {
@@ -565,7 +620,15 @@ using namespace sfast;
 
 extern "C" int sfast_hip_attention(const void *q, const void *k, const void *v, void *out, const sfast_attn_params *p,
                                    sfast_stream_t stream) {
+    return sfast_hip_attention_bias(q, k, v, nullptr, nullptr, out, p, stream);
+}
+
+extern "C" int sfast_hip_attention_bias(const void *q, const void *k, const void *v, const void *bias, const int64_t *bias_strides,
+                                        void *out, const sfast_attn_params *p, sfast_stream_t stream) {
     SFAST_REQUIRE(p && q && k && v && out, SFAST_ERR_INVALID, "attention: null argument");
+    SFAST_REQUIRE(!bias || bias_strides, SFAST_ERR_INVALID, "attention: a bias needs its (b, h, q) strides");
+    SFAST_REQUIRE(!bias || (bias_strides[0] >= 0 && bias_strides[1] >= 0 && bias_strides[2] >= 0), SFAST_ERR_INVALID,
+                  "attention: negative bias strides");
     SFAST_REQUIRE(p->B > 0 && p->H > 0 && p->Sq > 0 && p->Skv > 0 && p->D > 0, SFAST_ERR_INVALID, "attention: bad shape");
     hipStream_t st = (hipStream_t)stream;
     AttnArgs a{};
@@ -587,6 +650,13 @@ extern "C" int sfast_hip_attention(const void *q, const void *k, const void *v, 
     }
     a.scale = p->scale;
     a.scale_log2e = p->scale * 1.44269504088896340736f;
+    a.bias = bias;
+    a.inv_scale = p->scale != 0.f ? 1.0f / p->scale : 0.f;
+    int64_t bspan = 0;
+    if (bias) {
+        for (int i = 0; i < 3; ++i) a.bs[i] = bias_strides[i];
+        bspan = ((int64_t)(p->Sq - 1) * a.bs[2] + p->Skv) * 2;
+    }
     const bool half = p->dtype == SFAST_F16 || p->dtype == SFAST_BF16;
     const bool d_ok = p->D == 40 || p->D == 64 || p->D == 80 || p->D == 128 || p->D == 160;
     bool vec = half && d_ok && aligned16(q) && aligned16(k) && aligned16(v) && aligned8(out);
@@ -599,12 +669,17 @@ extern "C" int sfast_hip_attention(const void *q, const void *k, const void *v, 
     vec = vec && p->ks[1] < (1 << 24) && p->vs[1] < (1 << 24);  // 64-row tile advance and row offsets stay in 32 bits
     a.kspan = (uint32_t)kspan;
     a.vspan = (uint32_t)vspan;
+    if (bias) {  // MFMA path: dword-aligned 4-key groups, descriptor range below 2^31 bytes
+        vec = vec && half && bspan < (1ll << 31) && a.bs[2] % 2 == 0 && a.bs[0] % 2 == 0 && a.bs[1] % 2 == 0 && (((uintptr_t)bias) & 3) == 0;
+        a.bspan = (uint32_t)bspan;
+    }
     if (vec && p->variant != 100 && p->scale > 0.f) {
         int nw = 4;
         const int64_t blocks4 = (int64_t)ceil_div(p->Sq, 128) * p->H * p->B;
         if (blocks4 < 256) nw = 2;
         if (p->variant == 2 || p->variant == 4) nw = p->variant;
-        set_kernel_name("attn_fwd[D=%d,BQ=%d]", p->D, nw * 32);
+        if (bias) nw = 4;
+        set_kernel_name("attn_fwd[D=%d,BQ=%d]%s", p->D, nw * 32, bias ? "+bias" : "");
         if (p->dtype == SFAST_F16) return attn_launch<f16>(a, nw, st);
         return attn_launch<bf16>(a, nw, st);
     }

@@ -447,32 +447,48 @@ __device__ __forceinline__ void flush_staged_tile(const IgemmArgs &a, char *lds,
     float *red = reinterpret_cast<float *>(lds + SCR);
     if (ctid < NTF) *reinterpret_cast<f32x4 *>(red + ctid * 4) = f32x4{s1a, s2a, s1b, s2b};
     __syncthreads();
-    // slot j of this tile <-> unit n0/unit + j; fixed summation order: chunk columns ascending, row phases ascending
+    // slot j of this tile <-> unit n0/unit + j. Eight lanes per slot: lane l sums the row phases l, l+8, ... of the slot's chunk
+    // columns, then a fixed three-step butterfly -- the order of summation is the same in every launch (bitwise reproducible), and
+    // no thread walks the whole scratch array alone (a single-thread walk was ~2 us of serial LDS round trips per workgroup).
+    constexpr int LPS = 8;
+    static_assert(NTC % 64 == 0, "slot lanes must not straddle waves");
     const int ufirst = n0 / unit;
     const int nend = min(n0 + BNO, a.N);
-    if (ctid < a.gn_slots) {
-        const int U = ufirst + ctid;
+    const int j = ctid / LPS, l = ctid % LPS;
+    {
+        const int U = ufirst + j;
         const int lo = max(n0, U * unit), hi_ = min(nend, (U + 1) * unit);
-        float mean = 0.f, m2 = 0.f;
-        if (hi_ > lo) {
-            const float sh = (float)*reinterpret_cast<const T *>(lds + (lo - n0) * 2);
-            float s1 = 0.f, s2 = 0.f;
+        const bool live = j < a.gn_slots && hi_ > lo;
+        float s1 = 0.f, s2 = 0.f;
+        if (live) {
             for (int cc = (lo - n0) >> 3; cc <= (hi_ - 1 - n0) >> 3; ++cc) {
                 const int part = ((n0 + cc * 8) / unit == U) ? 0 : 2;
-                for (int j = 0; j < RPP; ++j) {
-                    const float *q = red + (j * CPR + cc) * 4 + part;
+#pragma unroll 4
+                for (int r = l; r < RPP; r += LPS) {
+                    const float *q = red + (r * CPR + cc) * 4 + part;
                     s1 += q[0];
                     s2 += q[1];
                 }
             }
-            const float cnt = (float)(hi_ - lo) * (float)min(BM, a.M - m0);
-            mean = sh + s1 / cnt;
-            m2 = fmaxf(s2 - s1 * s1 / cnt, 0.f);
         }
-        const int tile_m = m0 / BM, tile_n = n0 / BNO;
-        float *o = a.gn_stats + (((int64_t)tile_m * a.tiles_n + tile_n) * a.gn_slots + ctid) * 2;
-        o[0] = mean;
-        o[1] = m2;
+#pragma unroll
+        for (int off = 1; off < LPS; off <<= 1) {
+            s1 += __shfl_xor(s1, off, 64);
+            s2 += __shfl_xor(s2, off, 64);
+        }
+        if (j < a.gn_slots && l == 0) {
+            float mean = 0.f, m2 = 0.f;
+            if (hi_ > lo) {
+                const float sh = (float)*reinterpret_cast<const T *>(lds + (lo - n0) * 2);
+                const float cnt = (float)(hi_ - lo) * (float)min(BM, a.M - m0);
+                mean = sh + s1 / cnt;
+                m2 = fmaxf(s2 - s1 * s1 / cnt, 0.f);
+            }
+            const int tile_m = m0 / BM, tile_n = n0 / BNO;
+            float *o = a.gn_stats + (((int64_t)tile_m * a.tiles_n + tile_n) * a.gn_slots + j) * 2;
+            o[0] = mean;
+            o[1] = m2;
+        }
     }
 }
 

@@ -154,6 +154,7 @@ __device__ __forceinline__ void gn_apply_rows(const T *__restrict__ x, const T *
 struct GnPre {
     const float *p[2];
     int rb_rows[2], n_rb[2], bno[2], tiles_n[2], slots[2], unit[2], nch[2], coff[2];
+    int kl;  // lanes per record slot in the merge prologue
 };
 
 // Chan et al. pairwise update: (n, mean, M2) <- (n, mean, M2) (+) (ni, mi, M2i)
@@ -187,39 +188,75 @@ __global__ void gn_nhwc_apply_kernel(const T *__restrict__ x, const T *__restric
         u32x4 ga_raw = {0u, 0u, 0u, 0u}, be_raw = {0u, 0u, 0u, 0u};
         if (pre_ok && gamma) ga_raw = *reinterpret_cast<const u32x4 *>(gamma + tx0 * 8);
         if (pre_ok && beta) be_raw = *reinterpret_cast<const u32x4 *>(beta + tx0 * 8);
-        // merge the producers' records: thread (group, k) takes row blocks k, k+8, ... of every unit slot of its group in
-        // ascending channel order, then the eight lanes of a group are merged in order -> fixed order, bitwise reproducible
-        if (tid < g.G * RS) {
-            const int grp = tid / RS, k = tid % RS;
+        // merge the producers' records in three fixed-order stages (bitwise reproducible):
+        //   1. lane k of slot si (KL lanes per slot, all threads busy, loads batched) merges row blocks k, k+KL, ... of that slot;
+        //   2. one thread per slot merges its KL lanes;  3. one thread per group merges the slots of the group in channel order.
+        // (The first version let 8 threads per group walk every record through dependent loads: 20-50 us of prologue per workgroup.)
+        const int S0 = pre.tiles_n[0] * pre.slots[0];
+        const int S_tot = S0 + (g.C1 < g.C ? pre.tiles_n[1] * pre.slots[1] : 0);
+        const int KL = pre.kl;
+        float *lane_rec = tmp;                    // [S_tot][KL][3]
+        float *slot_rec = tmp + S_tot * KL * 3;   // [S_tot][3]
+        auto slot_geom = [&](int si, int &s_, int &tn, int &jj, float &cnt) {
+            s_ = si < S0 ? 0 : 1;
+            const int sl = si - (s_ ? S0 : 0);
+            tn = sl / pre.slots[s_];
+            jj = sl - tn * pre.slots[s_];
+            const int U = (tn * pre.bno[s_]) / pre.unit[s_] + jj;
+            const int lo = max(tn * pre.bno[s_], U * pre.unit[s_]), hi = min(min((tn + 1) * pre.bno[s_], pre.nch[s_]), (U + 1) * pre.unit[s_]);
+            cnt = hi > lo ? (float)(hi - lo) * (float)pre.rb_rows[s_] : 0.f;
+        };
+        for (int w = tid; w < S_tot * KL; w += blockDim.x) {
+            const int si = w / KL, k = w - si * KL;
+            int s_, tn, jj;
+            float cnt;
+            slot_geom(si, s_, tn, jj, cnt);
             float n = 0.f, mu = 0.f, m2 = 0.f;
-            int c = grp * g.cpg;
-            const int cend = c + g.cpg;
-            while (c < cend) {
-                const int s = c < g.C1 ? 0 : 1;
-                const int cl = c - pre.coff[s];
-                const int Ul = cl / pre.unit[s];
-                const int uend = min((Ul + 1) * pre.unit[s], pre.nch[s]);
-                for (int tn = cl / pre.bno[s]; tn <= (uend - 1) / pre.bno[s]; ++tn) {
-                    const int j = Ul - (tn * pre.bno[s]) / pre.unit[s];
-                    const int lo = max(tn * pre.bno[s], cl), hi = min((tn + 1) * pre.bno[s], uend);
-                    const float cnt = (float)(hi - lo) * (float)pre.rb_rows[s];
-                    for (int rb = k; rb < pre.n_rb[s]; rb += RS) {
-                        const float2 v = *reinterpret_cast<const float2 *>(
-                            pre.p[s] + ((((int64_t)b * pre.n_rb[s] + rb) * pre.tiles_n[s] + tn) * pre.slots[s] + j) * 2);
-                        chan_merge(n, mu, m2, cnt, v.x, v.y);
-                    }
+            if (cnt > 0.f) {
+                const float *base = pre.p[s_] + ((((int64_t)b * pre.n_rb[s_]) * pre.tiles_n[s_] + tn) * pre.slots[s_] + jj) * 2;
+                const int64_t rstride = (int64_t)pre.tiles_n[s_] * pre.slots[s_] * 2;
+                int rb = k;
+                for (; rb + 3 * KL < pre.n_rb[s_]; rb += 4 * KL) {
+                    float2 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float2 *>(base + (rb + u * KL) * rstride);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) chan_merge(n, mu, m2, cnt, v[u].x, v[u].y);
                 }
-                c = uend + pre.coff[s];
+                for (; rb < pre.n_rb[s_]; rb += KL) {
+                    const float2 v = *reinterpret_cast<const float2 *>(base + rb * rstride);
+                    chan_merge(n, mu, m2, cnt, v.x, v.y);
+                }
             }
-            tmp[tid * 3] = n;
-            tmp[tid * 3 + 1] = mu;
-            tmp[tid * 3 + 2] = m2;
+            lane_rec[w * 3] = n;
+            lane_rec[w * 3 + 1] = mu;
+            lane_rec[w * 3 + 2] = m2;
+        }
+        __syncthreads();
+        for (int si = tid; si < S_tot; si += blockDim.x) {
+            float n = 0.f, mu = 0.f, m2 = 0.f;
+            for (int k = 0; k < KL; ++k) chan_merge(n, mu, m2, lane_rec[(si * KL + k) * 3], lane_rec[(si * KL + k) * 3 + 1], lane_rec[(si * KL + k) * 3 + 2]);
+            slot_rec[si * 3] = n;
+            slot_rec[si * 3 + 1] = mu;
+            slot_rec[si * 3 + 2] = m2;
         }
         __syncthreads();
         if (tid < g.G) {
             float n = 0.f, mu = 0.f, m2 = 0.f;
-#pragma unroll
-            for (int j = 0; j < RS; ++j) chan_merge(n, mu, m2, tmp[(tid * RS + j) * 3], tmp[(tid * RS + j) * 3 + 1], tmp[(tid * RS + j) * 3 + 2]);
+            int c = tid * g.cpg;
+            const int cend = c + g.cpg;
+            while (c < cend) {
+                const int s_ = c < g.C1 ? 0 : 1;
+                const int cl = c - pre.coff[s_];
+                const int Ul = cl / pre.unit[s_];
+                const int uend = min((Ul + 1) * pre.unit[s_], pre.nch[s_]);
+                for (int tn = cl / pre.bno[s_]; tn <= (uend - 1) / pre.bno[s_]; ++tn) {
+                    const int jj = Ul - (tn * pre.bno[s_]) / pre.unit[s_];
+                    const int si = (s_ ? S0 : 0) + tn * pre.slots[s_] + jj;
+                    chan_merge(n, mu, m2, slot_rec[si * 3], slot_rec[si * 3 + 1], slot_rec[si * 3 + 2]);
+                }
+                c = uend + pre.coff[s_];
+            }
             mean[tid] = mu;
             rstd[tid] = rsqrtf(fmaxf(m2 / n, 0.f) + eps);  // biased variance (group_norm.py:48)
         }
@@ -745,13 +782,22 @@ static int gn_launch_pre(const void *x, const void *x2, const void *gamma, const
     const int NT = g.TXB * g.TY;
     int threads = ((NT + 63) / 64) * 64;
     if (threads < g.G * 8) threads = ((g.G * 8 + 63) / 64) * 64;
-    const size_t smem_apply = (size_t)(2 * g.G + g.G * 24) * sizeof(float);
+    GnPre pr = pre;
+    const int s_tot = pr.tiles_n[0] * pr.slots[0] + (g.C1 < g.C ? pr.tiles_n[1] * pr.slots[1] : 0);
+    pr.kl = threads / (s_tot > 0 ? s_tot : 1);
+    if (pr.kl < 1) pr.kl = 1;
+    if (pr.kl > 16) pr.kl = 16;
+    const size_t smem_apply = (size_t)(2 * g.G + (size_t)s_tot * pr.kl * 3 + (size_t)s_tot * 3) * sizeof(float);
+    if (smem_apply > 60 * 1024) {
+        set_error("group_norm_apply: %d record slots per sample exceed the merge scratch", s_tot);
+        return SFAST_ERR_UNSUPPORTED;
+    }
     if (p->act == SFAST_ACT_SILU)
         hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, true, true>), dim3(pl.napply, p->N), dim3(threads), smem_apply, st, (const T *)x,
-                           (const T *)x2, (const T *)gamma, (const T *)beta, (T *)y, (const float *)nullptr, g, pl.rows_apply, 0, p->eps, pre);
+                           (const T *)x2, (const T *)gamma, (const T *)beta, (T *)y, (const float *)nullptr, g, pl.rows_apply, 0, p->eps, pr);
     else
         hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, false, true>), dim3(pl.napply, p->N), dim3(threads), smem_apply, st, (const T *)x,
-                           (const T *)x2, (const T *)gamma, (const T *)beta, (T *)y, (const float *)nullptr, g, pl.rows_apply, 0, p->eps, pre);
+                           (const T *)x2, (const T *)gamma, (const T *)beta, (T *)y, (const float *)nullptr, g, pl.rows_apply, 0, p->eps, pr);
     return check_launch("group_norm_apply");
 }
 

@@ -105,20 +105,20 @@ class _NativeUNetForward:
             self._warned = True
         return self.orig_forward(*args, **kwargs)
 
-    def _prepare(self, key, sample, timestep, ehs, added, down_res, mid_res):
+    def _prepare(self, key, sample, timestep, ehs, added, down_res, mid_res, emask=None):
         eng = self.engine
-        B, H, W, S, ctrl = key
+        B, H, W, S, ctrl, has_mask = key
         # everything below (kernel-attribute setup, autotune launches and their event timing, warm-up, capture) must run with
         # the MODEL's device current, whatever device the caller has selected (reference: graphs.py wraps capture and replay
         # in torch.cuda.device(execution_env.device))
         with torch.cuda.device(eng.device):
-            plan = eng.get_plan(B, H, W, S, ctrl)
+            plan = eng.get_plan(B, H, W, S, ctrl, has_mask)
         env = get_per_device_graph_execution_env(eng.device)
         graph = None
         # warm-up: runs the whole plan eagerly (also validates every launch before capture)
         torch.cuda.synchronize(eng.device)
         with torch.cuda.device(eng.device), torch.cuda.stream(torch.cuda.Stream(device=eng.device)):
-            eng.load_inputs(plan, sample, timestep, ehs, added, down_res, mid_res)
+            eng.load_inputs(plan, sample, timestep, ehs, added, down_res, mid_res, emask)
             for _ in range(self.warmups if self.enable_graph else 1):
                 plan.run(torch.cuda.current_stream(eng.device).cuda_stream)
         torch.cuda.synchronize(eng.device)
@@ -135,9 +135,14 @@ class _NativeUNetForward:
                  down_block_additional_residuals=None, mid_block_additional_residual=None,
                  down_intrablock_additional_residuals=None, encoder_attention_mask=None, return_dict=True):
         extra = dict(class_labels=class_labels, timestep_cond=timestep_cond, attention_mask=attention_mask,
-                     down_intrablock_additional_residuals=down_intrablock_additional_residuals,
-                     encoder_attention_mask=encoder_attention_mask)
+                     down_intrablock_additional_residuals=down_intrablock_additional_residuals)
         bad = [k for k, v in extra.items() if v is not None]
+        # encoder_attention_mask (text padding) is an input of the native plan: an additive key bias of every cross-attention
+        # launch (reference passes attn_bias through, libs/xformers/xformers_attention.py:30-47)
+        emask = encoder_attention_mask
+        if emask is not None and not (torch.is_tensor(emask) and emask.device.type == "cuda" and emask.shape[0] == sample.shape[0]
+                                      and ((emask.ndim == 2) or (emask.ndim == 3 and emask.shape[1] == 1))):
+            bad.append("encoder_attention_mask (need [B, S] or [B, 1, S] on the GPU)")
         if cross_attention_kwargs:
             bad.append("cross_attention_kwargs")
         eng = self.engine
@@ -165,7 +170,7 @@ class _NativeUNetForward:
                                   encoder_hidden_states=encoder_hidden_states, return_dict=return_dict,
                                   **{k: v for k, v in given.items() if v is not None})
         B, _, H, W = sample.shape
-        key = (B, H, W, encoder_hidden_states.shape[1], ctrl)
+        key = (B, H, W, encoder_hidden_states.shape[1], ctrl, emask is not None)
         entry = self._cached.get(key)
         if entry is None:
             with self._lock:
@@ -174,7 +179,7 @@ class _NativeUNetForward:
                     logger.info("sfast: building native UNet plan for %s (graph=%s)", key, self.enable_graph)
                     try:
                         entry = self._prepare(key, sample, timestep, encoder_hidden_states, added_cond_kwargs,
-                                              down_block_additional_residuals, mid_block_additional_residual)
+                                              down_block_additional_residuals, mid_block_additional_residual, emask)
                     except (NotImplementedError, KeyError) as e:
                         # this signature is outside the plan's coverage (e.g. a latent size the levels do not divide, a
                         # parameter the planner expected but a wrapper renamed): keep the module's own forward for it
@@ -184,13 +189,13 @@ class _NativeUNetForward:
                     self._cached[key] = entry
         if entry is _FALLBACK:
             given = dict(added_cond_kwargs=added_cond_kwargs, down_block_additional_residuals=down_block_additional_residuals,
-                         mid_block_additional_residual=mid_block_additional_residual)
+                         mid_block_additional_residual=mid_block_additional_residual, encoder_attention_mask=encoder_attention_mask)
             return self.orig_forward(sample, timestep, encoder_hidden_states=encoder_hidden_states, return_dict=return_dict,
                                      **{k: v for k, v in given.items() if v is not None})
         plan, graph, env = entry
         with env.lock, torch.cuda.device(eng.device):
             eng.load_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs,
-                            down_block_additional_residuals, mid_block_additional_residual)
+                            down_block_additional_residuals, mid_block_additional_residual, emask)
             if graph is not None:
                 graph.replay()
             else:

@@ -568,7 +568,7 @@ class UNet2DEngine:
         self._add(plan, "misc", name, 0.0, 3.0 * B * Cc * Hh * Ww * self.esize,
                   lambda s, ap=ap: L.check(lib.sfast_hip_add_strided(sp, dp, C.byref(ap), s), name))
 
-    def _op_attn(self, plan, name, q, k, v, out, B, Hh, Sq, Skv, D, qs, ks, vs, os_, q_off=0, k_off=0, v_off=0):
+    def _op_attn(self, plan, name, q, k, v, out, B, Hh, Sq, Skv, D, qs, ks, vs, os_, q_off=0, k_off=0, v_off=0, bias=None, bias_strides=None):
         lib = self.lib
         p = L.AttnParams()
         p.dtype, p.B, p.H, p.Sq, p.Skv, p.D = self.dt, B, Hh, Sq, Skv, D
@@ -585,8 +585,15 @@ class UNet2DEngine:
         plan.keep.append(p)
         plan.writer.pop(id(out), None)
 
+        bptr = bias.data_ptr() if bias is not None else None
+        bstr = (C.c_int64 * 3)(*bias_strides) if bias is not None else None
+        plan.keep.append(bstr)
+
         def launch(stream, p=p):
-            L.check(lib.sfast_hip_attention(qp, kp, vp, op, C.byref(p), stream), name)
+            if bptr is not None:  # additive bias broadcast over heads / queries (diffusers encoder_attention_mask)
+                L.check(lib.sfast_hip_attention_bias(qp, kp, vp, bptr, bstr, op, C.byref(p), stream), name)
+            else:
+                L.check(lib.sfast_hip_attention(qp, kp, vp, op, C.byref(p), stream), name)
 
         flops = 4.0 * B * Hh * Sq * Skv * D
         nbytes = (2.0 * B * Sq * Hh * D + 2.0 * B * Skv * Hh * D) * self.esize
@@ -668,8 +675,9 @@ class UNet2DEngine:
             # deferred: all K/V projections of equal width become ONE grouped launch at the top of the plan (_emit_kv_groups)
             plan.kv_requests.append((bp + ".attn2.to_kv", P[bp + ".attn2.to_k.weight"], P[bp + ".attn2.to_v.weight"], kv, Cc))
             skv = (S_ctx * 2 * Cc, 2 * Cc, D)
+            ebias = plan.static_in.get("encoder_attention_bias")
             self._op_attn(plan, bp + ".attn2", q, kv, kv, a, B, heads, S, S_ctx, D, (S * Cc, Cc, D), skv, skv, (S * Cc, Cc, D),
-                          k_off=0, v_off=Cc)
+                          k_off=0, v_off=Cc, bias=ebias, bias_strides=(ebias.stride(0), 0, 0) if ebias is not None else None)
             pool.put(q)
             self._op_gemm(plan, bp + ".attn2.to_out", a, [P[bp + ".attn2.to_out.0.weight"]], P[bp + ".attn2.to_out.0.bias"], t,
                           M, Cc, Cc, Cc, Cc, residual=t, ldr=Cc)
@@ -700,7 +708,7 @@ class UNet2DEngine:
         return names
 
     # ------------------------------------------------------------------------------------------
-    def build_plan(self, B, H, W, S_ctx, ctrl=False):
+    def build_plan(self, B, H, W, S_ctx, ctrl=False, enc_mask=False):
         """`ctrl`: the plan also takes ControlNet residuals (one NCHW tensor per skip connection + one for the mid block,
         diffusers `down_block_additional_residuals` / `mid_block_additional_residual`) as static inputs."""
         if not self._emulated:
@@ -719,6 +727,11 @@ class UNet2DEngine:
         ctx = torch.zeros((B, S_ctx, self.ctx_dim), dtype=dt, device=dev)
         out = torch.zeros((B, self.out_ch, H, W), dtype=dt, device=dev)
         plan.static_in = {"sample": sample, "timestep": tbuf, "encoder_hidden_states": ctx}
+        if enc_mask:
+            # additive key bias of the cross-attention layers: (1 - encoder_attention_mask) * -10000 as diffusers'
+            # UNet2DConditionModel.forward builds it, [B, S_ctx] broadcast over heads and queries (row padded to 8 halves)
+            ld = (S_ctx + 7) // 8 * 8
+            plan.static_in["encoder_attention_bias"] = torch.zeros((B, ld), dtype=dt, device=dev)[:, :S_ctx]
         plan.static_out = out
         lib = self.lib
 
@@ -951,7 +964,8 @@ class UNet2DEngine:
         statistics from those launches' epilogues (sfast_epilogue_ext / sfast_hip_group_norm_apply) instead of running its own
         statistics kernel. Runs after autotuning: the record layout follows the tile shape that was chosen for the producer."""
         import os
-        if os.environ.get("SFAST_GN_FUSE", "1") in ("0", "false", "off", ""):
+        mode = os.environ.get("SFAST_GN_FUSE", "1")
+        if mode in ("0", "false", "off", ""):
             return
         import math
         lib = self.lib
@@ -983,6 +997,8 @@ class UNet2DEngine:
                 lays.append(lay)
             if lays is None:
                 continue
+            if mode == "nosplit" and any(l.rb_rows < 64 for l in lays):
+                continue  # A/B knob: only producers whose own epilogue writes the records (no split-K reduce in between)
             for w, lay in zip(srcs, lays):
                 if w["stats"][0] is None:
                     w["ext"].gn_unit, w["ext"].gn_rows_per_sample = unit, p.HW
@@ -1054,20 +1070,39 @@ class UNet2DEngine:
         return out
 
     # ------------------------------------------------------------------------------------------
-    def get_plan(self, B, H, W, S_ctx, ctrl=False):
-        key = (B, H, W, S_ctx, bool(ctrl))
+    def get_plan(self, B, H, W, S_ctx, ctrl=False, enc_mask=False):
+        key = (B, H, W, S_ctx, bool(ctrl), bool(enc_mask))
         plan = self._plans.get(key)
         if plan is None:
             with self._lock:
                 plan = self._plans.get(key)
                 if plan is None:
-                    plan = self.build_plan(B, H, W, S_ctx, ctrl) if ctrl else self.build_plan(B, H, W, S_ctx)
+                    kw = {}
+                    if ctrl:
+                        kw["ctrl"] = True
+                    if enc_mask:
+                        kw["enc_mask"] = True
+                    plan = self.build_plan(B, H, W, S_ctx, **kw)
                     self._plans[key] = plan
         return plan
 
+    @staticmethod
+    def encoder_attention_bias(mask, dtype):
+        """diffusers UNet2DConditionModel.forward: a 2-D keep-mask [B, S] (bool / 0-1) becomes the additive bias
+        (1 - mask) * -10000; a 3-D tensor [B, 1, S] is already a bias. Returns [B, S] in `dtype`."""
+        if mask.ndim == 3 and mask.shape[1] == 1:
+            return mask[:, 0].to(dtype)
+        if mask.ndim != 2:
+            raise UnsupportedUNet(f"encoder_attention_mask of shape {tuple(mask.shape)}")
+        return ((1 - mask.to(dtype)) * -10000.0).to(dtype)
+
     def load_inputs(self, plan, sample, timestep, encoder_hidden_states, added_cond_kwargs=None,
-                    down_block_additional_residuals=None, mid_block_additional_residual=None):
+                    down_block_additional_residuals=None, mid_block_additional_residual=None, encoder_attention_mask=None):
         si = plan.static_in
+        if "encoder_attention_bias" in si:
+            if encoder_attention_mask is None:
+                raise ValueError("this plan takes an encoder_attention_mask")
+            si["encoder_attention_bias"].copy_(self.encoder_attention_bias(encoder_attention_mask, self.dtype))
         si["sample"].copy_(sample)
         if torch.is_tensor(timestep):
             si["timestep"].copy_(timestep.reshape(-1).to(torch.float32).expand(plan.B), non_blocking=True)
@@ -1089,13 +1124,13 @@ class UNet2DEngine:
             si["mid_block_additional_residual"].copy_(mid_block_additional_residual)
 
     def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, down_block_additional_residuals=None,
-                mid_block_additional_residual=None):
+                mid_block_additional_residual=None, encoder_attention_mask=None):
         """Eager (no graph) execution on the current stream; returns a fresh NCHW tensor."""
         B, _, H, W = sample.shape
         ctrl = down_block_additional_residuals is not None
-        plan = self.get_plan(B, H, W, encoder_hidden_states.shape[1], ctrl)
+        plan = self.get_plan(B, H, W, encoder_hidden_states.shape[1], ctrl, encoder_attention_mask is not None)
         self.load_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs, down_block_additional_residuals,
-                         mid_block_additional_residual)
+                         mid_block_additional_residual, encoder_attention_mask)
         plan.run(None if self._emulated else torch.cuda.current_stream(self.device).cuda_stream)
         return plan.static_out.clone()
 

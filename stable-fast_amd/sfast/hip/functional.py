@@ -426,9 +426,10 @@ def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dila
 
 
 @_on_device
-def attention(q, k, v, scale: Optional[float] = None, variant=0):
-    """softmax(q k^T * scale) v with q [B, Sq, H, D], k/v [B, Skv, H, D] (any b/s/h strides)."""
-    _require_cuda(q, k, v)
+def attention(q, k, v, scale: Optional[float] = None, variant=0, attn_bias=None):
+    """softmax(q k^T * scale + attn_bias) v with q [B, Sq, H, D], k/v [B, Skv, H, D] (any b/s/h strides).
+    attn_bias: additive, broadcastable to [B, H, Sq, Skv] (xformers' tensor-bias form); -inf masks a key."""
+    _require_cuda(q, k, v, attn_bias)
     lib = L.init_device()
     if q.ndim != 4 or k.ndim != 4 or v.ndim != 4:
         raise L.SfastHipError("attention: expected [B, S, H, D] tensors")
@@ -446,7 +447,21 @@ def attention(q, k, v, scale: Optional[float] = None, variant=0):
     p.os = _i64x3(out.stride()[:3])
     p.scale = float(scale) if scale is not None else float(D) ** -0.5
     p.variant = int(variant)
-    rc = lib.sfast_hip_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), C.byref(p), _stream(q))
+    bptr, bstr = None, None
+    if attn_bias is not None:
+        bias = attn_bias
+        if bias.dtype != q.dtype:
+            bias = bias.to(q.dtype)
+        while bias.ndim < 4:
+            bias = bias.unsqueeze(0)
+        try:
+            bias = bias.expand(B, H, Sq, Skv)  # broadcast dims get stride 0: nothing is materialised
+        except RuntimeError:
+            raise L.SfastHipError(f"attention: attn_bias {tuple(attn_bias.shape)} is not broadcastable to {(B, H, Sq, Skv)}")
+        if bias.stride(3) != 1 and Skv > 1:
+            bias = bias.contiguous()
+        bptr, bstr = bias.data_ptr(), _i64x3(bias.stride()[:3])
+    rc = lib.sfast_hip_attention_bias(_ptr(q), _ptr(k), _ptr(v), bptr, bstr, _ptr(out), C.byref(p), _stream(q))
     L.check(rc, "sfast_hip_attention")
     return out
 

@@ -29,7 +29,7 @@ EXPORTS = [
     "sfast_hip_gemm_workspace_bytes", "sfast_hip_gemm", "sfast_hip_gemm_ex", "sfast_hip_gemm_stats_layout",
     "sfast_hip_conv2d_workspace_bytes", "sfast_hip_conv2d", "sfast_hip_conv2d_ex", "sfast_hip_conv2d_stats_layout",
     "sfast_hip_group_norm_apply",
-    "sfast_hip_attention", "sfast_hip_strided_copy", "sfast_hip_timestep_embedding",
+    "sfast_hip_attention", "sfast_hip_attention_bias", "sfast_hip_strided_copy", "sfast_hip_timestep_embedding",
     "sfast_hip_gemv_grouped", "sfast_hip_gemm_grouped", "sfast_hip_cfg_ddim_step", "sfast_hip_linear_step", "sfast_hip_igemm_plan", "sfast_hip_set_trace", "sfast_hip_image_postprocess", "sfast_hip_add_strided",
 ]
 
@@ -168,6 +168,8 @@ def _declare(lib):
     lib.sfast_hip_conv2d.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(ConvParams), vp, sz, vp]
     lib.sfast_hip_attention.restype = C.c_int
     lib.sfast_hip_attention.argtypes = [vp, vp, vp, vp, C.POINTER(AttnParams), vp]
+    lib.sfast_hip_attention_bias.restype = C.c_int
+    lib.sfast_hip_attention_bias.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_int64 * 3), vp, C.POINTER(AttnParams), vp]
     lib.sfast_hip_strided_copy.restype = C.c_int
     lib.sfast_hip_strided_copy.argtypes = [vp, vp, C.POINTER(CopyParams), vp]
     lib.sfast_hip_timestep_embedding.restype = C.c_int

@@ -2,8 +2,9 @@
 
 Schema from /root/reference/src/sfast/libs/xformers/xformers_attention.py:46-48; q/k/v are
 [B, S, H, D] (possibly strided views, /root/reference/src/sfast/libs/diffusers/xformers_attention.py:66-69).
-xformers itself is an external dependency of the reference and is not used here. `attn_bias` and
-dropout are not part of the UNet hot path and are rejected loudly.
+xformers itself is an external dependency of the reference and is not used here. `attn_bias` is taken in its
+tensor form (additive, broadcastable to [B, H, Sq, Skv] -- what diffusers' attention processors pass for
+attention_mask / encoder_attention_mask, reference :30-47); dropout is not part of the inference path and is rejected loudly.
 """
 from typing import Optional
 
@@ -15,13 +16,13 @@ _lib = torch.library.Library("sfast_xformers", "DEF")
 
 
 def memory_efficient_attention(query, key, value, attn_bias=None, p=0.0, scale=None, op=None):
-    if attn_bias is not None:
-        raise RuntimeError("sfast_xformers::memory_efficient_attention on ROCm: attn_bias is not supported")
+    if attn_bias is not None and not torch.is_tensor(attn_bias):
+        raise RuntimeError("sfast_xformers::memory_efficient_attention on ROCm: attn_bias must be a tensor (additive bias)")
     if p != 0.0:
         raise RuntimeError("sfast_xformers::memory_efficient_attention on ROCm: dropout is not supported")
     if query.ndim == 3:  # [B, S, D] single-head form
-        return F.attention(query.unsqueeze(2), key.unsqueeze(2), value.unsqueeze(2), scale).squeeze(2)
-    return F.attention(query, key, value, scale)
+        return F.attention(query.unsqueeze(2), key.unsqueeze(2), value.unsqueeze(2), scale, attn_bias=attn_bias).squeeze(2)
+    return F.attention(query, key, value, scale, attn_bias=attn_bias)
 
 
 _lib.define("memory_efficient_attention(Tensor query, Tensor key, Tensor value, Tensor? attn_bias=None, float p=0.0, "

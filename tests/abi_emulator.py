@@ -300,12 +300,19 @@ class EmuLib:
         return 0
 
     def sfast_hip_attention(self, q, k, v, out, ref, stream):
+        return self.sfast_hip_attention_bias(q, k, v, None, None, out, ref, stream)
+
+    def sfast_hip_attention_bias(self, q, k, v, bias, bstr, out, ref, stream):
         p = _p(ref)
         self.calls.append("attention")
         qv = _strided(q, (p.B, p.Sq, p.H, p.D), tuple(p.qs) + (1,), p.dtype)
         kv = _strided(k, (p.B, p.Skv, p.H, p.D), tuple(p.ks) + (1,), p.dtype)
         vv = _strided(v, (p.B, p.Skv, p.H, p.D), tuple(p.vs) + (1,), p.dtype)
-        o = R.attention_ref(qv, kv, vv, p.scale)
+        bv = None
+        if bias:
+            st = tuple(bstr) if not hasattr(bstr, "_obj") else tuple(bstr._obj)
+            bv = _strided(bias, (p.B, p.H, p.Sq, p.Skv), st + (1,), p.dtype)
+        o = R.attention_ref(qv, kv, vv, p.scale, bv)
         _strided(out, (p.B, p.Sq, p.H, p.D), tuple(p.os) + (1,), p.dtype).copy_(o)
         return 0
 

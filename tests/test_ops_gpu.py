@@ -642,3 +642,58 @@ def test_out_scale_applies_before_the_output_rounding():
     compare("linear out_scale", y, want, *tol(y.dtype, 4.0), kernel=last_kernel())
     assert torch.isfinite(y).all() and not torch.isfinite(F().linear(q * 8, kk * 8)).all()  # unscaled logits overflow f16 ...
     assert torch.isfinite(F().linear(q * 8, kk * 8, out_scale=2.0 ** -10)).all()            # ... scaled in fp32 they do not
+
+
+# ---- attention bias / masks (xformers attn_bias, diffusers attention_mask) ----------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Sq,Skv,D", [(2, 8, 1024, 77, 80), (2, 8, 4096, 77, 40), (1, 10, 1024, 1024, 64), (2, 5, 300, 333, 64),
+                                          (1, 8, 256, 256, 160), (2, 4, 64, 130, 128)])
+def test_attention_additive_bias_full_tensor(dtype, B, H, Sq, Skv, D):
+    q, k, v = (rnd(B, s_, H, D, dtype=dtype, seed=300 + i) for i, s_ in enumerate((Sq, Skv, Skv)))
+    bias = rnd(B, H, Sq, Skv, dtype=dtype, seed=303, scale=2.0)
+    y = F().attention(q, k, v, attn_bias=bias)
+    kname = last_kernel()
+    assert "attn_fwd" in kname and "+bias" in kname
+    compare(f"attention bias {(B, H, Sq, Skv, D)} {dtype}", y, R.attention_ref(q, k, v, None, bias), *tol(dtype, 2.0), kernel=kname)
+
+
+@pytest.mark.parametrize("Skv,valid", [(77, 60), (128, 64), (200, 1), (77, 77)])
+def test_attention_key_padding_mask_broadcast(Skv, valid):
+    """diffusers' encoder_attention_mask: [B, Skv] -> additive (1 - mask) * -10000 broadcast over heads and queries; and the hard
+    form with -inf, including fully masked 64-key tiles at the tail."""
+    B, H, Sq, D = 2, 8, 640, 40
+    q, k, v = (rnd(B, s_, H, D, seed=310 + i) for i, s_ in enumerate((Sq, Skv, Skv)))
+    keep = torch.zeros(B, Skv, device=DEV)
+    keep[0, :valid] = 1
+    keep[1, :max(1, valid // 2)] = 1
+    for neg in (-10000.0, float("-inf")):
+        bias = ((1 - keep) * 1.0).masked_fill(keep == 0, neg).masked_fill(keep == 1, 0.0).half()[:, None, None, :]
+        y = F().attention(q, k, v, attn_bias=bias)
+        want = R.attention_ref(q, k, v, None, bias)
+        compare(f"attention key mask Skv={Skv} valid={valid} neg={neg}", y, want, *tol(q.dtype, 2.0), kernel=last_kernel())
+        # equals attention over the kept keys only
+        only = F().attention(q[:1], k[:1, :valid], v[:1, :valid])
+        assert rel(y[:1], only) < 2e-3
+    op = torch.ops.sfast_xformers.memory_efficient_attention(q, k, v, bias, 0.0, None, None)
+    assert torch.equal(op, y)
+
+
+def test_attention_bias_leading_masked_tiles_and_generic_path():
+    """-inf over the FIRST tiles of a row (running max still -inf when real keys arrive) and the generic kernel (odd head dim)."""
+    B, H, Sq, Skv, D = 1, 2, 128, 256, 64
+    q, k, v = (rnd(B, s_, H, D, seed=320 + i) for i, s_ in enumerate((Sq, Skv, Skv)))
+    bias = torch.zeros(B, H, Sq, Skv, device=DEV, dtype=torch.float16)
+    bias[:, :, :, :192] = float("-inf")
+    bias[:, :, 5, :] = 0.0
+    y = F().attention(q, k, v, attn_bias=bias)
+    compare("attention bias leading -inf tiles", y, R.attention_ref(q, k, v, None, bias), *tol(q.dtype, 2.0), kernel=last_kernel())
+    q2, k2, v2 = (rnd(1, s_, 3, 24, seed=330 + i) for i, s_ in enumerate((50, 70, 70)))
+    b2 = rnd(1, 3, 50, 70, seed=333)
+    y2 = F().attention(q2, k2, v2, attn_bias=b2)
+    assert last_kernel() == "attn_naive"
+    compare("attention bias generic", y2, R.attention_ref(q2, k2, v2, None, b2), *tol(q2.dtype, 2.0), kernel="attn_naive")
+
+
+def rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / b.norm())

@@ -41,6 +41,16 @@ b)  # statistics hand-over: new op tests, whole-UNet tests, A/B of the fusion an
   run bench_fused2  600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
   prof sd15 --steps 10 --warmup 2
   ;;
+c)  # after the merge-prologue / slot-combine fixes: statistics tests, attention bias tests, A/B of the fusion modes
+  run t_stats  900 $PYT tests/test_ops_gpu.py -k "statistics or out_scale or attention"
+  run t_unet   900 $PYT tests/test_unet_gpu.py -k "sd15 or tiny or compile"
+  SFAST_GN_FUSE=0 run bench_nofuse 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  run bench_fused   600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --dump-kernels gpurun_out/kernels.json
+  SFAST_GN_FUSE=nosplit run bench_nosplit 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  SFAST_GN_FUSE=0 run bench_nofuse2 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  run bench_fused2  600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  prof sd15 --steps 10 --warmup 2
+  ;;
 quick)
   run t_quick  900 $PYT tests/test_ops_gpu.py tests/test_unet_gpu.py -k "${2:-not zzz}"
   run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json --no-cpu-baseline
