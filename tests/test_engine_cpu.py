@@ -270,3 +270,28 @@ def test_groupnorm_statistics_come_from_the_producers(built_lib):
     assert err2 < 4e-3, err2
     plan2 = eng.get_plan(1, 64, 64, 20, True)
     assert 0 < plan2.gn_fused < plan.gn_fused
+
+
+def test_encoder_attention_mask_is_a_plan_input(built_lib):
+    """Text-padding mask -> additive key bias of every cross-attention launch (diffusers' (1 - mask) * -10000); own plan-cache key."""
+    cfg = U.tiny_config()
+    m = U.build(cfg, seed=31, dtype=torch.float16)
+    eng = UNet2DEngine.from_module(m, _lib=EmuLib())
+    g = torch.Generator().manual_seed(32)
+    sample = torch.randn(2, 4, 16, 16, generator=g).half()
+    ehs = torch.randn(2, 20, cfg["cross_attention_dim"], generator=g).half()
+    mask = torch.ones(2, 20)
+    mask[0, 12:] = 0
+    mask[1, 5:] = 0
+    y = eng.forward(sample, 700, ehs, encoder_attention_mask=mask)
+    with torch.no_grad():
+        want = m.float()(sample.float(), 700, ehs.float(), encoder_attention_mask=mask).sample
+        plain = m(sample.float(), 700, ehs.float()).sample
+    err = float((y.float() - want).norm() / want.norm())
+    assert err < 4e-3, err
+    assert float((plain - want).norm() / want.norm()) > 1e-2  # the mask matters for this input
+    assert len(eng._plans) == 1 and list(eng._plans)[0][-1] is True
+    # [B, 1, S] additive-bias form is taken as is
+    bias3 = ((1 - mask) * -10000.0)[:, None, :]
+    y3 = eng.forward(sample, 700, ehs, encoder_attention_mask=bias3)
+    assert torch.equal(y3, y)

@@ -439,3 +439,28 @@ def test_module_from_params_drives_compile_unet():
     assert torch.equal(got, want)
     with pytest.raises(RuntimeError):
         shell.conv_in(sample)
+
+
+def test_encoder_attention_mask_native_and_through_compile():
+    """encoder_attention_mask no longer drops the UNet to eager: it is a static input of the native plan (attention bias kernel)."""
+    from sfast.compilers.diffusion_pipeline_compiler import CompilationConfig, compile_unet
+    cfg = U.tiny_config()
+    m = U.build(cfg, seed=14, dtype=torch.float16, device=DEV)
+    ref = U.build(cfg, seed=14, dtype=torch.float32, device=DEV)
+    sample, ehs = _inputs(cfg, 2, seed=5, S=77)
+    mask = torch.ones(2, 77, device=DEV)
+    mask[0, 30:] = 0
+    mask[1, 9:] = 0
+    with torch.no_grad():
+        want = ref(sample.float(), 400, ehs.float(), encoder_attention_mask=mask).sample
+    y = _engine(m).forward(sample, 400, ehs, encoder_attention_mask=mask)
+    err = rel_l2(y, want)
+    log_value("tiny unet encoder_attention_mask vs fp32 oracle", rel_l2=err)
+    assert err < 4e-3, err
+    config = CompilationConfig.Default()
+    config.enable_cuda_graph = True
+    cm = compile_unet(U.build(cfg, seed=14, dtype=torch.float16, device=DEV), config)
+    out = cm(sample, 400, encoder_hidden_states=ehs, encoder_attention_mask=mask.bool(), return_dict=False)[0]
+    assert not cm.forward._warned and torch.equal(out, y)
+    out2 = cm(sample, 400, encoder_hidden_states=ehs, encoder_attention_mask=mask.bool(), return_dict=False)[0]  # graph replay
+    assert torch.equal(out2, y) and len(cm.forward._cached) == 1
