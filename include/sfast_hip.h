@@ -350,6 +350,26 @@ int sfast_hip_cfg_ddim_step(const void *eps_uc, const void *latents, void *laten
 int sfast_hip_linear_step(const void *model_output, const void *sample, void *out, const float *coef, const void *index,
                           int32_t index_is_i64, int64_t index_limit, int64_t numel, int32_t dtype, sfast_stream_t stream);
 
+/* ---- row-wise mix: out[r][:] = wx*x[r][:] + wy*y[r][:] + vec[(r / vec_rows) % vec_mod][:]  (fp32 math) -------------------
+ * The elementwise glue of the spatio-temporal (Stable Video Diffusion) UNet the reference compiles in
+ * examples/optimize_stable_video_diffusion_pipeline.py: diffusers' AlphaBlender (x = a*x_spatial + (1-a)*x_temporal with
+ * a = sigmoid(mix_factor), `mix_factor` != NULL: read from the live parameter on the device, 1-a when switch_spatial_to_temporal),
+ * the frame-position embedding added to every token of a frame (vec_rows = tokens per frame, vec_mod = frames) and the
+ * single-key cross-attention result added to every token of a sample (vec_rows = tokens per sample). y, vec may be NULL;
+ * out may alias x or y. C % 8 == 0, f16 / bf16. */
+typedef struct {
+    int32_t dtype;
+    int64_t M;          /* rows */
+    int32_t C;          /* row length, dense */
+    int32_t vec_rows, vec_mod;
+    int64_t ld_vec;
+    float wx, wy;       /* used when mix_factor == NULL */
+    int32_t switch_spatial_to_temporal;
+} sfast_mix_params;
+
+int sfast_hip_mix_rows(const void *x, const void *y, const void *vec, const void *mix_factor, void *out,
+                       const sfast_mix_params *p, sfast_stream_t stream);
+
 /* ---- image post-process: NCHW f16/bf16/f32 image -> NHWC uint8 or float32 ----------------------
  * replaces the reference's patched VaeImageProcessor.postprocess / pt_to_pil / pt_to_numpy
  * (libs/diffusers/image_processor.py:23-108: denormalize (x/2+0.5).clamp(0,1), permute(0,2,3,1), and for PIL

@@ -347,7 +347,8 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
         // exact lazy rescale: O and l only need rescaling when some row's running max actually grows
         if (__any(mloc > m_run)) {
             const float m_new = fmaxf(m_run, mloc);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            // (rows whose keys so far are all masked keep m = -inf: -inf - -inf would poison O with NaN)
+            const float alpha = (BIAS && m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f((m_run - m_new) * c);
             m_run = m_new;
             if constexpr (!MFMA_ROWSUM) l_run *= alpha;
 #pragma unroll

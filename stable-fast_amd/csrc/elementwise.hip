@@ -83,6 +83,42 @@ __global__ void __launch_bounds__(256) linear_step_kernel(const T *__restrict__ 
     out[i] = Elem<T>::from_f32(fmaf(a, Elem<T>::to_f32(x[i]), b * Elem<T>::to_f32(eps[i])));
 }
 
+// out[r][:] = wx * x[r][:] + wy * y[r][:] + vec[(r / vec_rows) % vec_mod][:]   (fp32 math, 16 bytes per thread)
+// The weights are constants, or -- AlphaBlender of the spatio-temporal UNet (diffusers `learned_with_images`, image_only_indicator
+// = 0) -- derived ON THE DEVICE from the live `mix_factor` parameter: a = sigmoid(mix) (1 - a when `switch_`), wx = a, wy = 1 - a.
+struct MixArgs {
+    const void *x, *y, *vec, *mix;
+    void *out;
+    int64_t M;
+    int C, vec_rows, vec_mod, switch_;
+    int64_t ld_vec;
+    float wx, wy;
+};
+template <typename T> __global__ void __launch_bounds__(256) mix_rows_kernel(const MixArgs a) {
+    const int cpr = a.C / 8;
+    const int64_t total = a.M * cpr;
+    float wx = a.wx, wy = a.wy;
+    if (a.mix) {
+        const float m = Elem<T>::to_f32(*(const T *)a.mix);
+        float al = 1.0f / (1.0f + __expf(-m));
+        if (a.switch_) al = 1.0f - al;
+        wx = al;
+        wy = 1.0f - al;
+    }
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
+        const int64_t r = idx / cpr;
+        const int c = (int)(idx - r * cpr) * 8;
+        float fx[8], fy[8], fv[8], o[8];
+        unpack8<T>(*reinterpret_cast<const u32x4 *>((const T *)a.x + r * a.C + c), fx);
+        if (a.y) unpack8<T>(*reinterpret_cast<const u32x4 *>((const T *)a.y + r * a.C + c), fy);
+        if (a.vec) unpack8<T>(*reinterpret_cast<const u32x4 *>((const T *)a.vec + ((r / a.vec_rows) % a.vec_mod) * a.ld_vec + c), fv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = wx * fx[i] + (a.y ? wy * fy[i] : 0.f) + (a.vec ? fv[i] : 0.f);
+        *reinterpret_cast<u32x4 *>((T *)a.out + r * a.C + c) = pack8<T>(o);
+    }
+}
+
 template <typename T> __global__ void __launch_bounds__(256) strided_add_kernel(const CopyArgs a) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < a.total; idx += stride) {
@@ -231,6 +267,43 @@ extern "C" int sfast_hip_linear_step(const void *model_output, const void *sampl
     default: set_error("linear_step: dtype %d", dtype); return SFAST_ERR_UNSUPPORTED;
     }
     return check_launch("linear_step");
+}
+
+extern "C" int sfast_hip_mix_rows(const void *x, const void *y, const void *vec, const void *mix_factor, void *out,
+                                  const sfast_mix_params *p, sfast_stream_t stream) {
+    SFAST_REQUIRE(p && x && out, SFAST_ERR_INVALID, "mix_rows: null argument");
+    SFAST_REQUIRE(p->M > 0 && p->C > 0 && p->C % 8 == 0, SFAST_ERR_UNSUPPORTED, "mix_rows: C=%d must be a positive multiple of 8", p->C);
+    SFAST_REQUIRE(!vec || (p->vec_rows > 0 && p->vec_mod > 0 && p->ld_vec % 8 == 0), SFAST_ERR_INVALID, "mix_rows: bad row-vector geometry");
+    SFAST_REQUIRE(aligned16(x) && aligned16(out) && (!y || aligned16(y)) && (!vec || aligned16(vec)), SFAST_ERR_UNSUPPORTED,
+                  "mix_rows: operands must be 16-byte aligned");
+    MixArgs a{};
+    a.x = x;
+    a.y = y;
+    a.vec = vec;
+    a.mix = mix_factor;
+    a.out = out;
+    a.M = p->M;
+    a.C = p->C;
+    a.vec_rows = p->vec_rows > 0 ? p->vec_rows : 1;
+    a.vec_mod = p->vec_mod > 0 ? p->vec_mod : 1;
+    a.switch_ = p->switch_spatial_to_temporal;
+    a.ld_vec = p->ld_vec;
+    a.wx = p->wx;
+    a.wy = p->wy;
+    const int64_t total = p->M * (p->C / 8);
+    int64_t blocks = ceil_div64(total, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    set_kernel_name("mix_rows");
+    hipStream_t st = (hipStream_t)stream;
+    if (p->dtype == SFAST_F16)
+        hipLaunchKernelGGL(mix_rows_kernel<f16>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else if (p->dtype == SFAST_BF16)
+        hipLaunchKernelGGL(mix_rows_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else {
+        set_error("mix_rows: dtype %d", p->dtype);
+        return SFAST_ERR_UNSUPPORTED;
+    }
+    return check_launch("mix_rows");
 }
 
 extern "C" int sfast_hip_image_postprocess(const void *image, void *out, const sfast_image_params *p, sfast_stream_t stream) {

@@ -502,18 +502,20 @@ class UNet2DEngine:
         self._add(plan, "temb", name, 2.0 * M * ntot * K, (M * K + ntot * K + ntot + M * ntot) * self.esize, launch, lane=lane)
 
     def _op_conv(self, plan, name, x, x2, w, bias, out, B, H, W, C1, C2, Cout, k, stride, pad, *, ups=False, rowbias=None,
-                 ld_rowbias=0, rowbias_offset=0, z=None, xs=None, os_=None, kind=None, act=L.ACT_NONE, pad_extra=0):
+                 ld_rowbias=0, rowbias_offset=0, z=None, xs=None, os_=None, kind=None, act=L.ACT_NONE, pad_extra=0, kw=None, pad_w=None):
         lib = self.lib
         Cin = C1 + C2
+        kw = k if kw is None else kw          # kernel height k, width kw (the temporal (3,1,1) convs run as 3 x 1 over [frames, pixels])
+        pad_w = pad if pad_w is None else pad_w
         p = L.ConvParams()
-        p.dtype, p.B, p.H, p.W, p.Cin, p.Cout, p.KH, p.KW = self.dt, B, H, W, Cin, Cout, k, k
+        p.dtype, p.B, p.H, p.W, p.Cin, p.Cout, p.KH, p.KW = self.dt, B, H, W, Cin, Cout, k, kw
         p.stride_h = p.stride_w = stride
-        p.pad_h = p.pad_w = pad
+        p.pad_h, p.pad_w = pad, pad_w
         p.dil_h = p.dil_w = 1
         p.upsample2x, p.C1 = int(ups), C1
         Hin, Win = (2 * H, 2 * W) if ups else (H, W)
         Ho = (Hin + 2 * pad + pad_extra - (k - 1) - 1) // stride + 1
-        Wo = (Win + 2 * pad + pad_extra - (k - 1) - 1) // stride + 1
+        Wo = (Win + 2 * pad_w + pad_extra - (kw - 1) - 1) // stride + 1
         p.pad_h_extra = p.pad_w_extra = pad_extra
         p.xs = (C.c_int64 * 4)(*(xs or (H * W * C1, W * C1, C1, 1)))
         p.x2s = (C.c_int64 * 4)(*((H * W * C2, W * C2, C2, 1) if C2 else (0, 0, 0, 0)))
@@ -548,8 +550,8 @@ class UNet2DEngine:
             plan.writer.pop(id(out), None)
 
         M = B * Ho * Wo
-        flops = 2.0 * M * Cout * Cin * k * k
-        nbytes = (B * H * W * Cin + Cout * Cin * k * k + Cout + M * Cout + (M * Cout if z is not None else 0)) * self.esize
+        flops = 2.0 * M * Cout * Cin * k * kw
+        nbytes = (B * H * W * Cin + Cout * Cin * k * kw + Cout + M * Cout + (M * Cout if z is not None else 0)) * self.esize
         self._add(plan, kind or ("conv3x3" if k == 3 else "conv1x1"), name, flops, nbytes, launch, tune=(p, launch_with),
                   needs=LANE_TEMB if rowbias is not None else None)
         return Ho, Wo
@@ -568,7 +570,8 @@ class UNet2DEngine:
         self._add(plan, "misc", name, 0.0, 3.0 * B * Cc * Hh * Ww * self.esize,
                   lambda s, ap=ap: L.check(lib.sfast_hip_add_strided(sp, dp, C.byref(ap), s), name))
 
-    def _op_attn(self, plan, name, q, k, v, out, B, Hh, Sq, Skv, D, qs, ks, vs, os_, q_off=0, k_off=0, v_off=0, bias=None, bias_strides=None):
+    def _op_attn(self, plan, name, q, k, v, out, B, Hh, Sq, Skv, D, qs, ks, vs, os_, q_off=0, k_off=0, v_off=0, bias=None, bias_strides=None,
+                 out_off=0, kind=None, variant=0):
         lib = self.lib
         p = L.AttnParams()
         p.dtype, p.B, p.H, p.Sq, p.Skv, p.D = self.dt, B, Hh, Sq, Skv, D
@@ -577,11 +580,11 @@ class UNet2DEngine:
         p.vs = (C.c_int64 * 3)(*vs)
         p.os = (C.c_int64 * 3)(*os_)
         p.scale = float(D) ** -0.5
-        p.variant = 0
+        p.variant = variant
         qp = q.data_ptr() + q_off * self.esize
         kp = k.data_ptr() + k_off * self.esize
         vp = v.data_ptr() + v_off * self.esize
-        op = out.data_ptr()
+        op = out.data_ptr() + out_off * self.esize
         plan.keep.append(p)
         plan.writer.pop(id(out), None)
 
@@ -598,7 +601,7 @@ class UNet2DEngine:
         flops = 4.0 * B * Hh * Sq * Skv * D
         nbytes = (2.0 * B * Sq * Hh * D + 2.0 * B * Skv * Hh * D) * self.esize
         cross = not (Sq == Skv and q is k)
-        self._add(plan, "attn_cross" if cross else "attn_self", name, flops, nbytes, launch, needs=LANE_KV if cross else None)
+        self._add(plan, kind or ("attn_cross" if cross else "attn_self"), name, flops, nbytes, launch, needs=LANE_KV if cross else None)
 
     # ------------------------------------------------------------------------------------------
     # network pieces

@@ -247,3 +247,144 @@ def module_from_params(cfg: dict, params: Dict[str, torch.Tensor]) -> torch.nn.M
     first = next(iter(params.values()))
     root.dtype = first.dtype
     return root
+
+
+SVD_CONFIG = dict(
+    sample_size=96, in_channels=8, out_channels=4,
+    down_block_types=("CrossAttnDownBlockSpatioTemporal", "CrossAttnDownBlockSpatioTemporal", "CrossAttnDownBlockSpatioTemporal",
+                      "DownBlockSpatioTemporal"),
+    up_block_types=("UpBlockSpatioTemporal", "CrossAttnUpBlockSpatioTemporal", "CrossAttnUpBlockSpatioTemporal",
+                    "CrossAttnUpBlockSpatioTemporal"),
+    block_out_channels=(320, 640, 1280, 1280), addition_time_embed_dim=256, projection_class_embeddings_input_dim=768,
+    layers_per_block=2, cross_attention_dim=1024, transformer_layers_per_block=1, num_attention_heads=(5, 10, 20, 20), num_frames=25,
+)
+
+
+def svd_param_shapes(cfg: dict) -> Dict[str, Tuple[int, ...]]:
+    """Parameter inventory of diffusers `UNetSpatioTemporalConditionModel` (state-dict names); 1,524,623,082 parameters for
+    SVD_CONFIG (the published size of the SVD / SVD-XT UNet)."""
+    boc = tuple(cfg["block_out_channels"])
+    n = len(boc)
+    Lp = cfg.get("layers_per_block", 2)
+    d_ = cfg.get("transformer_layers_per_block", 1)
+    depth = tuple(d_) if isinstance(d_, (tuple, list)) else (d_,) * n
+    ctx = cfg["cross_attention_dim"]
+    T = boc[0] * 4
+    out: Dict[str, Tuple[int, ...]] = {}
+
+    def conv(name, cout, cin, k):
+        out[name + ".weight"] = (cout, cin, k, k)
+        out[name + ".bias"] = (cout,)
+
+    def conv3(name, cout, cin):
+        out[name + ".weight"] = (cout, cin, 3, 1, 1)
+        out[name + ".bias"] = (cout,)
+
+    def linear(name, cout, cin, bias=True):
+        out[name + ".weight"] = (cout, cin)
+        if bias:
+            out[name + ".bias"] = (cout,)
+
+    def norm(name, c):
+        out[name + ".weight"] = (c,)
+        out[name + ".bias"] = (c,)
+
+    def resnet(name, cin, cout):
+        s, t = name + ".spatial_res_block", name + ".temporal_res_block"
+        norm(s + ".norm1", cin)
+        conv(s + ".conv1", cout, cin, 3)
+        linear(s + ".time_emb_proj", cout, T)
+        norm(s + ".norm2", cout)
+        conv(s + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(s + ".conv_shortcut", cout, cin, 1)
+        norm(t + ".norm1", cout)
+        conv3(t + ".conv1", cout, cout)
+        linear(t + ".time_emb_proj", cout, T)
+        norm(t + ".norm2", cout)
+        conv3(t + ".conv2", cout, cout)
+        out[name + ".time_mixer.mix_factor"] = (1,)
+
+    def attn_block(b, c, kv, pre_ff=False):
+        if pre_ff:
+            norm(b + ".norm_in", c)
+            linear(b + ".ff_in.net.0.proj", 8 * c, c)
+            linear(b + ".ff_in.net.2", c, 4 * c)
+        for k_, kvd in (("attn1", c), ("attn2", kv)):
+            norm(f"{b}.norm{1 if k_ == 'attn1' else 2}", c)
+            linear(f"{b}.{k_}.to_q", c, c, bias=False)
+            linear(f"{b}.{k_}.to_k", c, kvd, bias=False)
+            linear(f"{b}.{k_}.to_v", c, kvd, bias=False)
+            linear(f"{b}.{k_}.to_out.0", c, c)
+        norm(b + ".norm3", c)
+        linear(b + ".ff.net.0.proj", 8 * c, c)
+        linear(b + ".ff.net.2", c, 4 * c)
+
+    def transformer(name, c, d):
+        norm(name + ".norm", c)
+        linear(name + ".proj_in", c, c)
+        for j in range(d):
+            attn_block(f"{name}.transformer_blocks.{j}", c, ctx)
+        for j in range(d):
+            attn_block(f"{name}.temporal_transformer_blocks.{j}", c, ctx, pre_ff=True)
+        linear(name + ".time_pos_embed.linear_1", 4 * c, c)
+        linear(name + ".time_pos_embed.linear_2", c, 4 * c)
+        out[name + ".time_mixer.mix_factor"] = (1,)
+        linear(name + ".proj_out", c, c)
+
+    conv("conv_in", boc[0], cfg.get("in_channels", 8), 3)
+    linear("time_embedding.linear_1", T, boc[0])
+    linear("time_embedding.linear_2", T, T)
+    linear("add_embedding.linear_1", T, cfg["projection_class_embeddings_input_dim"])
+    linear("add_embedding.linear_2", T, T)
+    ch = boc[0]
+    for i, t in enumerate(cfg["down_block_types"]):
+        for j in range(Lp):
+            resnet(f"down_blocks.{i}.resnets.{j}", ch if j == 0 else boc[i], boc[i])
+        if t == "CrossAttnDownBlockSpatioTemporal":
+            for j in range(Lp):
+                transformer(f"down_blocks.{i}.attentions.{j}", boc[i], depth[i])
+        ch = boc[i]
+        if i < n - 1:
+            conv(f"down_blocks.{i}.downsamplers.0.conv", ch, ch, 3)
+    resnet("mid_block.resnets.0", boc[-1], boc[-1])
+    resnet("mid_block.resnets.1", boc[-1], boc[-1])
+    transformer("mid_block.attentions.0", boc[-1], depth[-1])
+    rev, rdepth = boc[::-1], depth[::-1]
+    prev = rev[0]
+    for i, t in enumerate(cfg["up_block_types"]):
+        co, ci = rev[i], rev[min(i + 1, n - 1)]
+        for j in range(Lp + 1):
+            resnet(f"up_blocks.{i}.resnets.{j}", (prev if j == 0 else co) + (ci if j == Lp else co), co)
+        if t == "CrossAttnUpBlockSpatioTemporal":
+            for j in range(Lp + 1):
+                transformer(f"up_blocks.{i}.attentions.{j}", co, rdepth[i])
+        if i < n - 1:
+            conv(f"up_blocks.{i}.upsamplers.0.conv", co, co, 3)
+        prev = co
+    norm("conv_norm_out", boc[0])
+    conv("conv_out", cfg.get("out_channels", 4), boc[0], 3)
+    return out
+
+
+def random_svd_params(cfg: dict, seed: int = 0, dtype=torch.float16, device="cuda") -> Dict[str, torch.Tensor]:
+    """Seeded synthetic weights of the spatio-temporal UNet; 4-D / 5-D weights in channels_last / channels_last_3d."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    params = {}
+    for name, shape in svd_param_shapes(cfg).items():
+        if name.endswith("mix_factor"):
+            t = torch.randn(shape, generator=g, device=device)
+        elif len(shape) == 1:
+            t = (1.0 if ("norm" in name and name.endswith("weight")) else 0.0) + 0.05 * torch.randn(shape, generator=g, device=device)
+        else:
+            fan_in = 1
+            for s_ in shape[1:]:
+                fan_in *= s_
+            t = torch.randn(shape, generator=g, device=device) * (1.0 / math.sqrt(fan_in))
+        t = t.to(dtype)
+        if t.ndim == 4:
+            t = t.contiguous(memory_format=torch.channels_last)
+        elif t.ndim == 5:
+            t = t.contiguous(memory_format=torch.channels_last_3d)
+        params[name] = t
+    return params

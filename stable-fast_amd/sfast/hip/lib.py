@@ -30,7 +30,7 @@ EXPORTS = [
     "sfast_hip_conv2d_workspace_bytes", "sfast_hip_conv2d", "sfast_hip_conv2d_ex", "sfast_hip_conv2d_stats_layout",
     "sfast_hip_group_norm_apply",
     "sfast_hip_attention", "sfast_hip_attention_bias", "sfast_hip_strided_copy", "sfast_hip_timestep_embedding",
-    "sfast_hip_gemv_grouped", "sfast_hip_gemm_grouped", "sfast_hip_cfg_ddim_step", "sfast_hip_linear_step", "sfast_hip_igemm_plan", "sfast_hip_set_trace", "sfast_hip_image_postprocess", "sfast_hip_add_strided",
+    "sfast_hip_gemv_grouped", "sfast_hip_gemm_grouped", "sfast_hip_cfg_ddim_step", "sfast_hip_linear_step", "sfast_hip_mix_rows", "sfast_hip_igemm_plan", "sfast_hip_set_trace", "sfast_hip_image_postprocess", "sfast_hip_add_strided",
 ]
 
 
@@ -78,6 +78,11 @@ class GnStatsLayout(C.Structure):
 
     def nbytes(self):
         return int(self.n_rb) * int(self.tiles_n) * int(self.slots) * 8
+
+
+class MixParams(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("M", C.c_int64), ("C", C.c_int32), ("vec_rows", C.c_int32), ("vec_mod", C.c_int32),
+                ("ld_vec", C.c_int64), ("wx", C.c_float), ("wy", C.c_float), ("switch_spatial_to_temporal", C.c_int32)]
 
 
 class GemvGroupedParams(C.Structure):
@@ -178,6 +183,8 @@ def _declare(lib):
     lib.sfast_hip_set_trace.argtypes = [C.c_void_p]
     lib.sfast_hip_igemm_plan.restype = C.c_int
     lib.sfast_hip_igemm_plan.argtypes = [C.c_int32] * 6 + [C.POINTER(C.c_int32 * 5)]
+    lib.sfast_hip_mix_rows.restype = C.c_int
+    lib.sfast_hip_mix_rows.argtypes = [vp, vp, vp, vp, vp, C.POINTER(MixParams), vp]
     lib.sfast_hip_linear_step.restype = C.c_int
     lib.sfast_hip_linear_step.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int64, C.c_int64, C.c_int32, vp]
     lib.sfast_hip_cfg_ddim_step.restype = C.c_int

@@ -316,6 +316,26 @@ class EmuLib:
         _strided(out, (p.B, p.Sq, p.H, p.D), tuple(p.os) + (1,), p.dtype).copy_(o)
         return 0
 
+    def sfast_hip_mix_rows(self, x, y, vec, mix, out, ref, stream):
+        p = _p(ref)
+        self.calls.append("mix_rows")
+        xv = _flat(x, p.M * p.C, p.dtype).reshape(p.M, p.C).float()
+        wx, wy = p.wx, p.wy
+        if mix:
+            a = torch.sigmoid(_flat(mix, 1, p.dtype).float())[0]
+            if p.switch_spatial_to_temporal:
+                a = 1.0 - a
+            wx, wy = a, 1.0 - a
+        o = wx * xv
+        if y:
+            o = o + wy * _flat(y, p.M * p.C, p.dtype).reshape(p.M, p.C).float()
+        if vec:
+            rows = (torch.arange(p.M) // p.vec_rows) % p.vec_mod
+            vv = _strided(vec, (p.vec_mod, p.C), (p.ld_vec, 1), p.dtype).float()
+            o = o + vv[rows]
+        _flat(out, p.M * p.C, p.dtype).reshape(p.M, p.C).copy_(o)
+        return 0
+
     def sfast_hip_strided_copy(self, src, dst, ref, stream):
         p = _p(ref)
         self.calls.append("strided_copy")

@@ -650,11 +650,19 @@ def test_out_scale_applies_before_the_output_rounding():
                                           (1, 8, 256, 256, 160), (2, 4, 64, 130, 128)])
 def test_attention_additive_bias_full_tensor(dtype, B, H, Sq, Skv, D):
     q, k, v = (rnd(B, s_, H, D, dtype=dtype, seed=300 + i) for i, s_ in enumerate((Sq, Skv, Skv)))
-    bias = rnd(B, H, Sq, Skv, dtype=dtype, seed=303, scale=2.0)
+    # rows of the bias padded to a multiple of 8 elements, as xformers requires of its attn_bias (and diffusers pads its masks):
+    # the MFMA kernel reads 4-key groups with dword-aligned loads
+    pad = (Skv + 7) // 8 * 8
+    bias = rnd(B, H, Sq, pad, dtype=dtype, seed=303, scale=2.0)[..., :Skv]
     y = F().attention(q, k, v, attn_bias=bias)
     kname = last_kernel()
     assert "attn_fwd" in kname and "+bias" in kname
     compare(f"attention bias {(B, H, Sq, Skv, D)} {dtype}", y, R.attention_ref(q, k, v, None, bias), *tol(dtype, 2.0), kernel=kname)
+    if Skv % 2:  # a dense odd-width bias is re-laid with padded rows by the wrapper: still the MFMA kernel, same result
+        y2 = F().attention(q[:1, :64], k[:1], v[:1], attn_bias=bias[:1, :, :64].contiguous())
+        assert "+bias" in last_kernel()
+        compare(f"attention bias unaligned {(B, H, Sq, Skv, D)} {dtype}", y2, R.attention_ref(q[:1, :64], k[:1], v[:1], None, bias[:1, :, :64]),
+                *tol(dtype, 2.0), kernel=last_kernel())
 
 
 @pytest.mark.parametrize("Skv,valid", [(77, 60), (128, 64), (200, 1), (77, 77)])
