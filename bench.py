@@ -38,8 +38,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="sd15", choices=["sd15", "sdxl", "vae"],
-                    help="sd15 (the BASELINE metric) | sdxl | vae (SD VAE decode 64x64 latent -> 512x512, SURVEY 8f rank 1)")
+    ap.add_argument("--config", default="sd15", choices=["sd15", "sdxl", "vae", "svd"],
+                    help="sd15 (the BASELINE metric) | sdxl | vae (SD VAE decode 64x64 latent -> 512x512, SURVEY 8f rank 1) | "
+                         "svd (SVD-XT 576x1024, 25 frames, BASELINE configs[4])")
+    ap.add_argument("--frames", type=int, default=25, help="--config svd: frames per video")
     ap.add_argument("--images", type=int, default=1, help="images per GPU (UNet batch is 2x this: CFG)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--through-compile", action="store_true",
@@ -50,7 +52,7 @@ def parse():
     return ap.parse_args()
 
 
-def per_op_timing(loop, reps=2, burst=4):
+def per_op_timing(loop, reps=2, burst=4):  # noqa: C901
     """Eager replay of the step with HIP events on the launch stream. Every op is launched `burst` times back to
     back between one event pair (the pair's own ~2-3 us of record overhead would otherwise be charged to every
     5-15 us kernel), `reps` rounds; seconds = mean per launch. Runs after the timed region: repeating in-place
@@ -82,6 +84,7 @@ def per_op_timing(loop, reps=2, burst=4):
 
 
 _IGEMM_WAVES = {("128x128", False): (2, 2), ("128x160", False): (4, 1), ("64x64", False): (2, 2), ("64x160", False): (2, 1),
+                ("128x64", False): (2, 2), ("64x128", False): (2, 2),
                 ("256x128", False): (4, 2), ("128x128", True): (2, 2), ("64x128", True): (2, 2)}
 
 
@@ -163,7 +166,7 @@ def roofline_from(rows):
         f["launches"] += 1
     # per family: absolute rates and the fraction of the roofline SURVEY section 8(d) assigns to it (MFMA for
     # attention / conv / GEMM main loops, HBM for the normalisations and the weight-streaming GEMVs)
-    mfma_fams = ("conv3x3", "conv1x1", "linear", "geglu", "attn_self", "attn_cross")
+    mfma_fams = ("conv3x3", "conv1x1", "linear", "geglu", "attn_self", "attn_cross", "conv_temporal", "attn_temporal")
     families = {k: dict(ms=v["seconds"] * 1e3, launches=v["launches"],
                         tflops=(v["flops"] / v["seconds"] / 1e12 if v["flops"] else None),
                         gbs=v["bytes"] / v["seconds"] / 1e9,
@@ -377,6 +380,85 @@ def bench_vae(args, dev, rank, world, use_dist):
     print(json.dumps(out))
 
 
+def bench_svd(args, dev, rank, world, use_dist):
+    """`--config svd`: one step = one CFG batch-2 forward of the SVD-XT spatio-temporal UNet (576x1024 -> 72x128 latent, 25 frames),
+    replayed as a hipGraph. Seeded random-init weights of the published architecture (1.52 B parameters)."""
+    from sfast.engine import SVDUNetEngine, capture_plan_graph
+    from sfast.engine.unet_spec import SVD_CONFIG, random_svd_params
+    cfg = SVD_CONFIG
+    params = random_svd_params(cfg, seed=0, dtype=torch.float16, device=dev)
+    eng = SVDUNetEngine(cfg, params)
+    B, Fr, H, W = 2 * args.images, args.frames, 72, 128
+    g = torch.Generator(device=dev).manual_seed(1 + rank)
+    sample = torch.randn(B, Fr, 8, H, W, generator=g, device=dev).half()
+    ehs = torch.randn(B, 1, 1024, generator=g, device=dev).half()
+    tids = torch.tensor([[6.0, 127.0, 0.02]] * B, device=dev)
+    plan = eng.get_plan(B, Fr, H, W)
+    eng.load_inputs(plan, sample, 500.0, ehs, tids)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        plan.run(stream.cuda_stream)
+    torch.cuda.synchronize()
+    graph, _ = capture_plan_graph(plan, stream)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            graph.replay()
+    sync_all()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        for _ in range(args.steps):
+            graph.replay()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+    if rank != 0:
+        return
+    summ = plan.summary()
+    tflop = sum(v["gflop"] for v in summ.values()) / 1e3
+    ms = elapsed / args.steps * 1e3
+    out = {"metric": "UNet iters/sec SVD-XT 576x1024 25 frames fp16", "value": world * args.steps / elapsed, "unit": "it/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f16", "data": "synthetic",
+           "config": {"workload": f"UNetSpatioTemporalConditionModel (SVD-XT, 1.52 B parameters), CFG batch {B} x {Fr} frames x [8,{H},{W}] latent, "
+                                  "hipGraph replay, seeded random-init weights", "videos_per_gpu": args.images, "frames": Fr,
+                      "parallelism": f"replicas x{world}"},
+           "outputs_finite": bool(torch.isfinite(plan.static_out).all()), "kernel_launches_per_step": len(plan.ops),
+           "algorithmic_tflop_per_step": tflop, "achieved_tflops": tflop / (ms * 1e-3), "gn_fused": plan.gn_fused,
+           "activation_pool_gb": plan.pool.total_bytes() / 1e9}
+    if not args.no_roofline and world == 1:
+        class _H:
+            pass
+        holder = _H()
+        holder.plan = plan
+        rows = per_op_timing(holder, reps=1, burst=2)
+        roof, families, total = roofline_from(rows)
+        out["roofline"], out["kernel_families"], out["sum_of_kernel_ms_eager"] = roof, families, total * 1e3
+    if not args.no_cpu_baseline and world == 1:
+        sys.path.insert(0, ROOT)
+        from oracle import svd_ref as SR
+        ref = SR.build("svd", seed=0)
+        torch.set_num_threads(os.cpu_count() or 1)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            ref(sample[:1, :2].float().cpu(), 500.0, ehs[:1].float().cpu(), tids[:1].cpu())
+            t_cpu = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / (t_cpu * B * Fr / 2.0), "unit": "it/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": f"one fp32 forward of the oracle restatement (oracle/svd_ref.py) on 1 video x 2 frames at 72x128 "
+                                         f"({t_cpu:.1f} s), scaled linearly to {B} x {Fr} frames"}
+    print(json.dumps(out), flush=True)
+
+
 def torchrun_argv(n, argv, port=None):
     """Command that re-launches this script as `n` ranks of one node (what the driver does itself for N > 1)."""
     if port is None:
@@ -416,6 +498,11 @@ def main():
 
     if args.config == "vae":
         bench_vae(args, dev, rank, world, use_dist)
+        if use_dist:
+            dist.destroy_process_group()
+        return
+    if args.config == "svd":
+        bench_svd(args, dev, rank, world, use_dist)
         if use_dist:
             dist.destroy_process_group()
         return

@@ -161,6 +161,13 @@ int sfast_hip_gemm(const void *x, const void *const *w_segs, const void *bias,
                    const sfast_gemm_params *p, void *workspace, size_t workspace_bytes,
                    sfast_stream_t stream);
 
+/* ---- weight-only int8 linear: out = act(dq_scale * (x . Wq^T) + bias), Wq int8 [N][K] -------------------------------
+ * sfast::cutlass_qlinear_dynamic / quantized::linear_dynamic of the reference (csrc/operators/cutlass/cutlass_qlinear.cc:73-89,
+ * cutlass_qlinear_dynamic_kernel.cu:259-294: per-tensor scale = weight.q_scale(), zero point ignored, f16 / bf16 activations,
+ * fp32 accumulate). p: M, N, K, ldx, ldo in elements, ldw in BYTES (= elements of the int8 matrix), act; the rest must be 0. */
+int sfast_hip_qlinear_w8(const void *x, const void *w_int8, const void *bias, void *out, const sfast_gemm_params *p,
+                         float dq_scale, sfast_stream_t stream);
+
 /* ---- grouped GEMM: n_groups problems of identical shape in one launch ----------------------------------------
  * out_g[M,N] = act(x_g[M,K] . W_g[N,K]^T + bias_g),  g = 0 .. n_groups-1  (<= SFAST_MAX_GEMM_GROUPS).
  * Two callers: (1) the cross-attention K/V projections of all transformer blocks of one UNet level, which read the SAME text

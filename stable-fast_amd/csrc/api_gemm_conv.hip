@@ -316,6 +316,36 @@ extern "C" int sfast_hip_gemm_grouped(const void *const *x, const void *const *w
     return igemm_run_grouped(a, p->dtype, n_groups, x, w_segs, p->n_wseg, bias, out, (hipStream_t)stream);
 }
 
+extern "C" int sfast_hip_qlinear_w8(const void *x, const void *w_int8, const void *bias, void *out, const sfast_gemm_params *p,
+                                    float dq_scale, sfast_stream_t stream) {
+    SFAST_REQUIRE(p && x && w_int8 && out, SFAST_ERR_INVALID, "qlinear_w8: null argument");
+    SFAST_REQUIRE(p->M > 0 && p->N > 0 && p->K > 0, SFAST_ERR_INVALID, "qlinear_w8: bad shape %dx%dx%d", p->M, p->N, p->K);
+    SFAST_REQUIRE(is_half(p->dtype), SFAST_ERR_UNSUPPORTED, "qlinear_w8: activations must be f16 / bf16 (dtype %d)", p->dtype);
+    SFAST_REQUIRE(!p->geglu && p->n_wseg <= 1 && p->rows_per_batch == 0 && p->in_act == SFAST_ACT_NONE, SFAST_ERR_UNSUPPORTED,
+                  "qlinear_w8: plain linear (+bias, +activation) only");
+    SFAST_REQUIRE(p->K % 8 == 0 && p->ldx % 8 == 0 && p->ldw % 8 == 0 && p->ldw >= p->K && p->ldx >= p->K && p->N % 4 == 0 && p->ldo % 4 == 0 &&
+                      p->ldo >= p->N && aligned16(x) && aligned8(w_int8) && aligned8(out) && (!bias || aligned8(bias)),
+                  SFAST_ERR_UNSUPPORTED, "qlinear_w8: K, ldx, ldw (bytes) must be multiples of 8, N and ldo of 4, operands aligned");
+    IgemmArgs a{};
+    a.x = x;
+    for (int i = 0; i < SFAST_MAX_WSEG; ++i) a.w[i] = w_int8;
+    a.bias = bias;
+    a.out = out;
+    a.M = p->M;
+    a.N = p->N;
+    a.K = p->K;
+    a.ldx = p->ldx;
+    a.ldw = p->ldw;
+    a.ldo = p->ldo;
+    a.rows_per_seg = p->N;
+    a.rows_per_batch = 1;
+    a.act = p->act;
+    a.res_before_act = 0;
+    a.alpha = 1.0f;
+    a.out_scale = dq_scale;
+    return igemm_run_w8(a, p->dtype, (hipStream_t)stream);
+}
+
 extern "C" size_t sfast_hip_conv2d_workspace_bytes(const sfast_conv_params *p) {
     if (!p || !is_half(p->dtype) || p->Cout < 16) return 0;
     ConvGeom g = conv_geom(p, nullptr);

@@ -26,6 +26,7 @@ struct IgemmArgs {
     int gn_unit;       // channels per statistics unit (divides every consumer's channels-per-group)
     int gn_slots;      // unit slots per tile_n (host: stats_slots(BNO, unit))
     int gn_rows_per_sample;  // host-side validation only
+    int w_int8;              // weights are int8 [N][K] (ldw in bytes), dequantised to T while they are staged (igemm_w8_kernel)
 };
 
 // statistics slots a tile of `bno` output columns can overlap: units are `unit` channels wide, tile origins multiples of bno
@@ -46,6 +47,8 @@ bool igemm_stats_layout(int M, int N, int K, bool geglu, int variant, int split,
 void igemm_plan_query(int M, int N, int K, bool geglu, int variant, int split, bool glds_ok, int out[5]);
 size_t igemm_workspace_bytes(int M, int N, int K, bool geglu, int variant, int split, bool glds_ok);
 bool igemm_glds_eligible(const IgemmArgs &a, int mode);
+// weight-only int8 linear (sfast::cutlass_qlinear_dynamic): register-staged pipe, no split-K
+int igemm_run_w8(IgemmArgs &a, int dtype, hipStream_t st);
 // grouped launch (register-staged pipe): n_groups problems of identical [M, N, K] sharing x (api: sfast_hip_gemm_grouped)
 int igemm_run_grouped(IgemmArgs &a, int dtype, int n_groups, const void *const *xs, const void *const *w_segs, int n_wseg,
                       const void *const *bias, void *const *out, hipStream_t st);

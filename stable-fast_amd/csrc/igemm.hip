@@ -36,7 +36,7 @@ namespace sfast {
 
 
 // MODE 0: linear (row m -> x + m*ldx). MODE 1: conv (implicit im2col, NHWC).
-template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GEGLU, bool STAGED = false>
+template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GEGLU, bool STAGED = false, bool W8 = false>
 __device__ __forceinline__ void igemm_body(const IgemmArgs &a) {
     using vec8 = typename Elem<T>::vec8;
     constexpr int NT = WM * WN * 64;
@@ -116,7 +116,10 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs &a) {
                 const int rs = a.rows_per_seg;
                 const int seg = (n >= rs) + (n - rs >= rs) + (n - rs - rs >= rs);
                 const void *base = seg == 0 ? a.w[0] : seg == 1 ? a.w[1] : seg == 2 ? a.w[2] : a.w[3];
-                wrow[i] = (const T *)base + (int64_t)(n - seg * a.rows_per_seg) * a.ldw;
+                if constexpr (W8)  // int8 rows: ldw counts bytes; kept as a T pointer of half the element offset (only its address is used)
+                    wrow[i] = (const T *)((const char *)base + (int64_t)(n - seg * a.rows_per_seg) * a.ldw);
+                else
+                    wrow[i] = (const T *)base + (int64_t)(n - seg * a.rows_per_seg) * a.ldw;
             } else {
                 wrow[i] = nullptr;
             }
@@ -178,7 +181,15 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs &a) {
 #pragma unroll
         for (int i = 0; i < WCH; ++i) {
             const bool ok = kvalid & (wrow[i] != nullptr);
-            wreg[i] = ldg16(wrow[i] + ks, (const T *)a.w[0], ok);
+            if constexpr (W8) {
+                // 8 int8 weights (8 bytes) of this chunk; widened to T when the tile is written to LDS (store_tile)
+                typedef const u32x2 __attribute__((address_space(1))) * g2_ptr;
+                const g2_ptr q = ok ? (g2_ptr)(const void *)((const char *)wrow[i] + ks) : (g2_ptr)(const void *)g_zero16;
+                const u32x2 v = *q;
+                wreg[i] = u32x4{v[0], v[1], 0u, 0u};
+            } else {
+                wreg[i] = ldg16(wrow[i] + ks, (const T *)a.w[0], ok);
+            }
         }
     };
     auto store_tile = [&](int stage) {
@@ -188,8 +199,19 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs &a) {
         for (int i = 0; i < XCH; ++i)
             *reinterpret_cast<u32x4 *>(xs + lds_off(rbase + i * RPP, kc)) = xreg[i];
 #pragma unroll
-        for (int i = 0; i < WCH; ++i)
-            *reinterpret_cast<u32x4 *>(ws + lds_off(rbase + i * RPP, kc)) = wreg[i];
+        for (int i = 0; i < WCH; ++i) {
+            if constexpr (W8) {
+                vec8 w;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int b8 = (int)(int8_t)((wreg[i][e >> 2] >> (8 * (e & 3))) & 0xffu);
+                    w[e] = Elem<T>::from_f32((float)b8);  // exact: |int8| <= 128 is representable in f16 and bf16
+                }
+                *reinterpret_cast<u32x4 *>(ws + lds_off(rbase + i * RPP, kc)) = __builtin_bit_cast(u32x4, w);
+            } else {
+                *reinterpret_cast<u32x4 *>(ws + lds_off(rbase + i * RPP, kc)) = wreg[i];
+            }
+        }
     };
 
     // epilogue operands (bias / row-bias / residual) are requested now and consumed after the K loop when the
@@ -261,6 +283,15 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs &a) {
 template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GEGLU, bool STAGED = false>
 __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, 2 * (BM + BN) * 128)) igemm_kernel(const IgemmArgs a) {
     igemm_body<T, BM, BN, WM, WN, MODE, GEGLU, STAGED>(a);
+}
+
+// Weight-only int8 linear: out = dq_scale * (x . Wq^T) + bias with Wq int8 [N][K] -- the reference's cutlass_qlinear_dynamic
+// (csrc/operators/cutlass/cutlass_qlinear_dynamic_kernel.cu:259-294: mixed f16 x s8 tensor-op GEMM, alpha = weight.q_scale()).
+// Here the int8 rows are widened to T on their way into LDS (the MFMA then runs the ordinary f16 / bf16 tile), the scale is the
+// epilogue's out_scale: half the weight bytes cross HBM, the arithmetic is exact in the weights.
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, 2 * (BM + BN) * 128)) igemm_w8_kernel(const IgemmArgs a) {
+    igemm_body<T, BM, BN, WM, WN, 0, false, false, true>(a);
 }
 
 // Grouped launch: blockIdx.z selects one of up to SFAST_MAX_GEMM_GROUPS independent problems of identical shape that share the
@@ -508,6 +539,7 @@ static const Variant kVariants[] = {
     {18, 64, 64, 2, 2, 1, 3, 0.60f},
     // pipe 2: wave-specialised LDS-DMA (igemm_glds_ws.hip): 4 producer waves + WM*WN consumer waves
     {21, 128, 128, 2, 2, 2, 4, 1.00f}, {22, 128, 160, 4, 1, 2, 4, 1.00f}, {23, 64, 64, 2, 2, 2, 4, 0.60f},
+    {24, 128, 64, 2, 2, 2, 3, 0.80f},  {25, 64, 128, 2, 2, 2, 3, 0.80f},  // autotuner candidates (ids >= 16 are skipped by the analytic planner)
 };
 static const Variant kGegluVariants[] = {
     {1, 128, 128, 2, 2, 0, 2, 1.00f},  {3, 64, 128, 2, 2, 0, 2, 0.75f},  {11, 128, 128, 2, 2, 1, 4, 1.00f},
@@ -769,6 +801,37 @@ int igemm_grouped_init() {
     if (!rc) rc = set_attr_grouped<f16, 128, 128, 2, 2>();
     if (!rc) rc = set_attr_grouped<bf16, 128, 128, 2, 2>();
     return rc;
+}
+
+template <typename T, int BM, int BN> static int w8_launch(const IgemmArgs &a, hipStream_t st) {
+    constexpr int smem = 2 * (BM + BN) * 128;
+    auto kern = igemm_w8_kernel<T, BM, BN, 2, 2>;
+    static bool attr_done = false;  // idempotent; re-applied per process (cheap)
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n, 1), dim3(256), smem, st, a);
+    return check_launch("igemm_w8");
+}
+
+int igemm_run_w8(IgemmArgs &a, int dtype, hipStream_t st) {
+    const bool big = (int64_t)ceil_div(a.M, 64) * ceil_div(a.N, 64) > 4 * 256 && a.M >= 128;
+    const int BM = big ? 128 : 64, BN = big ? 128 : 64;
+    a.tiles_m = ceil_div(a.M, BM);
+    a.tiles_n = ceil_div(a.N, BN);
+    a.ktiles = ceil_div(a.K, 64);
+    a.ktiles_per_split = a.ktiles;
+    a.splits = 1;
+    a.partial = nullptr;
+    a.trace = nullptr;
+    a.stage_out = 0;
+    a.gn_stats = nullptr;
+    a.w_int8 = 1;
+    if (a.out_scale == 0.f) a.out_scale = 1.0f;
+    set_kernel_name("igemm_w8_%s[%dx%d,reg]", dtype == SFAST_F16 ? "f16" : "bf16", BM, BN);
+    if (dtype == SFAST_F16) return big ? w8_launch<f16, 128, 128>(a, st) : w8_launch<f16, 64, 64>(a, st);
+    return big ? w8_launch<bf16, 128, 128>(a, st) : w8_launch<bf16, 64, 64>(a, st);
 }
 
 // n_groups problems of identical [M, N, K]; per group an activation pointer (usually shared), up to two stacked weight segments, a bias and an output.

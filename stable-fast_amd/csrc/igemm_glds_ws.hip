@@ -261,10 +261,14 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, igemm_min_waves((WM * WN 
 
 // ---- host side ------------------------------------------------------------------------------------------
 // variant ids 21.. (igemm.hip kVariants, pipe 2): tile, consumer waves WM x WN, producer waves, ring depth
+// (128x64 / 64x128 with a 3-deep ring: 72 KB of LDS -> two workgroups per CU; M = 8192 x N = 320 becomes 320 / 384 workgroups = ONE
+//  round on 256 CUs where the 64x64 tile needs 640 = two rounds of ~5 us workgroups)
 #define SFAST_FOR_WS_VARIANTS(T, MODE, OP) \
     OP(T, 128, 128, 2, 2, 4, 4, MODE, false) \
     OP(T, 128, 160, 4, 1, 4, 4, MODE, false) \
-    OP(T, 64, 64, 2, 2, 4, 4, MODE, false)
+    OP(T, 64, 64, 2, 2, 4, 4, MODE, false)   \
+    OP(T, 128, 64, 2, 2, 4, 3, MODE, false)  \
+    OP(T, 64, 128, 2, 2, 4, 3, MODE, false)
 
 #define SFAST_FOR_WS_GEGLU_VARIANTS(T, OP) \
     OP(T, 128, 128, 2, 2, 4, 4, 0, true)   \

@@ -302,6 +302,85 @@ class _NativeControlNetForward:
         return ControlNetOutput(down, mid)
 
 
+class _NativeSVDForward:
+    """Replacement for `UNetSpatioTemporalConditionModel.forward` (Stable Video Diffusion): per-shape plan cache + hipGraph replay
+    (reference: examples/optimize_stable_video_diffusion_pipeline.py hands the SVD pipeline to the same compile())."""
+
+    def __init__(self, module, engine, orig_forward, enable_graph):
+        self.module, self.engine, self.orig_forward, self.enable_graph = module, engine, orig_forward, enable_graph
+        self._cached = {}
+        self._lock = threading.Lock()
+        self._warned = False
+        self.__self__ = module
+        self.__name__ = "forward"
+
+    def _prepare(self, key, sample, timestep, ehs, tids):
+        eng = self.engine
+        with torch.cuda.device(eng.device):
+            plan = eng.get_plan(*key)
+        graph = None
+        torch.cuda.synchronize(eng.device)
+        with torch.cuda.device(eng.device), torch.cuda.stream(torch.cuda.Stream(device=eng.device)):
+            eng.load_inputs(plan, sample, timestep, ehs, tids)
+            plan.run(torch.cuda.current_stream(eng.device).cuda_stream)
+        torch.cuda.synchronize(eng.device)
+        env = get_per_device_graph_execution_env(eng.device)
+        if self.enable_graph:
+            from ..engine import capture_plan_graph
+            with env.lock:
+                with torch.cuda.device(eng.device):
+                    graph, _ = capture_plan_graph(plan, env.stream, pool=env.mempool)
+                torch.cuda.synchronize(eng.device)
+        return plan, graph, env
+
+    def __call__(self, sample, timestep, encoder_hidden_states, added_time_ids, return_dict=True):
+        eng = self.engine
+        ok = (torch.is_tensor(sample) and sample.ndim == 5 and sample.device.type == "cuda" and sample.dtype == eng.dtype
+              and torch.is_tensor(encoder_hidden_states) and encoder_hidden_states.ndim == 3 and encoder_hidden_states.shape[1] == 1
+              and torch.is_tensor(added_time_ids))
+        entry = None
+        if ok:
+            B, Fr, _, H, W = sample.shape
+            key = (B, Fr, H, W)
+            entry = self._cached.get(key)
+            if entry is None:
+                with self._lock:
+                    entry = self._cached.get(key)
+                    if entry is None:
+                        try:
+                            entry = self._prepare(key, sample, timestep, encoder_hidden_states, added_time_ids)
+                        except (NotImplementedError, KeyError) as e:
+                            logger.warning("sfast: no native plan for SVD UNet call %s (%s: %s); this shape runs the original forward",
+                                           key, type(e).__name__, e)
+                            entry = _FALLBACK
+                        self._cached[key] = entry
+        if not ok or entry is _FALLBACK:
+            if not ok and not self._warned:
+                logger.warning("sfast: SVD UNet call not handled by the native engine; running the original forward")
+                self._warned = True
+            return self.orig_forward(sample, timestep, encoder_hidden_states, added_time_ids, return_dict=return_dict)
+        plan, graph, env = entry
+        with env.lock, torch.cuda.device(eng.device):
+            eng.load_inputs(plan, sample, timestep, encoder_hidden_states, added_time_ids)
+            if graph is not None:
+                graph.replay()
+            else:
+                plan.run(torch.cuda.current_stream(eng.device).cuda_stream)
+            out = plan.static_out.clone()
+        if not return_dict:
+            return (out,)
+        return _make_output(out)
+
+
+def _looks_like_svd_unet(m):
+    if not all(hasattr(m, a) for a in ("conv_in", "time_embedding", "add_embedding", "down_blocks", "mid_block", "up_blocks", "conv_out", "config")):
+        return False
+    try:
+        return hasattr(m.down_blocks[0].resnets[0], "temporal_res_block")
+    except Exception:
+        return False
+
+
 def _looks_like_controlnet(m):
     return all(hasattr(m, a) for a in ("conv_in", "time_embedding", "down_blocks", "mid_block", "controlnet_cond_embedding",
                                        "controlnet_down_blocks", "controlnet_mid_block", "config"))
@@ -379,6 +458,18 @@ def compile_unet(m, config):
         if cn is not None:
             m.forward = _NativeControlNetForward(m, cn, m.forward, enable_cuda_graph)
             m._sfast_engine = cn
+            return m
+    if config.enable_jit and device.type == "cuda" and _looks_like_svd_unet(m):
+        from ..engine import SVDUNetEngine, UnsupportedUNet
+        try:
+            svd = SVDUNetEngine.from_module(m)
+        except UnsupportedUNet as e:
+            logger.warning("sfast: %s is outside the native spatio-temporal engine's coverage (%s); keeping the eager forward",
+                           type(m).__name__, e)
+            svd = None
+        if svd is not None:
+            m.forward = _NativeSVDForward(m, svd, m.forward, enable_cuda_graph)
+            m._sfast_engine = svd
             return m
     if config.enable_jit and device.type == "cuda" and _looks_like_unet2d_condition(m):
         from ..engine import UNet2DEngine, UnsupportedUNet

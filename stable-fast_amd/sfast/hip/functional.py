@@ -553,3 +553,28 @@ def linear_step(model_output, sample, coef, index=None, out=None):
     L.check(lib.sfast_hip_linear_step(_ptr(mo), _ptr(x), _ptr(out), cptr, iptr, i64, n, mo.numel(), _dtype(mo), _stream(mo)),
             "sfast_hip_linear_step")
     return out
+
+
+@_on_device
+def qlinear_w8(x, w_int8, scale, bias=None, act=None):
+    """act(scale * (x @ w_int8^T) + bias): weight-only int8 linear (w_int8 [N, K] torch.int8, per-tensor `scale`)."""
+    _require_cuda(x, w_int8, bias)
+    lib = L.init_device()
+    if w_int8.dtype != torch.int8 or w_int8.ndim != 2 or w_int8.shape[1] != x.shape[-1]:
+        raise L.SfastHipError("qlinear_w8: weight must be an int8 [N, K] matrix matching the input's last dimension")
+    w = w_int8 if w_int8.stride(1) == 1 else w_int8.contiguous()
+    K = x.shape[-1]
+    lead = x.shape[:-1]
+    x2d = x.reshape(-1, K)
+    if x2d.stride(-1) != 1:
+        x2d = x2d.contiguous()
+    M, N = x2d.shape[0], w.shape[0]
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    if bias is not None:
+        bias = bias.to(x.dtype).contiguous()
+    p = L.GemmParams()
+    p.dtype, p.M, p.N, p.K = _dtype(x), M, N, K
+    p.ldx, p.ldw, p.ldo = (x2d.stride(0) if M > 1 else K), (w.stride(0) if N > 1 else K), N
+    p.n_wseg, p.rows_per_seg, p.act, p.alpha = 1, N, _act(act), 1.0
+    L.check(lib.sfast_hip_qlinear_w8(_ptr(x2d), _ptr(w), _ptr(bias), _ptr(out), C.byref(p), float(scale), _stream(x)), "sfast_hip_qlinear_w8")
+    return out.reshape(*lead, N)

@@ -30,7 +30,7 @@ EXPORTS = [
     "sfast_hip_conv2d_workspace_bytes", "sfast_hip_conv2d", "sfast_hip_conv2d_ex", "sfast_hip_conv2d_stats_layout",
     "sfast_hip_group_norm_apply",
     "sfast_hip_attention", "sfast_hip_attention_bias", "sfast_hip_strided_copy", "sfast_hip_timestep_embedding",
-    "sfast_hip_gemv_grouped", "sfast_hip_gemm_grouped", "sfast_hip_cfg_ddim_step", "sfast_hip_linear_step", "sfast_hip_mix_rows", "sfast_hip_igemm_plan", "sfast_hip_set_trace", "sfast_hip_image_postprocess", "sfast_hip_add_strided",
+    "sfast_hip_gemv_grouped", "sfast_hip_gemm_grouped", "sfast_hip_qlinear_w8", "sfast_hip_cfg_ddim_step", "sfast_hip_linear_step", "sfast_hip_mix_rows", "sfast_hip_igemm_plan", "sfast_hip_set_trace", "sfast_hip_image_postprocess", "sfast_hip_add_strided",
 ]
 
 
@@ -163,6 +163,8 @@ def _declare(lib):
     lib.sfast_hip_group_norm_apply.restype = C.c_int
     lib.sfast_hip_group_norm_apply.argtypes = [vp, vp, vp, vp, vp, C.POINTER(GnParams), vp, C.POINTER(GnStatsLayout), vp,
                                                C.POINTER(GnStatsLayout), vp]
+    lib.sfast_hip_qlinear_w8.restype = C.c_int
+    lib.sfast_hip_qlinear_w8.argtypes = [vp, vp, vp, vp, C.POINTER(GemmParams), C.c_float, vp]
     lib.sfast_hip_gemm_grouped.restype = C.c_int
     lib.sfast_hip_gemm_grouped.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(GemmParams), C.c_int32, vp]
     lib.sfast_hip_gemv_grouped.restype = C.c_int

@@ -198,3 +198,25 @@ def linear_gelu(input, weight, bias=None):
 
 _def("linear_relu(Tensor input, Tensor weight, Tensor? bias=None) -> Tensor", linear_relu)
 _def("linear_gelu(Tensor input, Tensor weight, Tensor? bias=None) -> Tensor", linear_gelu)
+
+
+# ---- weight-only int8 dynamic linear (reference csrc/operators/cutlass/cutlass_qlinear.cc:73-89) -------------------------------
+def cutlass_qlinear_dynamic(input, weight, bias=None):
+    """`weight`: a per-tensor-affine quantized qint8 tensor [N, K] (torch.quantize_per_tensor); like the reference the zero point
+    is ignored (weight.int_repr() * weight.q_scale()). f16 / bf16 inputs run the int8-weight MFMA kernel, anything else (fp32
+    inputs, shapes outside its alignment rules) dequantises the weight and takes the ordinary linear kernel -- the reference's own
+    fallback (cutlass_qlinear_dynamic_kernel.cu:272-279, :231-238)."""
+    if not weight.is_quantized:
+        raise RuntimeError("weight should be quantized")
+    w8, scale = weight.int_repr(), float(weight.q_scale())
+    N, K = w8.shape
+    if input.dtype in (torch.float16, torch.bfloat16) and K % 8 == 0 and N % 4 == 0:
+        return F.qlinear_w8(input, w8, scale, bias)
+    wd = (w8.to(torch.float32) * scale).to(input.dtype)
+    return F.linear(input, wd, bias)
+
+
+# the weight is a QuantizedCUDA tensor: registered like the reference (CompositeImplicitAutograd, cutlass_qlinear.cc:83-87) so that the
+# quantized dispatch key of that argument does not hide the implementation
+_lib.define("cutlass_qlinear_dynamic(Tensor input, Tensor weight, Tensor? bias=None) -> Tensor")
+_lib.impl("cutlass_qlinear_dynamic", cutlass_qlinear_dynamic, "CompositeImplicitAutograd")

@@ -74,3 +74,23 @@ def test_mix_rows_kernel(M, C_, rows, mod):
     L.check(lib.sfast_hip_mix_rows(x.data_ptr(), None, vec.data_ptr(), None, out.data_ptr(), C.byref(p2), st), "mix")
     idx = (torch.arange(M, device=DEV) // rows) % mod
     compare(f"mix_rows rowvec {M}x{C_}", out, x.float() + vec.float()[idx], 2e-3, 2e-3, kernel="mix_rows")
+
+
+def test_compile_unet_recognises_the_spatio_temporal_unet():
+    from sfast.compilers.diffusion_pipeline_compiler import CompilationConfig, compile_unet
+    from sfast.engine import SVDUNetEngine
+    cfg = S.tiny_svd_config()
+    m = S.build(cfg, seed=53, dtype=torch.float16, device=DEV)
+    ref = S.build(cfg, seed=53, dtype=torch.float16, device=DEV)
+    config = CompilationConfig.Default()
+    config.enable_cuda_graph = True
+    m = compile_unet(m, config)
+    assert isinstance(m._sfast_engine, SVDUNetEngine)
+    g = torch.Generator().manual_seed(54)
+    sample = torch.randn(1, 5, 8, 16, 16, generator=g).to(DEV, torch.float16)
+    ehs = torch.randn(1, 1, cfg["cross_attention_dim"], generator=g).to(DEV, torch.float16)
+    tids = torch.tensor([[6.0, 127.0, 0.02]], device=DEV, dtype=torch.float16)
+    out = m(sample, torch.tensor(400.0, device=DEV), ehs, tids, return_dict=False)[0]
+    out2 = m(sample, torch.tensor(400.0, device=DEV), ehs, tids).sample  # graph replay
+    want = SVDUNetEngine.from_module(ref).forward(sample, 400.0, ehs, tids)
+    assert torch.equal(out, want) and torch.equal(out2, want) and len(m.forward._cached) == 1

@@ -51,6 +51,13 @@ c)  # after the merge-prologue / slot-combine fixes: statistics tests, attention
   run bench_fused2  600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
   prof sd15 --steps 10 --warmup 2
   ;;
+d)  # attention bias / masks, SVD, int8 linear, then the whole suite (without the 4-minute SDXL test) and the SVD bench line
+  run t_new   1200 $PYT tests/test_ops_gpu.py -k "attention" tests/test_svd_gpu.py tests/test_reference_api_gpu.py -k "attention or svd or mix_rows or qlinear or compile_unet"
+  run t_mask   600 $PYT tests/test_unet_gpu.py -k "encoder_attention_mask"
+  run t_all   1800 $PYT tests --deselect tests/test_sdxl_gpu.py
+  run bench_svd 1200 python bench.py --config svd --steps 3 --warmup 1 --no-cpu-baseline
+  run bench    600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --dump-kernels gpurun_out/kernels.json
+  ;;
 quick)
   run t_quick  900 $PYT tests/test_ops_gpu.py tests/test_unet_gpu.py -k "${2:-not zzz}"
   run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json --no-cpu-baseline
