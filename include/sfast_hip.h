@@ -297,7 +297,10 @@ int sfast_hip_attention(const void *q, const void *k, const void *v, void *out,
                         const sfast_attn_params *p, sfast_stream_t stream);
 /* out = softmax(q k^T * scale + bias) v: the `attn_bias` argument of sfast_xformers::memory_efficient_attention
  * (libs/xformers/xformers_attention.py:30-47) / diffusers' attention_mask. bias[b][h][q][key] in the dtype of q, key stride 1,
- * element strides bias_strides = (b, h, q), 0 = broadcast (a key-padding mask is (Skv, 0, 0)); -inf entries mask a key.
+ * element strides bias_strides = (b, h, q), 0 = broadcast (a key-padding mask is (ld, 0, 0)); -inf entries mask a key.
+ * The MFMA kernel reads the bias in groups of 4 keys with dword loads: it is taken when the strides are even, the base is
+ * 4-byte aligned and every row is READABLE up to the next multiple of 4 keys (rows padded to 8 elements -- xformers' own
+ * requirement on attn_bias -- satisfy all of it; the padding values are never used); other layouts run the generic kernel.
  * bias == NULL is sfast_hip_attention. */
 int sfast_hip_attention_bias(const void *q, const void *k, const void *v, const void *bias, const int64_t *bias_strides,
                              void *out, const sfast_attn_params *p, sfast_stream_t stream);

@@ -369,8 +369,9 @@ extern "C" int sfast_hip_conv2d_stats_layout(const sfast_conv_params *p, const s
     const int64_t M = (int64_t)p->B * g.Ho * g.Wo;
     const int K = p->KH * p->KW * p->Cin;
     const int C2 = p->Cin - p->C1;
+    // the conditions of conv_route()'s MFMA branch that do not depend on pointers (dense NHWC activations, K-contiguous weights)
     const bool igemm = is_half(p->dtype) && p->Cout >= 16 && p->Cout % 8 == 0 && M > 0 && M <= INT32_MAX && K % 8 == 0 && p->C1 % 8 == 0 &&
-                       C2 % 8 == 0 && g.out_dense && g.ldo % 8 == 0 && p->variant < 100;
+                       C2 % 8 == 0 && g.x_dense && g.x2_dense && g.w_kcontig && g.out_dense && g.ldo % 8 == 0 && p->variant < 100;
     const bool glds_ok = !p->upsample2x && p->C1 % 64 == 0 && C2 % 64 == 0 && p->KH * p->KW <= 32;
     StatsLayout l{};
     if (!igemm || !igemm_stats_layout((int)M, p->Cout, K, false, p->variant, p->split_k, glds_ok, ext->gn_unit, ext->gn_rows_per_sample, l)) {

@@ -656,7 +656,9 @@ extern "C" int sfast_hip_attention_bias(const void *q, const void *k, const void
     int64_t bspan = 0;
     if (bias) {
         for (int i = 0; i < 3; ++i) a.bs[i] = bias_strides[i];
-        bspan = ((int64_t)(p->Sq - 1) * a.bs[2] + p->Skv) * 2;
+        // the kernel reads whole 4-key groups: the last group of a row may reach up to 3 elements past key Skv-1 (caller's contract:
+        // every bias row is readable up to the next multiple of 4 keys -- rows padded to 8 elements, as xformers requires, satisfy it)
+        bspan = ((int64_t)(p->Sq - 1) * a.bs[2] + (p->Skv + 3) / 4 * 4) * 2;
     }
     const bool half = p->dtype == SFAST_F16 || p->dtype == SFAST_BF16;
     const bool d_ok = p->D == 40 || p->D == 64 || p->D == 80 || p->D == 128 || p->D == 160;

@@ -179,3 +179,122 @@ def make_graphed_callable(func, example_inputs=None, example_kwarg_inputs=None, 
     graphed._deps = deps
     graphed._training = training
     return graphed
+
+
+# ---- per-module automatic graphing (reference cuda/graphs.py:296-352 + hooks/module_jit_hook.py:9-85) ---------------------------
+class AutoGraphCraphCompiler:
+    """Compiler object of the reference's module hook (its spelling): decides from the call's inputs / outputs whether a module
+    call can be replayed from a hipGraph (only tensors / scalars / strings in nested containers) and captures it."""
+
+    def __init__(self, **kwargs):
+        self.kwargs = kwargs
+        self._is_compiling = threading.local()
+
+    def is_compiling(self):
+        return getattr(self._is_compiling, "value", False)
+
+    def get_inputs_key(self, func, inputs, kwargs):
+        from ..utils.copy import can_be_perfectly_copied
+        if not can_be_perfectly_copied((inputs, kwargs)):
+            return None
+        return (hash_arg(inputs), hash_arg(kwargs))
+
+    def get_outputs_key(self, func, outputs):
+        from ..utils.copy import can_be_perfectly_copied
+        if not can_be_perfectly_copied(outputs):
+            return None
+        return hash_arg(outputs)
+
+    def compile(self, func, inputs, kwargs):
+        self._is_compiling.value = True
+        try:
+            graphed = simple_make_graphed_callable(func, inputs, kwargs, **self.kwargs)
+            wrapped = func.forward if isinstance(func, torch.nn.Module) else func
+
+            @functools.wraps(wrapped)
+            def functionalized(*args, **kw):
+                return graphed(*args, **kw)
+
+            owner = _owner_module(func)
+            if owner is not None:
+                functionalized.__self__ = owner
+            return functionalized
+        finally:
+            self._is_compiling.value = False
+
+
+class _LazyCompiledForward:
+    """Per-module call cache: the first call of an input signature runs eagerly (it reveals whether the outputs can be graphed and
+    whether the call mutates its inputs), later calls replay the captured graph; signatures that cannot be graphed stay eager."""
+    _CANNOT, _READY = object(), object()
+
+    def __init__(self, module, compiler):
+        self.module, self.compiler = module, compiler
+        self.forward = module.forward
+        self.cache = {}
+        self.lock = threading.Lock()
+        self.__self__ = module
+        self.__name__ = "forward"
+
+    def __call__(self, *args, **kwargs):
+        c = self.compiler
+        if c.is_compiling():
+            return self.forward(*args, **kwargs)
+        key = c.get_inputs_key(self.forward, args, kwargs)
+        if key is None:
+            return self.forward(*args, **kwargs)
+        hit = self.cache.get(key)
+        if hit is not None and hit is not self._CANNOT and hit is not self._READY:
+            return hit(*args, **kwargs)
+        with self.lock:
+            hit = self.cache.get(key)
+            if hit is self._CANNOT:
+                return self.forward(*args, **kwargs)
+            if hit is self._READY:
+                try:
+                    hit = self.cache[key] = c.compile(self.forward, args, kwargs)
+                except Exception:
+                    self.cache[key] = self._CANNOT
+                    logger.exception("Failed to graph %s", type(self.module).__name__)
+                    raise
+                return hit(*args, **kwargs)
+            if hit is not None:
+                return hit(*args, **kwargs)
+            out = self.forward(*args, **kwargs)
+            if c.get_outputs_key(self.forward, out) is None:
+                self.cache[key] = self._CANNOT
+            elif c.get_inputs_key(self.forward, args, kwargs) == key:  # inputs not mutated by the call
+                self.cache[key] = c.compile(self.forward, args, kwargs)
+            else:
+                self.cache[key] = self._READY
+            return out
+
+
+def apply_auto_graph_compiler_to_all_modules(m, filter_func=None, recursive=True, **kwargs):
+    """Wrap the forward of `m` (recursive=False) or of every module the filter accepts, walking like the reference's patch_module:
+    `filter_func(stack)` sees the [(name, module), ...] path from the root; an accepted module is wrapped and not descended into."""
+    compiler = AutoGraphCraphCompiler(**kwargs)
+
+    def wrap(mod):
+        if not isinstance(mod.forward, _LazyCompiledForward):
+            mod.forward = _LazyCompiledForward(mod, compiler)
+        return mod
+
+    if not recursive:
+        return wrap(m)
+    filt = filter_func if filter_func is not None else (lambda stack: True)
+
+    def walk(mod, stack):
+        for name, child in mod.named_children():
+            stack.append((name, child))
+            if filt(stack):
+                wrap(child)
+            else:
+                walk(child, stack)
+            stack.pop()
+
+    root = [(None, m)]
+    if filt(root):
+        return wrap(m)
+    walk(m, root)
+    return m

@@ -454,12 +454,17 @@ def attention(q, k, v, scale: Optional[float] = None, variant=0, attn_bias=None)
             bias = bias.to(q.dtype)
         while bias.ndim < 4:
             bias = bias.unsqueeze(0)
-        if bias.shape[-1] == Skv and (Skv % 2 or bias.stride(-1) != 1) and any(st % 2 for st, n in zip(bias.stride()[:3], bias.shape[:3]) if n > 1):
-            # rows at odd element offsets cannot be read with dword loads: re-lay the (un-broadcast) bias with rows padded to 8
-            # elements -- what xformers demands of its callers and diffusers does for its masks
-            padded = torch.zeros(bias.shape[:3] + ((Skv + 7) // 8 * 8,), dtype=bias.dtype, device=bias.device)
-            padded[..., :Skv] = bias
-            bias = padded[..., :Skv]
+        if bias.shape[-1] == Skv:
+            # the MFMA kernel reads 4-key groups with dword loads: rows must start at even element offsets and be readable up to the
+            # next multiple of 4 keys. A bias that is not laid out that way (odd row strides, or a dense tensor whose last row ends
+            # at an odd key count) is re-laid, un-broadcast, with rows padded to 8 elements -- what xformers demands of its callers
+            odd = bias.stride(-1) != 1 or any(st % 2 for st, n in zip(bias.stride()[:3], bias.shape[:3]) if n > 1)
+            last = bias.storage_offset() + sum((n - 1) * st for n, st in zip(bias.shape[:3], bias.stride()[:3])) + (Skv + 3) // 4 * 4
+            short = last * bias.element_size() > bias.untyped_storage().nbytes()
+            if odd or short or bias.storage_offset() % 2:
+                padded = torch.zeros(bias.shape[:3] + ((Skv + 7) // 8 * 8,), dtype=bias.dtype, device=bias.device)
+                padded[..., :Skv] = bias
+                bias = padded[..., :Skv]
         try:
             bias = bias.expand(B, H, Sq, Skv)  # broadcast dims get stride 0: nothing is materialised
         except RuntimeError:

@@ -159,7 +159,7 @@ def test_geglu_split_k(split):
 
 @pytest.mark.parametrize("M,K,N", [(8192, 320, 320), (8192, 320, 960), (2048, 2560, 640), (512, 1280, 1280), (154, 768, 640),
                                    (4095, 328, 324), (77, 64, 36), (130, 1280, 1280)])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23, 24, 25])
 def test_linear_variants(M, K, N, variant):
     x = rnd(M, K, seed=40)
     w = rnd(N, K, seed=41, scale=K ** -0.5)
@@ -216,7 +216,7 @@ def test_linear_epilogues(dtype, epi):
     compare(f"linear_epi {epi} {dtype}", y, want, *tol(dtype, 2.0), kernel=last_kernel())
 
 
-@pytest.mark.parametrize("variant", [11, 12, 13, 15, 21, 22, 23])
+@pytest.mark.parametrize("variant", [11, 12, 13, 15, 21, 22, 23, 24, 25])
 def test_dma_pipe_epilogues_bf16(variant):
     M, K, N = 700, 1280, 640
     dt = torch.bfloat16
@@ -304,7 +304,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23, 24, 25])
 def test_conv_igemm(case, variant):
     name, B, Cin, H, W, Cout, k, stride, pad, ex = case
     x = cl(rnd(B, Cin, H, W, seed=70))
@@ -563,7 +563,8 @@ def _stats_reference(y_nhwc_2d, lay):
     return rec
 
 
-@pytest.mark.parametrize("variant,split", [(0, 0), (1, 1), (2, 1), (3, 1), (5, 1), (11, 1), (12, 1), (13, 1), (21, 1), (22, 1), (23, 1), (21, 4), (23, 6), (3, 3)])
+@pytest.mark.parametrize("variant,split", [(0, 0), (1, 1), (2, 1), (3, 1), (5, 1), (11, 1), (12, 1), (13, 1), (21, 1), (22, 1), (23, 1), (24, 1), (25, 1),
+                                           (21, 4), (23, 6), (3, 3)])
 @pytest.mark.parametrize("cin,cout,hw,unit", [(320, 320, 32, 10), (640, 1280, 16, 20)])
 def test_conv_epilogue_emits_groupnorm_statistics(variant, split, cin, cout, hw, unit):
     import numpy as np
@@ -574,7 +575,7 @@ def test_conv_epilogue_emits_groupnorm_statistics(variant, split, cin, cout, hw,
     try:
         y, stats, lay = F().conv2d(x, w, b, z=z, padding=1, variant=variant, split_k=split, gn_unit=unit)
     except Exception as e:  # a tile that does not divide H*W cannot emit statistics: the library says so instead of guessing
-        assert (hw * hw) % {1: 128, 2: 128, 5: 256, 11: 128, 12: 128, 21: 128, 22: 128}.get(variant, 64) != 0 or "statistics" in str(e), e
+        assert (hw * hw) % {1: 128, 2: 128, 5: 256, 11: 128, 12: 128, 21: 128, 22: 128, 24: 128}.get(variant, 64) != 0 or "statistics" in str(e), e
         pytest.skip(f"variant {variant}: {e}")
     k = last_kernel()
     assert "+gnstats" in k

@@ -213,3 +213,24 @@ def test_qlinear_dynamic_op_takes_a_quantized_weight():
     # fp32 activations: dequantised weight through the ordinary kernel (the reference's own fallback)
     y32 = torch.ops.sfast.cutlass_qlinear_dynamic(x.float(), qw, lin.bias.float())
     torch.testing.assert_close(y32, want, rtol=1e-3, atol=1e-3)
+
+
+def test_auto_graph_compiler_on_modules():
+    """reference cuda/graphs.py:302-352: per-module lazy graphing -- first call eager, then hipGraph replay per input signature."""
+    from sfast.cuda.graphs import AutoGraphCraphCompiler, apply_auto_graph_compiler_to_all_modules
+    net = nn.Sequential(nn.Linear(64, 128), nn.GELU(), nn.Linear(128, 32)).cuda().half().eval()
+    ref = nn.Sequential(*[m for m in net]).eval()
+    with torch.no_grad():
+        x = torch.randn(8, 64, device="cuda", dtype=torch.float16)
+        want = ref(x).clone()
+        apply_auto_graph_compiler_to_all_modules(net, filter_func=lambda stack: isinstance(stack[-1][1], nn.Linear))
+        assert hasattr(net[0].forward, "cache") and not hasattr(net[1].forward, "cache")
+        y1 = net(x)        # eager pass, decides graphability and captures
+        y2 = net(x * 1.0)  # replay
+        torch.testing.assert_close(y1, want)
+        torch.testing.assert_close(y2, want)
+        assert len(net[0].forward.cache) == 1
+        y3 = net(torch.randn(3, 64, device="cuda", dtype=torch.float16))  # second signature
+        assert y3.shape == (3, 32) and len(net[0].forward.cache) == 2
+    c = AutoGraphCraphCompiler()
+    assert c.get_inputs_key(None, (x,), {}) is not None and c.get_inputs_key(None, (object(),), {}) is None and not c.is_compiling()
