@@ -27,7 +27,17 @@ struct IgemmArgs {
     int gn_slots;      // unit slots per tile_n (host: stats_slots(BNO, unit))
     int gn_rows_per_sample;  // host-side validation only
     int w_int8;              // weights are int8 [N][K] (ldw in bytes), dequantised to T while they are staged (igemm_w8_kernel)
+    // ---- block -> (tile, K-split) map over the 8 XCDs (decode_block, igemm_device.h) ----------------------------
+    // xmap = 1: 1-D grid of tiles*splits blocks; XCD b%8 owns a box of x_sp K-splits x x_tm tile rows x x_tn tile columns
+    // (2^x_lxn boxes along n, 2^x_lxm along m, the rest of the 8 along the K-splits). xmap = 0: grid (tiles, splits), every XCD a
+    // contiguous run of row-major tiles.
+    int xmap, x_lxn, x_lxm, x_tn, x_tm, x_sp;
 };
+
+// launch grid of the MFMA kernels for the block map carried by `a`
+static inline dim3 igemm_grid(const IgemmArgs &a) {
+    return a.xmap ? dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits), 1, 1) : dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)a.splits, 1);
+}
 
 // statistics slots a tile of `bno` output columns can overlap: units are `unit` channels wide, tile origins multiples of bno
 static inline int stats_slots(int bno, int unit) { return (bno - 1) / unit + 2; }

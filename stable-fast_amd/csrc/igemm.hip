@@ -61,18 +61,10 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs &a) {
     const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    // XCD-aware tile order: hardware places block b on XCD b%8; give each XCD a contiguous run
-    // of logical tiles (n fastest) so tiles sharing an activation row-panel share one L2.
-    int lid;
-    {
-        const int nblk = a.tiles_m * a.tiles_n;
-        const int bid = blockIdx.x;
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int tile_n = lid % a.tiles_n, tile_m = lid / a.tiles_n;
+    const BlockTile bt = decode_block(a);  // XCD-aware (tile, K-split) of this workgroup
+    const int tile_n = bt.tile_n, tile_m = bt.tile_m;
     const int m0 = tile_m * BM, n0 = tile_n * BNO;
-    const int kt_begin = blockIdx.y * a.ktiles_per_split;
+    const int kt_begin = bt.split * a.ktiles_per_split;
     const int kt_end = min(a.ktiles, kt_begin + a.ktiles_per_split);
 
     const int kc = tid & 7;
@@ -276,7 +268,7 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs &a) {
     // ---- epilogue: batched operand loads, fp32 math, 8-byte stores (igemm_device.h) -------------------------
     trace_mark(a, 4);
     run_epilogue<T, BM, BNO, FN, FM, GEGLU, EPI_EARLY, NT, STAGED>(a, acc, epi, smem, m0, n0, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi,
-                                                             tid, blockIdx.y);
+                                                             tid, bt.split);
     trace_finish(a);
 }
 
@@ -557,7 +549,7 @@ template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GEGLU, bool
 static int launch_one(const IgemmArgs &a, hipStream_t st) {
     constexpr int smem = 2 * (BM + BN) * 128;
     auto kern = igemm_kernel<T, BM, BN, WM, WN, MODE, GEGLU, STAGED>;
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n, a.splits), dim3(WM * WN * 64), smem, st, a);
+    hipLaunchKernelGGL(kern, igemm_grid(a), dim3(WM * WN * 64), smem, st, a);
     return check_launch("igemm");
 }
 
@@ -586,6 +578,7 @@ static int set_attr_one() {
     OP(T, 64, 128, 2, 2, 0, true)
 
 static int g_pipe_pref = -1;  // -1 auto, 0 force register pipe, 1 force LDS-DMA pipe (SFAST_IGEMM_PIPE)
+static int g_xmap_pref = 1;   // SFAST_XCD_MAP=0: legacy block order everywhere (A/B of choose_xcd_map)
 static int g_stage_pref = 0;  // 1: stage every eligible output tile through LDS (SFAST_STAGE_OUT=1), not only those that emit statistics
 
 int igemm_grouped_init();
@@ -606,6 +599,8 @@ int igemm_init() {
     if (!rc) rc = igemm_glds_ws_init();
     const char *so = getenv("SFAST_STAGE_OUT");
     g_stage_pref = (so && so[0] == '1') ? 1 : 0;
+    const char *xm = getenv("SFAST_XCD_MAP");
+    g_xmap_pref = (xm && xm[0] == '0') ? 0 : 1;
     const char *e = getenv("SFAST_IGEMM_PIPE");
     if (e && e[0] == 'r') g_pipe_pref = 0;
     if (e && e[0] == 'g') g_pipe_pref = 1;
@@ -873,6 +868,38 @@ int igemm_run_grouped(IgemmArgs &a, int dtype, int n_groups, const void *const *
     return check_launch("igemm_grouped");
 }
 
+// Block -> (tile, K-split) map over the 8 XCD L2s (decode_block, igemm_device.h). Every factorisation 8 = xs * xm * xn into K-split,
+// row and column boxes that divides (splits, tiles_m, tiles_n) is priced by the bytes it pulls across the fabric,
+// activations * xn + weights * xm, and the cheapest wins; K-split boxes replicate nothing, so split problems hand the whole
+// factor to xs when they can (each XCD then streams only its K-slice of both operands: the 1280-channel convs of the 16x16 level
+// read their 29-59 MB of weights ONCE instead of once per XCD that owns a tile of the column). Ties go to fewer column boxes
+// (an activation panel stays in one L2, as in the legacy order). No dividing factorisation: legacy order (xmap = 0).
+static void choose_xcd_map(IgemmArgs &a, int mode, bool geglu) {
+    a.xmap = 0;
+    if (!g_xmap_pref) return;
+    // unique operand bytes (a conv reads every input pixel once, whatever its im2col row count)
+    const double act_bytes = mode ? (double)(a.M / (a.Ho * a.Wo)) * a.H * a.W * (a.ups ? 0.25 : 1.0) * (a.C1 + a.C2) * 2.0 : (double)a.M * a.K * 2.0;
+    const double w_bytes = (geglu ? 2.0 : 1.0) * (double)a.N * a.K * 2.0;
+    double best = 1e300;
+    for (int lxs = 3; lxs >= 0; --lxs) {
+        if (a.splits % (1 << lxs)) continue;
+        for (int lxn = 0; lxn + lxs <= 3; ++lxn) {
+            const int lxm = 3 - lxs - lxn;
+            if (a.tiles_m % (1 << lxm) || a.tiles_n % (1 << lxn)) continue;
+            const double cost = act_bytes * (1 << lxn) + w_bytes * (1 << lxm);
+            if (cost < best) {
+                best = cost;
+                a.xmap = 1;
+                a.x_lxn = lxn;
+                a.x_lxm = lxm;
+                a.x_tn = a.tiles_n >> lxn;
+                a.x_tm = a.tiles_m >> lxm;
+                a.x_sp = a.splits >> lxs;
+            }
+        }
+    }
+}
+
 // entry used by api_gemm_conv.hip. mode: 0 linear, 1 conv. Fills plan fields of `a`.
 int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int split, void *ws, size_t ws_bytes,
               hipStream_t st) {
@@ -887,6 +914,7 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
     a.splits = p.splits;
     a.partial = nullptr;
     a.trace = g_igemm_trace;
+    choose_xcd_map(a, mode, geglu);
     if (a.out_scale == 0.f) a.out_scale = 1.0f;
     // staged (LDS -> 16-byte row segments) stores need 16-byte aligned output rows; statistics additionally whole tiles per sample
     const int bno_sel = geglu ? p.v.BN / 2 : p.v.BN;
@@ -913,8 +941,10 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
     }
     char pipe[8];
     snprintf(pipe, sizeof(pipe), p.v.pipe == 2 ? "ws%d" : p.v.pipe ? "dma%d" : "reg", p.v.ns);
-    set_kernel_name("igemm_%s_%s%s[%dx%d,split=%d,%s]%s", mode ? "conv" : "lin", dtype == SFAST_F16 ? "f16" : "bf16",
-                    geglu ? "_geglu" : "", p.v.BM, p.v.BN, p.splits, pipe, a.gn_stats ? "+gnstats" : (a.stage_out ? "+staged" : ""));
+    char xmap[24] = "";
+    if (a.xmap) snprintf(xmap, sizeof(xmap), "@xcd%dx%dx%d", 8 >> (a.x_lxm + a.x_lxn), 1 << a.x_lxm, 1 << a.x_lxn);  // K-split x row x column boxes
+    set_kernel_name("igemm_%s_%s%s[%dx%d,split=%d,%s]%s%s", mode ? "conv" : "lin", dtype == SFAST_F16 ? "f16" : "bf16",
+                    geglu ? "_geglu" : "", p.v.BM, p.v.BN, p.splits, pipe, a.gn_stats ? "+gnstats" : (a.stage_out ? "+staged" : ""), xmap);
     int rc;
     if (p.v.pipe == 2)
         rc = igemm_glds_ws_launch(a, dtype, mode, geglu, p.v.BM, p.v.BN, p.v.ns, st);

@@ -58,6 +58,7 @@ __device__ __forceinline__ void touch_args(const IgemmArgs &a) {
                  "s"(a.out), "s"(a.partial), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.ldx), "s"(a.ldw), "s"(a.ldo), "s"(a.ldr),
                  "s"(a.ld_rowbias), "s"(a.rows_per_seg), "s"(a.rows_per_batch), "s"(a.act), "s"(a.res_before_act), "s"(a.alpha));
     asm volatile("" ::"s"(a.tiles_m), "s"(a.tiles_n), "s"(a.ktiles), "s"(a.ktiles_per_split), "s"(a.splits), "s"(a.trace));
+    asm volatile("" ::"s"(a.xmap), "s"(a.x_lxn), "s"(a.x_lxm), "s"(a.x_tn), "s"(a.x_tm), "s"(a.x_sp));
 }
 __device__ __forceinline__ void touch_conv_args(const IgemmArgs &a) {
     asm volatile("" ::"s"(a.H), "s"(a.W), "s"(a.C1), "s"(a.C2), "s"(a.Ho), "s"(a.Wo), "s"(a.KH), "s"(a.KW), "s"(a.stride_h), "s"(a.stride_w),
@@ -96,6 +97,45 @@ struct PixelDecoder {
         }
     }
 };
+// ---- which tile / K-split a workgroup computes ------------------------------------------------------------------
+// The hardware places block b on XCD b % 8 and each XCD has its own L2, so what an XCD's blocks have in common decides how often
+// an operand crosses the fabric: a weight element is fetched once per XCD that owns a tile in its column box and K-split, an
+// activation element once per XCD that owns a tile in its row box and K-split.
+//  * xmap = 1 (host: choose_xcd_map picks the factorisation of 8 into K-split x row x column boxes that minimises
+//    activation_bytes * column_boxes + weight_bytes * row_boxes; K-split boxes replicate nothing): inside a box the order is
+//    tile_n fastest, then tile_m, then split.
+//  * xmap = 0 (tile counts that do not divide): each XCD a contiguous run of row-major tiles, splits on blockIdx.y.
+struct BlockTile {
+    int tile_m, tile_n, split;
+};
+__device__ __forceinline__ BlockTile decode_block(const IgemmArgs &a) {
+    BlockTile t;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, k = bid >> 3;
+    if (a.xmap) {
+        const int jn = xcd & ((1 << a.x_lxn) - 1);
+        const int im = (xcd >> a.x_lxn) & ((1 << a.x_lxm) - 1);
+        const int is = xcd >> (a.x_lxn + a.x_lxm);
+        const int q = fdiv22(k, a.x_tn, __builtin_amdgcn_rcpf((float)a.x_tn));  // grids stay far below 2^22 blocks
+        const int s = fdiv22(q, a.x_tm, __builtin_amdgcn_rcpf((float)a.x_tm));
+        t.tile_n = jn * a.x_tn + (k - q * a.x_tn);
+        t.tile_m = im * a.x_tm + (q - s * a.x_tm);
+        t.split = is * a.x_sp + s;
+    } else {
+        const int nblk = a.tiles_m * a.tiles_n;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        t.tile_m = lid / a.tiles_n;
+        t.tile_n = lid - t.tile_m * a.tiles_n;
+        t.split = blockIdx.y;
+    }
+    // everything above is wave-uniform; the float reciprocal runs on the VALU, so pin the results back into SGPRs
+    t.tile_m = __builtin_amdgcn_readfirstlane(t.tile_m);
+    t.tile_n = __builtin_amdgcn_readfirstlane(t.tile_n);
+    t.split = __builtin_amdgcn_readfirstlane(t.split);
+    return t;
+}
+
 // row -> batch index for the per-batch row bias (time-embedding projection): same trick
 struct BatchOfRow {
     int d;

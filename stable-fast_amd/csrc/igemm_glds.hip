@@ -66,16 +66,10 @@ __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, NS *
     const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    int lid;
-    {
-        const int nblk = a.tiles_m * a.tiles_n;
-        const int bid = blockIdx.x;
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int tile_n = lid % a.tiles_n, tile_m = lid / a.tiles_n;
+    const BlockTile bt = decode_block(a);  // XCD-aware (tile, K-split) of this workgroup
+    const int tile_n = bt.tile_n, tile_m = bt.tile_m;
     const int m0 = tile_m * BM, n0 = tile_n * BNO;
-    const int kt_begin = blockIdx.y * a.ktiles_per_split;
+    const int kt_begin = bt.split * a.ktiles_per_split;
     const int kt_end = min(a.ktiles, kt_begin + a.ktiles_per_split);
 
     // staging role of this thread: tile row (tid>>3) + i*RPP, PHYSICAL chunk tid&7, which must hold
@@ -299,7 +293,7 @@ __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, NS *
     // ---- epilogue: batched operand loads, fp32 math, 8-byte stores (igemm_device.h) -------------------------
     trace_mark(a, 4);
     run_epilogue<T, BM, BNO, FN, FM, GEGLU, EPI_EARLY, NT, STAGED>(a, acc, epi, smem, m0, n0, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi,
-                                                             tid, blockIdx.y);
+                                                             tid, bt.split);
     trace_finish(a);
 }
 
@@ -355,7 +349,7 @@ static int glds_dispatch(const IgemmArgs &a, int BM_, int BN_, int NS_, bool geg
 #define LAUNCH_OP(TT, BM, BN, WM, WN, NS, MODE_, G_)                                                         \
     if (BM_ == BM && BN_ == BN && NS_ == NS && geglu == G_) {                                                             \
         auto kern = igemm_glds_kernel<TT, BM, BN, WM, WN, NS, MODE_, G_>;                                    \
-        hipLaunchKernelGGL(kern, dim3(a.tiles_m *a.tiles_n, a.splits), dim3(WM *WN * 64), NS *(BM + BN) * 128, st, a); \
+        hipLaunchKernelGGL(kern, igemm_grid(a), dim3(WM *WN * 64), NS *(BM + BN) * 128, st, a); \
         return check_launch("igemm_glds");                                                                   \
     }
     if constexpr (std::is_same<T, f16>::value) {
@@ -364,7 +358,7 @@ static int glds_dispatch(const IgemmArgs &a, int BM_, int BN_, int NS_, bool geg
     if (BM_ == BM && BN_ == BN && NS_ == NS && MODE == MODE_ && g_igemm_exp == E) {                                     \
         auto kern = igemm_glds_kernel<f16, BM, BN, WM, WN, NS, MODE_, false, E>;                                        \
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, NS *(BM + BN) * 128); \
-        hipLaunchKernelGGL(kern, dim3(a.tiles_m *a.tiles_n, a.splits), dim3(WM *WN * 64), NS *(BM + BN) * 128, st, a);  \
+        hipLaunchKernelGGL(kern, igemm_grid(a), dim3(WM *WN * 64), NS *(BM + BN) * 128, st, a);  \
         return check_launch("igemm_glds_exp");                                                                          \
     }
             LAUNCH_EXP(128, 160, 4, 1, 4, 1, 1) LAUNCH_EXP(128, 160, 4, 1, 4, 1, 2) LAUNCH_EXP(128, 160, 4, 1, 4, 1, 3)

@@ -54,16 +54,10 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, igemm_min_waves((WM * WN 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    int lid;
-    {
-        const int nblk = a.tiles_m * a.tiles_n;
-        const int bid = blockIdx.x;
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int tile_n = lid % a.tiles_n, tile_m = lid / a.tiles_n;
+    const BlockTile bt = decode_block(a);  // XCD-aware (tile, K-split) of this workgroup
+    const int tile_n = bt.tile_n, tile_m = bt.tile_m;
     const int m0 = tile_m * BM, n0 = tile_n * BNO;
-    const int kt_begin = blockIdx.y * a.ktiles_per_split;
+    const int kt_begin = bt.split * a.ktiles_per_split;
     const int kt_end = min(a.ktiles, kt_begin + a.ktiles_per_split);
 
     if (wave >= WM * WN) {
@@ -255,7 +249,7 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, igemm_min_waves((WM * WN 
 
     trace_mark(a, 4);
     run_epilogue<T, BM, BNO, FN, FM, GEGLU, EPI_EARLY, NC, STAGED>(a, acc, epi, smem, m0, n0, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi,
-                                                             tid, blockIdx.y);
+                                                             tid, bt.split);
     trace_finish(a);
 }
 
@@ -310,12 +304,12 @@ static int ws_dispatch(const IgemmArgs &a, int BM_, int BN_, int NS_, bool geglu
         if constexpr (!G_) {                                                                                                   \
             if (a.stage_out) {                                                                                                 \
                 auto ks = igemm_glds_ws_kernel<TT, BM, BN, WM, WN, PW, NS, MODE_, false, true>;                                \
-                hipLaunchKernelGGL(ks, dim3(a.tiles_m *a.tiles_n, a.splits), dim3((WM * WN + PW) * 64), NS *(BM + BN) * 128, st, a); \
+                hipLaunchKernelGGL(ks, igemm_grid(a), dim3((WM * WN + PW) * 64), NS *(BM + BN) * 128, st, a); \
                 return check_launch("igemm_glds_ws_staged");                                                                   \
             }                                                                                                                  \
         }                                                                                                                      \
         auto kern = igemm_glds_ws_kernel<TT, BM, BN, WM, WN, PW, NS, MODE_, G_>;                                               \
-        hipLaunchKernelGGL(kern, dim3(a.tiles_m *a.tiles_n, a.splits), dim3((WM * WN + PW) * 64), NS *(BM + BN) * 128, st, a); \
+        hipLaunchKernelGGL(kern, igemm_grid(a), dim3((WM * WN + PW) * 64), NS *(BM + BN) * 128, st, a); \
         return check_launch("igemm_glds_ws");                                                                                  \
     }
     if (!geglu) {

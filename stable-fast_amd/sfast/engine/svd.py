@@ -296,7 +296,7 @@ class SVDUNetEngine(UNet2DEngine):
         plan.keep.append(cp)
         ae_ptr, ab_ptr = act_emb.data_ptr(), act_bf.data_ptr()
         self._add(plan, "misc", "emb.repeat_per_frame", 0.0, BF * T * 4.0,
-                  lambda s: L.check(lib.sfast_hip_strided_copy(ae_ptr, ab_ptr, C.byref(cp), s), "emb.repeat_per_frame"), lane=LANE_TEMB)
+                  lambda s, cp=cp: L.check(lib.sfast_hip_strided_copy(ae_ptr, ab_ptr, C.byref(cp), s), "emb.repeat_per_frame"), lane=LANE_TEMB)
         rnames = self._st_resnet_names()
         offs, tot = {}, 0
         for rn in rnames:
@@ -309,8 +309,25 @@ class SVDUNetEngine(UNet2DEngine):
                                   [P[rn + ".time_emb_proj.bias"] for rn in grp], temb_bf, BF, T, T, tot, out_offset=offs[grp[0]], lane=LANE_TEMB)
         # ---- conv_in on the frames (NCHW per frame, read through strides) -----------------------------------------------------
         h = pool.get(BF * H * W * c0)
-        self._op_conv(plan, "conv_in", sample, None, P["conv_in.weight"], P["conv_in.bias"], h, BF, H, W, self.in_ch, 0, c0, 3, 1, 1,
-                      xs=(self.in_ch * H * W, W, 1, H * W), kind="conv_in")
+        if self.in_ch % 8 == 0:
+            # 8 latent + conditioning channels: one strided copy to NHWC makes conv_in an MFMA implicit GEMM (K = 72) -- read through
+            # NCHW strides it ran on the generic small-channel kernel: 18 ms of a 292 ms step at 25 x 72 x 128 (profiles/r02_bench_svd_run5)
+            x_nhwc = pool.get(BF * H * W * self.in_ch)
+            cpi = L.CopyParams()
+            cpi.elem_bytes, cpi.ndim = 2, 3
+            cpi.shape = (C.c_int64 * 4)(BF, H * W, self.in_ch, 1)
+            cpi.src_strides = (C.c_int64 * 4)(self.in_ch * H * W, 1, H * W, 0)
+            cpi.dst_strides = (C.c_int64 * 4)(H * W * self.in_ch, self.in_ch, 1, 0)
+            plan.keep.append(cpi)
+            sp_, dp_ = sample.data_ptr(), x_nhwc.data_ptr()
+            self._add(plan, "misc", "sample.to_nhwc", 0.0, 2.0 * BF * H * W * self.in_ch * self.esize,
+                      lambda s, cpi=cpi: L.check(lib.sfast_hip_strided_copy(sp_, dp_, C.byref(cpi), s), "sample.to_nhwc"))
+            self._op_conv(plan, "conv_in", x_nhwc, None, P["conv_in.weight"], P["conv_in.bias"], h, BF, H, W, self.in_ch, 0, c0, 3, 1, 1,
+                          kind="conv_in")
+            pool.put(x_nhwc)
+        else:
+            self._op_conv(plan, "conv_in", sample, None, P["conv_in.weight"], P["conv_in.bias"], h, BF, H, W, self.in_ch, 0, c0, 3, 1, 1,
+                          xs=(self.in_ch * H * W, W, 1, H * W), kind="conv_in")
         skips = [(h, c0)]
         ch, cH, cW = c0, H, W
         for i, t in enumerate(self.down_types):

@@ -179,6 +179,32 @@ def test_linear_split_k(split, variant):
     compare(f"linear split{split} v{variant}", y, R.linear_ref(x, w, b, residual=r), *tol(x.dtype), kernel=last_kernel())
 
 
+@pytest.mark.parametrize("variant,split,want", [(3, 1, "@xcd1x2x4"), (3, 8, "@xcd8x1x1"), (3, 2, "@xcd2x1x4"), (13, 4, "@xcd4x1x2"),
+                                                (21, 1, "@xcd1x4x2"), (23, 4, "@xcd4x1x2"), (1, 3, "@xcd1x4x2")])
+def test_linear_xcd_box_map(variant, split, want):
+    """Block -> (tile, K-split) boxes per XCD (igemm.hip choose_xcd_map): weight-heavy problems put the XCD factor on the K-splits first,
+    then on the cheaper of row / column boxes; the map must stay a bijection whatever the factorisation."""
+    x, w, b = rnd(512, 1024, seed=47), rnd(1280, 1024, seed=48, scale=1024 ** -0.5), rnd(1280, seed=49)
+    r = rnd(512, 1280, seed=50)
+    y = F().linear(x, w, b, residual=r, variant=variant, split_k=split)
+    assert last_kernel().endswith(want), last_kernel()  # tags: K-split x row x column boxes
+    compare(f"linear xcd map v{variant} split{split}", y, R.linear_ref(x, w, b, residual=r), *tol(x.dtype), kernel=last_kernel())
+
+
+def test_geglu_and_conv_xcd_box_map():
+    x, w, b = rnd(512, 1280, seed=51), rnd(2 * 5120, 1280, seed=52, scale=1280 ** -0.5), rnd(2 * 5120, seed=53)
+    for variant in (1, 11, 21):
+        y = F().linear(x, w, b, geglu=True, variant=variant, split_k=1)
+        assert "@xcd1x1x8" in last_kernel(), last_kernel()  # 26 MB of weights: every XCD owns an eighth of the columns
+        compare(f"geglu xcd map v{variant}", y, R.linear_ref(x, w, b, geglu=True), *tol(x.dtype), kernel=last_kernel())
+    x, w, b = cl(rnd(2, 1280, 16, 16, seed=54)), cl(rnd(1280, 1280, 3, 3, seed=55, scale=11520 ** -0.5)), rnd(1280, seed=56)
+    want = R.conv2d_ref(x, w, b, None, 1.0, 1, 1)
+    for variant, split, tag in ((21, 4, "@xcd4x1x2"), (21, 8, "@xcd8x1x1"), (4, 2, "@xcd2x1x4"), (23, 1, "@xcd1x2x4"), (13, 6, "@xcd2x1x4")):
+        y = F().conv2d(x, w, b, padding=1, variant=variant, split_k=split)
+        assert last_kernel().endswith(tag), last_kernel()
+        compare(f"conv xcd map v{variant} split{split}", y, want, *tol(x.dtype, 2.0), kernel=last_kernel())
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("epi", ["res_after", "res_before_relu", "gelu", "silu", "rowbias", "segs3", "inplace_res", "strided_out"])
 def test_linear_epilogues(dtype, epi):

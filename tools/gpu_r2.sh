@@ -58,6 +58,23 @@ d)  # attention bias / masks, SVD, int8 linear, then the whole suite (without th
   run bench_svd 1200 python bench.py --config svd --steps 3 --warmup 1 --no-cpu-baseline
   run bench    600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --dump-kernels gpurun_out/kernels.json
   ;;
+e)  # re-run of what session d failed on + SVD bench + SD1.5 line
+  run t_new   1200 $PYT tests/test_ops_gpu.py -k "attention or igemm or variant" tests/test_svd_gpu.py tests/test_reference_api_gpu.py -k "attention or svd or qlinear or compile_unet or auto_graph"
+  run t_mask   600 $PYT tests/test_unet_gpu.py -k "encoder_attention_mask"
+  run bench_svd 1200 python bench.py --config svd --steps 3 --warmup 1 --no-cpu-baseline
+  run bench    600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --dump-kernels gpurun_out/kernels.json
+  ;;
+f)  # XCD box map (choose_xcd_map): whole suite, then A/B against the legacy order on SD1.5 / SDXL (own tune cache per mode), SVD line
+  run t_all   1800 $PYT tests --deselect tests/test_sdxl_gpu.py
+  export SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_cache_xmap1.json
+  run bench_map    600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --dump-kernels gpurun_out/kernels.json
+  SFAST_XCD_MAP=0 SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_cache_xmap0.json run bench_legacy 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  run bench_map2   600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  SFAST_XCD_MAP=0 SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_cache_xmap0.json run bench_legacy2 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  run sdxl_map     900 python bench.py --config sdxl --steps 10 --warmup 2 --no-cpu-baseline --no-roofline
+  SFAST_XCD_MAP=0 SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_cache_xmap0.json run sdxl_legacy 900 python bench.py --config sdxl --steps 10 --warmup 2 --no-cpu-baseline --no-roofline
+  run bench_svd   1200 python bench.py --config svd --steps 3 --warmup 1 --no-cpu-baseline
+  ;;
 quick)
   run t_quick  900 $PYT tests/test_ops_gpu.py tests/test_unet_gpu.py -k "${2:-not zzz}"
   run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json --no-cpu-baseline
