@@ -12,6 +12,7 @@
 //   * a virtual channel concat (x | x2) lets the UNet's up-blocks normalise torch.cat([h, skip])
 //     without materialising it.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace sfast {
@@ -716,7 +717,19 @@ struct GnPlan {
     int nsplit, rows_stats, rows_apply, napply;
 };
 
-static GnPlan gn_plan(const sfast_gn_params *p) {
+// workgroups of the one-pass apply kernel (sfast_hip_group_norm_apply), over all samples: every workgroup merges the sample's
+// statistics records in its prologue, so fewer, fatter workgroups trade prologue repeats against streaming width.
+// SFAST_GN_APPLY_WGS overrides (A/B knob).
+static int gn_apply_wgs_target() {
+    static int v = [] {
+        const char *e = getenv("SFAST_GN_APPLY_WGS");
+        const int n = e ? atoi(e) : 0;
+        return n > 0 ? n : 256;
+    }();
+    return v;
+}
+
+static GnPlan gn_plan(const sfast_gn_params *p, int apply_wgs = 256) {
     GnPlan pl{};
     const int cpg = p->G > 0 ? p->C / p->G : 0;
     pl.fast = p->layout == SFAST_NHWC && p->dtype != SFAST_F32 && p->G > 0 && p->C % p->G == 0 &&
@@ -743,7 +756,7 @@ static GnPlan gn_plan(const sfast_gn_params *p) {
     if (pl.nsplit < 1) pl.nsplit = 1;
     pl.rows_stats = ceil_div(p->HW, pl.nsplit);
     pl.nsplit = ceil_div(p->HW, pl.rows_stats);
-    int wanta = ceil_div(256, p->N);
+    int wanta = ceil_div(apply_wgs, p->N);
     int na = wanta < max_split ? wanta : max_split;
     if (na < 1) na = 1;
     pl.rows_apply = ceil_div(p->HW, na);
@@ -911,7 +924,7 @@ extern "C" int sfast_hip_group_norm(const void *x, const void *x2, const void *g
     SFAST_REQUIRE(p->C1 == p->C || (x2 && p->layout == SFAST_NHWC), SFAST_ERR_INVALID,
                   "group_norm: concat needs x2 and NHWC");
     hipStream_t st = (hipStream_t)stream;
-    GnPlan pl = gn_plan(p);
+    GnPlan pl = gn_plan(p, gn_apply_wgs_target());
     const bool ptr_ok = aligned16(x) && aligned16(y) && (p->C1 == p->C || aligned16(x2)) && (!gamma || aligned16(gamma)) &&
                         (!beta || aligned16(beta));
     const bool al4 = ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)(x2 ? x2 : x)) | ((uintptr_t)(gamma ? gamma : x)) |

@@ -161,8 +161,8 @@ def tune_plan(plan, device, dtype_tag="f16", verbose=False):
                     continue
                 bno = bn // 2 if geglu else bn
                 wgs = -(-M // bm) * -(-N // bno) * s
-                if wgs > 8192 or (s > 1 and wgs > 2048):
-                    continue
+                if (s > 1 and wgs > 2048) or (s == 1 and wgs > 8192 and bm * bn < 128 * 128):
+                    continue  # no split-K once the tiles alone fill the chip; no 64-wide tiles on problems of > 8192 of them
                 p.variant, p.split_k = v, s
                 if launch_with(sp, ws.data_ptr(), ws.numel()) != 0:
                     continue

@@ -239,3 +239,21 @@ def test_denoise_loop_replicas_gloo_world2(built_lib):
             c32 = torch.tensor(coefs[i], dtype=torch.float32).tolist()  # the loop keeps its coefficient table in float32
             lat = cfg_ddim_ref(eps.flatten(), lat.flatten(), c32, 7.5).to(torch.float16).reshape(lat.shape)
         assert torch.equal(res[0][2][r], lat.float()), r
+
+
+def test_packaged_tune_cache_is_well_formed():
+    """The (variant, split-K) choices shipped with the package (measured on an MI355X, profiles/r02_tune_cache_run6.json): every entry
+    names a known kernel variant and a split the planner accepts; importing them is what spares a fresh process the timing runs."""
+    import json
+    from sfast.engine import autotune
+    with open(autotune.PACKAGED_CACHE) as f:
+        d = json.load(f)
+    assert len(d) > 100
+    for k, (v, s) in d.items():
+        arch, dt, kind, mnk, epi = k.split("|")
+        assert arch == "gfx950" and dt in ("f16", "bf16") and kind in ("gemm", "conv"), k
+        assert len(mnk.split("x")) == 3
+        geglu = kind == "gemm" and epi.startswith("(1,")
+        assert v in (autotune.GEGLU_VARIANTS if geglu else autotune.VARIANTS) and s in autotune.SPLITS, (k, v, s)
+    n0 = len(autotune.export_cache())
+    assert autotune.import_cache(d) >= 0 and len(autotune.export_cache()) >= max(n0, len(d))

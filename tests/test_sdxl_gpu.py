@@ -74,8 +74,8 @@ def test_sdxl_full_size_unet_parity():
     log_value("sdxl B=2 128x128 full-size parity", engine_vs_fp32=e_engine, eager16_vs_fp32=e_eager, engine_vs_eager16=rel_l2(y, y16),
               f16_storage_floor=floor, max_abs_engine=float((y.float() - y32).abs().max()), ref_absmax=float(y32.abs().max()),
               dispatches=None)
-    assert e_engine < 4e-3, (e_engine, e_eager, floor)
-    assert e_engine < 1.5 * e_eager + 1e-4, (e_engine, e_eager)
+    assert e_engine < 2e-3, (e_engine, e_eager, floor)   # measured 1.16e-3
+    assert e_engine < e_eager, (e_engine, e_eager)        # eager fp16: 2.2e-3
     assert e_engine < 1.5 * floor + 2e-4, (e_engine, floor)  # the engine sits at the f16-storage floor of this network
 
 
@@ -101,5 +101,5 @@ def test_sd15_batch16_parity():
         y32 = ref(sample.float(), t, ehs.float()).sample
     e_engine, e_eager = rel_l2(y, y32), rel_l2(y16, y32)
     log_value("sd15 B=16 parity", engine_vs_fp32=e_engine, eager16_vs_fp32=e_eager, rows01_vs_B2_plan=e_batch)
-    assert e_engine < 4e-3 and e_engine < 1.5 * e_eager + 1e-4, (e_engine, e_eager)
+    assert e_engine < 2.5e-3 and e_engine < e_eager, (e_engine, e_eager)   # SD1.5 B=16: measured 1.60e-3 vs 2.98e-3
     assert e_batch < 2e-3, e_batch

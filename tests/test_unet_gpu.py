@@ -3,11 +3,18 @@ hipGraph replay, and behind sfast.compilers.compile()) vs the oracle UNet.
 
 Tolerance: BASELINE.json asks for <= 1e-3 relative vs "the diffusers fp16 UNet". diffusers is not
 installable, so the stand-ins are the oracle restatement in fp32 (ground truth) and the same
-restatement run eagerly in fp16 on the GPU (= what diffusers fp16 computes). An fp16 pipeline cannot
-be closer to the fp32 truth than fp16 storage rounding of ~100 chained layers allows (the CPU
-emulation of the plan with exact per-op math already sits at ~1.3e-3), so the asserted bar is:
-relative L2 error vs fp32 oracle <= 4e-3 AND not worse than 1.5x the eager-fp16 stand-in's own
-error; every measured value is logged to gpurun_out/parity.jsonl and quoted in DESIGN.md.
+restatement run eagerly in fp16 on the GPU (= what diffusers fp16 computes). The error budget
+(tools/error_budget.py, profiles/r02_error_budget_sd15_gpu.jsonl) splits the engine's distance to
+the fp32 truth: rounding every activation to f16 ONCE per op with otherwise exact fp32 arithmetic
+already costs 1.63e-3 on SD1.5 (1.06e-3 on SDXL) -- the floor of ANY pipeline that stores f16
+activations -- the engine measures 1.60e-3 (1.16e-3), its f16 attention probabilities contribute
+7.6e-5, and eager PyTorch fp16 sits at 3.35e-3 (2.2e-3). 1e-3 against fp32 is therefore not
+reachable with f16 activations; against the fp16 pipeline the target names, the engine is the
+more accurate of the two. Asserted on the full-size models: <= 2.5e-3 vs the fp32 oracle AND
+better than the eager-fp16 stand-in's own error (SDXL additionally: within 1.5x of the measured
+storage floor); the tiny topologies (random weights, no averaging over width) keep 4e-3 where
+they exercise plumbing. Every measured value is logged to gpurun_out/parity.jsonl and quoted in
+DESIGN.md.
 """
 import os
 import types
@@ -92,8 +99,8 @@ def test_sd15_unet_parity_and_graph(sd15):
     log_value("sd15 B=2 parity", engine_vs_fp32=e_engine, eager16_vs_fp32=e_eager, engine_vs_eager16=e_cross,
               max_abs_engine=float((y.float() - y32).abs().max()), ref_absmax=float(y32.abs().max()))
     assert torch.isfinite(y).all()
-    assert e_engine < 4e-3, (e_engine, e_eager)
-    assert e_engine < 1.5 * e_eager + 1e-4, (e_engine, e_eager)
+    assert e_engine < 2.5e-3, (e_engine, e_eager)      # measured 1.60e-3; f16-storage floor 1.63e-3
+    assert e_engine < e_eager, (e_engine, e_eager)     # closer to the truth than the fp16 pipeline it replaces (3.35e-3)
 
     # hipGraph replay reproduces the eager plan bit for bit, and is deterministic
     plan = eng.get_plan(2, 64, 64, 77)

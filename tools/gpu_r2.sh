@@ -75,6 +75,15 @@ f)  # XCD box map (choose_xcd_map): whole suite, then A/B against the legacy ord
   SFAST_XCD_MAP=0 SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_cache_xmap0.json run sdxl_legacy 900 python bench.py --config sdxl --steps 10 --warmup 2 --no-cpu-baseline --no-roofline
   run bench_svd   1200 python bench.py --config svd --steps 3 --warmup 1 --no-cpu-baseline
   ;;
+g)  # GroupNorm apply: workgroup-count sweep (prologue repeats vs streaming width), same tune cache for all
+  export SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_cache_xmap1.json
+  run bench_w256   600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  SFAST_GN_APPLY_WGS=64  run bench_w64  600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  SFAST_GN_APPLY_WGS=128 run bench_w128 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  SFAST_GN_APPLY_WGS=512 run bench_w512 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  SFAST_GN_FUSE=0 run bench_nofuse 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  run bench_w256b  600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  ;;
 quick)
   run t_quick  900 $PYT tests/test_ops_gpu.py tests/test_unet_gpu.py -k "${2:-not zzz}"
   run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json --no-cpu-baseline
