@@ -84,6 +84,22 @@ g)  # GroupNorm apply: workgroup-count sweep (prologue repeats vs streaming widt
   SFAST_GN_FUSE=0 run bench_nofuse 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
   run bench_w256b  600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
   ;;
+final)  # the round's evidence: default bench line (packaged tune cache), through-compile gap, rocprof steady window, PMC traffic,
+        # SDXL / VAE / SVD lines, the whole GPU suite as the driver runs it, smoke
+  unset SFAST_TUNE_CACHE
+  run smoke      600 python __graft_entry__.py smoke
+  run bench_default 1200 python bench.py --dump-kernels gpurun_out/kernels.json
+  run bench_compile  900 python bench.py --steps 30 --warmup 5 --through-compile --no-cpu-baseline --no-roofline
+  run bench_torchrun 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  prof sd15 --steps 10 --warmup 2
+  export SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_cache.json
+  run pmc        1500 bash tools/gpu_pmc_bench.sh
+  unset SFAST_TUNE_CACHE
+  run bench_sdxl 1200 python bench.py --config sdxl --steps 20 --warmup 3 --no-cpu-baseline
+  run bench_vae   900 python bench.py --config vae --steps 20 --warmup 3 --no-cpu-baseline
+  run bench_svd  1200 python bench.py --config svd --steps 3 --warmup 1 --no-cpu-baseline
+  run t_all      2400 $PYT tests
+  ;;
 quick)
   run t_quick  900 $PYT tests/test_ops_gpu.py tests/test_unet_gpu.py -k "${2:-not zzz}"
   run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json --no-cpu-baseline
