@@ -54,8 +54,14 @@ struct AttnArgs {
     int64_t bs[3];        // element strides (b, h, q); 0 = broadcast
     uint32_t bspan;       // bytes spanned by the bias rows of one (batch, head)
     float inv_scale;      // bias enters the RAW scores as bias / scale (the softmax scale is folded into the exp2 argument)
+    // XCD-aware block order (flash kernel): xmap = 1 -> 1-D grid of nqb * B * H blocks; the hardware puts block i on XCD i % 8, and
+    // all nqb query blocks of one (batch, head) are given to ONE XCD, so that head's K / V (re-read by every query block) cross the
+    // fabric once and then hit that XCD's L2. With the (q-block, head, batch) grid the query blocks of a head were spread over all
+    // eight L2s: 53 MB of fabric traffic per SD1.5 self-attention launch against 16 MB of operands (profiles/r02_pmc_traffic_run8.log).
+    int xmap, nqb;
 };
 extern unsigned long long *g_igemm_trace;  // igemm_glds.hip
+static int g_attn_xmap = 1;                // SFAST_XCD_MAP=0: (q-block, head, batch) grid as in round 1 (A/B)
 
 __device__ __forceinline__ f32x16 amfma32(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -103,8 +109,22 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+    int b, h, qb;
+    if (a.xmap) {
+        const int bid = blockIdx.x, xcd = bid & 7, k = bid >> 3;
+        int pl = (int)((float)k * __builtin_amdgcn_rcpf((float)a.nqb));  // k / nqb, exact after one correction each way (k < 2^22)
+        int r = k - pl * a.nqb;
+        pl += (r >= a.nqb) ? 1 : 0;
+        pl -= (r < 0) ? 1 : 0;
+        r = k - pl * a.nqb;
+        const int pair = __builtin_amdgcn_readfirstlane(xcd + 8 * pl);  // (batch, head) pairs: consecutive ones on different XCDs
+        qb = __builtin_amdgcn_readfirstlane(r);
+        b = pair / a.H;
+        h = pair - b * a.H;
+    } else {
+        b = blockIdx.z, h = blockIdx.y, qb = blockIdx.x;
+    }
+    const int q0 = qb * (NW * 32) + wave * 32;
     const int qrow = q0 + l31;
 
     const T *Qp = (const T *)a.q + (int64_t)b * a.qs[0] + (int64_t)h * a.qs[2];
@@ -576,19 +596,28 @@ template <typename T> static int attn_init_t() {
 }
 
 int attention_init() {
+    const char *xm = getenv("SFAST_XCD_MAP");
+    g_attn_xmap = (xm && xm[0] == '0') ? 0 : 1;
     int rc = attn_init_t<f16>();
     if (!rc) rc = attn_init_t<bf16>();
     return rc;
 }
 
+static dim3 attn_grid(AttnArgs &a, int rows_per_block) {
+    a.nqb = ceil_div(a.Sq, rows_per_block);
+    a.xmap = (g_attn_xmap && (a.B * a.H) % 8 == 0 && (int64_t)a.nqb * a.B * a.H < (1 << 22)) ? 1 : 0;
+    return a.xmap ? dim3((unsigned)(a.nqb * a.B * a.H), 1, 1) : dim3((unsigned)a.nqb, (unsigned)a.H, (unsigned)a.B);
+}
+
 template <typename T, int D>
-static int attn_launch_d(const AttnArgs &a, int nw, hipStream_t st) {
+static int attn_launch_d(const AttnArgs &a_in, int nw, hipStream_t st) {
+    AttnArgs a = a_in;
     if (a.bias) {  // biased instantiation: four waves per workgroup
-        const dim3 gridb(ceil_div(a.Sq, 128), a.H, a.B);
+        const dim3 gridb = attn_grid(a, 128);
         hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 0, true>), gridb, dim3(256), AttnGeom<D>::LDS_TOTAL, st, a);
         return check_launch("attention(bias)");
     }
-    const dim3 grid(ceil_div(a.Sq, nw * 32), a.H, a.B);
+    const dim3 grid = attn_grid(a, nw * 32);
     if constexpr (std::is_same<T, f16>::value && (D == 40 || D == 64)) {
         if (a.trace != nullptr && nw == 4) {
             hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1>), grid, dim3(256), AttnGeom<D>::LDS_TOTAL, st, a);

@@ -100,6 +100,17 @@ final)  # the round's evidence: default bench line (packaged tune cache), throug
   run bench_svd  1200 python bench.py --config svd --steps 3 --warmup 1 --no-cpu-baseline
   run t_all      2400 $PYT tests
   ;;
+h)  # XCD-aware block order of the flash kernel: tests, A/B (SFAST_XCD_MAP=0 = round-1 order for GEMMs and attention), traffic
+  run t_attn  1200 $PYT tests/test_ops_gpu.py -k "attention" tests/test_unet_gpu.py tests/test_svd_gpu.py tests/test_reference_api_gpu.py -k "attention or sd15 or tiny or svd or compile"
+  run bench_map    600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --dump-kernels gpurun_out/kernels.json
+  SFAST_XCD_MAP=0 run bench_legacy 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  run bench_map2   600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  SFAST_XCD_MAP=0 run bench_legacy2 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  run sdxl_map     900 python bench.py --config sdxl --steps 10 --warmup 2 --no-cpu-baseline --no-roofline
+  SFAST_XCD_MAP=0 run sdxl_legacy 900 python bench.py --config sdxl --steps 10 --warmup 2 --no-cpu-baseline --no-roofline
+  export SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_cache.json
+  run pmc        1500 bash tools/gpu_pmc_bench.sh
+  ;;
 quick)
   run t_quick  900 $PYT tests/test_ops_gpu.py tests/test_unet_gpu.py -k "${2:-not zzz}"
   run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json --no-cpu-baseline
