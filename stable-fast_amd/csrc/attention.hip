@@ -58,7 +58,7 @@ struct AttnArgs {
     // all nqb query blocks of one (batch, head) are given to ONE XCD, so that head's K / V (re-read by every query block) cross the
     // fabric once and then hit that XCD's L2. With the (q-block, head, batch) grid the query blocks of a head were spread over all
     // eight L2s: 53 MB of fabric traffic per SD1.5 self-attention launch against 16 MB of operands (profiles/r02_pmc_traffic_run8.log).
-    int xmap, nqb;
+    int xmap, nqb, ppx;  // ppx = (batch, head) pairs per XCD
 };
 extern unsigned long long *g_igemm_trace;  // igemm_glds.hip
 static int g_attn_xmap = 1;                // SFAST_XCD_MAP=0: (q-block, head, batch) grid as in round 1 (A/B)
@@ -117,7 +117,9 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnArgs a) {
         pl += (r >= a.nqb) ? 1 : 0;
         pl -= (r < 0) ? 1 : 0;
         r = k - pl * a.nqb;
-        const int pair = __builtin_amdgcn_readfirstlane(xcd + 8 * pl);  // (batch, head) pairs: consecutive ones on different XCDs
+        // (batch, head) pairs: an XCD owns CONSECUTIVE heads -- in the fused-QKV layout a head's row is D*2 bytes (80 B at D = 40)
+        // inside a 128-B line shared with its neighbour head; neighbours on different XCDs would each fetch the whole line
+        const int pair = __builtin_amdgcn_readfirstlane(xcd * a.ppx + pl);
         qb = __builtin_amdgcn_readfirstlane(r);
         b = pair / a.H;
         h = pair - b * a.H;
@@ -606,6 +608,7 @@ int attention_init() {
 static dim3 attn_grid(AttnArgs &a, int rows_per_block) {
     a.nqb = ceil_div(a.Sq, rows_per_block);
     a.xmap = (g_attn_xmap && (a.B * a.H) % 8 == 0 && (int64_t)a.nqb * a.B * a.H < (1 << 22)) ? 1 : 0;
+    a.ppx = a.B * a.H / 8;
     return a.xmap ? dim3((unsigned)(a.nqb * a.B * a.H), 1, 1) : dim3((unsigned)a.nqb, (unsigned)a.H, (unsigned)a.B);
 }
 

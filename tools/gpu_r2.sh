@@ -111,6 +111,14 @@ h)  # XCD-aware block order of the flash kernel: tests, A/B (SFAST_XCD_MAP=0 = r
   export SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_cache.json
   run pmc        1500 bash tools/gpu_pmc_bench.sh
   ;;
+i)  # attention: consecutive heads per XCD -- tests, bench, traffic
+  run t_attn   900 $PYT tests/test_ops_gpu.py -k "attention" tests/test_unet_gpu.py -k "sd15 or tiny"
+  run bench_map    600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --dump-kernels gpurun_out/kernels.json
+  SFAST_XCD_MAP=0 run bench_legacy 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  run bench_map2   600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  export SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_cache.json
+  run pmc        1500 bash tools/gpu_pmc_bench.sh
+  ;;
 quick)
   run t_quick  900 $PYT tests/test_ops_gpu.py tests/test_unet_gpu.py -k "${2:-not zzz}"
   run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json --no-cpu-baseline
