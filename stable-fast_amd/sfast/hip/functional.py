@@ -114,6 +114,8 @@ def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, act=None, x2=Non
         y = torch.empty(out_shape, dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     else:
         y = torch.empty(out_shape, dtype=x.dtype, device=x.device)
+    if y.numel() == 0:
+        return y  # empty batch / empty spatial extent: nothing to launch (torch semantics)
     p = L.GnParams(_dtype(x), L.NHWC if nhwc else L.NCHW, N, Ctot, HW, num_groups, C1, _act(act), float(eps))
     nb = lib.sfast_hip_group_norm_workspace_bytes(C.byref(p))
     ws, nb = _ws(nb, x)
@@ -157,6 +159,8 @@ def layer_norm(x, normalized_shape: Sequence[int], weight=None, bias=None, eps=1
     if bias is not None:
         bias = bias.to(x.dtype).contiguous()
     y = torch.empty_like(x)
+    if y.numel() == 0:
+        return y
     p = L.LnParams(_dtype(x), m, n, float(eps))
     rc = lib.sfast_hip_layer_norm(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), C.byref(p), _stream(x))
     L.check(rc, "sfast_hip_layer_norm")
@@ -232,6 +236,8 @@ def linear(x, weight, bias=None, *, act=None, residual=None, alpha=1.0, res_befo
         out2d = out.reshape(M, N)
         if out2d.data_ptr() != out.data_ptr():
             raise L.SfastHipError("linear: `out` must be viewable as [M, N]")
+    if M == 0 and not gn_unit:
+        return out2d.reshape(*lead, N) if out is None else out  # zero rows: nothing to launch
     ldo = out2d.stride(0) if M > 1 else N
     res2d = None
     ldr = 0
@@ -386,6 +392,8 @@ def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dila
         channels_last_out = _is_cl(x) or _is_cl(weight)
     fmt = torch.channels_last if channels_last_out else torch.contiguous_format
     y = torch.empty((B, Cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=fmt)
+    if y.numel() == 0 and not gn_unit:
+        return y  # empty batch: nothing to launch
     zz = None
     if z is not None:
         zz = z.to(x.dtype).expand(B, Cout, Ho, Wo)
@@ -439,6 +447,10 @@ def attention(q, k, v, scale: Optional[float] = None, variant=0, attn_bias=None)
         raise L.SfastHipError("attention: q/k/v shape or dtype mismatch")
     q, k, v = [t if t.stride(-1) == 1 else t.contiguous() for t in (q, k, v)]
     out = torch.empty((B, Sq, H, D), dtype=q.dtype, device=q.device)
+    if out.numel() == 0:
+        return out  # no queries
+    if Skv == 0:
+        raise L.SfastHipError("attention: no keys (softmax over an empty set is undefined)")
     p = L.AttnParams()
     p.dtype, p.B, p.H, p.Sq, p.Skv, p.D = _dtype(q), B, H, Sq, Skv, D
     p.qs = _i64x3(q.stride()[:3])

@@ -53,8 +53,21 @@ _def("cutlass_linear_geglu(Tensor input, Tensor weight0, Tensor? bias0, Tensor w
 
 # ---- conv + bias (+ alpha*z) (+ activation) ----------------------------------------------------------
 def _conv(input, weight, bias, z, alpha, stride, padding, dilation, transposed, output_padding, groups, act):
-    if transposed or groups != 1 or any(int(o) != 0 for o in output_padding):
-        raise RuntimeError("sfast conv ops on ROCm support groups == 1, non-transposed convolutions only")
+    if transposed or any(int(o) != 0 for o in output_padding):
+        raise RuntimeError("sfast conv ops on ROCm support non-transposed convolutions only")
+    if groups != 1:
+        # grouped / depthwise: one native launch per group on channel-sliced views (the reference leaves these to ATen,
+        # cudnn_convolution_impl.cc:1265-1286); the groups' outputs are joined by a copy -- data movement only
+        cin_g, cout_g = input.shape[1] // groups, weight.shape[0] // groups
+        if input.shape[1] != cin_g * groups or weight.shape[0] != cout_g * groups or weight.shape[1] != cin_g:
+            raise RuntimeError("sfast conv: channels are not divisible by groups")
+        outs = []
+        for g in range(groups):
+            zg = None if z is None else (z[:, g * cout_g:(g + 1) * cout_g] if z.shape[1] == weight.shape[0] else z)
+            outs.append(_conv(input[:, g * cin_g:(g + 1) * cin_g], weight[g * cout_g:(g + 1) * cout_g],
+                              None if bias is None else bias[g * cout_g:(g + 1) * cout_g], zg, alpha, stride, padding, dilation,
+                              False, output_padding, 1, act))
+        return torch.cat(outs, dim=1)
     if input.ndim == 3:  # 1-D conv as 2-D, like the reference (cudnn_convolution_impl.cc:1242-1252)
         y = _conv(input.unsqueeze(2), weight.unsqueeze(2), bias, None if z is None else z.unsqueeze(2), alpha,
                   [1, stride[0]], [0, padding[0]], [1, dilation[0]], transposed, [0, 0], groups, act)

@@ -732,3 +732,27 @@ def test_attention_bias_leading_masked_tiles_and_generic_path():
 def rel(a, b):
     a, b = a.double().flatten(), b.double().flatten()
     return float((a - b).norm() / b.norm())
+
+
+def test_empty_and_degenerate_inputs():
+    """Zero-row / zero-batch inputs return empty tensors of the right shape without a launch (torch semantics; the reference's
+    ops inherit them from ATen); an attention without keys is an error, not a NaN tensor."""
+    from sfast.hip.lib import SfastHipError
+    f = F()
+    w, b = rnd(64, 32, seed=1), rnd(64, seed=2)
+    y = f.linear(torch.empty(0, 32, device=DEV, dtype=torch.float16), w, b)
+    assert y.shape == (0, 64)
+    y = f.linear(torch.empty(3, 0, 32, device=DEV, dtype=torch.float16), w, b, act="gelu")
+    assert y.shape == (3, 0, 64)
+    x0 = torch.empty(0, 32, 8, 8, device=DEV, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    assert f.group_norm(x0, 4, rnd(32, seed=3), rnd(32, seed=4), act="silu").shape == (0, 32, 8, 8)
+    assert f.layer_norm(torch.empty(0, 5, 32, device=DEV, dtype=torch.float16), [32], rnd(32, seed=5), rnd(32, seed=6)).shape == (0, 5, 32)
+    assert f.conv2d(x0, cl(rnd(16, 32, 3, 3, seed=7)), rnd(16, seed=8), padding=1).shape == (0, 16, 8, 8)
+    q = torch.empty(2, 0, 4, 40, device=DEV, dtype=torch.float16)
+    k = rnd(2, 77, 4, 40, seed=9)
+    assert f.attention(q, k, k).shape == (2, 0, 4, 40)
+    with pytest.raises(SfastHipError):
+        f.attention(rnd(2, 16, 4, 40, seed=10), k[:, :0], k[:, :0])
+    # one row, one key, one channel group: smallest non-empty problems
+    y = f.attention(rnd(1, 1, 1, 40, seed=11), k[:1, :1, :1], k[:1, :1, :1])
+    compare("attention 1x1", y, k[:1, :1, :1].float(), *tol(torch.float16))

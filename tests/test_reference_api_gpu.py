@@ -83,6 +83,24 @@ def test_conv_bias_add_family(name, act):
         torch.testing.assert_close(fused, out, rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("groups,cin,cout", [(2, 64, 128), (4, 32, 32), (32, 32, 32)])
+def test_conv_bias_grouped_and_depthwise(groups, cin, cout):
+    """groups > 1 (the reference hands these to ATen, cudnn_convolution_impl.cc:1265-1286): per-group native launches."""
+    torch.manual_seed(1)
+    conv = nn.Conv2d(cin, cout, 3, padding=1, groups=groups).cuda().half()
+    x = torch.randn(2, cin, 20, 24, device="cuda", dtype=torch.float16)
+    z = torch.randn(2, cout, 20, 24, device="cuda", dtype=torch.float16)
+    with torch.no_grad():
+        want = conv(x)
+        got = torch.ops.sfast.cudnn_convolution_bias(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, False, [0, 0], groups)
+        torch.testing.assert_close(got, want, rtol=1e-2, atol=1e-2)
+        got = torch.ops.sfast.cudnn_convolution_bias_add_relu(x, conv.weight, conv.bias, z, 0.5, conv.stride, conv.padding, conv.dilation,
+                                                              False, [0, 0], groups)
+        torch.testing.assert_close(got, F.relu(want + 0.5 * z), rtol=1e-2, atol=1e-2)
+    with pytest.raises(RuntimeError):
+        torch.ops.sfast.cudnn_convolution_bias(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, True, [0, 0], groups)
+
+
 def test_lowp_linear_family():
     x = torch.randn(300, 640, device="cuda", dtype=torch.float16)
     lin = nn.Linear(640, 1280).cuda().half()

@@ -119,6 +119,10 @@ i)  # attention: consecutive heads per XCD -- tests, bench, traffic
   export SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_cache.json
   run pmc        1500 bash tools/gpu_pmc_bench.sh
   ;;
+j)  # new edge-case / grouped-conv tests, and the B = 16 (8 images per GPU, BASELINE configs[3] per-GPU shape) autotune pass
+  run t_new   900 $PYT tests/test_ops_gpu.py -k "empty or xcd" tests/test_reference_api_gpu.py -k "grouped or conv_bias"
+  SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_b16.json run bench_b16 1200 python bench.py --images 8 --steps 10 --warmup 2 --no-cpu-baseline
+  ;;
 quick)
   run t_quick  900 $PYT tests/test_ops_gpu.py tests/test_unet_gpu.py -k "${2:-not zzz}"
   run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json --no-cpu-baseline
