@@ -569,7 +569,8 @@ def main():
     if rank == 0:
         value = world * args.steps / elapsed
         out = {
-            "metric": "UNet iters/sec SD1.5 512x512 bs=1 fp16" if args.config == "sd15" else "UNet iters/sec SDXL 1024x1024 bs=1 fp16",
+            "metric": (f"UNet iters/sec SD1.5 512x512 bs={args.images} fp16" if args.config == "sd15"
+                       else f"UNet iters/sec SDXL 1024x1024 bs={args.images} fp16"),
             "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_image_50_steps_unet_and_scheduler": elapsed / args.steps * 1e3 * 50 / max(1, args.images), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
