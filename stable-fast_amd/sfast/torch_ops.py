@@ -9,7 +9,8 @@ Schemas follow the reference headers:
 
 The implementations are registered for the CUDA (= ROCm) dispatch key only: calling them with CPU
 tensors is a dispatcher error, there is no ATen fallback (the hot path must not silently leave the
-HIP kernels). They are inference ops (no autograd formulas).
+HIP kernels). They are inference ops; the conv family additionally carries the reference's backward
+formula (its LoRA-training example differentiates through the fused convs).
 """
 import torch
 
@@ -90,12 +91,57 @@ def _mk_conv_bias_add(act):
     return op
 
 
+def _conv_autograd(name, act, has_z):
+    """Backward of the fused conv ops for the reference's LoRA-training use (its autograd Function,
+    cudnn_convolution_impl.cc:1289-1399): activation derivative from the saved OUTPUT, then the library convolution backward
+    (the reference calls torch::convolution_backward too -- training is not the path this package accelerates), the residual's
+    gradient reduced to z's shape and scaled by alpha. The forward stays the HIP kernel."""
+    def setup(ctx, inputs, output):
+        if has_z:
+            x, w, b, z, alpha, stride, padding, dilation, transposed, output_padding, groups = inputs
+        else:
+            (x, w, b, stride, padding, dilation, transposed, output_padding, groups), z, alpha = inputs, None, None
+        ctx.save_for_backward(x, w, output)
+        ctx.conv = (None if b is None else list(b.shape), list(stride), list(padding), list(dilation), bool(transposed),
+                    list(output_padding), int(groups))
+        ctx.z_shape = None if z is None else tuple(z.shape)
+        ctx.alpha = 1.0 if alpha is None else float(alpha)
+
+    def backward(ctx, grad):
+        x, w, y = ctx.saved_tensors
+        if act == "sigmoid":
+            g = grad * y * (1 - y)
+        elif act == "relu":
+            g = grad * (y > 0).to(grad.dtype)
+        elif act == "tanh":
+            g = grad * (1 - y * y)
+        else:
+            g = grad
+        g = g.contiguous()
+        bias_sizes, stride, padding, dilation, transposed, output_padding, groups = ctx.conv
+        need = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2] and bias_sizes is not None]
+        gx = gw = gb = None
+        if any(need):
+            gx, gw, gb = torch.ops.aten.convolution_backward(g, x, w, bias_sizes, stride, padding, dilation, transposed, output_padding,
+                                                             groups, need)
+        if not has_z:
+            return gx, gw, gb, None, None, None, None, None, None
+        gz = None
+        if ctx.z_shape is not None and ctx.needs_input_grad[3]:
+            gz = torch.zeros(ctx.z_shape, dtype=g.dtype, device=g.device) if ctx.alpha == 0.0 else g.sum_to_size(ctx.z_shape) * ctx.alpha
+        return gx, gw, gb, gz, None, None, None, None, None, None, None
+
+    torch.library.register_autograd(f"sfast::{name}", backward, setup_context=setup)
+
+
 _CONV_ARGS = "int[] stride, int[] padding, int[] dilation, bool transposed, int[] output_padding, int groups"
 for _suffix, _act in (("", None), ("_sigmoid", "sigmoid"), ("_relu", "relu"), ("_tanh", "tanh")):
     _def(f"cudnn_convolution_bias{_suffix}(Tensor input, Tensor weight, Tensor? bias, {_CONV_ARGS}) -> Tensor",
          _mk_conv_bias(_act))
     _def(f"cudnn_convolution_bias_add{_suffix}(Tensor input, Tensor weight, Tensor? bias, Tensor? z, Scalar? alpha, "
          f"{_CONV_ARGS}) -> Tensor", _mk_conv_bias_add(_act))
+    _conv_autograd(f"cudnn_convolution_bias{_suffix}", _act, False)
+    _conv_autograd(f"cudnn_convolution_bias_add{_suffix}", _act, True)
 
 
 # ---- low-precision GEMM family ---------------------------------------------------------------------------

@@ -101,6 +101,35 @@ def test_conv_bias_grouped_and_depthwise(groups, cin, cout):
         torch.ops.sfast.cudnn_convolution_bias(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, True, [0, 0], groups)
 
 
+@pytest.mark.parametrize("name,act", [("", None), ("_sigmoid", torch.sigmoid), ("_relu", F.relu), ("_tanh", torch.tanh)])
+def test_conv_ops_backward_matches_eager(name, act):
+    """The fused conv ops carry the reference's autograd formula (cudnn_convolution_impl.cc:1289-1399; its LoRA training example
+    differentiates through them): gradients of input / weight / bias / z against eager conv2d (+ alpha*z) (+ activation) in fp32."""
+    torch.manual_seed(3)
+    conv = nn.Conv2d(16, 32, 3, padding=1).cuda()
+    x = torch.randn(2, 16, 12, 12, device="cuda", requires_grad=True)
+    z = torch.randn(2, 32, 1, 1, device="cuda", requires_grad=True)   # broadcast residual: its gradient is summed back to this shape
+    w, b = conv.weight.detach().clone().requires_grad_(True), conv.bias.detach().clone().requires_grad_(True)
+    args = ([1, 1], [1, 1], [1, 1], False, [0, 0], 1)
+
+    def eager(x, w, b, z):
+        y = F.conv2d(x, w, b, padding=1) + 0.5 * z
+        return y if act is None else act(y)
+
+    y = getattr(torch.ops.sfast, f"cudnn_convolution_bias_add{name}")(x, w, b, z, 0.5, *args)
+    g = torch.randn_like(y)
+    got = torch.autograd.grad(y, (x, w, b, z), g)
+    want = torch.autograd.grad(eager(x, w, b, z), (x, w, b, z), g)
+    for a, e, n in zip(got, want, "xwbz"):
+        assert a.shape == e.shape, n
+        torch.testing.assert_close(a, e, rtol=2e-3, atol=2e-3, msg=lambda m, n=n: f"grad {n}: {m}")
+    y = getattr(torch.ops.sfast, f"cudnn_convolution_bias{name}")(x, w, b, *args)
+    got = torch.autograd.grad(y, (x, w, b), g)
+    want = torch.autograd.grad(eager(x, w, b, torch.zeros_like(z)), (x, w, b), g)
+    for a, e in zip(got, want):
+        torch.testing.assert_close(a, e, rtol=2e-3, atol=2e-3)
+
+
 def test_lowp_linear_family():
     x = torch.randn(300, 640, device="cuda", dtype=torch.float16)
     lin = nn.Linear(640, 1280).cuda().half()
