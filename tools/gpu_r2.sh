@@ -123,6 +123,15 @@ j)  # new edge-case / grouped-conv tests, and the B = 16 (8 images per GPU, BASE
   run t_new   900 $PYT tests/test_ops_gpu.py -k "empty or xcd" tests/test_reference_api_gpu.py -k "grouped or conv_bias"
   SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_b16.json run bench_b16 1200 python bench.py --images 8 --steps 10 --warmup 2 --no-cpu-baseline
   ;;
+lite)  # bench line + steady-window profile + new backward test (a second evidence set when the first landed on a slow box)
+  unset SFAST_TUNE_CACHE
+  rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Power|mclk" | head -6 >> gpurun_out/session.log
+  run t_bwd     600 $PYT tests/test_reference_api_gpu.py -k "backward or grouped"
+  run bench_default 1200 python bench.py --dump-kernels gpurun_out/kernels.json
+  run bench_compile  900 python bench.py --steps 30 --warmup 5 --through-compile --no-cpu-baseline --no-roofline
+  prof sd15 --steps 10 --warmup 2
+  rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Power|mclk" | head -6 >> gpurun_out/session.log
+  ;;
 quick)
   run t_quick  900 $PYT tests/test_ops_gpu.py tests/test_unet_gpu.py -k "${2:-not zzz}"
   run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json --no-cpu-baseline
