@@ -132,6 +132,13 @@ lite)  # bench line + steady-window profile + new backward test (a second eviden
   prof sd15 --steps 10 --warmup 2
   rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Power|mclk" | head -6 >> gpurun_out/session.log
   ;;
+nograph)  # are kernels slower inside the replayed graph than in an eager replay? rocprofv3 trace of both
+  unset SFAST_TUNE_CACHE
+  prof sd15 --steps 10 --warmup 2
+  mv gpurun_out/kernel_stats_sd15.csv gpurun_out/kernel_stats_graph.csv; mv gpurun_out/kernel_stats_sd15.txt gpurun_out/kernel_stats_graph.txt
+  prof sd15 --steps 10 --warmup 2 --no-graph
+  mv gpurun_out/kernel_stats_sd15.csv gpurun_out/kernel_stats_eager.csv; mv gpurun_out/kernel_stats_sd15.txt gpurun_out/kernel_stats_eager.txt
+  ;;
 quick)
   run t_quick  900 $PYT tests/test_ops_gpu.py tests/test_unet_gpu.py -k "${2:-not zzz}"
   run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json --no-cpu-baseline
