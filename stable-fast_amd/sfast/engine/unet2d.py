@@ -162,8 +162,12 @@ def capture_plan_graph(plan, stream, pool=None, tail=None, calibrate=True):
 
     Two graph shapes are possible: a single chain, or the chain with the time-embedding / text-K/V side lanes
     forked into parallel branches (`UNetPlan.run_forked`). Which one replays faster depends on how much idle
-    capacity the main chain leaves, so both are captured and the faster one (median of a few replays) is kept --
-    the same measure-then-commit policy as the kernel autotuner."""
+    capacity the main chain leaves, so both are captured and the faster one is kept -- the same measure-then-commit
+    policy as the kernel autotuner. The measure is the steady state of a denoise loop: 8 replays queued back to back
+    between one event pair (median of 3). A single replay followed by a host synchronisation charges every graph its
+    launch latency and ranked the forked shape first (5.64 vs 5.70 ms) although back to back it is the slower one
+    (5.60 vs 5.42 ms: with the side lanes reduced to ~8 grouped launches the fork / join edges cost more than the
+    overlap returns; tools/replay_gap_probe.py, profiles/r02_replay_gap_probe.log)."""
     dev = plan.engine.device
 
     def cap(forked):
@@ -192,14 +196,15 @@ def capture_plan_graph(plan, stream, pool=None, tail=None, calibrate=True):
             g.replay()
             g.replay()
             ts = []
-            for _ in range(5):
+            for _ in range(3):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(stream)
-                g.replay()
+                for _ in range(8):
+                    g.replay()
                 b.record(stream)
                 b.synchronize()
-                ts.append(a.elapsed_time(b))
-            t = sorted(ts)[2]
+                ts.append(a.elapsed_time(b) / 8)
+            t = sorted(ts)[1]
             cal = getattr(plan, "graph_calibration_ms", None) or {}
             cal["forked" if forked else "serial"] = t
             plan.graph_calibration_ms = cal
