@@ -87,11 +87,11 @@ def in_situ_timing(plan, idxs, reps=3):
     """Duration of the launches `idxs` of the plan INSIDE the step: the whole plan runs eagerly in program order, one launch per op,
     and only the chosen launches are bracketed by HIP events on the launch stream. This is what the roofline object quotes: the
     launch sees the caches its predecessor left behind, as in the graph replay and in the rocprofv3 trace of this command (a burst
-    of identical launches re-reads its own inputs from L2: the D = 40 flash kernel measured 38.6 us in bursts against 45.6 us in
-    the trace). The interval of an EMPTY event pair is measured and reported, not subtracted: the raw interval is conservative,
-    and it is what lands within ~5 % of the trace (inside the replayed graph the chip runs ~7 % slower than in an eager replay
-    with launch gaps -- sustained clocks -- and ROCm refuses timing events inside a captured graph:
-    "External events are disallowed in rocm", tools/graph_event_probe.py)."""
+    of identical launches re-reads its own inputs from L2 and reads ~20 % low). The interval of an EMPTY event pair is measured and
+    reported, not subtracted. Against the trace of the same session the raw intervals read ~10-15 % low on the long launches (self-
+    attention 77-80 us vs 83-87 us) and high on the 10 us ones; the trace shows the same per-dispatch durations for graph and eager
+    replays (profiles/r02_kernel_stats_{graph,eager}_replay_run15.txt), so the difference is how a marker-packet interval and a
+    dispatch's begin/end timestamps delimit a kernel, not a different execution."""
     stream = torch.cuda.current_stream()
     sp = stream.cuda_stream
     want = set(idxs)
@@ -122,13 +122,12 @@ def in_situ_timing(plan, idxs, reps=3):
 
 
 def differential_graph_timing(plan, idxs, replays=30, rounds=3):
-    """Time of the launches `idxs` INSIDE the replayed hipGraph, by difference: the step is captured twice on one stream -- complete,
-    and with those launches left out -- both graphs are replayed back to back in alternation, and HIP events around `replays`
-    replays give (t_full - t_without) / len(idxs) per launch. Events around a single launch read low on ROCm (the marker packets
-    carry no barrier bit and overlap the kernel they bracket: 41.8 us against 48.7 us in the rocprofv3 trace of the same session,
-    while the trace shows identical kernel durations in graph and eager replays, profiles/r02_kernel_stats_*_replay_run15.txt), and
-    timing events are refused inside a captured graph; milliseconds of replay have no such problem. Values computed by the
-    graph without the launches are garbage; nothing reads them."""
+    """What the replayed hipGraph loses when the launches `idxs` are left out: the step is captured twice on one stream -- complete,
+    and without those launches -- and HIP events around `replays` back-to-back replays of each give (t_full - t_without) per
+    step. ROCm refuses timing events inside a captured graph ("External events are disallowed in rocm",
+    tools/graph_event_probe.py), so this is the only event-based view from inside the graph; it is an EXCLUSIVE time (a kernel's
+    ramp-up and drain overlap its neighbours' and do not come back when it is removed) and reads ~20 % below the rocprofv3
+    per-dispatch durations. Values computed by the graph without the launches are garbage; nothing reads them."""
     s = torch.cuda.Stream()
     skip = set(idxs)
     graphs = []
@@ -208,17 +207,19 @@ def roofline_from(rows, plan=None):
     dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["seconds"])
     share = dom["seconds"] / total
     timing = "HIP events around bursts of 4 identical launches (eager replay of the plan)"
+    extra = {}
     if plan is not None:
-        try:
+        situ, overhead = in_situ_timing(plan, dom["idx"])
+        dom = dict(dom, seconds=sum(situ.values()))
+        timing = (f"HIP events around each of this symbol's launches inside an eager in-order replay of the whole step, 3 rounds; raw "
+                  f"intervals (an empty event pair measures {overhead * 1e6:.1f} us, not subtracted)")
+        try:  # second opinion from inside the replayed graph: what the step loses when these launches are left out
             dt, t_full, t_wo = differential_graph_timing(plan, dom["idx"])
-            dom = dict(dom, seconds=dt)
-            timing = (f"in-graph, by difference: HIP events around 30 back-to-back replays of the step captured as a serial hipGraph "
-                      f"({t_full * 1e3:.3f} ms) and of the same graph without this symbol's {len(dom['idx'])} launches ({t_wo * 1e3:.3f} ms), best of 3 rounds")
+            extra = dict(in_graph_exclusive_us=dt / len(dom["idx"]) * 1e6,
+                         in_graph_method=(f"difference of 30 back-to-back replays of the step as a serial hipGraph ({t_full * 1e3:.3f} ms) and of the "
+                                          f"same graph without this symbol's {len(dom['idx'])} launches ({t_wo * 1e3:.3f} ms), best of 3 rounds"))
         except RuntimeError:
-            situ, overhead = in_situ_timing(plan, dom["idx"])
-            dom = dict(dom, seconds=sum(situ.values()))
-            timing = (f"HIP events around each of this symbol's launches inside an eager in-order replay of the whole step, 3 rounds; raw "
-                      f"intervals (an empty event pair measures {overhead * 1e6:.1f} us, not subtracted)")
+            pass
     mfma = dom["flops"] > 0 and (dom["flops"] / MFMA_PEAK_TFLOPS / 1e12) > (dom["bytes"] / HBM_PEAK_GBS / 1e9)
     if mfma:
         achieved = dom["flops"] / dom["seconds"] / 1e12
@@ -228,7 +229,7 @@ def roofline_from(rows, plan=None):
         roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS)
     roof.update(kernel=dom_name, variants=sorted(dom["variants"])[:6], op_kinds=dom["kinds"],
                 launches_per_step=dom["launches"], avg_launch_us=dom["seconds"] / dom["launches"] * 1e6,
-                share_of_step=share, timing=timing, algorithmic_gflop_per_launch=dom["flops"] / dom["launches"] / 1e9,
+                share_of_step=share, timing=timing, **extra, algorithmic_gflop_per_launch=dom["flops"] / dom["launches"] / 1e9,
                 algorithmic_mbytes_per_launch=dom["bytes"] / dom["launches"] / 1e6, traffic=None)
     # HBM-side bytes per launch from the PMC counters: collected in their own rocprofv3 --pmc passes over this same
     # command (tools/gpu_pmc_bench.sh: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB units) and committed under profiles/
