@@ -190,7 +190,7 @@ def kernel_symbol(variant):
     return f"_ZN5sfast17igemm_glds_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi{m.group(6)}ELi{mode}ELb{int(geglu)}ELi0ELb0EEEvNS_9IgemmArgsE"
 
 
-def roofline_from(rows, plan=None):
+def roofline_from(rows, plan=None, config="sd15"):
     by_kernel = {}
     for i, r in enumerate(rows):
         sym = kernel_symbol(r["kernel"])
@@ -239,7 +239,9 @@ def roofline_from(rows, plan=None):
         here = os.path.dirname(os.path.abspath(__file__))
         path = os.environ.get("SFAST_TRAFFIC_PROFILE")
         if not path:
-            cands = sorted(glob.glob(os.path.join(here, "profiles", "r[0-9][0-9]_pmc_traffic_by_symbol.json")))
+            # counters belong to ONE bench command: the SD1.5 default has the plain name, other configs their own suffix
+            suffix = "" if config == "sd15" else f"_{config}"
+            cands = sorted(glob.glob(os.path.join(here, "profiles", f"r[0-9][0-9]_pmc_traffic_by_symbol{suffix}.json")))
             path = cands[-1] if cands else None
         if path:
             with open(path) as f:
@@ -438,7 +440,7 @@ def bench_vae(args, dev, rank, world, use_dist):
         holder = _L()
         holder.plan = plan
         rows = per_op_timing(holder)
-        roof, families, total = roofline_from(rows, plan)
+        roof, families, total = roofline_from(rows, plan, "vae")
         out["roofline"], out["kernel_families"], out["sum_of_kernel_ms_eager"] = roof, families, total * 1e3
     if not args.no_cpu_baseline and world == 1:
         # baselines beside it: the oracle restatement of the same decoder (a) eagerly on this GPU through PyTorch-ROCm,
@@ -535,7 +537,7 @@ def bench_svd(args, dev, rank, world, use_dist):
         holder = _H()
         holder.plan = plan
         rows = per_op_timing(holder, reps=1, burst=2)
-        roof, families, total = roofline_from(rows, plan)
+        roof, families, total = roofline_from(rows, plan, "svd")
         out["roofline"], out["kernel_families"], out["sum_of_kernel_ms_eager"] = roof, families, total * 1e3
     if not args.no_cpu_baseline and world == 1:
         sys.path.insert(0, ROOT)
@@ -683,7 +685,7 @@ def main():
             out["weight_broadcast"] = {"bytes": bytes_bcast, "seconds": t_bcast, "gb_per_s": bytes_bcast / max(t_bcast, 1e-9) / 1e9}
         if not args.no_roofline and world == 1:
             rows = per_op_timing(loop)
-            roof, families, eager_total = roofline_from(rows, loop.plan)
+            roof, families, eager_total = roofline_from(rows, loop.plan, args.config if args.images == 1 else f"{args.config}_bs{args.images}")
             out["roofline"] = roof
             out["kernel_families"] = families
             out["sum_of_kernel_ms_eager"] = eager_total * 1e3
