@@ -532,6 +532,7 @@ static const Variant kVariants[] = {
     // pipe 2: wave-specialised LDS-DMA (igemm_glds_ws.hip): 4 producer waves + WM*WN consumer waves
     {21, 128, 128, 2, 2, 2, 4, 1.00f}, {22, 128, 160, 4, 1, 2, 4, 1.00f}, {23, 64, 64, 2, 2, 2, 4, 0.60f},
     {24, 128, 64, 2, 2, 2, 3, 0.80f},  {25, 64, 128, 2, 2, 2, 3, 0.80f},  // autotuner candidates (ids >= 16 are skipped by the analytic planner)
+    {26, 64, 64, 2, 2, 2, 3, 0.60f},   // 48 KB ring: three workgroups per CU
 };
 static const Variant kGegluVariants[] = {
     {1, 128, 128, 2, 2, 0, 2, 1.00f},  {3, 64, 128, 2, 2, 0, 2, 0.75f},  {11, 128, 128, 2, 2, 1, 4, 1.00f},

@@ -25,8 +25,15 @@ template <int N> __device__ __forceinline__ void ws_wait_vmcnt() {
 typedef const u32x4 __attribute__((address_space(1))) * ws_src_t;
 typedef __attribute__((address_space(3))) void *ws_dst_t;
 
+// Waves per SIMD the register allocator must leave room for. The 64x64 tile with a 3-stage ring (48 KB of LDS) is meant to run
+// THREE workgroups per CU (24 waves = 6 per SIMD, <= 80 registers): M = 8192, N = 320 problems have 640 tiles -- 2.5 per CU -- and
+// with two resident workgroups a third of the CUs run a second, mostly empty round.
+constexpr int ws_min_waves(int threads, int lds_bytes) {
+    return (threads == 512 && lds_bytes <= 48 * 1024) ? 6 : igemm_min_waves(threads, lds_bytes);
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int PW, int NS, int MODE, bool GEGLU, bool STAGED = false>
-__global__ void __launch_bounds__((WM * WN + PW) * 64, igemm_min_waves((WM * WN + PW) * 64, NS *(BM + BN) * 128))
+__global__ void __launch_bounds__((WM * WN + PW) * 64, ws_min_waves((WM * WN + PW) * 64, NS *(BM + BN) * 128))
     igemm_glds_ws_kernel(const IgemmArgs a) {
     using vec8 = typename Elem<T>::vec8;
     constexpr int NC = WM * WN * 64;  // consumer threads
@@ -261,6 +268,7 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, igemm_min_waves((WM * WN 
     OP(T, 128, 128, 2, 2, 4, 4, MODE, false) \
     OP(T, 128, 160, 4, 1, 4, 4, MODE, false) \
     OP(T, 64, 64, 2, 2, 4, 4, MODE, false)   \
+    OP(T, 64, 64, 2, 2, 4, 3, MODE, false)   \
     OP(T, 128, 64, 2, 2, 4, 3, MODE, false)  \
     OP(T, 64, 128, 2, 2, 4, 3, MODE, false)
 

@@ -23,7 +23,7 @@ _cache_lock = threading.Lock()
 _loaded_files = set()
 
 SPLITS = (1, 2, 3, 4, 6, 8, 12, 16, 24)
-VARIANTS = (1, 2, 3, 5, 11, 12, 13, 15, 16, 17, 18, 21, 22, 23, 24, 25)
+VARIANTS = (1, 2, 3, 5, 11, 12, 13, 15, 16, 17, 18, 21, 22, 23, 24, 25, 26)
 GEGLU_VARIANTS = (1, 3, 11, 13, 16, 18, 21, 23)
 MAX_SLAB_BYTES = 192 << 20
 

@@ -159,7 +159,7 @@ def test_geglu_split_k(split):
 
 @pytest.mark.parametrize("M,K,N", [(8192, 320, 320), (8192, 320, 960), (2048, 2560, 640), (512, 1280, 1280), (154, 768, 640),
                                    (4095, 328, 324), (77, 64, 36), (130, 1280, 1280)])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23, 24, 25])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23, 24, 25, 26])
 def test_linear_variants(M, K, N, variant):
     x = rnd(M, K, seed=40)
     w = rnd(N, K, seed=41, scale=K ** -0.5)
@@ -242,7 +242,7 @@ def test_linear_epilogues(dtype, epi):
     compare(f"linear_epi {epi} {dtype}", y, want, *tol(dtype, 2.0), kernel=last_kernel())
 
 
-@pytest.mark.parametrize("variant", [11, 12, 13, 15, 21, 22, 23, 24, 25])
+@pytest.mark.parametrize("variant", [11, 12, 13, 15, 21, 22, 23, 24, 25, 26])
 def test_dma_pipe_epilogues_bf16(variant):
     M, K, N = 700, 1280, 640
     dt = torch.bfloat16
@@ -330,7 +330,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23, 24, 25])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22, 23, 24, 25, 26])
 def test_conv_igemm(case, variant):
     name, B, Cin, H, W, Cout, k, stride, pad, ex = case
     x = cl(rnd(B, Cin, H, W, seed=70))

@@ -139,6 +139,15 @@ nograph)  # are kernels slower inside the replayed graph than in an eager replay
   prof sd15 --steps 10 --warmup 2 --no-graph
   mv gpurun_out/kernel_stats_sd15.csv gpurun_out/kernel_stats_eager.csv; mv gpurun_out/kernel_stats_sd15.txt gpurun_out/kernel_stats_eager.txt
   ;;
+k)  # ws 64x64 with a 3-stage ring (three workgroups per CU): op tests, then SD1.5 / SDXL with a fresh tuning pass against the packaged choices
+  run t_v26   900 $PYT tests/test_ops_gpu.py -k "variants or split_k or statistics"
+  run bench_pkg    600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  SFAST_TUNE_PACKAGED=0 SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_v26.json run bench_tuned 900 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --dump-kernels gpurun_out/kernels.json
+  run bench_pkg2   600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  SFAST_TUNE_PACKAGED=0 SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_v26.json run bench_tuned2 900 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  SFAST_TUNE_PACKAGED=0 SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_v26.json run sdxl_tuned 1200 python bench.py --config sdxl --steps 10 --warmup 2 --no-cpu-baseline --no-roofline
+  run sdxl_pkg     900 python bench.py --config sdxl --steps 10 --warmup 2 --no-cpu-baseline --no-roofline
+  ;;
 quick)
   run t_quick  900 $PYT tests/test_ops_gpu.py tests/test_unet_gpu.py -k "${2:-not zzz}"
   run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json --no-cpu-baseline
