@@ -18,6 +18,7 @@ Weights are read from the live parameter storage at every launch (the reference'
 `preserve_parameters=True` / LoRA in-place update contract, README.md:228-265): nothing is baked.
 """
 import ctypes as C
+import os
 import threading
 from collections import defaultdict
 
@@ -561,6 +562,38 @@ class UNet2DEngine:
                   needs=LANE_TEMB if rowbias is not None else None)
         return Ho, Wo
 
+    def _conv_in(self, plan, sample, h, B, H, W, c0):
+        """conv_in on the NCHW latent. With fewer than 8 input channels (4 for SD) the conv read through NCHW strides runs on the
+        generic small-channel kernel (37 us at 2 x 64 x 64: 0.7 % of the SD1.5 step); padded to 8 channels it is an MFMA implicit
+        GEMM with K = 72. Two strided copies per step make the padded operands: the sample into a zero-initialised NHWC8 buffer
+        and the LIVE weight (the contract: parameters are read at every launch) into a zero-initialised [Cout][3][3][8] image; the
+        padding lanes are written once, at plan build, and belong to no pool (nothing else may touch them)."""
+        lib, P, cin = self.lib, self.params, self.in_ch
+        w = P["conv_in.weight"]
+        if not (cin < 8 and w.shape[2] == 3 and w.shape[3] == 3 and w.stride(2) == 3 * w.stride(3)) or os.environ.get("SFAST_CONV_IN_PAD", "1") == "0":
+            self._op_conv(plan, "conv_in", sample, None, w, P["conv_in.bias"], h, B, H, W, cin, 0, c0, 3, 1, 1,
+                          xs=(cin * H * W, W, 1, H * W), kind="conv_in")
+            return
+        x8 = torch.zeros(B * H * W * 8, dtype=self.dtype, device=self.device)
+        w8 = torch.zeros(c0 * 9 * 8, dtype=self.dtype, device=self.device)
+        plan.keep += [x8, w8]
+
+        def copy(name, src, dst, shape, sst, dst_st, lane=LANE_MAIN):
+            cp = L.CopyParams()
+            cp.elem_bytes, cp.ndim = self.esize, 3
+            cp.shape = (C.c_int64 * 4)(*shape, 1)
+            cp.src_strides = (C.c_int64 * 4)(*sst, 0)
+            cp.dst_strides = (C.c_int64 * 4)(*dst_st, 0)
+            plan.keep.append(cp)
+            sp_, dp_ = src.data_ptr(), dst.data_ptr()
+            nbytes = 2.0 * shape[0] * shape[1] * shape[2] * self.esize
+            self._add(plan, "misc", name, 0.0, nbytes, lambda s, cp=cp: L.check(lib.sfast_hip_strided_copy(sp_, dp_, C.byref(cp), s), name), lane=lane)
+
+        copy("conv_in.weight.pad8", w, w8, (c0, 9, cin), (w.stride(0), w.stride(3), w.stride(1)), (72, 8, 1))
+        copy("sample.to_nhwc8", sample, x8, (B, H * W, cin), (cin * H * W, 1, H * W), (H * W * 8, 8, 1))
+        w8v = torch.as_strided(w8, (c0, 8, 3, 3), (72, 1, 24, 8))
+        self._op_conv(plan, "conv_in", x8, None, w8v, P["conv_in.bias"], h, B, H, W, 8, 0, c0, 3, 1, 1, kind="conv_in")
+
     def _op_add_nchw(self, plan, name, src_nchw, dst_nhwc, B, Cc, Hh, Ww):
         """dst[b][h][w][c] += src[b][c][h][w] (dense NHWC buffer += NCHW tensor)."""
         lib = self.lib
@@ -821,8 +854,7 @@ class UNet2DEngine:
 
         # ---- conv_in (reads the NCHW sample through strides, writes NHWC) -----------------------
         h = pool.get(B * H * W * c0)
-        self._op_conv(plan, "conv_in", sample, None, P["conv_in.weight"], P["conv_in.bias"], h, B, H, W, self.in_ch, 0, c0, 3, 1, 1,
-                      xs=(self.in_ch * H * W, W, 1, H * W), kind="conv_in")
+        self._conv_in(plan, sample, h, B, H, W, c0)
         if self.is_controlnet:
             h = self._controlnet_cond_embedding(plan, h, B, H, W, c0)
         skips = [(h, c0)]
@@ -971,7 +1003,6 @@ class UNet2DEngine:
         """GroupNorm as ONE pass: every large GroupNorm whose input tensor(s) were written by MFMA GEMM / conv launches gets its
         statistics from those launches' epilogues (sfast_epilogue_ext / sfast_hip_group_norm_apply) instead of running its own
         statistics kernel. Runs after autotuning: the record layout follows the tile shape that was chosen for the producer."""
-        import os
         mode = os.environ.get("SFAST_GN_FUSE", "1")
         if mode in ("0", "false", "off", ""):
             return

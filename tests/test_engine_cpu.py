@@ -125,8 +125,9 @@ def test_sd15_plan_op_inventory(built_lib):
     assert abs(total / 2 - 804) / 804 < 0.02, total
     assert abs(s["attn_self"]["gflop"] / 2 - 122.5) < 1.0 and abs(s["geglu"]["gflop"] / 2 - 102.3) < 1.0
     assert abs((s["conv3x3"]["gflop"] + s["conv_in"]["gflop"] + s["conv_out"]["gflop"]) / 2 - 400.3) < 2.0
-    # nothing is materialised for concat / upsample: no copy ops at all in the SD1.5 plan
-    assert "misc" in s and s["misc"]["count"] == 1
+    # nothing is materialised for concat / upsample; the only copies of the SD1.5 plan pad conv_in's 4-channel operands to 8
+    # channels for the MFMA path (the latent and the live weight: 64 KB + 46 KB per step)
+    assert "misc" in s and s["misc"]["count"] == 1 + 2
     assert plan.ws[1] > 0  # split-K slabs for the 8x8 / 16x16 levels
 
 

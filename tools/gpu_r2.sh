@@ -148,6 +148,14 @@ k)  # ws 64x64 with a 3-stage ring (three workgroups per CU): op tests, then SD1
   SFAST_TUNE_PACKAGED=0 SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_v26.json run sdxl_tuned 1200 python bench.py --config sdxl --steps 10 --warmup 2 --no-cpu-baseline --no-roofline
   run sdxl_pkg     900 python bench.py --config sdxl --steps 10 --warmup 2 --no-cpu-baseline --no-roofline
   ;;
+l)  # conv_in padded to 8 channels (MFMA) vs the small-channel kernel
+  run t_unet  1200 $PYT tests/test_unet_gpu.py tests/test_vae_gpu.py -k "not sdxl_full"
+  run bench_pad    600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --dump-kernels gpurun_out/kernels.json
+  SFAST_CONV_IN_PAD=0 run bench_nopad 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  run bench_pad2   600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  SFAST_CONV_IN_PAD=0 run bench_nopad2 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
+  run smoke      600 python __graft_entry__.py smoke
+  ;;
 quick)
   run t_quick  900 $PYT tests/test_ops_gpu.py tests/test_unet_gpu.py -k "${2:-not zzz}"
   run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json --no-cpu-baseline
