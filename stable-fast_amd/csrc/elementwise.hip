@@ -187,6 +187,7 @@ extern "C" int sfast_hip_strided_copy(const void *src, void *dst, const sfast_co
     int64_t blocks = ceil_div64(a.total, 256);
     if (blocks > 65536) blocks = 65536;
     const dim3 grid((unsigned)blocks);
+    set_kernel_name("strided_copy[%dB]", p->elem_bytes);
     switch (p->elem_bytes) {
     case 1: hipLaunchKernelGGL(strided_copy_kernel<uint8_t>, grid, dim3(256), 0, st, a); break;
     case 2: hipLaunchKernelGGL(strided_copy_kernel<uint16_t>, grid, dim3(256), 0, st, a); break;

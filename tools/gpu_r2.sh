@@ -156,6 +156,14 @@ l)  # conv_in padded to 8 channels (MFMA) vs the small-channel kernel
   SFAST_CONV_IN_PAD=0 run bench_nopad2 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline
   run smoke      600 python __graft_entry__.py smoke
   ;;
+final2)  # last evidence pass of the round: smoke, default bench line + through-compile, steady-window profile, whole GPU suite
+  unset SFAST_TUNE_CACHE
+  run smoke      600 python __graft_entry__.py smoke
+  run bench_default 1200 python bench.py --dump-kernels gpurun_out/kernels.json
+  run bench_compile  900 python bench.py --steps 30 --warmup 5 --through-compile --no-cpu-baseline --no-roofline
+  prof sd15 --steps 10 --warmup 2
+  run t_all      2400 $PYT tests
+  ;;
 quick)
   run t_quick  900 $PYT tests/test_ops_gpu.py tests/test_unet_gpu.py -k "${2:-not zzz}"
   run bench    900 python bench.py --steps 30 --warmup 5 --dump-kernels gpurun_out/kernels.json --no-cpu-baseline
