@@ -19,6 +19,7 @@ Rank 0 prints ONE JSON line. Besides the contract keys it carries
 """
 import argparse
 import json
+import re
 import os
 import sys
 import time
@@ -170,7 +171,7 @@ def kernel_symbol(variant):
     of one tile shape share a symbol, so the split factor is dropped. A trailing "+staged" / "+gnstats" marks the
     instantiation with LDS-staged stores (last template argument)."""
     import re
-    m = re.match(r"igemm_(conv|lin)_(f16|bf16)(_geglu)?\[(\d+x\d+),split=\d+,(reg|dma(\d)|ws(\d))\](\+staged|\+gnstats)?", variant)
+    m = re.match(r"igemm_(conv|lin)_(f16|bf16)(_geglu)?\[(\d+x\d+),split=(\d+),(reg|dma(\d)|ws(\d))\](\+staged|\+gnstats)?", variant)
     if not m:
         ma = re.match(r"attn_fwd\[D=(\d+),BQ=(\d+)\](\+bias)?", variant)
         if ma:  # attn_fwd_kernel<T, D, NW, TRACE = 0, BIAS = false>: one wave per 32 queries
@@ -181,13 +182,15 @@ def kernel_symbol(variant):
     geglu = m.group(3) is not None
     bm, bn = m.group(4).split("x")
     wm, wn = _IGEMM_WAVES[(m.group(4), geglu)]
-    staged = int(m.group(8) is not None)
-    if m.group(5) == "reg":
+    # staged stores (and statistics from the tile flush) only without split-K: a split GEMM writes fp32 slabs and the
+    # statistics come from splitk_reduce_rows_kernel behind it (igemm.hip igemm_run)
+    staged = int(m.group(9) is not None and int(m.group(5)) == 1)
+    if m.group(6) == "reg":
         return f"_ZN5sfast12igemm_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi{mode}ELb{int(geglu)}ELb{staged}EEEvNS_9IgemmArgsE"
-    if m.group(5).startswith("ws"):
-        return (f"_ZN5sfast20igemm_glds_ws_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi4ELi{m.group(7)}ELi{mode}ELb{int(geglu)}ELb{staged}EEE"
+    if m.group(6).startswith("ws"):
+        return (f"_ZN5sfast20igemm_glds_ws_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi4ELi{m.group(8)}ELi{mode}ELb{int(geglu)}ELb{staged}EEE"
                 "vNS_9IgemmArgsE")
-    return f"_ZN5sfast17igemm_glds_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi{m.group(6)}ELi{mode}ELb{int(geglu)}ELi0ELb0EEEvNS_9IgemmArgsE"
+    return f"_ZN5sfast17igemm_glds_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi{m.group(7)}ELi{mode}ELb{int(geglu)}ELi0ELb0EEEvNS_9IgemmArgsE"
 
 
 def roofline_from(rows, plan=None, config="sd15"):
@@ -220,6 +223,10 @@ def roofline_from(rows, plan=None, config="sd15"):
                                           f"same graph without this symbol's {len(dom['idx'])} launches ({t_wo * 1e3:.3f} ms), best of 3 rounds"))
         except RuntimeError:
             pass
+    split_note = {}
+    if any(re.search(r"split=([2-9]|\d\d)", v) for v in dom["variants"]):
+        split_note = dict(interval_includes="the split-K reduce launch (splitk_reduce[_rows]_kernel, 5-10 us) that follows each launch of this "
+                                            "symbol: one C-ABI call, one event interval; the rocprofv3 per-symbol average excludes it")
     mfma = dom["flops"] > 0 and (dom["flops"] / MFMA_PEAK_TFLOPS / 1e12) > (dom["bytes"] / HBM_PEAK_GBS / 1e9)
     if mfma:
         achieved = dom["flops"] / dom["seconds"] / 1e12
@@ -229,7 +236,7 @@ def roofline_from(rows, plan=None, config="sd15"):
         roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS)
     roof.update(kernel=dom_name, variants=sorted(dom["variants"])[:6], op_kinds=dom["kinds"],
                 launches_per_step=dom["launches"], avg_launch_us=dom["seconds"] / dom["launches"] * 1e6,
-                share_of_step=share, timing=timing, **extra, algorithmic_gflop_per_launch=dom["flops"] / dom["launches"] / 1e9,
+                share_of_step=share, timing=timing, **extra, **split_note, algorithmic_gflop_per_launch=dom["flops"] / dom["launches"] / 1e9,
                 algorithmic_mbytes_per_launch=dom["bytes"] / dom["launches"] / 1e6, traffic=None)
     # HBM-side bytes per launch from the PMC counters: collected in their own rocprofv3 --pmc passes over this same
     # command (tools/gpu_pmc_bench.sh: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB units) and committed under profiles/
