@@ -8,7 +8,8 @@ the same call signature, by a native implementation whenever the update is a det
     prev_sample = A(t) * sample + B(t) * model_output
 
 which covers DDIM-family schedulers at eta = 0 for `epsilon` and `v_prediction` models (the configuration BASELINE.json's
-metric is quoted on: 50-step DDIM). The coefficient table over all training timesteps is built on the host once per
+metric is quoted on: 50-step DDIM) and the first-order Euler update of `EulerDiscreteScheduler` (the default of diffusers' SDXL
+pipelines; there `scale_model_input` is a kernel of the same form too). The coefficient table over all training timesteps is built on the host once per
 `set_timesteps()`; the timestep stays wherever the pipeline keeps it -- a 0-d CUDA tensor is read by the kernel itself, so the
 step introduces no host synchronisation (diffusers' own DDIM step indexes `alphas_cumprod` with the device timestep, which does).
 Anything else -- eta > 0, clipping / thresholding, variance noise, schedulers of another family -- keeps the original method
@@ -122,13 +123,121 @@ class NativeDDIMStep:
         return SchedulerOutput(prev)
 
 
+def euler_like(s):
+    """diffusers' EulerDiscreteScheduler (SDXL's default) or a subclass / declared look-alike: a sigma schedule, a host-side step index
+    and a deterministic first-order update. Recognised by class name, not by attributes: the multistep / ancestral / Heun families
+    carry the same attributes (`sigmas`, `_step_index`) with different arithmetic."""
+    names = {c.__name__ for c in type(s).__mro__}
+    if "EulerDiscreteScheduler" not in names and not getattr(s, "_sfast_euler_like", False):
+        return False
+    if not (hasattr(s, "sigmas") and hasattr(s, "_init_step_index") and hasattr(s, "scale_model_input") and hasattr(s, "step")):
+        return False
+    return _cfg(s, "prediction_type", "epsilon") in ("epsilon", "v_prediction")
+
+
+class _EulerTables:
+    """(A, B) rows of the update and the input scale per step index, rebuilt whenever `set_timesteps` installs new sigmas.
+        epsilon:       prev = x + (s' - s) e                                   x_in = x / sqrt(s^2 + 1)
+        v_prediction:  prev = x (1 + (s' - s) s / (s^2 + 1)) + v (s' - s) / sqrt(s^2 + 1)
+    (diffusers EulerDiscreteScheduler.step with s_churn = 0: sigma_hat = sigma, derivative = (x - x0) / sigma, dt = s' - s)."""
+
+    def __init__(self, scheduler):
+        self.scheduler = scheduler
+        self._key, self._step, self._scale = None, None, None
+
+    def get(self, device):
+        sig = self.scheduler.sigmas
+        key = (id(sig), int(sig.numel()), str(device), float(sig[0]), float(sig[-2]) if sig.numel() > 1 else 0.0)
+        if key != self._key:
+            sg = torch.as_tensor(sig).double().cpu()
+            s0, s1 = sg[:-1], sg[1:]
+            dt = s1 - s0
+            if _cfg(self.scheduler, "prediction_type", "epsilon") == "v_prediction":
+                a, b = 1.0 + dt * s0 / (s0 * s0 + 1.0), dt / torch.sqrt(s0 * s0 + 1.0)
+            else:
+                a, b = torch.ones_like(dt), dt
+            self._step = torch.stack([a, b], dim=1).to(torch.float32).to(device).contiguous()
+            self._scale = torch.stack([1.0 / torch.sqrt(s0 * s0 + 1.0), torch.zeros_like(s0)], dim=1).to(torch.float32).to(device).contiguous()
+            self._key = key
+        return self._step, self._scale
+
+
+def _native_tensor(t, like=None):
+    return (torch.is_tensor(t) and t.device.type == "cuda" and t.dtype in (torch.float16, torch.bfloat16, torch.float32)
+            and (like is None or t.shape == like.shape))
+
+
+class NativeEulerStep:
+    """Replacement for `EulerDiscreteScheduler.step` (same signature): one kernel, `prev = A[i] x + B[i] model_output` in fp32, the
+    step index kept on the host exactly as diffusers keeps it (`_init_step_index` on first use, `+= 1` per call). Stochastic churn
+    (s_churn > 0) and anything else the two-term form does not cover take the original method."""
+
+    def __init__(self, scheduler, orig_step, tables):
+        self.scheduler, self.orig_step, self.tables = scheduler, orig_step, tables
+        self.__self__ = scheduler
+        self.__name__ = "step"
+        self.native_calls = 0
+
+    def __call__(self, model_output, timestep, sample, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, generator=None,
+                 return_dict=True, **kw):
+        s = self.scheduler
+        if (kw or s_churn != 0.0 or not (_native_tensor(model_output) and _native_tensor(sample, model_output))
+                or sample.dtype != model_output.dtype):  # diffusers upcasts an fp32 sample before the update: keep its arithmetic
+            return self.orig_step(model_output, timestep, sample, s_churn=s_churn, s_tmin=s_tmin, s_tmax=s_tmax, s_noise=s_noise,
+                                  generator=generator, return_dict=return_dict, **kw)
+        from ...hip import functional as F
+        if getattr(s, "step_index", None) is None:
+            s._init_step_index(timestep)
+        i = int(s.step_index)
+        step_tab, _ = self.tables.get(model_output.device)
+        prev = F.linear_step(model_output, sample, step_tab, i)
+        s._step_index = i + 1
+        self.native_calls += 1
+        if not return_dict:
+            return (prev,)
+
+        def pred_x0():  # only if a callback asks: x0 = x - s e   /   x / (s^2 + 1) - v s / sqrt(s^2 + 1)
+            sg = float(torch.as_tensor(s.sigmas)[i])
+            if _cfg(s, "prediction_type", "epsilon") == "v_prediction":
+                return (sample.float() / (sg * sg + 1.0) - model_output.float() * sg / math.sqrt(sg * sg + 1.0)).to(model_output.dtype)
+            return (sample.float() - sg * model_output.float()).to(model_output.dtype)
+
+        return SchedulerOutput(prev, pred_x0)
+
+
+class NativeEulerScale:
+    """Replacement for `EulerDiscreteScheduler.scale_model_input`: `sample / sqrt(sigma_i^2 + 1)` as one launch of the same kernel."""
+
+    def __init__(self, scheduler, orig, tables):
+        self.scheduler, self.orig, self.tables = scheduler, orig, tables
+        self.__self__ = scheduler
+        self.__name__ = "scale_model_input"
+
+    def __call__(self, sample, timestep, *a, **kw):
+        s = self.scheduler
+        if a or kw or not _native_tensor(sample) or sample.dtype == torch.float32:
+            return self.orig(sample, timestep, *a, **kw)
+        from ...hip import functional as F
+        if getattr(s, "step_index", None) is None:
+            s._init_step_index(timestep)
+        _, scale_tab = self.tables.get(sample.device)
+        out = F.linear_step(sample, sample, scale_tab, int(s.step_index))
+        s.is_scale_input_called = True
+        return out
+
+
 def patch_scheduler(scheduler):
     """In-place: route `scheduler.step` to the native kernel when the scheduler is of a supported family. Returns True if patched."""
-    if scheduler is None or isinstance(getattr(scheduler, "step", None), NativeDDIMStep):
+    if scheduler is None or isinstance(getattr(scheduler, "step", None), (NativeDDIMStep, NativeEulerStep)):
         return scheduler is not None
     if ddim_like(scheduler):
         scheduler.step = NativeDDIMStep(scheduler, scheduler.step)
         # DDIM's scale_model_input is the identity (diffusers DDIMScheduler.scale_model_input returns `sample`): nothing to fuse
+        return True
+    if euler_like(scheduler):
+        tables = _EulerTables(scheduler)
+        scheduler.step = NativeEulerStep(scheduler, scheduler.step, tables)
+        scheduler.scale_model_input = NativeEulerScale(scheduler, scheduler.scale_model_input, tables)
         return True
     logger.info("sfast: trace_scheduler: %s is not a supported scheduler family; its step stays eager", type(scheduler).__name__)
     return False

@@ -3,6 +3,8 @@ and the weight broadcast of the multi-GPU path (world_size 2 over gloo)."""
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -257,3 +259,78 @@ def test_packaged_tune_cache_is_well_formed():
         assert v in (autotune.GEGLU_VARIANTS if geglu else autotune.VARIANTS) and s in autotune.SPLITS, (k, v, s)
     n0 = len(autotune.export_cache())
     assert autotune.import_cache(d) >= 0 and len(autotune.export_cache()) >= max(n0, len(d))
+
+
+class _EulerRef:
+    """The arithmetic of diffusers' EulerDiscreteScheduler (s_churn = 0), restated for the tests: Karras-free sigma schedule from
+    SD's scaled-linear betas, `scale_model_input`, and the first-order step for epsilon / v-prediction models."""
+    _sfast_euler_like = True
+    init_noise_sigma = 1.0
+
+    def __init__(self, prediction_type="epsilon", n=10, device="cpu"):
+        import types
+        self.config = types.SimpleNamespace(prediction_type=prediction_type, num_train_timesteps=1000)
+        betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float64) ** 2
+        acp = torch.cumprod(1.0 - betas, dim=0)
+        sig = ((1 - acp) / acp) ** 0.5
+        ts = torch.linspace(999, 0, n).round().long()
+        self.timesteps = ts.to(device)
+        self.sigmas = torch.cat([sig[ts], torch.zeros(1, dtype=torch.float64)]).to(torch.float32).to(device)
+        self._step_index = None
+        self.is_scale_input_called = False
+
+    @property
+    def step_index(self):
+        return self._step_index
+
+    def _init_step_index(self, timestep):
+        self._step_index = int((self.timesteps == int(timestep)).nonzero()[0])
+
+    def scale_model_input(self, sample, timestep):
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        sigma = self.sigmas[self._step_index]
+        self.is_scale_input_called = True
+        return sample / ((sigma ** 2 + 1) ** 0.5)
+
+    def step(self, model_output, timestep, sample, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, generator=None, return_dict=True):
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        sigma = self.sigmas[self._step_index]
+        x = sample.to(torch.float32)
+        if self.config.prediction_type == "epsilon":
+            x0 = x - sigma * model_output
+        else:
+            x0 = model_output * (-sigma / (sigma ** 2 + 1) ** 0.5) + (x / (sigma ** 2 + 1))
+        derivative = (x - x0) / sigma
+        dt = self.sigmas[self._step_index + 1] - sigma
+        prev = (x + derivative * dt).to(model_output.dtype)
+        self._step_index += 1
+        import types
+        return (prev,) if not return_dict else types.SimpleNamespace(prev_sample=prev, pred_original_sample=x0)
+
+
+@pytest.mark.parametrize("pred", ["epsilon", "v_prediction"])
+def test_euler_coefficient_tables_reproduce_the_scheduler_arithmetic(pred):
+    """trace_scheduler for EulerDiscreteScheduler (SDXL's default): the per-step-index (A, B) rows of `prev = A x + B model_output`
+    and the input scale, checked against the scheduler's own arithmetic on the host (the kernel that applies them is GPU-tested)."""
+    from sfast.libs.diffusers.scheduler import _EulerTables, euler_like, ddim_like
+    s = _EulerRef(pred)
+    assert euler_like(s) and not ddim_like(s)
+    step_tab, scale_tab = _EulerTables(s).get("cpu")
+    assert step_tab.shape == (10, 2) and scale_tab.shape == (10, 2) and step_tab.dtype == torch.float32
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    for i, t in enumerate(s.timesteps):
+        e = torch.randn(2, 4, 8, 8, generator=g)
+        want_in = s.scale_model_input(x, t)
+        torch.testing.assert_close(scale_tab[i, 0] * x, want_in, rtol=1e-5, atol=1e-6)
+        assert float(scale_tab[i, 1]) == 0.0
+        want = s.step(e, t, x).prev_sample
+        torch.testing.assert_close(step_tab[i, 0] * x + step_tab[i, 1] * e, want, rtol=1e-4, atol=1e-4)
+        x = want
+    assert s.step_index == 10
+    # a multistep solver carries the same attributes with different arithmetic: never recognised by attributes alone
+    other = _EulerRef(pred)
+    other._sfast_euler_like = False
+    assert not euler_like(other)

@@ -471,3 +471,39 @@ def test_encoder_attention_mask_native_and_through_compile():
     assert not cm.forward._warned and torch.equal(out, y)
     out2 = cm(sample, 400, encoder_hidden_states=ehs, encoder_attention_mask=mask.bool(), return_dict=False)[0]  # graph replay
     assert torch.equal(out2, y) and len(cm.forward._cached) == 1
+
+
+@pytest.mark.parametrize("pred", ["epsilon", "v_prediction"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_native_scheduler_step_matches_euler(pred, dtype):
+    """trace_scheduler for EulerDiscreteScheduler (the default of diffusers' SDXL pipelines): `scale_model_input` and `step` as one
+    kernel launch each, against the scheduler's own eager arithmetic over a whole schedule; step index, `is_scale_input_called`,
+    tuple return and the fall-back for stochastic churn behave as in diffusers."""
+    from test_host_cpu import _EulerRef
+    from sfast.libs.diffusers.scheduler import NativeEulerScale, NativeEulerStep, patch_scheduler
+    ref, nat = _EulerRef(pred, device=DEV), _EulerRef(pred, device=DEV)
+    assert patch_scheduler(nat) and isinstance(nat.step, NativeEulerStep) and isinstance(nat.scale_model_input, NativeEulerScale)
+    assert patch_scheduler(nat)  # idempotent
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(2, 4, 32, 32, generator=g) * float(ref.sigmas[0])).to(DEV, dtype)
+    xr = x.clone()
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    for t in ref.timesteps:
+        e = torch.randn(2, 4, 32, 32, generator=g).to(DEV, dtype)
+        a, b = nat.scale_model_input(x, t), ref.scale_model_input(xr, t)
+        assert rel_l2(a, b) < tol and nat.is_scale_input_called
+        out = nat.step(e, t, x)
+        want = ref.step(e, t, xr)
+        assert nat.step_index == ref.step_index
+        assert rel_l2(out.prev_sample, want.prev_sample) < tol, (int(t), rel_l2(out.prev_sample, want.prev_sample))
+        assert rel_l2(out.pred_original_sample, want.pred_original_sample.to(dtype)) < tol
+        x, xr = out.prev_sample, want.prev_sample
+    assert nat.step.native_calls == len(ref.timesteps)
+    # tuple form, and s_churn > 0 keeps the original method (stochastic: not a two-term update)
+    n2 = _EulerRef(pred, device=DEV)
+    patch_scheduler(n2)
+    t0 = n2.timesteps[0]
+    (p,) = n2.step(e, t0, x, return_dict=False)
+    assert p.shape == x.shape and n2.step.native_calls == 1
+    n2.step(e, n2.timesteps[1], x, s_churn=0.5)
+    assert n2.step.native_calls == 1 and n2.step_index == 2
