@@ -756,3 +756,23 @@ def test_empty_and_degenerate_inputs():
     # one row, one key, one channel group: smallest non-empty problems
     y = f.attention(rnd(1, 1, 1, 40, seed=11), k[:1, :1, :1], k[:1, :1, :1])
     compare("attention 1x1", y, k[:1, :1, :1].float(), *tol(torch.float16))
+
+
+def test_golden_ops_round2():
+    """The round-2 entry points against the committed fixtures (tests/golden/ops_r2.pt): no oracle involved at run time."""
+    g = torch.load(os.path.join(GOLDEN, "ops_r2.pt"))
+    d = lambda t: t.to(DEV)  # noqa: E731
+    for name in ("attention_full_bias", "attention_key_padding_mask"):
+        c = g[name]
+        y = F().attention(d(c["q"]), d(c["k"]), d(c["v"]), attn_bias=d(c["bias"]))
+        compare(f"golden {name}", y, c["y"], 3e-3, 2e-3, kernel=last_kernel())
+        y = torch.ops.sfast_xformers.memory_efficient_attention(d(c["q"]), d(c["k"]), d(c["v"]), d(c["bias"]).expand(2, 3, 70, 77), 0.0, None, None)
+        compare(f"golden {name} via sfast_xformers", y, c["y"], 3e-3, 2e-3)
+    for name in ("ddim_step_eps", "euler_step_eps"):
+        c = g[name]
+        coef = torch.tensor([c["coef"]], dtype=torch.float32, device=DEV)
+        y = F().linear_step(d(c["model_output"]), d(c["sample"]), coef, 0)
+        compare(f"golden {name}", y, c["y"], 2e-3, 2e-3)
+    c = g["euler_step_eps"]
+    coef = torch.tensor([[c["scale"], 0.0]], dtype=torch.float32, device=DEV)
+    compare("golden euler scale_model_input", F().linear_step(d(c["sample"]), d(c["sample"]), coef, 0), c["y_scaled"], 2e-3, 2e-3)

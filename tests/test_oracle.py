@@ -177,3 +177,28 @@ def test_closed_form_known_answers():
     wc[0, 0, 1, 1], wc[1, 1, 1, 1] = 1.0, 1.0
     torch.testing.assert_close(R.conv2d_ref(img, wc, padding=1), img)
     torch.testing.assert_close(R.conv2d_ref(img, wc, padding=1, stride=2), img[:, :, ::2, ::2])
+
+
+def test_oracle_reproduces_golden_round2():
+    """Round-2 fixtures (tests/golden/make_golden_r2.py): attention bias / key-padding mask, the scheduler rows, the tiny SVD UNet."""
+    from oracle import svd_ref as S
+    gold = torch.load(os.path.join(GOLDEN, "ops_r2.pt"))
+    c = gold["attention_full_bias"]
+    torch.testing.assert_close(R.attention_ref(c["q"].float(), c["k"].float(), c["v"].float(), attn_bias=c["bias"].float()), c["y"], rtol=1e-4, atol=1e-4)
+    c = gold["attention_key_padding_mask"]
+    torch.testing.assert_close(R.attention_ref(c["q"].float(), c["k"].float(), c["v"].float(), attn_bias=c["bias"].float()), c["y"], rtol=1e-4, atol=1e-4)
+    for b, valid in enumerate(c["valid"]):  # independent of the bias code path: masked keys == keys that are not there
+        want = R.attention_ref(c["q"][b:b + 1].float(), c["k"][b:b + 1, :valid].float(), c["v"][b:b + 1, :valid].float())
+        torch.testing.assert_close(c["y"][b:b + 1], want, rtol=1e-4, atol=1e-4)
+    for name in ("ddim_step_eps", "euler_step_eps"):
+        c = gold[name]
+        a, bb = c["coef"]
+        torch.testing.assert_close(a * c["sample"].float() + bb * c["model_output"].float(), c["y"], rtol=1e-5, atol=1e-5)
+    c = gold["euler_step_eps"]
+    torch.testing.assert_close(c["scale"] * c["sample"].float(), c["y_scaled"], rtol=1e-5, atol=1e-6)
+    gold = torch.load(os.path.join(GOLDEN, "svd_tiny.pt"))
+    m = S.build(gold["config"], seed=gold["seed"])
+    m.load_state_dict({k: v.half().float() for k, v in m.state_dict().items()})
+    with torch.no_grad():
+        y = m(gold["sample"].float(), gold["timesteps"], gold["encoder_hidden_states"].float(), gold["added_time_ids"]).sample
+    torch.testing.assert_close(y, gold["y"], rtol=1e-3, atol=1e-4)

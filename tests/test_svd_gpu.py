@@ -94,3 +94,18 @@ def test_compile_unet_recognises_the_spatio_temporal_unet():
     out2 = m(sample, torch.tensor(400.0, device=DEV), ehs, tids).sample  # graph replay
     want = SVDUNetEngine.from_module(ref).forward(sample, 400.0, ehs, tids)
     assert torch.equal(out, want) and torch.equal(out2, want) and len(m.forward._cached) == 1
+
+
+def test_tiny_svd_unet_vs_golden_fixture():
+    """tests/golden/svd_tiny.pt: seeded inputs + the fp32 oracle's output, committed -- the HIP plan against it without running the oracle."""
+    import os
+    from sfast.engine import SVDUNetEngine
+    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "svd_tiny.pt"))
+    m = S.build(gold["config"], seed=gold["seed"])
+    m.load_state_dict({k: v.half().float() for k, v in m.state_dict().items()})
+    m = m.half().to(DEV)
+    eng = SVDUNetEngine.from_module(m)
+    y = eng.forward(gold["sample"].to(DEV), gold["timesteps"].to(DEV), gold["encoder_hidden_states"].to(DEV), gold["added_time_ids"].to(DEV))
+    e = rel_l2(y, gold["y"].to(DEV))
+    log_value("svd tiny vs golden fixture", engine_vs_golden=e)
+    assert torch.isfinite(y).all() and e < 4e-3, e
