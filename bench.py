@@ -345,25 +345,71 @@ class _DDIMSchedulerLike:
         return (out,) if not return_dict else _Config(prev_sample=out)
 
 
+class _EulerSchedulerLike:
+    """Harness stand-in with the call surface and arithmetic of diffusers' EulerDiscreteScheduler (the default of its SDXL pipelines;
+    s_churn = 0): sigma schedule from SD's scaled-linear betas, `scale_model_input`, first-order step, host-side step index."""
+    _sfast_euler_like = True
+
+    def __init__(self):
+        self.config = _Config(num_train_timesteps=1000, prediction_type="epsilon")
+        betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float64) ** 2
+        acp = torch.cumprod(1.0 - betas, dim=0)
+        self._sig_all = ((1 - acp) / acp) ** 0.5
+        self.sigmas, self.timesteps, self._step_index, self.is_scale_input_called = None, None, None, False
+        self.init_noise_sigma = 1.0
+
+    @property
+    def step_index(self):
+        return self._step_index
+
+    def set_timesteps(self, n, device=None):
+        ts = torch.linspace(999, 0, n).round().long()
+        self.timesteps = ts.to(device)
+        self.sigmas = torch.cat([self._sig_all[ts], torch.zeros(1, dtype=torch.float64)]).to(torch.float32).to(device)
+        self.init_noise_sigma = float((self.sigmas.max() ** 2 + 1) ** 0.5)
+        self._step_index = None
+
+    def _init_step_index(self, timestep):
+        self._step_index = int((self.timesteps == int(timestep)).nonzero()[0])
+
+    def scale_model_input(self, sample, timestep):
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        sigma = self.sigmas[self._step_index]
+        self.is_scale_input_called = True
+        return sample / ((sigma ** 2 + 1) ** 0.5)
+
+    def step(self, model_output, timestep, sample, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, generator=None, return_dict=True):
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        sigma = self.sigmas[self._step_index]
+        x = sample.to(torch.float32)
+        x0 = x - sigma * model_output
+        prev = (x + (x - x0) / sigma * (self.sigmas[self._step_index + 1] - sigma)).to(model_output.dtype)
+        self._step_index += 1
+        return (prev,) if not return_dict else _Config(prev_sample=prev)
+
+
 class _PipelineLike:
-    """The denoise loop of diffusers' StableDiffusionPipeline.__call__ (classifier-free guidance), prompt embeddings given."""
+    """The denoise loop of diffusers' StableDiffusion(XL)Pipeline.__call__ (classifier-free guidance), prompt embeddings given."""
 
     def __init__(self, unet, scheduler, device):
         self.unet, self.scheduler, self.vae, self.device = unet, scheduler, None, device
 
     @torch.no_grad()
-    def denoise(self, latents, prompt_embeds, guidance_scale, timesteps):
+    def denoise(self, latents, prompt_embeds, guidance_scale, timesteps, added_cond_kwargs=None):
+        kw = {} if added_cond_kwargs is None else {"added_cond_kwargs": added_cond_kwargs}
         for t in timesteps:
             latent_model_input = torch.cat([latents] * 2)
             latent_model_input = self.scheduler.scale_model_input(latent_model_input, t)
-            noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=prompt_embeds, return_dict=False)[0]
+            noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=prompt_embeds, return_dict=False, **kw)[0]
             noise_pred_uncond, noise_pred_text = noise_pred.chunk(2)
             noise_pred = noise_pred_uncond + guidance_scale * (noise_pred_text - noise_pred_uncond)
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
         return latents
 
 
-def through_compile(args, cfg, params, dev, latents, ehs, engine_ms):
+def through_compile(args, cfg, params, dev, latents, ehs, engine_ms, added=None):
     """The same step measured through the DROP-IN surface: a module with diffusers' parameter layout + a pipeline-shaped denoise
     loop + `sfast.compilers.compile(pipe, config)` with enable_cuda_graph and trace_scheduler -- i.e. what a stable-fast user
     runs (reference examples/optimize_stable_diffusion_pipeline.py:127-151), including the per-step input copies, the output
@@ -371,7 +417,8 @@ def through_compile(args, cfg, params, dev, latents, ehs, engine_ms):
     from sfast.compilers.diffusion_pipeline_compiler import CompilationConfig, compile
     from sfast.engine.unet_spec import module_from_params
     unet = module_from_params(cfg, params)
-    sched = _DDIMSchedulerLike()
+    euler = added is not None  # SDXL: its pipelines' default scheduler
+    sched = _EulerSchedulerLike() if euler else _DDIMSchedulerLike()
     pipe = _PipelineLike(unet, sched, dev)
     config = CompilationConfig.Default()
     config.enable_cuda_graph = True
@@ -379,18 +426,21 @@ def through_compile(args, cfg, params, dev, latents, ehs, engine_ms):
     compile(pipe, config)
     sched.set_timesteps(50, device=dev)
     ts = list(sched.timesteps)
-    lat = latents.clone()
-    pipe.denoise(lat, ehs, 7.5, ts[:3])  # builds + captures the plan
+    lat = latents.clone() * (sched.init_noise_sigma if euler else 1.0)
+    pipe.denoise(lat, ehs, 7.5, ts[:3], added)  # builds + captures the plan
     torch.cuda.synchronize()
-    steps = min(args.steps, 100)
+    steps = min(args.steps, 50 if euler else 100)  # the Euler step index walks the 50-entry sigma table once
     seq = [ts[i % 50] for i in range(steps)]
+    if euler:
+        sched._step_index = None
     t0 = time.perf_counter()
-    out = pipe.denoise(lat, ehs, 7.5, seq)
+    out = pipe.denoise(lat, ehs, 7.5, seq, added)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     ms = el / steps * 1e3
     return {"value": steps / el, "unit": "it/s", "ms_per_step": ms, "steps": steps, "gap_vs_fused_loop": ms / engine_ms - 1.0,
-            "native_scheduler_steps": getattr(sched.step, "native_calls", 0), "outputs_finite": bool(torch.isfinite(out).all()),
+            "scheduler": type(sched).__name__, "native_scheduler_steps": getattr(sched.step, "native_calls", 0),
+            "outputs_finite": bool(torch.isfinite(out).all()),
             "path": "module_from_params -> sfast.compilers.compile(enable_cuda_graph, trace_scheduler) -> pipeline-shaped CFG loop"}
 
 
@@ -700,8 +750,12 @@ def main():
                 os.makedirs(os.path.dirname(os.path.abspath(args.dump_kernels)), exist_ok=True)
                 with open(args.dump_kernels, "w") as f:
                     json.dump(rows, f, indent=1)
-        if args.through_compile and world == 1 and args.config == "sd15" and args.images == 1:
-            out["through_compile"] = through_compile(args, cfg, params, dev, latents, ehs, elapsed / args.steps * 1e3)
+        if args.through_compile and world == 1 and args.images == 1:
+            added = None
+            if args.config == "sdxl":
+                si = loop.plan.static_in
+                added = {"text_embeds": si["text_embeds"].reshape(2, -1).clone(), "time_ids": si["time_ids"].reshape(2, -1).clone()}
+            out["through_compile"] = through_compile(args, cfg, params, dev, latents, ehs, elapsed / args.steps * 1e3, added)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.config, args.images)
         print(json.dumps(out), flush=True)
