@@ -147,7 +147,9 @@ class _EulerTables:
 
     def get(self, device):
         sig = self.scheduler.sigmas
-        key = (id(sig), int(sig.numel()), str(device), float(sig[0]), float(sig[-2]) if sig.numel() > 1 else 0.0)
+        # identity of the installed schedule without touching its values (a device-resident `sigmas` would cost a sync per step):
+        # `set_timesteps` binds a new tensor, in-place edits bump `_version`
+        key = (id(sig), sig.data_ptr() if torch.is_tensor(sig) else 0, int(len(sig)), getattr(sig, "_version", 0), str(device))
         if key != self._key:
             sg = torch.as_tensor(sig).double().cpu()
             s0, s1 = sg[:-1], sg[1:]
