@@ -588,9 +588,11 @@ template <typename T, int D> static int attn_set_attr_bias() {
 
 template <typename T> static int attn_init_t() {
     int rc = 0;
-#define A_INIT(D)                                  \
-    if (!rc) rc = attn_set_attr<T, D, 2>();        \
-    if (!rc) rc = attn_set_attr<T, D, 4>();        \
+#define A_INIT(D)                                             \
+    if constexpr (D < 128) {                                  \
+        if (!rc) rc = attn_set_attr<T, D, 2>();               \
+    }                                                         \
+    if (!rc) rc = attn_set_attr<T, D, 4>();                   \
     if (!rc) rc = attn_set_attr_bias<T, D>();
     A_INIT(40) A_INIT(64) A_INIT(80) A_INIT(128) A_INIT(160)
 #undef A_INIT
@@ -627,10 +629,13 @@ static int attn_launch_d(const AttnArgs &a_in, int nw, hipStream_t st) {
             return check_launch("attention(trace)");
         }
     }
-    if (nw == 2)
-        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2>), grid, dim3(128), AttnGeom<D>::LDS_TOTAL, st, a);
-    else
-        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4>), grid, dim3(256), AttnGeom<D>::LDS_TOTAL, st, a);
+    if constexpr (D < 128) {  // the 2-wave form of the wide heads would sit at the 512-register limit (and spill): never launched
+        if (nw == 2) {
+            hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2>), grid, dim3(128), AttnGeom<D>::LDS_TOTAL, st, a);
+            return check_launch("attention");
+        }
+    }
+    hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4>), grid, dim3(256), AttnGeom<D>::LDS_TOTAL, st, a);
     return check_launch("attention");
 }
 
@@ -713,7 +718,7 @@ extern "C" int sfast_hip_attention_bias(const void *q, const void *k, const void
         const int64_t blocks4 = (int64_t)ceil_div(p->Sq, 128) * p->H * p->B;
         if (blocks4 < 256) nw = 2;
         if (p->variant == 2 || p->variant == 4) nw = p->variant;
-        if (bias) nw = 4;
+        if (bias || p->D >= 128) nw = 4;  // wide heads and the biased instantiation: four waves per workgroup only
         set_kernel_name("attn_fwd[D=%d,BQ=%d]%s", p->D, nw * 32, bias ? "+bias" : "");
         if (p->dtype == SFAST_F16) return attn_launch<f16>(a, nw, st);
         return attn_launch<bf16>(a, nw, st);

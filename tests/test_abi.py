@@ -132,7 +132,7 @@ def test_bench_kernel_symbols_name_real_device_kernels(built_lib):
     import bench
     with open(L.LIB_PATH, "rb") as f:
         blob = f.read()
-    variants = ["attn_fwd[D=160,BQ=64]", "attn_fwd[D=40,BQ=128]", "attn_fwd[D=80,BQ=64]", "attn_fwd[D=64,BQ=128]",
+    variants = ["attn_fwd[D=160,BQ=128]", "attn_fwd[D=40,BQ=128]", "attn_fwd[D=80,BQ=64]", "attn_fwd[D=64,BQ=128]",
                 "igemm_conv_f16[128x128,split=1,ws4]", "igemm_conv_f16[128x128,split=12,reg]", "igemm_conv_f16[128x160,split=2,reg]",
                 "igemm_conv_f16[128x160,split=4,ws4]", "igemm_conv_f16[64x64,split=3,ws4]", "igemm_lin_f16[128x128,split=1,dma2]",
                 "igemm_lin_f16[128x128,split=4,ws4]", "igemm_lin_f16[64x64,split=1,reg]", "igemm_lin_f16[64x64,split=6,ws4]",
