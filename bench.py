@@ -316,6 +316,7 @@ class _DDIMSchedulerLike:
     pipeline would run without trace_scheduler; compile(..., trace_scheduler=True) replaces it."""
 
     init_noise_sigma = 1.0
+    _sfast_ddim_like = True  # declared look-alike: patch_scheduler recognises DDIM by class name or this opt-in, never by attributes
 
     def __init__(self):
         self.config = _Config(num_train_timesteps=1000, prediction_type="epsilon", clip_sample=False, thresholding=False,

@@ -26,7 +26,7 @@
  *   sfast_hip_softmax_rows  <- the VAE decoder's single-head attention (compile_vae path), between two sfast_hip_gemm calls
  *   sfast_hip_add_strided   <- ControlNet residual adds of UNet2DConditionModel.forward
  *   sfast_hip_image_postprocess <- patched VaeImageProcessor (libs/diffusers/image_processor.py:13-108)
- *   sfast_hip_timestep_embedding, sfast_hip_cfg_ddim_step, sfast_hip_linear_step
+ *   sfast_hip_timestep_embedding, sfast_hip_cfg_ddim_step, sfast_hip_linear_step, sfast_hip_schedule_advance
  *                          <- host-side glue of the denoise loop that the reference leaves to
  *                             diffusers / trace_scheduler (compilers/diffusion_pipeline_compiler.py:103-107)
  *
@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define SFAST_HIP_ABI_VERSION 3
+#define SFAST_HIP_ABI_VERSION 4
 
 typedef void *sfast_stream_t; /* hipStream_t */
 
@@ -350,6 +350,15 @@ int sfast_hip_timestep_embedding(const float *timesteps /* [B] device */, void *
 int sfast_hip_cfg_ddim_step(const void *eps_uc, const void *latents, void *latents_out,
                             void *unet_in, const float *coef, float guidance, int64_t numel,
                             int32_t dtype, sfast_stream_t stream);
+
+/* ---- device-side schedule cursor ---------------------------------------------------------------------------
+ * idx = *cursor mod n_steps; ts_out[0:ts_cols] = ts_table[idx][:]; coef_out[0:coef_cols] = coef_table[idx][:]; *cursor = idx + 1
+ * (mod n_steps). Recorded as the first node of the step's hipGraph it replaces the per-step host-issued copies of the timestep
+ * and the scheduler coefficients (the reference's pipeline loop feeds `t` from the host every iteration,
+ * examples/optimize_stable_diffusion_pipeline.py:127-151): one denoise iteration = one graph launch. All float tables.          */
+int sfast_hip_schedule_advance(int32_t *cursor, const float *ts_table, int32_t ts_cols, float *ts_out,
+                               const float *coef_table, int32_t coef_cols, float *coef_out, int32_t n_steps,
+                               sfast_stream_t stream);
 
 /* ---- scheduler update in linear form: out = A*sample + B*model_output, fp32 math ---------------------------
  * (A, B) = coef[2*idx], coef[2*idx+1] with idx = *index (device int32 / int64 scalar, clamped to [0, index_limit)) or 0 when

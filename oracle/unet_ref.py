@@ -37,6 +37,7 @@ SD15_CONFIG = dict(
     attention_head_dim=8, transformer_layers_per_block=1, norm_num_groups=32, norm_eps=1e-5,
     use_linear_projection=False, flip_sin_to_cos=True, freq_shift=0,
     addition_embed_type=None, addition_time_embed_dim=None, projection_class_embeddings_input_dim=None,
+    time_cond_proj_dim=None, class_embed_type=None,
 )
 
 SDXL_CONFIG = dict(
@@ -74,12 +75,18 @@ def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0.0, max_period=
 
 
 class TimestepEmbedding(nn.Module):
-    def __init__(self, cin, dim):
+    """diffusers TimestepEmbedding; `cond_proj_dim` (UNet config `time_cond_proj_dim`, the LCM guidance-scale embedding w):
+    a bias-free Linear whose output is added to the sinusoid BEFORE the MLP (`sample = sample + cond_proj(condition)`)."""
+
+    def __init__(self, cin, dim, cond_proj_dim=None):
         super().__init__()
         self.linear_1 = nn.Linear(cin, dim)
         self.linear_2 = nn.Linear(dim, dim)
+        self.cond_proj = nn.Linear(cond_proj_dim, cin, bias=False) if cond_proj_dim is not None else None
 
-    def forward(self, x):
+    def forward(self, x, condition=None):
+        if condition is not None:
+            x = x + self.cond_proj(condition)
         return self.linear_2(F.silu(self.linear_1(x)))
 
 
@@ -291,7 +298,16 @@ class UNet2DConditionModel(nn.Module):
         temb = boc[0] * 4
         g, eps, lp, L = c.norm_num_groups, c.norm_eps, c.use_linear_projection, c.layers_per_block
         self.conv_in = nn.Conv2d(c.in_channels, boc[0], 3, padding=1)
-        self.time_embedding = TimestepEmbedding(boc[0], temb)
+        self.time_embedding = TimestepEmbedding(boc[0], temb, getattr(c, "time_cond_proj_dim", None))
+        # class conditioning (diffusers UNet2DConditionModel._set_class_embedding): "timestep" embeds class_labels through the
+        # sinusoid + an MLP, "projection" feeds a float vector of width projection_class_embeddings_input_dim to the MLP
+        cet = getattr(c, "class_embed_type", None)
+        if cet == "timestep":
+            self.class_embedding = TimestepEmbedding(boc[0], temb)
+        elif cet == "projection":
+            self.class_embedding = TimestepEmbedding(c.projection_class_embeddings_input_dim, temb)
+        elif cet is not None:
+            raise NotImplementedError(f"class_embed_type {cet}")
         if c.addition_embed_type == "text_time":
             self.add_embedding = TimestepEmbedding(c.projection_class_embeddings_input_dim, temb)
         self.down_blocks = nn.ModuleList()
@@ -328,7 +344,11 @@ class UNet2DConditionModel(nn.Module):
         return self.conv_in.weight.device
 
     def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, return_dict=True,
-                down_block_additional_residuals=None, mid_block_additional_residual=None, encoder_attention_mask=None, **_):
+                down_block_additional_residuals=None, mid_block_additional_residual=None, encoder_attention_mask=None,
+                timestep_cond=None, class_labels=None, cross_attention_kwargs=None, **_):
+        # cross_attention_kwargs: only {"scale": s} is meaningful without LoRA / IP-Adapter processors, and then it is a no-op
+        # (diffusers scales the LoRA layers by it; this restatement has none)
+        assert not cross_attention_kwargs or set(cross_attention_kwargs) <= {"scale"}
         c = self.config
         B = sample.shape[0]
         if encoder_attention_mask is not None:
@@ -343,7 +363,14 @@ class UNet2DConditionModel(nn.Module):
             t = torch.tensor([t], dtype=torch.float32, device=sample.device)
         t = t.to(sample.device).reshape(-1).expand(B)
         t_emb = timestep_embedding(t, c.block_out_channels[0], c.flip_sin_to_cos, c.freq_shift).to(sample.dtype)
-        emb = self.time_embedding(t_emb)
+        emb = self.time_embedding(t_emb, timestep_cond)
+        cet = getattr(c, "class_embed_type", None)
+        if cet is not None:
+            if class_labels is None:
+                raise ValueError("class_labels should be provided when num_class_embeds > 0")
+            if cet == "timestep":
+                class_labels = timestep_embedding(class_labels.reshape(-1), c.block_out_channels[0], c.flip_sin_to_cos, c.freq_shift).to(sample.dtype)
+            emb = emb + self.class_embedding(class_labels.to(sample.dtype))
         if c.addition_embed_type == "text_time":
             te = added_cond_kwargs["text_embeds"]
             tid = added_cond_kwargs["time_ids"]

@@ -105,20 +105,20 @@ class _NativeUNetForward:
             self._warned = True
         return self.orig_forward(*args, **kwargs)
 
-    def _prepare(self, key, sample, timestep, ehs, added, down_res, mid_res, emask=None):
+    def _prepare(self, key, sample, timestep, ehs, added, down_res, mid_res, emask=None, tcond=None, clabels=None):
         eng = self.engine
-        B, H, W, S, ctrl, has_mask = key
+        B, H, W, S, ctrl, has_mask, has_tcond = key
         # everything below (kernel-attribute setup, autotune launches and their event timing, warm-up, capture) must run with
         # the MODEL's device current, whatever device the caller has selected (reference: graphs.py wraps capture and replay
         # in torch.cuda.device(execution_env.device))
         with torch.cuda.device(eng.device):
-            plan = eng.get_plan(B, H, W, S, ctrl, has_mask)
+            plan = eng.get_plan(B, H, W, S, ctrl, has_mask, has_tcond)
         env = get_per_device_graph_execution_env(eng.device)
         graph = None
         # warm-up: runs the whole plan eagerly (also validates every launch before capture)
         torch.cuda.synchronize(eng.device)
         with torch.cuda.device(eng.device), torch.cuda.stream(torch.cuda.Stream(device=eng.device)):
-            eng.load_inputs(plan, sample, timestep, ehs, added, down_res, mid_res, emask)
+            eng.load_inputs(plan, sample, timestep, ehs, added, down_res, mid_res, emask, tcond, clabels)
             for _ in range(self.warmups if self.enable_graph else 1):
                 plan.run(torch.cuda.current_stream(eng.device).cuda_stream)
         torch.cuda.synchronize(eng.device)
@@ -134,18 +134,32 @@ class _NativeUNetForward:
                  attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
                  down_block_additional_residuals=None, mid_block_additional_residual=None,
                  down_intrablock_additional_residuals=None, encoder_attention_mask=None, return_dict=True):
-        extra = dict(class_labels=class_labels, timestep_cond=timestep_cond, attention_mask=attention_mask,
-                     down_intrablock_additional_residuals=down_intrablock_additional_residuals)
+        extra = dict(attention_mask=attention_mask, down_intrablock_additional_residuals=down_intrablock_additional_residuals)
         bad = [k for k, v in extra.items() if v is not None]
+        eng = self.engine
         # encoder_attention_mask (text padding) is an input of the native plan: an additive key bias of every cross-attention
         # launch (reference passes attn_bias through, libs/xformers/xformers_attention.py:30-47)
         emask = encoder_attention_mask
         if emask is not None and not (torch.is_tensor(emask) and emask.device.type == "cuda" and emask.shape[0] == sample.shape[0]
                                       and ((emask.ndim == 2) or (emask.ndim == 3 and emask.shape[1] == 1))):
             bad.append("encoder_attention_mask (need [B, S] or [B, 1, S] on the GPU)")
-        if cross_attention_kwargs:
-            bad.append("cross_attention_kwargs")
-        eng = self.engine
+        # cross_attention_kwargs: diffusers pops "scale" and applies it to LoRA layers only. The engine refuses modules with LoRA /
+        # adapter parameters at construction (parameter inventory), so here the scale has nothing to act on and is accepted; any
+        # other key (ip_adapter_masks, gligen, ...) selects an attention processor the plan does not implement
+        if cross_attention_kwargs and set(cross_attention_kwargs) - {"scale"}:
+            bad.append("cross_attention_kwargs " + str(sorted(set(cross_attention_kwargs) - {"scale"})))
+        # timestep_cond (LCM-distilled UNets: the guidance-scale embedding w) and class_labels (class_embed_type "timestep" /
+        # "projection") are inputs of the native plan (examples/optimize_lcm_pipeline.py in the reference runs on the compiled UNet)
+        tcond, tdim, ctype = timestep_cond, getattr(eng, "tcond_dim", None), getattr(eng, "class_type", None)
+        if tcond is not None and not (torch.is_tensor(tcond) and tcond.device.type == "cuda" and tcond.ndim == 2 and tdim is not None
+                                      and tuple(tcond.shape) == (sample.shape[0], int(tdim))):
+            bad.append("timestep_cond (need [B, time_cond_proj_dim] on the GPU)")
+        # diffusers ignores class_labels when the UNet has no class embedding (get_class_embed returns None): so does the plan
+        clabels = class_labels if ctype is not None else None
+        if clabels is not None and not (torch.is_tensor(clabels) and clabels.device.type == "cuda"):
+            bad.append("class_labels (need a tensor on the GPU)")
+        if clabels is None and ctype is not None:
+            bad.append("class_labels missing")  # let the original forward raise diffusers' own error
         # ControlNet residuals (reference keeps ControlNet pipelines on the compiled UNet, :89-90): taken natively when
         # both kinds are present as tensors of the engine's dtype on its device
         ctrl = down_block_additional_residuals is not None or mid_block_additional_residual is not None
@@ -170,7 +184,7 @@ class _NativeUNetForward:
                                   encoder_hidden_states=encoder_hidden_states, return_dict=return_dict,
                                   **{k: v for k, v in given.items() if v is not None})
         B, _, H, W = sample.shape
-        key = (B, H, W, encoder_hidden_states.shape[1], ctrl, emask is not None)
+        key = (B, H, W, encoder_hidden_states.shape[1], ctrl, emask is not None, tcond is not None)
         entry = self._cached.get(key)
         if entry is None:
             with self._lock:
@@ -179,7 +193,7 @@ class _NativeUNetForward:
                     logger.info("sfast: building native UNet plan for %s (graph=%s)", key, self.enable_graph)
                     try:
                         entry = self._prepare(key, sample, timestep, encoder_hidden_states, added_cond_kwargs,
-                                              down_block_additional_residuals, mid_block_additional_residual, emask)
+                                              down_block_additional_residuals, mid_block_additional_residual, emask, tcond, clabels)
                     except (NotImplementedError, KeyError) as e:
                         # this signature is outside the plan's coverage (e.g. a latent size the levels do not divide, a
                         # parameter the planner expected but a wrapper renamed): keep the module's own forward for it
@@ -189,13 +203,14 @@ class _NativeUNetForward:
                     self._cached[key] = entry
         if entry is _FALLBACK:
             given = dict(added_cond_kwargs=added_cond_kwargs, down_block_additional_residuals=down_block_additional_residuals,
-                         mid_block_additional_residual=mid_block_additional_residual, encoder_attention_mask=encoder_attention_mask)
+                         mid_block_additional_residual=mid_block_additional_residual, encoder_attention_mask=encoder_attention_mask,
+                         timestep_cond=timestep_cond, class_labels=class_labels, cross_attention_kwargs=cross_attention_kwargs)
             return self.orig_forward(sample, timestep, encoder_hidden_states=encoder_hidden_states, return_dict=return_dict,
                                      **{k: v for k, v in given.items() if v is not None})
         plan, graph, env = entry
         with env.lock, torch.cuda.device(eng.device):
             eng.load_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs,
-                            down_block_additional_residuals, mid_block_additional_residual, emask)
+                            down_block_additional_residuals, mid_block_additional_residual, emask, tcond, clabels)
             if graph is not None:
                 graph.replay()
             else:

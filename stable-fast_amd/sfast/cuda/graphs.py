@@ -187,7 +187,12 @@ class AutoGraphCraphCompiler:
     call can be replayed from a hipGraph (only tensors / scalars / strings in nested containers) and captures it."""
 
     def __init__(self, **kwargs):
-        self.kwargs = kwargs
+        # the reference forwards **kwargs to simple_make_graphed_callable, which accepts none (a latent TypeError at the first capture,
+        # cuda/graphs.py:296-340 there): reject them where the mistake is made instead
+        if kwargs:
+            raise TypeError(f"AutoGraphCraphCompiler: unexpected keyword arguments {sorted(kwargs)} "
+                            "(simple_make_graphed_callable takes none)")
+        self.kwargs = {}
         self._is_compiling = threading.local()
 
     def is_compiling(self):
@@ -272,7 +277,8 @@ class _LazyCompiledForward:
 
 def apply_auto_graph_compiler_to_all_modules(m, filter_func=None, recursive=True, **kwargs):
     """Wrap the forward of `m` (recursive=False) or of every module the filter accepts, walking like the reference's patch_module:
-    `filter_func(stack)` sees the [(name, module), ...] path from the root; an accepted module is wrapped and not descended into."""
+    `filter_func(stack)` sees the [(name, module), ...] path from the root; an accepted CHILD is wrapped and not descended into, an
+    accepted root is wrapped and its children are still walked (utils/patch.py:1-19 there)."""
     compiler = AutoGraphCraphCompiler(**kwargs)
 
     def wrap(mod):
@@ -295,6 +301,6 @@ def apply_auto_graph_compiler_to_all_modules(m, filter_func=None, recursive=True
 
     root = [(None, m)]
     if filt(root):
-        return wrap(m)
+        wrap(m)
     walk(m, root)
     return m

@@ -6,8 +6,9 @@ guidance batch-2 UNet forward plus the scheduler step
 CUDA graph and the scheduler optionally traced (`trace_scheduler`,
 /root/reference/src/sfast/compilers/diffusion_pipeline_compiler.py:103-107). Here the guidance combine
 and the DDIM update are one HIP kernel recorded in the same graph as the UNet plan, and its output is
-written straight into the UNet's static input buffer, so a step is: two 16-byte device copies
-(timestep, coefficients) + one graph launch.
+written straight into the UNet's static input buffer; the timestep and the DDIM coefficients of the step come
+from device tables through a cursor the graph advances itself (`sfast_hip_schedule_advance`), so a step is one
+graph launch.
 """
 import ctypes as C
 
@@ -33,14 +34,18 @@ def ddim_schedule(num_steps=50, num_train=1000, beta_start=0.00085, beta_end=0.0
 
 
 class DenoiseLoop:
-    """Independent per-GPU denoise loop over `images` latents with classifier-free guidance."""
+    """Independent per-GPU denoise loop over `images` latents with classifier-free guidance.
+
+    One iteration = ONE graph launch and nothing else: the graph's first node (`sfast_hip_schedule_advance`) moves the current
+    row of the timestep / coefficient tables into the plan's static inputs and advances a device-side cursor, so the host issues
+    no per-step copies. The cross-attention K/V projections depend on the text context only -- constant over the 50 steps -- and
+    run ONCE, in `set_inputs`, not in every step's graph (`compile()` cannot do that: there the context may change per call)."""
 
     def __init__(self, engine, images=1, height=64, width=64, ctx_len=77, guidance=7.5, num_steps=50, use_graph=True):
         self.engine = engine
         self.images = images
         self.guidance = float(guidance)
-        # (`_emulated`: the CPU test-suite drives the loop through tests/abi_emulator.py; product engines always take the real library)
-        self.lib = engine.lib if getattr(engine, "_emulated", False) else L.init_device(engine.device)
+        self.lib = self._library(engine)
         dev, dt = engine.device, engine.dtype
         self.plan = engine.get_plan(2 * images, height, width, ctx_len)
         ts, rows = ddim_schedule(num_steps)
@@ -48,18 +53,46 @@ class DenoiseLoop:
         self.ts_table = torch.tensor(ts, dtype=torch.float32, device=dev).reshape(-1, 1).expand(-1, 2 * images).contiguous()
         self.coef_table = torch.tensor(rows, dtype=torch.float32, device=dev)
         self.coef = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.cursor = torch.zeros(1, dtype=torch.int32, device=dev)   # device-side step index, advanced by the graph itself
+        self._next = 0                                                # host mirror of the cursor
         self.latents = torch.zeros((images, engine.in_ch, height, width), dtype=dt, device=dev)
         self.use_graph = use_graph
         self.graph = None
         self.graph_forked = False
+        from .unet2d import LANE_KV
+        self._kv_lane = LANE_KV
+        self._step_ops = [op for op in self.plan.ops if op.lane != LANE_KV]   # what a step launches
+        self._ctx_ops = [op for op in self.plan.ops if op.lane == LANE_KV]    # what a new text context launches, once
+
+    @staticmethod
+    def _library(engine):
+        return L.init_device(engine.device)
+
+    def _stream_ptr(self):
+        return torch.cuda.current_stream(self.engine.device).cuda_stream
 
     def set_inputs(self, latents, ehs_uncond_cond):
-        """latents [images,4,H,W]; ehs_uncond_cond [2*images, ctx, dim] ordered [uncond..., cond...]."""
+        """latents [images,4,H,W]; ehs_uncond_cond [2*images, ctx, dim] ordered [uncond..., cond...]. Runs the text-side launches
+        (every cross-attention block's K/V projection) for this context."""
         self.latents.copy_(latents)
         si = self.plan.static_in
         si["sample"][: self.images].copy_(latents)
         si["sample"][self.images:].copy_(latents)
         si["encoder_hidden_states"].copy_(ehs_uncond_cond)
+        sp = self._stream_ptr()
+        for op in self._ctx_ops:
+            op.launch(sp)
+
+    def set_step(self, i):
+        """Next iteration to run (0-based, modulo the schedule length)."""
+        self._next = i % self.num_steps
+        self.cursor.fill_(self._next)
+
+    def _head(self, stream):
+        rc = self.lib.sfast_hip_schedule_advance(self.cursor.data_ptr(), self.ts_table.data_ptr(), self.ts_table.shape[1],
+                                                self.plan.static_in["timestep"].data_ptr(), self.coef_table.data_ptr(), 4,
+                                                self.coef.data_ptr(), self.num_steps, stream)
+        L.check(rc, "sfast_hip_schedule_advance")
 
     def _tail(self, stream):
         rc = self.lib.sfast_hip_cfg_ddim_step(self.plan.static_out.data_ptr(), self.latents.data_ptr(), self.latents.data_ptr(),
@@ -68,13 +101,13 @@ class DenoiseLoop:
         L.check(rc, "sfast_hip_cfg_ddim_step")
 
     def _launch_all(self, stream):
-        self.plan.run(stream)
+        self._head(stream)
+        for op in self._step_ops:
+            op.launch(stream)
         self._tail(stream)
 
     def capture(self, warmups=3):
         dev = self.engine.device
-        self.coef.copy_(self.coef_table[0])
-        self.plan.static_in["timestep"].copy_(self.ts_table[0])
         keep_lat = self.latents.clone()
         keep_in = self.plan.static_in["sample"].clone()
         torch.cuda.synchronize(dev)
@@ -84,20 +117,24 @@ class DenoiseLoop:
                 self._launch_all(side.cuda_stream)
         torch.cuda.synchronize(dev)
         if self.use_graph:
-            from .unet2d import capture_plan_graph
-            self.graph, self.graph_forked = capture_plan_graph(self.plan, side, tail=self._tail)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    self._launch_all(torch.cuda.current_stream(dev).cuda_stream)
+            self.graph = g
             torch.cuda.synchronize(dev)
         self.latents.copy_(keep_lat)
         self.plan.static_in["sample"].copy_(keep_in)
+        self.set_step(0)
 
     def step(self, i):
-        """Run denoise iteration i (0-based) on the current stream."""
+        """Run denoise iteration i (0-based) on the current stream: one graph launch. The host touches the device cursor only when
+        `i` is not the iteration the cursor already points at (a restart, a skipped step)."""
         idx = i % self.num_steps
-        self.plan.static_in["timestep"].copy_(self.ts_table[idx], non_blocking=True)
-        self.coef.copy_(self.coef_table[idx], non_blocking=True)
+        if idx != self._next:
+            self.cursor.fill_(idx)
+        self._next = (idx + 1) % self.num_steps
         if self.graph is not None:
             self.graph.replay()
-        elif getattr(self.engine, "_emulated", False):
-            self._launch_all(None)
         else:
-            self._launch_all(torch.cuda.current_stream(self.engine.device).cuda_stream)
+            self._launch_all(self._stream_ptr())

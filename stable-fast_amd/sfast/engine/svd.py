@@ -19,7 +19,7 @@ import ctypes as C
 import torch
 
 from ..hip import lib as L
-from .unet2d import LANE_KV, LANE_MAIN, LANE_TEMB, UNet2DEngine, UNetPlan, UnsupportedUNet, _Pool, _cfg_get
+from .unet2d import LANE_KV, LANE_MAIN, LANE_TEMB, UNet2DEngine, UNetPlan, UnsupportedUNet, _Pool, _cfg_get, live_norm_eps
 
 
 class SVDUNetEngine(UNet2DEngine):
@@ -41,7 +41,9 @@ class SVDUNetEngine(UNet2DEngine):
                     # Conv3d (3,1,1): [Cout][kt][1][1][Cin] physical order = the K-contiguous image of a 3 x 1 conv
                     p.data = d = d.contiguous(memory_format=torch.channels_last_3d)
                 params[name] = d
-        return cls(cfg, params, _lib=_lib)
+        eng = cls(cfg, params, _lib=_lib)
+        eng.norm_eps = live_norm_eps(m)
+        return eng
 
     def _parse_config(self):
         g = lambda k, d=None: _cfg_get(self.cfg, k, d)

@@ -50,6 +50,18 @@ class UnsupportedUNet(NotImplementedError):
     pass
 
 
+def live_norm_eps(m):
+    """eps of every normalisation layer, read from the LIVE module (module path -> eps) instead of a config default or a constant:
+    diffusers hands SVD's temporal resnets the spatial block's eps unless `temporal_eps` is set, custom UNets override `norm_eps`
+    per block, ... The planner's own values are only the fallback for parameter sets that come without a module."""
+    out = {}
+    for name, mod in m.named_modules():
+        e = getattr(mod, "eps", None)
+        if name and isinstance(e, (int, float)) and not isinstance(e, bool):
+            out[name] = float(e)
+    return out
+
+
 class _Pool:
     """Size-keyed free list of device buffers; a plan is executed in order on one stream, so a
     buffer released by the planner can be handed to any later op."""
@@ -234,6 +246,7 @@ class UNet2DEngine:
             raise L.SfastHipError("UNet2DEngine needs parameters on a ROCm device; there is no CPU path")
         self.dt = L.F16 if self.dtype == torch.float16 else L.BF16
         self.esize = 2
+        self.norm_eps = {}  # module path -> eps of the live normalisation layer (from_module); empty: the planner's defaults
         self._parse_config()
         self._plans = {}
         self._lock = threading.Lock()
@@ -260,7 +273,9 @@ class UNet2DEngine:
                     else:
                         p.data = d = d.contiguous(memory_format=torch.channels_last)
                 params[name] = d
-        return cls(cfg, params, _lib=_lib)
+        eng = cls(cfg, params, _lib=_lib)
+        eng.norm_eps = live_norm_eps(m)
+        return eng
 
     def refresh_parameters(self, m):
         """Re-bind after parameters were re-assigned (not needed for in-place `copy_` updates)."""
@@ -306,10 +321,17 @@ class UNet2DEngine:
         if self.add_type not in (None, "text_time"):
             raise UnsupportedUNet(f"addition_embed_type {self.add_type}")
         self.add_time_dim = g("addition_time_embed_dim")
-        for k in ("class_embed_type", "encoder_hid_dim_type", "time_embedding_type"):
+        for k in ("encoder_hid_dim_type", "time_embedding_type"):
             v = g(k)
             if v not in (None, "positional"):
                 raise UnsupportedUNet(f"{k}={v}")
+        # class conditioning: "timestep" (sinusoid -> MLP) and "projection" (float vector -> MLP) are plan inputs; an nn.Embedding
+        # table (class_embed_type None + num_class_embeds), "identity" and "simple_projection" are not built
+        self.class_type = g("class_embed_type")
+        if self.class_type not in (None, "timestep", "projection"):
+            raise UnsupportedUNet(f"class_embed_type={self.class_type}")
+        # LCM guidance embedding: `timestep_cond` [B, time_cond_proj_dim] -> bias-free Linear added to the sinusoid before the MLP
+        self.tcond_dim = g("time_cond_proj_dim")
         if g("act_fn", "silu") not in ("silu", "swish"):
             raise UnsupportedUNet("act_fn")
         if g("resnet_time_scale_shift", "default") != "default":
@@ -326,7 +348,7 @@ class UNet2DEngine:
         "center_input_sample": (False,), "downsample_padding": (1,), "mid_block_scale_factor": (1, 1.0), "dropout": (0, 0.0),
         "reverse_transformer_layers_per_block": (None,), "encoder_hid_dim": (None,), "num_class_embeds": (None,),
         "resnet_skip_time_act": (False,), "resnet_out_scale_factor": (1, 1.0), "time_embedding_dim": (None,),
-        "time_embedding_act_fn": (None,), "timestep_post_act": (None,), "time_cond_proj_dim": (None,), "conv_in_kernel": (3,),
+        "time_embedding_act_fn": (None,), "timestep_post_act": (None,), "conv_in_kernel": (3,),
         "conv_out_kernel": (3,), "attention_type": ("default", None), "class_embeddings_concat": (False,),
         "mid_block_only_cross_attention": (None, False), "cross_attention_norm": (None,), "attention_bias": (False, None),
         "global_pool_conditions": (False,), "controlnet_conditioning_channel_order": ("rgb", None),
@@ -338,7 +360,7 @@ class UNet2DEngine:
         "transformer_layers_per_block", "encoder_hid_dim_type", "attention_head_dim", "num_attention_heads", "dual_cross_attention",
         "use_linear_projection", "class_embed_type", "addition_embed_type", "addition_time_embed_dim", "upcast_attention",
         "resnet_time_scale_shift", "time_embedding_type", "projection_class_embeddings_input_dim", "addition_embed_type_num_heads",
-        "conditioning_embedding_out_channels", "conditioning_channels",
+        "conditioning_embedding_out_channels", "conditioning_channels", "time_cond_proj_dim",
     }
 
     def _config_items(self):
@@ -374,7 +396,8 @@ class UNet2DEngine:
                    up_block_types=self.up_types if not self.is_controlnet else (), cross_attention_dim=self.ctx_dim,
                    transformer_layers_per_block=self.depth, use_linear_projection=self.linear_proj, in_channels=self.in_ch,
                    out_channels=self.out_ch, addition_embed_type=self.add_type,
-                   projection_class_embeddings_input_dim=_cfg_get(self.cfg, "projection_class_embeddings_input_dim"))
+                   projection_class_embeddings_input_dim=_cfg_get(self.cfg, "projection_class_embeddings_input_dim"),
+                   time_cond_proj_dim=self.tcond_dim, class_embed_type=self.class_type)
         try:
             want = unet2d_param_shapes(cfg)
         except (KeyError, TypeError, IndexError) as e:
@@ -392,7 +415,7 @@ class UNet2DEngine:
             raise UnsupportedUNet(f"module has parameters the native plan would ignore: {extra[:3]}{' ...' if len(extra) > 3 else ''}")
         for k, shp in want.items():
             got = tuple(have[k].shape)
-            if "time_emb" in k or "add_embedding" in k or "time_embedding" in k:
+            if "time_emb" in k or "add_embedding" in k or "time_embedding" in k or "class_embedding" in k:
                 continue  # widths derive from the embedding dim, checked by the GEMM launches themselves
             if got != tuple(shp):
                 raise UnsupportedUNet(f"parameter {k} has shape {got}, the plan expects {tuple(shp)}")
@@ -412,6 +435,7 @@ class UNet2DEngine:
     def _op_gn(self, plan, name, x, x2, C1, Ctot, N, HW, y, eps, silu, prefix):
         lib = self.lib
         gamma, beta = self.params[prefix + ".weight"], self.params[prefix + ".bias"]
+        eps = self.norm_eps.get(prefix, eps)
         p = L.GnParams(self.dt, L.NHWC, N, Ctot, HW, self.groups, C1, L.ACT_SILU if silu else L.ACT_NONE, float(eps))
         self._need_ws(plan, lib.sfast_hip_group_norm_workspace_bytes(C.byref(p)))
         xp, x2p, gp, bp, yp = x.data_ptr(), (x2.data_ptr() if x2 is not None else None), gamma.data_ptr(), beta.data_ptr(), y.data_ptr()
@@ -435,7 +459,7 @@ class UNet2DEngine:
     def _op_ln(self, plan, name, x, y, M, N, prefix):
         lib = self.lib
         gamma, beta = self.params[prefix + ".weight"], self.params[prefix + ".bias"]
-        p = L.LnParams(self.dt, M, N, 1e-5)
+        p = L.LnParams(self.dt, M, N, float(self.norm_eps.get(prefix, 1e-5)))
         xp, gp, bp, yp = x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr()
         plan.keep.append(p)
         plan.writer.pop(id(y), None)
@@ -749,9 +773,12 @@ class UNet2DEngine:
         return names
 
     # ------------------------------------------------------------------------------------------
-    def build_plan(self, B, H, W, S_ctx, ctrl=False, enc_mask=False):
+    def build_plan(self, B, H, W, S_ctx, ctrl=False, enc_mask=False, tcond=False):
         """`ctrl`: the plan also takes ControlNet residuals (one NCHW tensor per skip connection + one for the mid block,
-        diffusers `down_block_additional_residuals` / `mid_block_additional_residual`) as static inputs."""
+        diffusers `down_block_additional_residuals` / `mid_block_additional_residual`) as static inputs.
+        `tcond`: the plan takes `timestep_cond` [B, time_cond_proj_dim] (LCM-distilled UNets)."""
+        if tcond and self.tcond_dim is None:
+            raise UnsupportedUNet("timestep_cond given, but the UNet has no time_embedding.cond_proj (time_cond_proj_dim is None)")
         if not self._emulated:
             L.init_device(self.device)
         nlev = len(self.boc)
@@ -786,10 +813,19 @@ class UNet2DEngine:
         self._add(plan, "misc", "timestep_embedding", 0.0, B * c0 * 2.0,
                   lambda s, tp=tp: L.check(lib.sfast_hip_timestep_embedding(tb_ptr, te_ptr, C.byref(tp), s), "timestep_embedding"),
                   lane=LANE_TEMB)
+        if tcond:
+            # TimestepEmbedding.forward: sample = sample + cond_proj(condition) -- one more GEMV whose residual operand is the sinusoid
+            tc = torch.zeros((B, int(self.tcond_dim)), dtype=dt, device=dev)
+            plan.static_in["timestep_cond"] = tc
+            t_emb2 = pool.get(B * c0)
+            self._op_gemm(plan, "time_embedding.cond_proj", tc, [P["time_embedding.cond_proj.weight"]], None, t_emb2, B, c0, int(self.tcond_dim),
+                          int(self.tcond_dim), c0, residual=t_emb, ldr=c0, kind="temb", lane=LANE_TEMB)
+            t_emb = t_emb2
         e1 = pool.get(B * T)
         self._op_gemm(plan, "time_embedding.linear_1", t_emb, [P["time_embedding.linear_1.weight"]], P["time_embedding.linear_1.bias"],
                       e1, B, T, c0, c0, T, act=L.ACT_SILU, kind="temb", lane=LANE_TEMB)
         act_emb = pool.get(B * T)
+        aug = None  # sum of the embeddings diffusers adds to `emb` after the time MLP: class embedding, then text_time
         if self.add_type == "text_time":
             Din = P["add_embedding.linear_1.weight"].shape[1]
             td = self.add_time_dim
@@ -826,12 +862,34 @@ class UNet2DEngine:
             aug = pool.get(B * T)
             self._op_gemm(plan, "add_embedding.linear_2", a1, [P["add_embedding.linear_2.weight"]], P["add_embedding.linear_2.bias"],
                           aug, B, T, T, T, T, kind="temb", lane=LANE_TEMB)
-            self._op_gemm(plan, "time_embedding.linear_2", e1, [P["time_embedding.linear_2.weight"]], P["time_embedding.linear_2.bias"],
-                          act_emb, B, T, T, T, T, act=L.ACT_SILU, residual=aug, ldr=T, res_before_act=True, kind="temb", lane=LANE_TEMB)
-        else:
-            # act_emb = silu(emb): the embedding is only ever consumed through SiLU (ResnetBlock2D)
-            self._op_gemm(plan, "time_embedding.linear_2", e1, [P["time_embedding.linear_2.weight"]], P["time_embedding.linear_2.bias"],
-                          act_emb, B, T, T, T, T, act=L.ACT_SILU, kind="temb", lane=LANE_TEMB)
+        if self.class_type is not None:
+            # emb = emb + class_embedding(class_labels): "timestep" embeds the labels through the same sinusoid as t, "projection"
+            # takes a float vector; the MLP's second Linear carries the text_time embedding (if any) as its residual operand
+            Dc = P["class_embedding.linear_1.weight"].shape[1]
+            if self.class_type == "timestep":
+                clab = torch.zeros((B,), dtype=torch.float32, device=dev)
+                ce_in = pool.get(B * Dc)
+                tp3 = L.TembParams(self.dt, B, Dc, int(self.flip), self.freq_shift, 10000.0)
+                plan.keep.append(tp3)
+                cl_ptr, ce_ptr = clab.data_ptr(), ce_in.data_ptr()
+                self._add(plan, "misc", "class_labels_embedding", 0.0, B * Dc * 2.0,
+                          lambda s, tp3=tp3: L.check(lib.sfast_hip_timestep_embedding(cl_ptr, ce_ptr, C.byref(tp3), s), "class_labels"),
+                          lane=LANE_TEMB)
+            else:
+                clab = torch.zeros((B, Dc), dtype=dt, device=dev)
+                ce_in = clab
+            plan.static_in["class_labels"] = clab
+            c1 = pool.get(B * T)
+            self._op_gemm(plan, "class_embedding.linear_1", ce_in, [P["class_embedding.linear_1.weight"]], P["class_embedding.linear_1.bias"],
+                          c1, B, T, Dc, Dc, T, act=L.ACT_SILU, kind="temb", lane=LANE_TEMB)
+            cemb = pool.get(B * T)
+            self._op_gemm(plan, "class_embedding.linear_2", c1, [P["class_embedding.linear_2.weight"]], P["class_embedding.linear_2.bias"],
+                          cemb, B, T, T, T, T, residual=aug, ldr=T if aug is not None else 0, kind="temb", lane=LANE_TEMB)
+            aug = cemb
+        # act_emb = silu(emb [+ aug]): the embedding is only ever consumed through SiLU (ResnetBlock2D)
+        self._op_gemm(plan, "time_embedding.linear_2", e1, [P["time_embedding.linear_2.weight"]], P["time_embedding.linear_2.bias"],
+                      act_emb, B, T, T, T, T, act=L.ACT_SILU, residual=aug, ldr=T if aug is not None else 0,
+                      res_before_act=aug is not None, kind="temb", lane=LANE_TEMB)
         # every resnet's time_emb_proj depends only on t: hoisted to the top of the graph
         rnames = self._resnet_names()
         offs, tot = {}, 0
@@ -1109,8 +1167,8 @@ class UNet2DEngine:
         return out
 
     # ------------------------------------------------------------------------------------------
-    def get_plan(self, B, H, W, S_ctx, ctrl=False, enc_mask=False):
-        key = (B, H, W, S_ctx, bool(ctrl), bool(enc_mask))
+    def get_plan(self, B, H, W, S_ctx, ctrl=False, enc_mask=False, tcond=False):
+        key = (B, H, W, S_ctx, bool(ctrl), bool(enc_mask), bool(tcond))
         plan = self._plans.get(key)
         if plan is None:
             with self._lock:
@@ -1121,6 +1179,8 @@ class UNet2DEngine:
                         kw["ctrl"] = True
                     if enc_mask:
                         kw["enc_mask"] = True
+                    if tcond:
+                        kw["tcond"] = True
                     plan = self.build_plan(B, H, W, S_ctx, **kw)
                     self._plans[key] = plan
         return plan
@@ -1136,8 +1196,18 @@ class UNet2DEngine:
         return ((1 - mask.to(dtype)) * -10000.0).to(dtype)
 
     def load_inputs(self, plan, sample, timestep, encoder_hidden_states, added_cond_kwargs=None,
-                    down_block_additional_residuals=None, mid_block_additional_residual=None, encoder_attention_mask=None):
+                    down_block_additional_residuals=None, mid_block_additional_residual=None, encoder_attention_mask=None,
+                    timestep_cond=None, class_labels=None):
         si = plan.static_in
+        if "timestep_cond" in si:
+            if timestep_cond is None:
+                raise ValueError("this plan takes a timestep_cond")
+            si["timestep_cond"].copy_(timestep_cond)
+        if "class_labels" in si:
+            if class_labels is None:
+                raise ValueError("class_labels should be provided when the UNet has a class embedding")  # diffusers' own error
+            cl = si["class_labels"]
+            cl.copy_(class_labels.reshape(cl.shape) if cl.ndim == 2 else class_labels.reshape(-1).to(torch.float32).expand(plan.B))
         if "encoder_attention_bias" in si:
             if encoder_attention_mask is None:
                 raise ValueError("this plan takes an encoder_attention_mask")
@@ -1163,13 +1233,13 @@ class UNet2DEngine:
             si["mid_block_additional_residual"].copy_(mid_block_additional_residual)
 
     def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, down_block_additional_residuals=None,
-                mid_block_additional_residual=None, encoder_attention_mask=None):
+                mid_block_additional_residual=None, encoder_attention_mask=None, timestep_cond=None, class_labels=None):
         """Eager (no graph) execution on the current stream; returns a fresh NCHW tensor."""
         B, _, H, W = sample.shape
         ctrl = down_block_additional_residuals is not None
-        plan = self.get_plan(B, H, W, encoder_hidden_states.shape[1], ctrl, encoder_attention_mask is not None)
+        plan = self.get_plan(B, H, W, encoder_hidden_states.shape[1], ctrl, encoder_attention_mask is not None, timestep_cond is not None)
         self.load_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs, down_block_additional_residuals,
-                         mid_block_additional_residual, encoder_attention_mask)
+                         mid_block_additional_residual, encoder_attention_mask, timestep_cond, class_labels)
         plan.run(None if self._emulated else torch.cuda.current_stream(self.device).cuda_stream)
         return plan.static_out.clone()
 

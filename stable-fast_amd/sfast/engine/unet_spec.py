@@ -19,6 +19,7 @@ SD15_CONFIG = dict(
     attention_head_dim=8, transformer_layers_per_block=1, norm_num_groups=32, norm_eps=1e-5,
     use_linear_projection=False, flip_sin_to_cos=True, freq_shift=0, addition_embed_type=None,
     addition_time_embed_dim=None, projection_class_embeddings_input_dim=None,
+    time_cond_proj_dim=None, class_embed_type=None,
 )
 
 SDXL_CONFIG = dict(
@@ -90,6 +91,15 @@ def unet2d_param_shapes(cfg: dict) -> Dict[str, Tuple[int, ...]]:
     conv("conv_in", boc[0], cfg.get("in_channels", 4), 3)
     linear("time_embedding.linear_1", T, boc[0])
     linear("time_embedding.linear_2", T, T)
+    if cfg.get("time_cond_proj_dim") is not None:       # LCM: w-embedding added to the sinusoid before the MLP
+        linear("time_embedding.cond_proj", boc[0], cfg["time_cond_proj_dim"], bias=False)
+    cet = cfg.get("class_embed_type")
+    if cet == "timestep":
+        linear("class_embedding.linear_1", T, boc[0])
+        linear("class_embedding.linear_2", T, T)
+    elif cet == "projection":
+        linear("class_embedding.linear_1", T, cfg["projection_class_embeddings_input_dim"])
+        linear("class_embedding.linear_2", T, T)
     if cfg.get("addition_embed_type") == "text_time":
         linear("add_embedding.linear_1", T, cfg["projection_class_embeddings_input_dim"])
         linear("add_embedding.linear_2", T, T)

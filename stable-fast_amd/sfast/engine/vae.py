@@ -22,7 +22,7 @@ import threading
 import torch
 
 from ..hip import lib as L
-from .unet2d import UNet2DEngine, UNetPlan, UnsupportedUNet, _Pool, _as2d, _cfg_get
+from .unet2d import UNet2DEngine, UNetPlan, UnsupportedUNet, _Pool, _as2d, _cfg_get, live_norm_eps
 
 
 class UnsupportedVae(UnsupportedUNet):
@@ -46,6 +46,7 @@ class VaeDecoderEngine(UNet2DEngine):
             raise L.SfastHipError("VaeDecoderEngine needs parameters on a ROCm device; there is no CPU path")
         self.dt = L.F16 if self.dtype == torch.float16 else L.BF16
         self.esize = 2
+        self.norm_eps = {}
         self._parse_config()
         self._plans = {}
         self._lock = threading.Lock()
@@ -64,7 +65,9 @@ class VaeDecoderEngine(UNet2DEngine):
                 if p.ndim == 4 and not p.data.is_contiguous(memory_format=torch.channels_last):
                     p.data = p.data.contiguous(memory_format=torch.channels_last)
                 params[name] = p.data
-        return cls(cfg, params, _lib=_lib)
+        eng = cls(cfg, params, _lib=_lib)
+        eng.norm_eps = live_norm_eps(m)
+        return eng
 
     def _parse_config(self):
         P = self.params

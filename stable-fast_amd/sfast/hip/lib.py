@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "_lib", "libsfast_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # enums (include/sfast_hip.h)
 F16, BF16, F32 = 0, 1, 2
@@ -31,6 +31,7 @@ EXPORTS = [
     "sfast_hip_group_norm_apply",
     "sfast_hip_attention", "sfast_hip_attention_bias", "sfast_hip_strided_copy", "sfast_hip_timestep_embedding",
     "sfast_hip_gemv_grouped", "sfast_hip_gemm_grouped", "sfast_hip_qlinear_w8", "sfast_hip_cfg_ddim_step", "sfast_hip_linear_step", "sfast_hip_mix_rows", "sfast_hip_igemm_plan", "sfast_hip_set_trace", "sfast_hip_image_postprocess", "sfast_hip_add_strided",
+    "sfast_hip_schedule_advance",
 ]
 
 
@@ -189,6 +190,8 @@ def _declare(lib):
     lib.sfast_hip_mix_rows.argtypes = [vp, vp, vp, vp, vp, C.POINTER(MixParams), vp]
     lib.sfast_hip_linear_step.restype = C.c_int
     lib.sfast_hip_linear_step.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int64, C.c_int64, C.c_int32, vp]
+    lib.sfast_hip_schedule_advance.restype = C.c_int
+    lib.sfast_hip_schedule_advance.argtypes = [vp, vp, C.c_int32, vp, vp, C.c_int32, vp, C.c_int32, vp]
     lib.sfast_hip_cfg_ddim_step.restype = C.c_int
     lib.sfast_hip_cfg_ddim_step.argtypes = [vp, vp, vp, vp, vp, C.c_float, C.c_int64, C.c_int32, vp]
 

@@ -51,8 +51,17 @@ def _cfg(s, name, default=None):
     return getattr(c, name, default)
 
 
+_DDIM_CLASSES = ("DDIMScheduler", "DDIMParallelScheduler")
+
+
 def ddim_like(s):
-    """Duck-typed recognition of a DDIM-family scheduler (diffusers DDIMScheduler and subclasses / look-alikes)."""
+    """diffusers' DDIMScheduler / DDIMParallelScheduler, a subclass, or a declared look-alike (`_sfast_ddim_like = True`).
+    Recognised by class name, never by attributes: PNDMScheduler (the SD1.5 default), LCMScheduler, TCDScheduler and
+    DDIMInverseScheduler carry the same `alphas_cumprod` / `final_alpha_cumprod` / `step` surface with multistep, stochastic or
+    inverse arithmetic -- the reference's lazy_trace keeps each scheduler's own math, so anything else stays eager."""
+    names = {c.__name__ for c in type(s).__mro__}
+    if not (names & set(_DDIM_CLASSES)) and not getattr(s, "_sfast_ddim_like", False):
+        return False
     if not (hasattr(s, "alphas_cumprod") and hasattr(s, "step") and hasattr(s, "final_alpha_cumprod")):
         return False
     if _cfg(s, "prediction_type", "epsilon") not in ("epsilon", "v_prediction"):
@@ -143,14 +152,16 @@ class _EulerTables:
 
     def __init__(self, scheduler):
         self.scheduler = scheduler
-        self._key, self._step, self._scale = None, None, None
+        self._key, self._sig, self._step, self._scale = None, None, None, None
 
     def get(self, device):
         sig = self.scheduler.sigmas
         # identity of the installed schedule without touching its values (a device-resident `sigmas` would cost a sync per step):
-        # `set_timesteps` binds a new tensor, in-place edits bump `_version`
-        key = (id(sig), sig.data_ptr() if torch.is_tensor(sig) else 0, int(len(sig)), getattr(sig, "_version", 0), str(device))
-        if key != self._key:
+        # `set_timesteps` binds a new tensor, in-place edits bump `_version`. The keyed tensor is held by a strong reference and
+        # compared with `is`, so a freed schedule's id / storage address cannot be recycled into a false match.
+        key = (int(len(sig)), getattr(sig, "_version", 0), str(device))
+        if sig is not self._sig or key != self._key:
+            self._sig = sig
             sg = torch.as_tensor(sig).double().cpu()
             s0, s1 = sg[:-1], sg[1:]
             dt = s1 - s0

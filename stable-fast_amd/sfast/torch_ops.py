@@ -259,23 +259,95 @@ _def("linear_relu(Tensor input, Tensor weight, Tensor? bias=None) -> Tensor", li
 _def("linear_gelu(Tensor input, Tensor weight, Tensor? bias=None) -> Tensor", linear_gelu)
 
 
-# ---- weight-only int8 dynamic linear (reference csrc/operators/cutlass/cutlass_qlinear.cc:73-89) -------------------------------
-def cutlass_qlinear_dynamic(input, weight, bias=None):
+# ---- int8 dynamic linear (reference csrc/operators/cutlass/cutlass_qlinear.cc:10-89) ---------------------------------------------
+# The reference does not add an operator of its own shape here: it OVERRIDES `quantized::linear_dynamic(X, W_prepack, reduce_range)`
+# for the CUDA / QuantizedCUDA dispatch keys (cutlass_qlinear.cc:73-81), so that `torch.quantization.quantize_dynamic(unet)` modules
+# reach its kernel, and exposes the same function as `sfast::cutlass_qlinear_dynamic` (:83-88). Same binding here; the kernel behind
+# it is libsfast_hip's int8-weight MFMA GEMM (weights stay int8 in HBM, widened while staged into LDS; activations stay 16-bit --
+# the reference also quantises the activations per call, which only lowers accuracy: its own test tolerance is 3e-2).
+def cutlass_qlinear_dynamic_unpacked(input, weight, bias=None):
     """`weight`: a per-tensor-affine quantized qint8 tensor [N, K] (torch.quantize_per_tensor); like the reference the zero point
-    is ignored (weight.int_repr() * weight.q_scale()). f16 / bf16 inputs run the int8-weight MFMA kernel, anything else (fp32
-    inputs, shapes outside its alignment rules) dequantises the weight and takes the ordinary linear kernel -- the reference's own
-    fallback (cutlass_qlinear_dynamic_kernel.cu:272-279, :231-238)."""
+    is ignored (weight.int_repr() * weight.q_scale(), cutlass_qlinear_dynamic_kernel.cu:272-279). f16 / bf16 inputs run the
+    int8-weight MFMA kernel, anything else (fp32 inputs, shapes outside its alignment rules) dequantises the weight and takes the
+    ordinary linear kernel -- the reference's own fallback (:231-238)."""
     if not weight.is_quantized:
         raise RuntimeError("weight should be quantized")
-    w8, scale = weight.int_repr(), float(weight.q_scale())
+    return _qlinear_w8(input, weight.int_repr(), float(weight.q_scale()), bias)
+
+
+def _qlinear_w8(input, w8, scale, bias):
     N, K = w8.shape
+    if bias is not None and bias.dtype != input.dtype:
+        bias = bias.to(input.dtype)
     if input.dtype in (torch.float16, torch.bfloat16) and K % 8 == 0 and N % 4 == 0:
         return F.qlinear_w8(input, w8, scale, bias)
     wd = (w8.to(torch.float32) * scale).to(input.dtype)
     return F.linear(input, wd, bias)
 
 
-# the weight is a QuantizedCUDA tensor: registered like the reference (CompositeImplicitAutograd, cutlass_qlinear.cc:83-87) so that the
-# quantized dispatch key of that argument does not hide the implementation
-_lib.define("cutlass_qlinear_dynamic(Tensor input, Tensor weight, Tensor? bias=None) -> Tensor")
-_lib.impl("cutlass_qlinear_dynamic", cutlass_qlinear_dynamic, "CompositeImplicitAutograd")
+class _PackedOnDevice:
+    """What PackedLinearWeightCutlass holds in the reference (orig_weight, bias_ -- cutlass_qlinear.cc:21-24): the int8 weight image
+    and the bias of one packed-params object, resident on the activation's device. `LinearPackedParamsBase` is a C++ torchbind class
+    that Python cannot subclass, so the packed object the dispatcher hands over is PyTorch's own (CPU-packed) one and this record
+    hangs off it in a side table: filled by the QuantizedCUDA `linear_prepack` below with the tensors it was given (no copy), or on
+    first use from `linear_unpack` for objects packed elsewhere (the reference's `from_native`, :43-51)."""
+    __slots__ = ("w8", "scale", "bias")
+
+    def __init__(self, w8, scale, bias):
+        self.w8, self.scale, self.bias = w8, scale, bias
+
+
+_PACKED = {}         # packed-params object -> {device: _PackedOnDevice}
+_PACKED_LIMIT = 4096
+
+
+def _remember(packed, dev, rec):
+    if len(_PACKED) >= _PACKED_LIMIT:   # modules re-packed in a loop: keep the table bounded (records are re-derivable)
+        _PACKED.clear()
+    _PACKED.setdefault(packed, {})[dev] = rec
+
+
+def _device_record(packed, device):
+    per = _PACKED.get(packed)
+    rec = per.get(device) if per else None
+    if rec is None:
+        w, b = torch.ops.quantized.linear_unpack(packed)
+        if w.qscheme() not in (torch.per_tensor_affine, torch.per_tensor_symmetric):
+            raise RuntimeError(f"Unsupported qscheme: {w.qscheme()}")        # cutlass_qlinear.cc:29-30
+        rec = _PackedOnDevice(w.int_repr().to(device).contiguous(), float(w.q_scale()), b.to(device) if b is not None else None)
+        _remember(packed, device, rec)
+    return rec
+
+
+def quantized_linear_prepack_cuda(W, B=None):
+    """`quantized::linear_prepack` for QuantizedCUDA weights (what `quantize_dynamic(module.cuda())` calls; PyTorch-ROCm registers it
+    for QuantizedCPU only). Checks follow PackedLinearWeightCutlass::prepack (cutlass_qlinear.cc:26-41)."""
+    if W.qscheme() not in (torch.per_tensor_affine, torch.per_tensor_symmetric):
+        raise RuntimeError(f"Unsupported qscheme: {W.qscheme()}")
+    if B is not None and (B.dim() != 1 or B.shape[0] != W.shape[0]):
+        raise RuntimeError(f"bias should be a vector (1D Tensor) with {W.shape[0]} elements")
+    w8 = W.int_repr()
+    wq_cpu = torch._make_per_tensor_quantized_tensor(w8.cpu(), float(W.q_scale()), int(W.q_zero_point()))
+    packed = torch.ops.quantized.linear_prepack(wq_cpu, B.detach().float().cpu() if B is not None else None)
+    _remember(packed, W.device, _PackedOnDevice(w8.contiguous(), float(W.q_scale()), B.detach() if B is not None else None))
+    return packed
+
+
+def cutlass_qlinear_dynamic(X, W_prepack, reduce_range=False):
+    """QLinearInt8<false>::run_dynamic (cutlass_qlinear.cc:60-71): `reduce_range` is accepted and ignored, as there (:13-16)."""
+    rec = _device_record(W_prepack, X.device)
+    return _qlinear_w8(X, rec.w8, rec.scale, rec.bias)
+
+
+_PACKED_T = "__torch__.torch.classes.quantized.LinearPackedParamsBase"
+_lib.define(f"cutlass_qlinear_dynamic(Tensor X, {_PACKED_T} W_prepack, bool reduce_range=False) -> Tensor")
+_lib.impl("cutlass_qlinear_dynamic", cutlass_qlinear_dynamic, "CUDA")
+# the unpacked form (a QuantizedCUDA weight tensor): registered CompositeImplicitAutograd so that the quantized dispatch key of that
+# argument does not hide the implementation
+_lib.define("cutlass_qlinear_dynamic_unpacked(Tensor input, Tensor weight, Tensor? bias=None) -> Tensor")
+_lib.impl("cutlass_qlinear_dynamic_unpacked", cutlass_qlinear_dynamic_unpacked, "CompositeImplicitAutograd")
+
+_qlib = torch.library.Library("quantized", "IMPL")
+for _key in ("CUDA", "QuantizedCUDA"):                      # TORCH_LIBRARY_IMPL(quantized, {QuantizedCUDA, CUDA}) -- cutlass_qlinear.cc:73-81
+    _qlib.impl("linear_dynamic", cutlass_qlinear_dynamic, _key)
+_qlib.impl("linear_prepack", quantized_linear_prepack_cuda, "QuantizedCUDA")

@@ -25,7 +25,7 @@ from oracle import ops_ref as R  # noqa: E402
 from oracle.unet_ref import timestep_embedding as temb_ref  # noqa: E402
 from sfast.hip import lib as L  # noqa: E402
 
-_NP = {L.F16: np.float16, L.F32: np.float32}
+_NP = {L.F16: np.float16, L.F32: np.float32, "i32": np.int32}
 _ACT = {0: None, 1: "relu", 2: "gelu", 3: "gelu_tanh", 4: "silu", 5: "sigmoid", 6: "tanh"}
 
 
@@ -353,6 +353,17 @@ class EmuLib:
         _flat(out, p.B * p.dim, p.dtype).reshape(p.B, p.dim).copy_(e)
         return 0
 
+    def sfast_hip_schedule_advance(self, cursor, ts_table, ts_cols, ts_out, coef_table, coef_cols, coef_out, n_steps, stream):
+        self.calls.append("schedule_advance")
+        cur = _flat(cursor, 1, "i32")
+        idx = max(0, int(cur[0])) % n_steps
+        if ts_cols:
+            _flat(ts_out, ts_cols, L.F32).copy_(_flat(ts_table, n_steps * ts_cols, L.F32)[idx * ts_cols:(idx + 1) * ts_cols])
+        if coef_cols:
+            _flat(coef_out, coef_cols, L.F32).copy_(_flat(coef_table, n_steps * coef_cols, L.F32)[idx * coef_cols:(idx + 1) * coef_cols])
+        cur[0] = (idx + 1) % n_steps
+        return 0
+
     def sfast_hip_cfg_ddim_step(self, eps_uc, lat, lat_out, unet_in, coef, g, numel, dtype, stream):
         self.calls.append("cfg_ddim_step")
         g = float(getattr(g, "value", g))
@@ -366,3 +377,20 @@ class EmuLib:
             u[:numel].copy_(r)
             u[numel:].copy_(r)
         return 0
+
+
+def emulated_denoise_loop(engine, **kw):
+    """`sfast.engine.denoise.DenoiseLoop` driven through the host emulator: the product class knows nothing about emulation (it always
+    takes the real library and the device's current stream); the two seams it exposes are overridden HERE, in test code."""
+    from sfast.engine.denoise import DenoiseLoop
+
+    class EmulatedDenoiseLoop(DenoiseLoop):
+        @staticmethod
+        def _library(eng):
+            return eng.lib           # the EmuLib instance injected into the engine
+
+        def _stream_ptr(self):
+            return None              # the emulator has no streams
+
+    kw.setdefault("use_graph", False)
+    return EmulatedDenoiseLoop(engine, **kw)

@@ -48,3 +48,21 @@ def compare(name, got, want, atol, rtol, kernel=None):
 
 def log_value(name, **kw):
     _log(dict(case=name, **kw))
+
+
+def storage_floor(ref, fwd, y32, dtype=torch.float16, extra_leaf=(), extra_comp=()):
+    """rel. L2 of the fp32 oracle `ref` re-run (through `fwd()`) with every op output rounded to `dtype` once -- exact arithmetic,
+    16-bit activation STORAGE only: the error floor of any engine that keeps 16-bit activations (tools/error_budget.py)."""
+    import sys
+    tools = os.path.join(ROOT, "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import error_budget as EB
+    hs = EB.storage_hooks(ref, dtype, blocks=True, extra_leaf=extra_leaf, extra_comp=extra_comp)
+    try:
+        with torch.no_grad():
+            y = fwd()
+    finally:
+        for h in hs:
+            h.remove()
+    return rel_l2(y, y32)

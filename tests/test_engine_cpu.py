@@ -291,8 +291,110 @@ def test_encoder_attention_mask_is_a_plan_input(built_lib):
     err = float((y.float() - want).norm() / want.norm())
     assert err < 4e-3, err
     assert float((plain - want).norm() / want.norm()) > 1e-2  # the mask matters for this input
-    assert len(eng._plans) == 1 and list(eng._plans)[0][-1] is True
+    assert len(eng._plans) == 1 and list(eng._plans)[0][5] is True  # key = (B, H, W, S_ctx, ctrl, enc_mask, tcond)
     # [B, 1, S] additive-bias form is taken as is
     bias3 = ((1 - mask) * -10000.0)[:, None, :]
     y3 = eng.forward(sample, 700, ehs, encoder_attention_mask=bias3)
     assert torch.equal(y3, y)
+
+
+# ---- VERDICT r02 "eager cliffs": timestep_cond (LCM), class_labels, cross_attention_kwargs={"scale": s} are native plan inputs ----
+def test_plan_takes_timestep_cond_like_an_lcm_unet(built_lib):
+    """LCM-distilled UNets (`time_cond_proj_dim`, /root/reference/examples/optimize_lcm_pipeline.py): the guidance embedding w goes
+    through a bias-free Linear and is added to the sinusoid before the time MLP. One more GEMV (residual = sinusoid) in the plan."""
+    cfg = U.tiny_config(time_cond_proj_dim=32)
+    m16, m32 = _pair(cfg, 6)
+    assert "time_embedding.cond_proj.weight" in dict(m16.named_parameters())
+    eng = UNet2DEngine.from_module(m16, _lib=EmuLib())
+    g = torch.Generator().manual_seed(2)
+    s = torch.randn(2, 4, 16, 16, generator=g).half()
+    e = torch.randn(2, 77, 64, generator=g).half()
+    w = torch.randn(2, 32, generator=g).half()
+    y = eng.forward(s, 700, e, timestep_cond=w)
+    with torch.no_grad():
+        want = m32(s.float(), 700, e.float(), timestep_cond=w.float()).sample
+        without = m32(s.float(), 700, e.float()).sample
+    assert rel_l2(y, want) < 3e-3 and rel_l2(without, want) > 1e-2          # the condition matters and is applied
+    y0 = eng.forward(s, 700, e)                                             # same module called without it: its own plan
+    assert rel_l2(y0, without) < 3e-3 and len(eng._plans) == 2
+    names = [op.name for op in eng.get_plan(2, 16, 16, 77, False, False, True).ops]
+    assert "time_embedding.cond_proj" in names and names.index("time_embedding.cond_proj") < names.index("time_embedding.linear_1")
+    # a UNet without cond_proj refuses the input instead of ignoring it
+    eng2 = UNet2DEngine.from_module(U.build(U.tiny_config(), seed=1, dtype=torch.float16), _lib=EmuLib())
+    with pytest.raises(UnsupportedUNet):
+        eng2.forward(s, 700, e, timestep_cond=w)
+
+
+@pytest.mark.parametrize("cet", ["timestep", "projection"])
+def test_plan_takes_class_labels(built_lib, cet):
+    over = dict(class_embed_type=cet)
+    if cet == "projection":
+        over["projection_class_embeddings_input_dim"] = 40
+    cfg = U.tiny_config(**over)
+    m16, m32 = _pair(cfg, 8)
+    eng = UNet2DEngine.from_module(m16, _lib=EmuLib())
+    g = torch.Generator().manual_seed(3)
+    s = torch.randn(2, 4, 16, 16, generator=g).half()
+    e = torch.randn(2, 77, 64, generator=g).half()
+    labels = torch.tensor([3.0, 977.0]) if cet == "timestep" else torch.randn(2, 40, generator=g).half()
+    y = eng.forward(s, 120, e, class_labels=labels)
+    with torch.no_grad():
+        want = m32(s.float(), 120, e.float(), class_labels=labels.float()).sample
+        other = m32(s.float(), 120, e.float(), class_labels=labels.float().flip(0)).sample
+    assert rel_l2(y, want) < 3e-3 and rel_l2(other, want) > 1e-2
+    with pytest.raises(ValueError):
+        eng.forward(s, 120, e)  # diffusers: "class_labels should be provided ..."
+
+
+def test_class_embedding_and_text_time_stack(built_lib):
+    """emb = time MLP + class_emb + text_time aug: the class MLP's second Linear carries the text_time embedding as its residual."""
+    cfg = U.tiny_config(class_embed_type="timestep", addition_embed_type="text_time", addition_time_embed_dim=32,
+                        projection_class_embeddings_input_dim=64 + 6 * 32, time_cond_proj_dim=16)
+    m16, m32 = _pair(cfg, 10)
+    eng = UNet2DEngine.from_module(m16, _lib=EmuLib())
+    g = torch.Generator().manual_seed(4)
+    s = torch.randn(2, 4, 16, 16, generator=g).half()
+    e = torch.randn(2, 20, 64, generator=g).half()
+    added = dict(text_embeds=torch.randn(2, 64, generator=g).half(), time_ids=torch.tensor([[512., 512, 0, 0, 512, 512]] * 2).half())
+    w = torch.randn(2, 16, generator=g).half()
+    labels = torch.tensor([10.0, 500.0])
+    y = eng.forward(s, 400, e, added, timestep_cond=w, class_labels=labels)
+    with torch.no_grad():
+        want = m32(s.float(), 400, e.float(), added_cond_kwargs={k: v.float() for k, v in added.items()}, timestep_cond=w.float(),
+                   class_labels=labels).sample
+    assert rel_l2(y, want) < 3e-3
+
+
+def test_unknown_class_embedding_types_stay_unsupported(built_lib):
+    config, params = _shape_params(U.tiny_config())
+    config.class_embed_type = "identity"
+    with pytest.raises(UnsupportedUNet):
+        UNet2DEngine(config, params, _lib=EmuLib())
+    config.class_embed_type = None
+    config.num_class_embeds = 10
+    with pytest.raises(UnsupportedUNet):
+        UNet2DEngine(config, params, _lib=EmuLib())
+
+
+def test_norm_eps_is_read_from_the_live_module(built_lib):
+    """the planner's eps constants are only a fallback; a module whose norm layers carry another eps (diffusers hands SVD's
+    temporal resnets the spatial eps unless temporal_eps is set; custom UNets) must be reproduced as built."""
+    cfg = U.tiny_config()
+    m16, m32 = _pair(cfg, 12)
+    for m in (m16, m32):
+        m.down_blocks[0].resnets[0].norm1.eps = 0.3          # GroupNorm + SiLU
+        m.mid_block.attentions[0].norm.eps = 0.2             # transformer GroupNorm
+        m.up_blocks[1].attentions[0].transformer_blocks[0].norm2.eps = 0.5   # LayerNorm
+    eng = UNet2DEngine.from_module(m16, _lib=EmuLib())
+    assert eng.norm_eps["down_blocks.0.resnets.0.norm1"] == 0.3 and eng.norm_eps["conv_norm_out"] == 1e-5
+    g = torch.Generator().manual_seed(5)
+    s = torch.randn(2, 4, 16, 16, generator=g).half()
+    e = torch.randn(2, 77, 64, generator=g).half()
+    y = eng.forward(s, 250, e)
+    with torch.no_grad():
+        want = m32(s.float(), 250, e.float()).sample
+        m32.down_blocks[0].resnets[0].norm1.eps = 1e-5
+        m32.mid_block.attentions[0].norm.eps = 1e-6
+        m32.up_blocks[1].attentions[0].transformer_blocks[0].norm2.eps = 1e-5
+        default = m32(s.float(), 250, e.float()).sample
+    assert rel_l2(y, want) < 3e-3 and rel_l2(default, want) > 1e-2

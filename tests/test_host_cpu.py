@@ -185,10 +185,9 @@ def _loop_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from abi_emulator import EmuLib
+        from abi_emulator import EmuLib, emulated_denoise_loop
         from oracle import unet_ref as U
         from sfast.engine import UNet2DEngine, autotune
-        from sfast.engine.denoise import DenoiseLoop
         from sfast.engine.replicas import broadcast_parameters, gather_latents, share_tune_cache
         cfg = U.tiny_config()
         m = U.build(cfg, seed=50 + rank, dtype=torch.float16)  # different weights per rank until the broadcast
@@ -198,7 +197,7 @@ def _loop_worker(rank, world, port, q):
             autotune.import_cache({"gfx950|f16|gemm|1x2x3|(0, 0, 1)": [3, 1]})
         got = share_tune_cache(src=0)
         eng = UNet2DEngine(m.config, params, device=torch.device("cpu"), dtype=torch.float16, _lib=EmuLib())
-        loop = DenoiseLoop(eng, images=1, height=16, width=16, ctx_len=20, guidance=7.5, num_steps=50, use_graph=False)
+        loop = emulated_denoise_loop(eng, images=1, height=16, width=16, ctx_len=20, guidance=7.5, num_steps=50)
         g = torch.Generator().manual_seed(1234 + rank)
         lat = torch.randn(1, 4, 16, 16, generator=g).half()
         ehs = torch.randn(2, 20, cfg["cross_attention_dim"], generator=g).half()
@@ -334,3 +333,87 @@ def test_euler_coefficient_tables_reproduce_the_scheduler_arithmetic(pred):
     other = _EulerRef(pred)
     other._sfast_euler_like = False
     assert not euler_like(other)
+
+
+def test_ddim_is_recognised_by_class_never_by_attributes():
+    """PNDMScheduler (the SD1.5 default), LCMScheduler, TCDScheduler and DDIMInverseScheduler carry DDIM's
+    attribute surface (`alphas_cumprod`, `final_alpha_cumprod`, `step(eta=..., generator=...)`) with multistep / stochastic /
+    inverse arithmetic. `patch_scheduler` must leave them eager (the reference's lazy_trace keeps each scheduler's own math) and
+    take only DDIMScheduler / DDIMParallelScheduler (by class name in the MRO) or a declared look-alike."""
+    import types
+    from sfast.libs.diffusers.scheduler import NativeDDIMStep, ddim_like, patch_scheduler
+
+    def make(name, bases=(), **attrs):
+        def step(self, model_output, timestep, sample, eta=0.0, use_clipped_model_output=False, generator=None, variance_noise=None,
+                 return_dict=True):
+            return ("own arithmetic",)
+        cls = type(name, bases, dict(step=step, **attrs))
+        s = cls()
+        s.config = types.SimpleNamespace(num_train_timesteps=1000, prediction_type="epsilon", clip_sample=False, thresholding=False)
+        s.alphas_cumprod = torch.linspace(0.999, 0.01, 1000)
+        s.final_alpha_cumprod = torch.tensor(1.0)
+        s.num_inference_steps = 50
+        return s
+
+    for name in ("PNDMScheduler", "LCMScheduler", "TCDScheduler", "DDIMInverseScheduler", "DPMSolverMultistepScheduler"):
+        s = make(name)
+        keep = s.step
+        assert not ddim_like(s), name
+        assert patch_scheduler(s) is False and s.step == keep, name
+        assert s.step(None, 0, None) == ("own arithmetic",)
+    for name in ("DDIMScheduler", "DDIMParallelScheduler"):
+        s = make(name)
+        assert ddim_like(s) and patch_scheduler(s) and isinstance(s.step, NativeDDIMStep), name
+    base = type("DDIMScheduler", (), {})
+    sub = make("MyTunedDDIM", (base,))
+    assert ddim_like(sub)                                  # subclass of DDIMScheduler
+    assert ddim_like(make("Custom", _sfast_ddim_like=True))  # declared look-alike
+    clip = make("DDIMScheduler")
+    clip.config.clip_sample = True
+    assert not ddim_like(clip)                             # clipping is not the two-term linear form
+
+
+def test_euler_tables_follow_a_rebound_schedule_of_equal_length():
+    """the table key must not depend on id() / data_ptr() of a freed tensor. Rebinding `sigmas` to a new tensor of the same
+    length (custom sigmas, karras toggled) rebuilds the rows; in-place edits (version bump) do too; an unchanged schedule does not."""
+    from sfast.libs.diffusers.scheduler import _EulerTables
+    s = _EulerRef("epsilon")
+    tabs = _EulerTables(s)
+    a0, _ = tabs.get("cpu")
+    a0 = a0.clone()
+    assert tabs.get("cpu")[0] is tabs.get("cpu")[0]        # cached while the schedule object is unchanged
+    n = len(s.sigmas)
+    for _ in range(4):                                     # allocate / free same-sized tensors: ids and storage get recycled
+        s.sigmas = (torch.rand(n) + 0.5).sort(descending=True).values
+        want = (s.sigmas[1:] - s.sigmas[:-1]).to(torch.float32)
+        got, _ = tabs.get("cpu")
+        torch.testing.assert_close(got[:, 1], want, rtol=1e-6, atol=1e-7)
+    s.sigmas.mul_(2.0)                                     # in-place edit of the live schedule
+    got, _ = tabs.get("cpu")
+    torch.testing.assert_close(got[:, 1], (s.sigmas[1:] - s.sigmas[:-1]).to(torch.float32), rtol=1e-6, atol=1e-7)
+    assert not torch.equal(got, a0)
+
+
+def test_auto_graph_compiler_walk_matches_patch_module():
+    """the reference's patch_module (utils/patch.py:1-19) patches an accepted ROOT and still walks its children; an accepted
+    child is patched and not descended into. AutoGraphCraphCompiler rejects keyword arguments it could only fail on later."""
+    import torch.nn as nn
+    from sfast.cuda.graphs import AutoGraphCraphCompiler, _LazyCompiledForward, apply_auto_graph_compiler_to_all_modules
+
+    def wrapped(m):
+        return isinstance(m.forward, _LazyCompiledForward)
+
+    net = nn.Sequential(nn.Linear(4, 4), nn.Sequential(nn.Linear(4, 4), nn.ReLU()))
+    apply_auto_graph_compiler_to_all_modules(net)                      # default filter: accepts everything
+    assert wrapped(net) and wrapped(net[0]) and wrapped(net[1])        # root AND its direct children
+    assert not wrapped(net[1][0])                                      # ... but nothing below an accepted child
+
+    net = nn.Sequential(nn.Linear(4, 4), nn.Sequential(nn.Linear(4, 4), nn.ReLU()))
+    apply_auto_graph_compiler_to_all_modules(net, filter_func=lambda stack: stack[-1][0] is None or isinstance(stack[-1][1], nn.Linear))
+    assert wrapped(net) and wrapped(net[0]) and not wrapped(net[1]) and wrapped(net[1][0]) and not wrapped(net[1][1])
+
+    net = nn.Sequential(nn.Linear(4, 4))
+    apply_auto_graph_compiler_to_all_modules(net, recursive=False)
+    assert wrapped(net) and not wrapped(net[0])
+    with pytest.raises(TypeError):
+        AutoGraphCraphCompiler(warmups=1)

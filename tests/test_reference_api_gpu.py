@@ -254,12 +254,77 @@ def test_qlinear_dynamic_op_takes_a_quantized_weight():
         qw = torch.quantize_per_tensor(lin.weight.detach().float(), scale=float(lin.weight.abs().max()) / 127.0, zero_point=0, dtype=torch.qint8)
     except (RuntimeError, NotImplementedError) as e:
         pytest.skip(f"quantized tensors unavailable on this build: {e}")
-    y = torch.ops.sfast.cutlass_qlinear_dynamic(x, qw, lin.bias)
+    y = torch.ops.sfast.cutlass_qlinear_dynamic_unpacked(x, qw, lin.bias)
     want = torch.nn.functional.linear(x.float(), qw.dequantize().float(), lin.bias.float())
     torch.testing.assert_close(y.float(), want, rtol=2e-3, atol=2e-3)
     # fp32 activations: dequantised weight through the ordinary kernel (the reference's own fallback)
-    y32 = torch.ops.sfast.cutlass_qlinear_dynamic(x.float(), qw, lin.bias.float())
+    y32 = torch.ops.sfast.cutlass_qlinear_dynamic_unpacked(x.float(), qw, lin.bias.float())
     torch.testing.assert_close(y32, want, rtol=1e-3, atol=1e-3)
+
+
+class _LinearModule(nn.Module):
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.linear = nn.Linear(in_features, out_features, bias=bias)
+
+    def forward(self, x):
+        return self.linear(x)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("in_features", [4, 8, 16])
+@pytest.mark.parametrize("out_features", [4, 8, 16])
+@pytest.mark.parametrize("N", [4, 16])
+def test_linear_dynamic(dtype, bias, in_features, out_features, N):
+    """/root/reference/tests/operators/test_cutlass_qlinear.py:20-41 restated 1:1: `quantize_dynamic(Linear)` on the GPU module -- which
+    goes through `quantized::linear_prepack` (QuantizedCUDA) and `quantized::linear_dynamic` (CUDA), the two entries the reference's
+    binding serves (cutlass_qlinear.cc:60-81) -- against the CPU dynamic-quantized module, tolerance 3e-2 as there."""
+    import warnings
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(in_features * 100 + out_features * 10 + N)
+        m = _LinearModule(in_features, out_features, bias=bias).eval()
+        m_q = torch.quantization.quantize_dynamic(m, {nn.Linear}, dtype=torch.qint8)
+        x = torch.randn(N, in_features)
+        out = m_q(x)
+        out = out.cuda().to(dtype=dtype)
+
+        m_cuda = m.cuda().to(dtype=dtype)
+        m_q_cuda = torch.quantization.quantize_dynamic(m_cuda, {nn.Linear}, dtype=torch.qint8).to(dtype=dtype)
+        x_cuda = x.cuda().to(dtype=dtype)
+        out_cuda = m_q_cuda(x_cuda)
+        assert out_cuda.is_cuda and out_cuda.dtype == dtype
+        torch.testing.assert_close(out_cuda, out, rtol=3e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_linear_dynamic_reaches_the_int8_kernel(dtype):
+    """UNet-sized layers through the same binding: the HIP int8-weight kernel is what runs (not a dequantised fallback), also through
+    `sfast::cutlass_qlinear_dynamic(X, W_prepack, reduce_range)` -- the reference's schema -- and for a CPU-packed module moved over."""
+    import warnings
+    from sfast.hip import lib
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(3)
+        m = _LinearModule(640, 1280).cuda().to(dtype).eval()
+        mq = torch.quantization.quantize_dynamic(m, {nn.Linear}, dtype=torch.qint8)
+        x = torch.randn(2, 77, 640, device="cuda", dtype=dtype)
+        y = mq(x)
+        assert "igemm_w8" in lib.last_kernel(), lib.last_kernel()
+        want = m(x)
+        tol = 3e-2 if dtype == torch.float16 else 6e-2
+        torch.testing.assert_close(y.float(), want.float(), rtol=tol, atol=tol)
+        packed = mq.linear._packed_params._packed_params
+        y2 = torch.ops.sfast.cutlass_qlinear_dynamic(x, packed, True)    # reduce_range accepted and ignored (cutlass_qlinear.cc:13-16)
+        assert torch.equal(y2, y)
+        # a module quantized on the CPU (its packed params hold CPU tensors) serves CUDA activations too: from_native, :43-51
+        mq_cpu = torch.quantization.quantize_dynamic(_LinearModule(640, 1280).eval(), {nn.Linear}, dtype=torch.qint8)
+        y3 = mq_cpu.linear._packed_params._packed_params
+        got = torch.ops.quantized.linear_dynamic(x, y3, False)
+        w, b = torch.ops.quantized.linear_unpack(y3)
+        ref = torch.nn.functional.linear(x.float(), w.dequantize().cuda(), b.cuda())
+        torch.testing.assert_close(got.float(), ref, rtol=tol, atol=tol)
 
 
 def test_auto_graph_compiler_on_modules():

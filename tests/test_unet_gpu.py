@@ -23,7 +23,7 @@ import pytest
 import torch
 
 from oracle import unet_ref as U
-from parity import compare, log_value, rel_l2
+from parity import compare, log_value, rel_l2, storage_floor
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
@@ -94,13 +94,17 @@ def test_sd15_unet_parity_and_graph(sd15):
         ref = U.build("sd15", seed=0, dtype=torch.float32, device=DEV)
         ref.load_state_dict({k: v.float() for k, v in m.state_dict().items()})
         y32 = ref(sample.float(), 981, ehs.float()).sample
+        # f16-STORAGE floor of this network, measured here: the fp32 oracle with every op output rounded to f16 once (exact arithmetic)
+        floor = storage_floor(ref, lambda: ref(sample.float(), 981, ehs.float()).sample, y32)
         del ref
     e_engine, e_eager, e_cross = rel_l2(y, y32), rel_l2(y16, y32), rel_l2(y, y16)
-    log_value("sd15 B=2 parity", engine_vs_fp32=e_engine, eager16_vs_fp32=e_eager, engine_vs_eager16=e_cross,
+    log_value("sd15 B=2 parity", engine_vs_fp32=e_engine, eager16_vs_fp32=e_eager, engine_vs_eager16=e_cross, f16_storage_floor=floor,
               max_abs_engine=float((y.float() - y32).abs().max()), ref_absmax=float(y32.abs().max()))
     assert torch.isfinite(y).all()
-    assert e_engine < 2.5e-3, (e_engine, e_eager)      # measured 1.60e-3; f16-storage floor 1.63e-3
-    assert e_engine < e_eager, (e_engine, e_eager)     # closer to the truth than the fp16 pipeline it replaces (3.35e-3)
+    # floor-relative: no arithmetic error beyond what storing f16 activations costs ANY engine (measured: engine 1.60e-3,
+    # floor 1.63e-3); and closer to the truth than the fp16 pipeline it replaces (3.35e-3)
+    assert e_engine <= 1.1 * floor + 1e-4, (e_engine, floor, e_eager)
+    assert e_engine < e_eager, (e_engine, e_eager)
 
     # hipGraph replay reproduces the eager plan bit for bit, and is deterministic
     plan = eng.get_plan(2, 64, 64, 77)
@@ -192,10 +196,55 @@ def test_compile_drop_in_surface():
     o2 = pipe.unet(lat2, torch.tensor(500, device=DEV), encoder_hidden_states=ehs[:, :40], return_dict=False)[0]
     w2 = eager(lat2, 500, ehs[:, :40]).sample
     assert len(pipe.unet.forward._cached) == 2 and rel_l2(o2, w2) < 1e-2
+    # cross_attention_kwargs={"scale": s} (the LoRA scale diffusers pipelines pass along) has nothing to act on in a module without
+    # LoRA layers: accepted natively, same plan, same result
+    o2s = pipe.unet(lat2, torch.tensor(500, device=DEV), encoder_hidden_states=ehs[:, :40], cross_attention_kwargs={"scale": 0.5}, return_dict=False)[0]
+    assert torch.equal(o2s, o2) and not pipe.unet.forward._warned and len(pipe.unet.forward._cached) == 2
     # unsupported call forms fall back to the original forward instead of computing something else
-    o3 = pipe.unet(lat2, 500, encoder_hidden_states=ehs[:, :40], cross_attention_kwargs={"scale": 0.5}, return_dict=False)[0]
+    o3 = pipe.unet(lat2, 500, encoder_hidden_states=ehs[:, :40], cross_attention_kwargs={"ip_adapter_masks": None, "scale": 1.0}, return_dict=False)[0]
     assert pipe.unet.forward._warned  # took the eager path (two eager fp16 runs differ by conv algorithm noise)
     assert rel_l2(o3, w2) < 1e-2 and len(pipe.unet.forward._cached) == 2
+
+
+@pytest.mark.parametrize("option", ["timestep_cond", "class_timestep", "class_projection", "all"])
+def test_lcm_and_class_conditioned_calls_stay_native(option):
+    """VERDICT r02 "eager cliffs": `timestep_cond` (LCM-distilled UNets, /root/reference/examples/optimize_lcm_pipeline.py),
+    `class_labels` (class_embed_type "timestep" / "projection") and `cross_attention_kwargs={"scale": s}` are inputs of the native
+    plan: tiny UNet through compile_unet() + hipGraph replay vs the fp32 oracle, and the fallback warning does not fire."""
+    from sfast.compilers.diffusion_pipeline_compiler import CompilationConfig, compile_unet
+    over = {}
+    if option in ("timestep_cond", "all"):
+        over["time_cond_proj_dim"] = 256       # LCM's w-embedding width
+    if option in ("class_timestep", "all"):
+        over["class_embed_type"] = "timestep"
+    if option == "class_projection":
+        over.update(class_embed_type="projection", projection_class_embeddings_input_dim=96)
+    cfg = U.tiny_config(**over)
+    unet = U.build(cfg, seed=31, dtype=torch.float16, device=DEV)
+    ref = U.build(cfg, seed=31, dtype=torch.float32, device=DEV)
+    ref.load_state_dict({k: v.float() for k, v in unet.state_dict().items()})
+    config = CompilationConfig.Default()
+    config.enable_cuda_graph = True
+    unet = compile_unet(unet, config)
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(2, 4, 16, 16, generator=g).to(DEV, torch.float16)
+    ehs = torch.randn(2, 77, 64, generator=g).to(DEV, torch.float16)
+    kw = {}
+    if "time_cond_proj_dim" in over:
+        kw["timestep_cond"] = torch.randn(2, 256, generator=g).to(DEV, torch.float16)
+    if over.get("class_embed_type") == "timestep":
+        kw["class_labels"] = torch.tensor([7.0, 912.0], device=DEV)
+    if over.get("class_embed_type") == "projection":
+        kw["class_labels"] = torch.randn(2, 96, generator=g).to(DEV, torch.float16)
+    y = unet(x, 441, encoder_hidden_states=ehs, cross_attention_kwargs={"scale": 0.7}, return_dict=False, **kw)[0]
+    y2 = unet(x, 441, encoder_hidden_states=ehs, return_dict=False, **kw)[0]   # graph replay, no cross_attention_kwargs: same plan
+    with torch.no_grad():
+        want = ref(x.float(), 441, ehs.float(), **{k: v.float() for k, v in kw.items()}).sample
+        blind = ref(x.float(), 441, ehs.float(), **{k: torch.zeros_like(v.float()) for k, v in kw.items()}).sample
+    err = rel_l2(y, want)
+    log_value(f"tiny UNet {option} through compile_unet vs fp32 oracle", rel_l2=err, effect_of_the_input=rel_l2(blind, want))
+    assert not unet.forward._warned and len(unet.forward._cached) == 1 and torch.equal(y, y2)
+    assert err < 4e-3 and rel_l2(blind, want) > 1e-2, (err, rel_l2(blind, want))
 
 
 def test_live_weight_update_without_recapture():
@@ -352,6 +401,7 @@ def test_controlnet_engine_and_compiled_chain():
 class _DDIMLike:
     """diffusers DDIMScheduler call surface (public semantics): eager reference for the native step."""
     init_noise_sigma = 1.0
+    _sfast_ddim_like = True  # DDIM is recognised by class name or this opt-in, never by attributes
 
     def __init__(self, prediction_type="epsilon"):
         self.config = types.SimpleNamespace(num_train_timesteps=1000, prediction_type=prediction_type, clip_sample=False,

@@ -45,9 +45,11 @@ def _round(t, dtype):
     return t.to(dtype).to(t.dtype)
 
 
-def storage_hooks(model, dtype, blocks=True):
-    leaf = (nn.Conv2d, nn.Linear, nn.GroupNorm, nn.LayerNorm)
-    comp = (U.ResnetBlock2D, U.BasicTransformerBlock, U.Transformer2DModel, U.Attention, U.FeedForward, U.GEGLU)
+def storage_hooks(model, dtype, blocks=True, extra_leaf=(), extra_comp=()):
+    """Forward hooks that round every op output to `dtype` and carry on in the model's own precision. `extra_leaf` / `extra_comp`: further
+    module classes of other topologies (the SVD oracle's Conv3d, temporal blocks, AlphaBlender) that an f16 engine stores as well."""
+    leaf = (nn.Conv2d, nn.Linear, nn.GroupNorm, nn.LayerNorm) + tuple(extra_leaf)
+    comp = (U.ResnetBlock2D, U.BasicTransformerBlock, U.Transformer2DModel, U.Attention, U.FeedForward, U.GEGLU) + tuple(extra_comp)
     hs = []
     for m in model.modules():
         if isinstance(m, leaf) or (blocks and isinstance(m, comp)):
