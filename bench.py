@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--through-compile", action="store_true",
                     help="also time the same step through sfast.compilers.compile() + a pipeline-shaped loop (N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="skip the end-to-end ms/image leg (text encoder + 50 steps + VAE decode + post-process; sd15 only)")
+    ap.add_argument("--e2e-images", type=int, default=3, help="images timed by the end-to-end leg (after one warm-up image)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-kernels", default=None, help="write the per-op timing table to this JSON file")
     return ap.parse_args()
@@ -445,6 +448,101 @@ def through_compile(args, cfg, params, dev, latents, ehs, engine_ms, added=None)
             "path": "module_from_params -> sfast.compilers.compile(enable_cuda_graph, trace_scheduler) -> pipeline-shaped CFG loop"}
 
 
+def end_to_end(args, loop, dev, rank, world, use_dist):
+    """Second half of BASELINE.json's metric, "end-to-end ms/image at 1/2/4/8 GPU": ONE timed region per image holding everything the
+    reference's protocol times around `pipe(**kwargs)` (/root/reference/examples/optimize_stable_diffusion_pipeline.py:127-151) --
+    CLIP text encoding of the (uncond, cond) prompt pair, 50 CFG denoise iterations, VAE decode, image post-process, and the copy of
+    the uint8 image to the host. Pieces: a random-init `transformers.CLIPTextModel` of the SD1.5 text-encoder architecture
+    (CLIP ViT-L/14 text tower, 123,060,480 parameters), hipGraph-captured exactly as compile() captures `pipe.text_encoder`
+    (compilers/diffusion_pipeline_compiler.py: `_graphed_with_fallback`, reference :93-118); the fused DenoiseLoop graph (the bench's
+    own step); `post_quant_conv` as the eager 1x1 conv compile() leaves it; the native VAE decoder plan as a hipGraph
+    (compile_vae); `sfast_hip_image_postprocess`. Each GPU renders its own image (weak scaling, like the it/s line)."""
+    import torch.nn.functional as TF
+    from sfast.compilers.diffusion_pipeline_compiler import _graphed_with_fallback
+    from sfast.engine import VaeDecoderEngine, capture_plan_graph
+    from sfast.engine.unet_spec import SD_VAE_DECODER_CONFIG, random_vae_decoder_params
+    from sfast.hip import functional as Fn
+    from transformers import CLIPTextConfig, CLIPTextModel
+    images = args.images
+    torch.manual_seed(0)
+    tcfg = CLIPTextConfig(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+                          max_position_embeddings=77, hidden_act="quick_gelu", projection_dim=768)
+    text = CLIPTextModel(tcfg).to(dev, torch.float16).eval()
+    n_text = sum(p.numel() for p in text.parameters())
+    text.forward = _graphed_with_fallback(text.forward)
+    vcfg = SD_VAE_DECODER_CONFIG
+    vae = VaeDecoderEngine(vcfg, random_vae_decoder_params(vcfg, seed=0, dtype=torch.float16, device=dev))
+    hw = loop.latents.shape[-1]
+    vplan = vae.get_plan(images, hw, hw)
+    g = torch.Generator(device=dev).manual_seed(77 + rank)
+    pq_w = (torch.randn(4, 4, 1, 1, generator=g, device=dev) * 0.5).half()
+    pq_b = torch.zeros(4, device=dev, dtype=torch.float16)
+    lat0 = torch.randn(images, 4, hw, hw, generator=g, device=dev).half()
+    ids = torch.randint(0, 49408, (2 * images, 77), generator=g, device=dev)
+    ids[:, 0], ids[:, -1] = 49406, 49407
+    host = torch.empty((images, 8 * hw, 8 * hw, 3), dtype=torch.uint8).pin_memory()
+    vstream = torch.cuda.Stream(device=dev)
+    vae.load_inputs(vplan, lat0)
+    with torch.cuda.stream(vstream):
+        vplan.run(vstream.cuda_stream)
+    torch.cuda.synchronize()
+    vgraph, _ = capture_plan_graph(vplan, vstream)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+
+    def one_image(mark=False):
+        with torch.no_grad():
+            if mark:
+                ev[0].record()
+            ehs = text(ids)[0]                                   # [2 * images, 77, 768]: rows [uncond..., cond...]
+            if mark:
+                ev[1].record()
+            loop.set_inputs(lat0, ehs)                            # also runs the text-side K/V projections of the UNet, once
+            loop.set_step(0)
+            for i in range(50):
+                loop.step(i)
+            if mark:
+                ev[2].record()
+            z = TF.conv2d(loop.latents * (1.0 / 0.18215), pq_w, pq_b)   # latents / scaling_factor -> post_quant_conv
+            vae.load_inputs(vplan, z)
+            vgraph.replay()
+            if mark:
+                ev[3].record()
+            img = Fn.image_postprocess(vplan.static_out)          # [-1, 1] NCHW f16 -> uint8 NHWC
+            host.copy_(img, non_blocking=True)
+            if mark:
+                ev[4].record()
+            torch.cuda.synchronize()
+
+    one_image()   # warm-up: captures the text-encoder graph
+    one_image()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+        torch.cuda.synchronize()
+    n = max(1, args.e2e_images)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        one_image()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        dist.barrier()
+    one_image(mark=True)
+    parts = [ev[i].elapsed_time(ev[i + 1]) for i in range(4)]
+    ok = bool(host.float().std() > 0) and bool(torch.isfinite(loop.latents).all())
+    return {"ms_per_image_end_to_end": el / n / images * 1e3, "images_per_s_all_gpus": world * n * images / el, "images_timed_per_gpu": n * images,
+            "n_gpus": world, "breakdown_ms": {"text_encoder": parts[0], "denoise_50_steps": parts[1], "vae_decode": parts[2],
+                                              "postprocess_and_host_copy": parts[3]},
+            "text_encoder": {"arch": "CLIP ViT-L/14 text (transformers.CLIPTextModel, random init)", "params": n_text,
+                             "hipgraph": bool(getattr(text.forward, "_cached", None))},
+            "image": [8 * hw, 8 * hw, 3], "outputs_ok": ok,
+            "protocol": "one timed region per image: token ids on the device -> uint8 image on the host (text encode, 50-step CFG DDIM, "
+                        "post_quant_conv, VAE decode, post-process, D2H copy); reference examples/optimize_stable_diffusion_pipeline.py:127-151"}
+
+
 def bench_vae(args, dev, rank, world, use_dist):
     """`--config vae`: one step = one VAE decode (64x64 latent -> 512x512 image, bs = --images, fp16) replayed as a hipGraph."""
     from sfast.engine import VaeDecoderEngine, capture_plan_graph
@@ -759,6 +857,20 @@ def main():
             out["through_compile"] = through_compile(args, cfg, params, dev, latents, ehs, elapsed / args.steps * 1e3, added)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.config, args.images)
+    # end-to-end ms/image (every rank renders its own image; rank 0 reports the max-over-ranks time)
+    e2e = None
+    if args.config == "sd15" and not args.no_end_to_end and not args.no_graph:
+        try:
+            e2e = end_to_end(args, loop, dev, rank, world, use_dist)
+        except Exception as e:  # the it/s line is the contract; this leg must never take it down
+            if use_dist:
+                raise
+            e2e = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0:
+        if e2e is not None:
+            out["end_to_end"] = e2e
+            if "ms_per_image_end_to_end" in e2e:
+                out["ms_per_image_end_to_end"] = e2e["ms_per_image_end_to_end"]
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Round-3 GPU sessions (one gpurun call each): tools/gpu_r3.sh <stage>
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+STAGE=${1:-s1}
+export TMPDIR=/tmp
+PYT="python -m pytest -q --no-header --tb=short -p no:cacheprovider --timeout=900 --maxfail=30 -m gpu"
+run() { # name, timeout, command...
+  local name=$1 to=$2; shift 2
+  echo "=== $name ===" | tee -a gpurun_out/session.log
+  local t0=$(date +%s)
+  timeout $to "$@" > gpurun_out/$name.log 2>&1
+  echo "exit=$? $(( $(date +%s) - t0 ))s $(tail -n 1 gpurun_out/$name.log | cut -c1-300)" | tee -a gpurun_out/session.log
+}
+rm -f gpurun_out/parity.jsonl gpurun_out/session.log
+rocminfo 2>/dev/null | grep -E "gfx|Compute Unit" | head -2 >> gpurun_out/session.log
+case $STAGE in
+s1)  # review items: new parity tests, int8 binding, eager cliffs, smoke, default bench (+ end-to-end leg)
+  run t_parity_r3 1500 $PYT tests/test_parity_r3_gpu.py
+  run t_qlinear 600 $PYT tests/test_reference_api_gpu.py -k "linear_dynamic or qlinear or auto_graph"
+  run t_unet_new 900 $PYT tests/test_unet_gpu.py -k "lcm or compile_drop_in or sd15_unet_parity or scheduler or live_weight"
+  run smoke 600 python __graft_entry__.py smoke
+  run bench 900 python bench.py --steps 50 --warmup 10 --dump-kernels gpurun_out/kernels.json
+  ;;
+full)
+  run t_all 1500 $PYT tests
+  run smoke 600 python __graft_entry__.py smoke
+  ;;
+esac
+cut -c1-400 gpurun_out/session.log
