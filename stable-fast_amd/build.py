@@ -28,6 +28,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
 # results allocated to AGPRs cost ~150 v_accvgpr moves per 64-key tile (a quarter of the loop); the VGPR form of the MFMA
 # removes them and lowers the register total (D=40: 134+32 -> 138).
 EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# attention_q64.hip (one wave per SIMD, ~400 registers) is built WITHOUT that flag: the O accumulators and the MFMA operand fragments
+# belong in the AGPR half of the unified file, only the S^T tiles the softmax reads must be arch VGPRs.
 
 
 def hipcc():

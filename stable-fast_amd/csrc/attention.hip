@@ -35,50 +35,13 @@
 //     f16 probabilities then use packed round-toward-zero converts (the bias cancels in O / l).
 //   * built with the VGPR form of the MFMAs (build.py EXTRA_FLAGS): the softmax reads every S accumulator on the
 //     VALU each tile, AGPR-allocated results cost ~150 v_accvgpr moves per tile.
-#include "common.h"
-#include <type_traits>
-#include <math.h>
+#include "attention.h"
 
 namespace sfast {
 
-struct AttnArgs {
-    const void *q, *k, *v;
-    void *out;
-    int B, H, Sq, Skv, D;
-    int64_t qs[3], ks[3], vs[3], os[3];
-    float scale, scale_log2e;
-    uint32_t kspan, vspan;      // bytes spanned by the K / V rows of one (batch, head): buffer-descriptor ranges
-    unsigned long long *trace;  // profiling only (sfast_hip_set_trace): per-workgroup shader-cycle split of the tile loop
-    // additive attention bias (xformers attn_bias / diffusers attention_mask): bias[b][h][q][key], key stride 1
-    const void *bias;
-    int64_t bs[3];        // element strides (b, h, q); 0 = broadcast
-    uint32_t bspan;       // bytes spanned by the bias rows of one (batch, head)
-    float inv_scale;      // bias enters the RAW scores as bias / scale (the softmax scale is folded into the exp2 argument)
-    // XCD-aware block order (flash kernel): xmap = 1 -> 1-D grid of nqb * B * H blocks; the hardware puts block i on XCD i % 8, and
-    // all nqb query blocks of one (batch, head) are given to ONE XCD, so that head's K / V (re-read by every query block) cross the
-    // fabric once and then hit that XCD's L2. With the (q-block, head, batch) grid the query blocks of a head were spread over all
-    // eight L2s: 53 MB of fabric traffic per SD1.5 self-attention launch against 16 MB of operands (profiles/r02_pmc_traffic_run8.log).
-    int xmap, nqb, ppx;  // ppx = (batch, head) pairs per XCD
-};
 extern unsigned long long *g_igemm_trace;  // igemm_glds.hip
 static int g_attn_xmap = 1;                // SFAST_XCD_MAP=0: (q-block, head, batch) grid as in round 1 (A/B)
-
-__device__ __forceinline__ f32x16 amfma32(f16x8 a, f16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 amfma32(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
-template <int D> struct AttnGeom {
-    static constexpr int DP = (D + 15) / 16 * 16;  // QK^T contraction length (zero padded)
-    static constexpr int DO = (D + 31) / 32 * 32;  // padded output width
-    static constexpr int KSTR = DP + 8;            // K tile row stride (halves): odd number of 16-B slots
-    static constexpr int VSTR = 68;                // V^T tile row stride (halves): 136 B
-    static constexpr int STAGE = 64 * KSTR * 2 + DO * VSTR * 2;
-    static constexpr int LDS = 2 * STAGE;          // double-buffered K / V^T tiles
-    static constexpr int LDS_TOTAL = LDS + 4096 + 16 * VSTR;  // + dump area for idle staging lanes
-};
+static int g_attn_q64 = -1;                // SFAST_ATTN_Q64: 0 = never, 1 = whenever the shape allows, unset = by work-unit count
 
 // TRACE = 1 (profiling instantiation, chosen while a trace buffer is set): wave 0 sums s_memtime deltas of the tile
 // phases -- record [top, phase 1, phase 2, barrier wait, whole kernel, tiles] per workgroup (tools/attn_ab.py --trace).
@@ -602,8 +565,11 @@ template <typename T> static int attn_init_t() {
 int attention_init() {
     const char *xm = getenv("SFAST_XCD_MAP");
     g_attn_xmap = (xm && xm[0] == '0') ? 0 : 1;
+    const char *q6 = getenv("SFAST_ATTN_Q64");
+    g_attn_q64 = q6 ? (q6[0] == '0' ? 0 : 1) : -1;
     int rc = attn_init_t<f16>();
     if (!rc) rc = attn_init_t<bf16>();
+    if (!rc) rc = attention_q64_init();
     return rc;
 }
 
@@ -713,11 +679,24 @@ extern "C" int sfast_hip_attention_bias(const void *q, const void *k, const void
         vec = vec && half && bspan < (1ll << 31) && a.bs[2] % 2 == 0 && a.bs[0] % 2 == 0 && a.bs[1] % 2 == 0 && (((uintptr_t)bias) & 3) == 0;
         a.bspan = (uint32_t)bspan;
     }
+    if (vec && p->variant != 100 && p->scale > 0.f && !bias && (p->D == 40 || p->D == 64 || p->D == 80) && p->Skv >= 128) {
+        // second-generation kernel (attention_q64.hip): 64 query rows per wave, one wave per SIMD. A work unit is one wave's 64 rows;
+        // the chip has 1024 SIMDs, so below ~that many units the 32-row kernel (twice the units, half the work each) fills it better.
+        // variant 64 / 62: forced, 4 / 2 waves per workgroup; variant 32 (and 2 / 4): the 32-row kernel.
+        const int64_t units = (int64_t)ceil_div(p->Sq, 64) * p->H * p->B;
+        int use = (p->variant == 64 || p->variant == 62) ? 1 : (p->variant != 0 ? 0 : (g_attn_q64 >= 0 ? g_attn_q64 : (units >= 768 ? 1 : 0)));
+        if (use) {
+            const int nw = p->variant == 62 ? 2 : (p->variant == 64 ? 4 : (p->Sq % 256 == 0 || p->Sq > 1024 ? 4 : 2));
+            set_kernel_name("attn_q64[D=%d,BQ=%d]", p->D, nw * 64);
+            const int rc = attention_q64_launch(a, p->dtype, nw | (g_attn_xmap << 8), st);
+            if (rc != -1) return rc;
+        }
+    }
     if (vec && p->variant != 100 && p->scale > 0.f) {
         int nw = 4;
         const int64_t blocks4 = (int64_t)ceil_div(p->Sq, 128) * p->H * p->B;
         if (blocks4 < 256) nw = 2;
-        if (p->variant == 2 || p->variant == 4) nw = p->variant;
+        if (p->variant == 2 || p->variant == 4) nw = p->variant;  // (variant 32: the automatic choice of this kernel)
         if (bias || p->D >= 128) nw = 4;  // wide heads and the biased instantiation: four waves per workgroup only
         set_kernel_name("attn_fwd[D=%d,BQ=%d]%s", p->D, nw * 32, bias ? "+bias" : "");
         if (p->dtype == SFAST_F16) return attn_launch<f16>(a, nw, st);

@@ -1,0 +1,626 @@
+// Flash attention forward, second generation for gfx950: 64 query rows per wave, one wave per SIMD.
+//
+// Same contract as attention.hip (sfast_xformers::memory_efficient_attention on strided [B, S, H, D] views,
+// /root/reference/src/sfast/libs/xformers/xformers_attention.py:26-48); same swapped products (S^T = K . Q^T, O^T = V^T . P^T), same
+// LDS image (K rows padded to an odd number of 16-B slots, V transposed on its way in, ones row in the V^T padding), same
+// double-buffered stages and one barrier per 64-key tile. What changed, and why (VERDICT r02 "Next round" #3: 26-27 % MFMA-busy):
+//
+//   * a wave owns TWO 32-row query blocks. Every K / V^T fragment read from LDS feeds two MFMAs, and the per-tile fixed cost (staging
+//     a K / V tile through registers, fragment reads, the barrier) is spent once per 28-40 MFMAs instead of once per 14-16. The state
+//     (2 x O, 2 x two S^T tiles, Q, K / V fragments) needs ~400 registers: ONE wave per SIMD owns the unified 512-entry file, a
+//     workgroup of NW waves is one 64 * NW-row query block of one (batch, head).
+//   * the softmax costs ONE VALU instruction per score besides max / convert, down from two: Q is multiplied by scale * log2(e) when
+//     it is loaded (so scores arrive in log2 units), and the first QK^T MFMA of a tile takes its C operand from a register tile that
+//     holds -m_ref (the row's reference maximum), so the accumulator comes out as s - m_ref and P = exp2(acc) directly -- the
+//     fma(s, c, -m * c) per score of the first generation is gone (32 of 96 VALU instructions per 32 x 64 tile).
+//   * m_ref is a REFERENCE, not the running maximum: it only moves when some row's tile maximum exceeds it by more than THR (2^THR = 64:
+//     f16 probabilities up to 64, fp32 accumulation -- the quotient O / l is invariant to the reference). The exact lazy rescale of
+//     the first generation fired on most tiles of a random-data row set (P(any of 64 rows' max grows) ~ 1 for the first dozens of
+//     tiles); this one fires when a row's maximum grows 64-fold. When it does, O (which carries the denominator, below), the pending
+//     S^T tile and -m_ref are all moved by the same exact power-of-two-exponent shift (guide T13: everything at the old reference,
+//     exactly once; tests/test_parity_r3_gpu.py::test_peaked_attention_rows_force_the_rescale_path forces the branch).
+//   * the softmax denominator always comes out of the PV MFMAs: head dims with padding rows (40 -> 64, 80 -> 96) keep the ones row
+//     in the V^T padding; D = 64 (no padding) multiplies P by a constant all-ones A fragment into a third accumulator block -- four
+//     more MFMAs per query block and tile instead of 32 VALU adds in a loop whose VALU issue slots are the scarce resource.
+//   * the MFMA / VALU / LDS interleave is planned at compile time: the fillers of a tile (exp2 + convert of tile t, V^T fragment
+//     reads, row maxima of tile t+1, K fragment reads, staging stores) form one ordered list with weights; every MFMA gap takes the
+//     next slice of it at a uniform rate, deadlines (probabilities before the PV group that consumes them) are static_asserted.
+#include "attention.h"
+
+namespace sfast {
+
+namespace {
+
+template <int LO, int HI, typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, LO + Is>{}), ...);
+}
+template <int LO, int HI, typename F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (HI > LO) static_for_impl<LO, HI>(static_cast<F &&>(f), std::make_integer_sequence<int, HI - LO>{});
+}
+
+// MFMAs with EXPLICIT register files. gfx950 has one 512-entry register file per lane, split into arch VGPRs (what the VALU can touch)
+// and AGPRs (MFMA operands / results, load destinations). The S^T tiles are read by the softmax on the VALU every tile: their MFMAs
+// write VGPRs (C and D share one file per instruction: -m_ref, their C operand, is a VGPR tile too). Everything only the matrix pipe
+// touches -- the O accumulators, the Q / K / V^T fragments -- lives in AGPRs. hipcc picks ONE form for all MFMAs of a kernel: its AGPR
+// form cost ~550 v_accvgpr moves per tile here, its VGPR form ~180 at D = 64 (256 arch VGPRs cannot hold the state); with the classes
+// spelled out the loop has none. The compiler does not see inside an asm statement, so the hazards are this file's business (guide
+// section 5.7): an S^T result is first read by the VALU two MFMAs after its last MFMA (plan: row maxima released at gap NQK + 1) or,
+// outside the loop, behind an explicit s_nop; probabilities are converted at least one whole MFMA before the MFMA that reads them
+// (plan: deadline one gap early); K fragments are re-loaded two MFMAs after their last reader; O is only touched by the VALU behind
+// mfma_drain().
+template <typename T> struct MfmaAsm;
+#define SFAST_MFMA_ASM(T_, MNEMONIC)                                                                                                  \
+    template <> struct MfmaAsm<T_> {                                                                                                   \
+        using vec8 = typename Elem<T_>::vec8;                                                                                           \
+        /* S = A . B + C, C and S in VGPRs (distinct tiles), A / B in AGPRs */                                                          \
+        static __device__ __forceinline__ void qk_first(f32x16 &d, const vec8 &a, const vec8 &b, const f32x16 &c) {                     \
+            asm volatile(MNEMONIC " %0, %1, %2, %3" : "=&v"(d) : "a"(a), "a"(b), "v"(c));                                               \
+        }                                                                                                                               \
+        static __device__ __forceinline__ void qk_zero(f32x16 &d, const vec8 &a, const vec8 &b) {                                       \
+            asm volatile(MNEMONIC " %0, %1, %2, 0" : "=&v"(d) : "a"(a), "a"(b));                                                        \
+        }                                                                                                                               \
+        static __device__ __forceinline__ void qk_acc(f32x16 &d, const vec8 &a, const vec8 &b) {                                        \
+            asm volatile(MNEMONIC " %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));                                                        \
+        }                                                                                                                               \
+        /* O += A . P, O and A (V^T fragment) in AGPRs, P (just converted by the VALU) in VGPRs */                                      \
+        static __device__ __forceinline__ void pv_acc(f32x16 &o, const vec8 &a, const vec8 &p) {                                        \
+            asm volatile(MNEMONIC " %0, %1, %2, %0" : "+a"(o) : "a"(a), "v"(p));                                                        \
+        }                                                                                                                               \
+    };
+SFAST_MFMA_ASM(f16, "v_mfma_f32_32x32x16_f16")
+SFAST_MFMA_ASM(bf16, "v_mfma_f32_32x32x16_bf16")
+#undef SFAST_MFMA_ASM
+// every MFMA issued so far has written its result (8-pass 32x32x16: 12 wait states after the last one, rounded up)
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); }
+// The compiler may move a READ of an MFMA result (a v_accvgpr_read, a v_max) above mfma_drain(): to it an asm MFMA is an ordinary
+// definition that is complete when the statement ends, and it hoists such copies out of rarely taken branches into the hot loop (seen:
+// 64 v_accvgpr_read of O per tile pair, issued straight behind an MFMA). Passing the value through an empty asm AFTER the drain gives
+// it a new definition there; nothing that reads it can be scheduled earlier.
+__device__ __forceinline__ void pin_a(f32x16 &x) { asm volatile("" : "+a"(x)); }
+__device__ __forceinline__ void pin_v(f32x16 &x) { asm volatile("" : "+v"(x)); }
+
+// Compile-time plan of one tile iteration for head dim D and NW waves per workgroup.
+template <int D, int NW> struct Q64Plan {
+    using G = AttnGeom<D>;
+    static constexpr int NT = NW * 64;
+    static constexpr int KD = G::DP / 16;                 // QK^T k-steps
+    static constexpr int DB = G::DO / 32;                 // V^T blocks resident in LDS
+    static constexpr bool ONES_ROW = G::DO > D;           // denominator row lives in the V^T padding
+    static constexpr int DBX = DB + (ONES_ROW ? 0 : 1);   // accumulator blocks per query block (incl. the constant ones block)
+    static constexpr int KCH = G::DP / 8, VCH = D / 8;
+    static constexpr int KTASK = (64 * KCH + NT - 1) / NT, VTASK = (32 * VCH + NT - 1) / NT;
+    static constexpr int NQK = 4 * KD;                    // QK^T MFMAs per tile: (kd, kb, query block)
+    static constexpr int GP = 2 * DBX;                    // PV MFMAs per 16-key group: (db, query block)
+    static constexpr int NPV = 4 * GP;
+    static constexpr int NG = NQK + NPV;                  // MFMA gaps per tile
+    // filler items, in issue order
+    static constexpr int A_PER_G = DB + 8;                // per 16-key group g: DB V^T fragment reads, then 8 exp2-pair+convert items
+    static constexpr int NA = 4 * A_PER_G;
+    static constexpr int I_MX = NA;                       // 32 row-max items (v_max3) of tile t+1
+    static constexpr int I_KR = I_MX + 32;                // 2 * KD K-fragment reads of tile t+2
+    static constexpr int I_SV = I_KR + 2 * KD;            // VTASK * 8 V^T staging items (v_perm + ds_write_b32)
+    static constexpr int I_SK = I_SV + VTASK * 8;         // KTASK K staging stores
+    static constexpr int NI = I_SK + KTASK;
+    static constexpr int weight(int i) {
+        if (i < NA) return (i % A_PER_G) < DB ? 2 : 3;   // 2 ds_read_b64 | 2 v_exp + 1 v_cvt
+        if (i < I_KR) return 1;
+        if (i < I_SV) return 1;
+        if (i < I_SK) return 2;
+        return 3;                                          // ds_write_b128
+    }
+    static constexpr int total_weight() {
+        int w = 0;
+        for (int i = 0; i < NI; ++i) w += weight(i);
+        return w;
+    }
+    struct Starts {
+        int v[NG + 1];
+    };
+    // gap k (the fillers issued right behind MFMA k) takes items [v[k], v[k+1]): uniform rate in weight units. Items that need S^T(t+1)
+    // complete or the K fragments free (everything from I_MX on) are not released before the second PV MFMA (the row maxima read the
+    // results of the last QK^T MFMAs: their latency passes under the first PV MFMAs).
+    static constexpr Starts make() {
+        Starts s{};
+        const int W = total_weight();
+        int item = 0, cum = 0;
+        for (int k = 0; k < NG; ++k) {
+            s.v[k] = item;
+            const int target = (W * (k + 1) + NG - 1) / NG;
+            while (item < NI && cum < target) {
+                if (item >= I_MX && k < NQK + 1) break;
+                cum += weight(item);
+                ++item;
+            }
+        }
+        s.v[NG] = NI;
+        // the last gap takes whatever is left
+        return s;
+    }
+    static constexpr bool deadlines_ok() {
+        const Starts s = make();
+        for (int g = 0; g < 4; ++g) {
+            // every item of group g must have been issued in a gap BEFORE the first PV MFMA of group g (MFMA index NQK + g * GP)
+            const int last_item_of_g = (g + 1) * A_PER_G;      // exclusive
+            if (s.v[NQK + g * GP - 1] < last_item_of_g) return false;  // ... and one whole MFMA earlier (VALU write -> MFMA operand read)
+        }
+        return true;
+    }
+};
+
+template <typename T, int D, int NW>
+__global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) {
+    using vec8 = typename Elem<T>::vec8;
+    using MA = MfmaAsm<T>;
+    using G = AttnGeom<D>;
+    using P = Q64Plan<D, NW>;
+    constexpr int NT = P::NT;
+    constexpr int DP = G::DP, DO = G::DO, KSTR = G::KSTR, VSTR = G::VSTR, STAGE = G::STAGE;
+    constexpr int KD = P::KD, DB = P::DB, DBX = P::DBX, KCH = P::KCH, VCH = P::VCH, KTASK = P::KTASK, VTASK = P::VTASK;
+    constexpr bool ONES_ROW = P::ONES_ROW;
+    constexpr float THR = 6.0f;  // log2 units: the reference maximum moves when a row's tile maximum exceeds it 64-fold
+    static_assert(D % 8 == 0, "head dim must be a multiple of 8");
+    static_assert(P::deadlines_ok(), "filler plan: probabilities / V fragments of a group are issued after the group's first PV MFMA");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int b, h, qb;
+    if (a.xmap) {
+        const int bid = blockIdx.x, xcd = bid & 7, k = bid >> 3;
+        int pl = (int)((float)k * __builtin_amdgcn_rcpf((float)a.nqb));
+        int r = k - pl * a.nqb;
+        pl += (r >= a.nqb) ? 1 : 0;
+        pl -= (r < 0) ? 1 : 0;
+        r = k - pl * a.nqb;
+        const int pair = __builtin_amdgcn_readfirstlane(xcd * a.ppx + pl);
+        qb = __builtin_amdgcn_readfirstlane(r);
+        b = pair / a.H;
+        h = pair - b * a.H;
+    } else {
+        b = blockIdx.z, h = blockIdx.y, qb = blockIdx.x;
+    }
+    const int q0 = qb * (NW * 64) + wave * 64;
+
+    const T *Qp = (const T *)a.q + (int64_t)b * a.qs[0] + (int64_t)h * a.qs[2];
+    const T *Kp = (const T *)a.k + (int64_t)b * a.ks[0] + (int64_t)h * a.ks[2];
+    const T *Vp = (const T *)a.v + (int64_t)b * a.vs[0] + (int64_t)h * a.vs[2];
+
+    // ones row (V^T row D) / zero rows of the head-dim padding, both stages: never written by the tile loads
+    if constexpr (ONES_ROW) {
+        constexpr int PADW = (DO - D) * (VSTR / 2);
+        const uint32_t one2 = std::is_same<T, f16>::value ? 0x3C003C00u : 0x3F803F80u;
+        for (int i = tid; i < 2 * PADW; i += NT) {
+            const int st = i / PADW;
+            const int j = i - st * PADW;
+            reinterpret_cast<uint32_t *>(smem + st * STAGE + 64 * KSTR * 2 + D * VSTR * 2)[j] = (j < VSTR / 2) ? one2 : 0u;
+        }
+    }
+
+    // ---- Q fragments (B operand), pre-multiplied by scale * log2(e): scores arrive in log2 units -------------------------------
+    typedef const u32x4 __attribute__((address_space(1))) * gvec_ptr;
+    const float c = a.scale_log2e;
+    vec8 qf[2][KD];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int qrow = q0 + 32 * j + l31;
+#pragma unroll
+        for (int kd = 0; kd < KD; ++kd) {
+            const int d0 = kd * 16 + hi * 8;
+            const bool ok = d0 < D && qrow < a.Sq;
+            const gvec_ptr src = ok ? (gvec_ptr)(const void *)(Qp + (int64_t)qrow * a.qs[1] + d0) : (gvec_ptr)(const void *)g_zero16;
+            const u32x4 raw = *src;
+            float f[8];
+            unpack8<T>(raw, f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] *= c;
+            qf[j][kd] = __builtin_bit_cast(vec8, pack8<T>(f));
+            asm volatile("" : "+a"(qf[j][kd]));  // lives in the AGPR half from here on (every use is an MFMA operand)
+        }
+    }
+
+    // ---- staging: same tasks / LDS image as attention.hip ----------------------------------------------------------------------
+    u32x4 kreg[KTASK];
+    u32x4 vreg[VTASK][2];
+    constexpr int DUMP = G::LDS;
+    int kdst[2][KTASK], vdst[2][VTASK];
+#pragma unroll
+    for (int i = 0; i < KTASK; ++i) {
+        const int id = tid + i * NT;
+        const int key = id / KCH, ch = id - key * KCH;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) kdst[st][i] = id < 64 * KCH ? st * STAGE + key * (KSTR * 2) + ch * 16 : DUMP + tid * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < VTASK; ++i) {
+        const int id = tid + i * NT;
+        const int kp = id & 31, ch = id >> 5;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+            vdst[st][i] = ch < VCH ? st * STAGE + 64 * KSTR * 2 + (ch * 8) * (VSTR * 2) + kp * 4 : DUMP + tid * 4;
+    }
+    auto make_srd = [&](const T *base, uint32_t bytes) __attribute__((always_inline)) {
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)base);
+        const uint32_t hi32 = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)base >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(((uintptr_t)hi32 << 32) | lo), 0, (int)bytes, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t ksrd = make_srd(Kp, a.kspan), vsrd = make_srd(Vp, a.vspan);
+    const uint32_t ktile_bytes = (uint32_t)a.ks[1] * 128u, vtile_bytes = (uint32_t)a.vs[1] * 128u;
+    uint32_t koff[KTASK], voff[VTASK][2];
+#pragma unroll
+    for (int i = 0; i < KTASK; ++i) {
+        const int id = tid + i * NT;
+        const int key = id / KCH, ch = id - key * KCH;
+        koff[i] = (id < 64 * KCH && ch * 8 < D) ? ((uint32_t)key * (uint32_t)a.ks[1] + ch * 8) * 2u : 0x80000000u;
+    }
+#pragma unroll
+    for (int i = 0; i < VTASK; ++i) {
+        const int id = tid + i * NT;
+        const int kp = id & 31, ch = id >> 5;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            voff[i][j] = ch < VCH ? ((uint32_t)(2 * kp + j) * (uint32_t)a.vs[1] + ch * 8) * 2u : 0x80000000u;
+    }
+    auto prefetch_k = [&](u32x4 (&dst)[KTASK]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < KTASK; ++i) {
+            dst[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ksrd, koff[i], 0, 0));
+            koff[i] += ktile_bytes;
+        }
+    };
+    auto prefetch_v = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < VTASK; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                vreg[i][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vsrd, voff[i][j], 0, 0));
+                voff[i][j] += vtile_bytes;
+            }
+    };
+    auto stage_k_one = [&](int st, int i, const u32x4 (&src)[KTASK]) __attribute__((always_inline)) {
+        *reinterpret_cast<u32x4 *>(smem + kdst[st][i]) = src[i];
+    };
+    auto stage_v_one = [&](int st, int i, int e) __attribute__((always_inline)) {
+        const uint32_t w0 = vreg[i][0][e >> 1], w1 = vreg[i][1][e >> 1];
+        const uint32_t packed = __builtin_amdgcn_perm(w1, w0, (e & 1) ? 0x07060302u : 0x05040100u);
+        *reinterpret_cast<uint32_t *>(smem + vdst[st][i] + e * (VSTR * 2)) = packed;
+    };
+
+    // ---- state -------------------------------------------------------------------------------------------------------------------
+    f32x16 o[2][DBX];     // O^T accumulators; the denominator is row D (ONES_ROW) or every row of block DB (constant ones fragment)
+    f32x16 negm[2];       // -m_ref of the lane's query row in all 16 registers: C operand of the first QK^T MFMA of a tile
+    f32x16 s[2][2][2];    // [tile parity][query block][key block]: S^T - m_ref in log2 units
+    float mloc[2];        // row maximum of the tile about to be exponentiated (relative to m_ref), both half-waves merged
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int db = 0; db < DBX; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[j][db][r] = 0.f;
+    const int ntiles = (a.Skv + 63) / 64;
+
+    auto qk_frag = [&](const char *Ksm, int kb, int kd) __attribute__((always_inline)) -> vec8 {
+        return *reinterpret_cast<const vec8 *>(Ksm + (kb * 32 + l31) * (KSTR * 2) + (kd * 16 + hi * 8) * 2);
+    };
+    auto row_max = [&](const f32x16 (&t)[2]) __attribute__((always_inline)) -> float {
+        float m = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, t[kb][r]);
+        return fmaxf(m, __shfl_xor(m, 32, 64));
+    };
+    auto mask_tail = [&](f32x16 (&t)[2], int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (key >= a.Skv) t[kb][r] = -INFINITY;
+            }
+    };
+    vec8 kf[2][KD];
+    auto read_kf = [&](const char *Ksm) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kd = 0; kd < KD; ++kd)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) kf[kb][kd] = qk_frag(Ksm, kb, kd);
+    };
+    vec8 ones8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones8[i] = Elem<T>::from_f32(1.0f);
+    asm volatile("" : "+a"(ones8));
+
+    // ---- prologue: K(0), V(0) -> stage 0, K(1) -> stage 1; S(0) = K(0) . Q^T (C = 0), m_ref = its row maximum; K(2) -> stage 0 ------
+    {
+        u32x4 k1[KTASK], k2[KTASK];
+        prefetch_k(kreg);
+        prefetch_v();
+        prefetch_k(k1);
+        prefetch_k(k2);
+#pragma unroll
+        for (int i = 0; i < KTASK; ++i) stage_k_one(0, i, kreg);
+#pragma unroll
+        for (int i = 0; i < VTASK; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) stage_v_one(0, i, e);
+#pragma unroll
+        for (int i = 0; i < KTASK; ++i) stage_k_one(1, i, k1);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                MA::qk_zero(s[0][j][kb], qk_frag(smem, kb, 0), qf[j][0]);
+#pragma unroll
+                for (int kd = 1; kd < KD; ++kd) MA::qk_acc(s[0][j][kb], qk_frag(smem, kb, kd), qf[j][kd]);
+            }
+        read_kf(smem + STAGE);
+        mfma_drain();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) pin_v(s[0][j][kb]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (a.Skv < 64) mask_tail(s[0][j], 0);
+            const float m0 = row_max(s[0][j]);  // finite: every row has at least one key
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[0][j][kb][r] -= m0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[j][r] = -m0;
+            mloc[j] = 0.f;
+        }
+        prefetch_k(kreg);  // K(3), V(1): staged by iteration 0
+        prefetch_v();
+        __syncthreads();  // every wave has read K(0) and K(1)
+#pragma unroll
+        for (int i = 0; i < KTASK; ++i) stage_k_one(0, i, k2);
+        __syncthreads();  // K(2) visible
+    }
+
+    using Buf0 = std::integral_constant<int, 0>;
+    using Buf1 = std::integral_constant<int, 1>;
+    constexpr typename P::Starts ST = P::make();
+
+    auto tile = [&](int kt, auto CUR) __attribute__((always_inline)) {
+        constexpr int cur = decltype(CUR)::value, nxt = cur ^ 1;
+        const char *Kn2 = smem + cur * STAGE;                  // K(kt+2)
+        const char *Vcu = smem + cur * STAGE + 64 * KSTR * 2;  // V^T(kt)
+
+        if (kt > 0 && (kt + 1) * 64 > a.Skv) {  // tail tile (once per kernel): keys >= Skv leave the softmax
+            mfma_drain();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                pin_v(s[cur][j][0]);
+                pin_v(s[cur][j][1]);
+                mask_tail(s[cur][j], kt);
+                mloc[j] = row_max(s[cur][j]);
+            }
+        }
+        // the reference maximum moves only when some row's tile maximum exceeds it by more than THR. Everything still at the old
+        // reference -- O (with the denominator inside), the pending tile, -m_ref itself -- moves by the same shift, once.
+        if (__any(fmaxf(mloc[0], mloc[1]) > THR)) {
+            mfma_drain();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int db = 0; db < DBX; ++db) pin_a(o[j][db]);
+                pin_v(s[cur][j][0]);
+                pin_v(s[cur][j][1]);
+                const float dlt = fmaxf(mloc[j], 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-dlt);
+#pragma unroll
+                for (int db = 0; db < DBX; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[j][db][r] *= alpha;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[cur][j][kb][r] -= dlt;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[j][r] -= dlt;
+            }
+            asm volatile("s_nop 3" ::: "memory");  // VALU write -> MFMA C operand
+        }
+
+        auto v_frag = [&](int grp, int db) __attribute__((always_inline)) -> u32x4 {
+            const int base = (grp >> 1) * 32 + 16 * (grp & 1) + 4 * hi;
+            const char *vrow = Vcu + (db * 32 + l31) * (VSTR * 2);
+            const u32x2 v0 = *reinterpret_cast<const u32x2 *>(vrow + base * 2);
+            const u32x2 v1 = *reinterpret_cast<const u32x2 *>(vrow + (base + 8) * 2);
+            return u32x4{v0[0], v0[1], v1[0], v1[1]};
+        };
+        u32x4 vf[4][DB];
+        u32x4 pf[2][4];  // f16 / bf16 probabilities: [query block][16-key group] = B operand of the PV MFMAs
+        float mpart[2][4];
+
+        // one filler item of the plan (Q64Plan): compile-time index -> what it does
+        auto item = [&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (i < P::NA) {
+                constexpr int g = i / P::A_PER_G, w = i % P::A_PER_G;
+                if constexpr (w < DB) {
+                    vf[g][w] = v_frag(g, w);
+                } else {
+                    constexpr int j = (w - DB) >> 2, jj = (w - DB) & 3, kb = g >> 1, r0 = 8 * (g & 1) + 2 * jj;
+                    const float p0 = __builtin_amdgcn_exp2f(s[cur][j][kb][r0]);
+                    const float p1 = __builtin_amdgcn_exp2f(s[cur][j][kb][r0 + 1]);
+                    if constexpr (std::is_same<T, f16>::value) {
+                        // round toward zero: numerator and denominator see the same rounded values (the ones row / block), the bias cancels
+                        pf[j][g][jj] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(p0, p1));
+                    } else {
+                        typename Elem<T>::vec2 pr;
+                        pr[0] = Elem<T>::from_f32(p0);
+                        pr[1] = Elem<T>::from_f32(p1);
+                        pf[j][g][jj] = __builtin_bit_cast(uint32_t, pr);
+                    }
+                }
+            } else if constexpr (i < P::I_KR) {
+                constexpr int m = i - P::I_MX, j = m >> 4, q = m & 15;
+                // volatile asm: a plain fmaxf is not ordered against sched_barrier and sinks behind the last MFMA
+                if constexpr (q < 4)
+                    asm volatile("v_max_f32 %0, %1, %2"
+                                 : "=v"(mpart[j][q])
+                                 : "v"(s[nxt][j][0][2 * q]), "v"(s[nxt][j][0][2 * q + 1]));
+                else
+                    asm volatile("v_max3_f32 %0, %0, %1, %2"
+                                 : "+v"(mpart[j][q & 3])
+                                 : "v"(s[nxt][j][q >> 3][2 * (q & 7)]), "v"(s[nxt][j][q >> 3][2 * (q & 7) + 1]));
+            } else if constexpr (i < P::I_SV) {
+                constexpr int m = i - P::I_KR;
+                kf[m & 1][m >> 1] = qk_frag(Kn2, m & 1, m >> 1);
+            } else if constexpr (i < P::I_SK) {
+                constexpr int m = i - P::I_SV;
+                stage_v_one(nxt, m >> 3, m & 7);
+            } else {
+                stage_k_one(nxt, i - P::I_SK, kreg);
+            }
+        };
+        auto gap = [&](auto K) __attribute__((always_inline)) {
+            constexpr int k = decltype(K)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<ST.v[k], ST.v[k + 1]>(item);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+
+        // ---- phase 1: S^T(kt+1) - m_ref = K . Q^T + (-m_ref)   ||   P(kt) = exp2(S^T(kt) - m_ref), V^T(kt) fragment reads ----------
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, P::NQK>([&](auto Gi) __attribute__((always_inline)) {
+            constexpr int g = decltype(Gi)::value;
+            constexpr int kd = g >> 2, kb = (g >> 1) & 1, j = g & 1;
+            if constexpr (kd == 0) {
+                MA::qk_first(s[nxt][j][kb], kf[kb][0], qf[j][0], negm[j]);
+            } else {
+                MA::qk_acc(s[nxt][j][kb], kf[kb][kd], qf[j][kd]);
+            }
+            gap(Gi);
+        });
+        // ---- phase 2: O^T += V^T . P^T   ||   rest of P(kt), row maxima of S^T(kt+1), K(kt+2) fragments, staging of K(kt+3) / V(kt+1)
+        static_for<0, P::NPV>([&](auto Gi) __attribute__((always_inline)) {
+            constexpr int g = decltype(Gi)::value;
+            constexpr int grp = g / P::GP, db = (g % P::GP) >> 1, j = g & 1;
+            if constexpr (db < DB) {
+                MA::pv_acc(o[j][db], __builtin_bit_cast(vec8, vf[grp][db]), __builtin_bit_cast(vec8, pf[j][grp]));
+            } else {
+                MA::pv_acc(o[j][db], ones8, __builtin_bit_cast(vec8, pf[j][grp]));  // denominator block: sum_k P[q][k] in every row
+            }
+            gap(std::integral_constant<int, P::NQK + g>{});
+        });
+        // the staging registers are free again: global loads of K(kt+4), V(kt+2), staged by the NEXT iteration -- a full iteration of
+        // flight time. Tiles past the end are out of the descriptors' range and read 0 (unconditional: no branch here).
+        prefetch_k(kreg);
+        prefetch_v();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float m4 = fmaxf(fmaxf(mpart[j][0], mpart[j][1]), fmaxf(mpart[j][2], mpart[j][3]));
+            mloc[j] = fmaxf(m4, __shfl_xor(m4, 32, 64));
+        }
+        __syncthreads();
+    };
+
+    int kt = 0;
+    for (; kt + 1 < ntiles; kt += 2) {
+        tile(kt, Buf0{});
+        tile(kt + 1, Buf1{});
+    }
+    if (kt < ntiles) tile(kt, Buf0{});
+
+    // ---- epilogue: normalise and store 4 consecutive d per lane ----------------------------------------------------------------------
+    mfma_drain();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int db = 0; db < DBX; ++db) pin_a(o[j][db]);
+        float l_tot;
+        if constexpr (ONES_ROW) {
+            constexpr int RR = D % 32;
+            constexpr int LREG = (RR & 3) + 4 * (RR >> 3);
+            constexpr int LHI = (RR >> 2) & 1;
+            l_tot = __shfl(o[j][D / 32][LREG], l31 + 32 * LHI, 64);
+        } else {
+            l_tot = o[j][DB][0];
+        }
+        const float inv = 1.0f / l_tot;
+        const int qrow = q0 + 32 * j + l31;
+        if (qrow < a.Sq) {
+            T *Op = (T *)a.out + (int64_t)b * a.os[0] + (int64_t)qrow * a.os[1] + (int64_t)h * a.os[2];
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = db * 32 + 8 * g + 4 * hi;
+                    if (d < D) {
+                        *reinterpret_cast<u32x2 *>(Op + d) =
+                            pack4<T>(o[j][db][4 * g] * inv, o[j][db][4 * g + 1] * inv, o[j][db][4 * g + 2] * inv, o[j][db][4 * g + 3] * inv);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int D, int NW> int q64_set_attr() {
+    auto kern = attn_q64_kernel<T, D, NW>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, AttnGeom<D>::LDS_TOTAL);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(attn_q64 D=%d): %s", D, hipGetErrorString(e));
+        return SFAST_ERR_LAUNCH;
+    }
+    return 0;
+}
+
+template <typename T, int D> int q64_launch_d(AttnArgs &a, int nw, int xmap_enabled, hipStream_t st) {
+    const int rows = nw * 64;
+    a.nqb = ceil_div(a.Sq, rows);
+    a.xmap = (xmap_enabled && (a.B * a.H) % 8 == 0 && (int64_t)a.nqb * a.B * a.H < (1 << 22)) ? 1 : 0;
+    a.ppx = a.B * a.H / 8;
+    const dim3 grid = a.xmap ? dim3((unsigned)(a.nqb * a.B * a.H), 1, 1) : dim3((unsigned)a.nqb, (unsigned)a.H, (unsigned)a.B);
+    if (nw == 2)
+        hipLaunchKernelGGL((attn_q64_kernel<T, D, 2>), grid, dim3(128), AttnGeom<D>::LDS_TOTAL, st, a);
+    else
+        hipLaunchKernelGGL((attn_q64_kernel<T, D, 4>), grid, dim3(256), AttnGeom<D>::LDS_TOTAL, st, a);
+    return check_launch("attention_q64");
+}
+
+template <typename T> int q64_launch_t(AttnArgs &a, int nw, int xmap_enabled, hipStream_t st) {
+    switch (a.D) {
+    case 40: return q64_launch_d<T, 40>(a, nw, xmap_enabled, st);
+    case 64: return q64_launch_d<T, 64>(a, nw, xmap_enabled, st);
+    case 80: return q64_launch_d<T, 80>(a, nw, xmap_enabled, st);
+    }
+    return -1;
+}
+
+template <typename T> int q64_init_t() {
+    int rc = 0;
+#define Q_INIT(D)                                \
+    if (!rc) rc = q64_set_attr<T, D, 2>();       \
+    if (!rc) rc = q64_set_attr<T, D, 4>();
+    Q_INIT(40) Q_INIT(64) Q_INIT(80)
+#undef Q_INIT
+    return rc;
+}
+
+}  // namespace
+
+int attention_q64_init() {
+    int rc = q64_init_t<f16>();
+    if (!rc) rc = q64_init_t<bf16>();
+    return rc;
+}
+
+// nw: waves per workgroup (2 or 4). Caller guarantees: no bias, D in {40, 64, 80}, f16 / bf16, the vector-path alignment rules.
+int attention_q64_launch(const AttnArgs &a_in, int dtype, int nw_and_xmap, hipStream_t st) {
+    AttnArgs a = a_in;
+    const int nw = nw_and_xmap & 0xff, xmap = (nw_and_xmap >> 8) & 1;
+    if (a.bias != nullptr || !(a.D == 40 || a.D == 64 || a.D == 80) || !(nw == 2 || nw == 4)) return -1;
+    if (dtype == SFAST_F16) return q64_launch_t<f16>(a, nw, xmap, st);
+    if (dtype == SFAST_BF16) return q64_launch_t<bf16>(a, nw, xmap, st);
+    return -1;
+}
+
+}  // namespace sfast

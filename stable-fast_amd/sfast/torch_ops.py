@@ -297,19 +297,22 @@ class _PackedOnDevice:
         self.w8, self.scale, self.bias = w8, scale, bias
 
 
-_PACKED = {}         # packed-params object -> {device: _PackedOnDevice}
+# hash(packed) -> (packed, {device: _PackedOnDevice}). The dispatcher hands every call a NEW Python wrapper of the same C++ object: the
+# wrappers hash alike (by the C++ pointer) but implement no __eq__, so the table is keyed by the hash itself; the entry keeps one wrapper
+# -- and with it the C++ object -- alive, so the pointer cannot be recycled for another weight while its record is cached.
+_PACKED = {}
 _PACKED_LIMIT = 4096
 
 
 def _remember(packed, dev, rec):
     if len(_PACKED) >= _PACKED_LIMIT:   # modules re-packed in a loop: keep the table bounded (records are re-derivable)
         _PACKED.clear()
-    _PACKED.setdefault(packed, {})[dev] = rec
+    _PACKED.setdefault(hash(packed), (packed, {}))[1][dev] = rec
 
 
 def _device_record(packed, device):
-    per = _PACKED.get(packed)
-    rec = per.get(device) if per else None
+    ent = _PACKED.get(hash(packed))
+    rec = ent[1].get(device) if ent else None
     if rec is None:
         w, b = torch.ops.quantized.linear_unpack(packed)
         if w.qscheme() not in (torch.per_tensor_affine, torch.per_tensor_symmetric):

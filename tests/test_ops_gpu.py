@@ -407,14 +407,79 @@ ATTN_CASES = [
 ]
 
 
+def _q64_covers(D, Skv):
+    """attention_q64.hip (64 query rows per wave): head dims 40 / 64 / 80, at least two 64-key tiles, no bias."""
+    return D in (40, 64, 80) and Skv >= 128
+
+
 @pytest.mark.parametrize("case", ATTN_CASES, ids=[str(c) for c in ATTN_CASES])
-@pytest.mark.parametrize("variant", [0, 2, 4])
+@pytest.mark.parametrize("variant", [0, 2, 4, 32, 62, 64])   # 2 / 4 / 32: the 32-row kernel; 62 / 64: the 64-row kernel, 2 / 4 waves per workgroup
 def test_attention(case, variant):
     B, H, Sq, Skv, D = case
     q, k, v = rnd(B, Sq, H, D, seed=100), rnd(B, Skv, H, D, seed=101), rnd(B, Skv, H, D, seed=102)
     o = F().attention(q, k, v, variant=variant)
-    assert "attn_fwd" in last_kernel()
+    if variant in (62, 64) and _q64_covers(D, Skv):
+        assert last_kernel() == f"attn_q64[D={D},BQ={(variant - 60) * 64}]", last_kernel()
+    elif variant in (2, 4, 32):
+        assert "attn_fwd" in last_kernel()
+    else:
+        assert "attn_fwd" in last_kernel() or "attn_q64" in last_kernel()
     compare(f"attn {case} v{variant}", o, R.attention_ref(q, k, v), *tol(q.dtype), kernel=last_kernel())
+
+
+Q64_CASES = [
+    # B, H, Sq, Skv, D: ragged query blocks (rows past Sq inside a wave's second 32-row block, inside its first, whole idle waves),
+    # ragged / odd / even key-tile counts (2 .. 9 tiles), every head dim of the kernel
+    (1, 2, 64, 128, 40), (1, 2, 65, 129, 64), (1, 3, 31, 192, 80), (2, 2, 200, 320, 80), (1, 3, 97, 193, 40), (1, 2, 129, 191, 64),
+    (1, 1, 257, 448, 40), (1, 2, 300, 576, 64), (2, 4, 512, 512, 80), (1, 8, 1024, 1024, 40), (3, 5, 130, 257, 64),
+]
+
+
+@pytest.mark.parametrize("case", Q64_CASES, ids=[str(c) for c in Q64_CASES])
+@pytest.mark.parametrize("variant", [62, 64])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_attention_q64_shapes(case, variant, dtype):
+    B, H, Sq, Skv, D = case
+    q, k, v = (rnd(B, s_, H, D, dtype=dtype, seed=140 + i) for i, s_ in enumerate((Sq, Skv, Skv)))
+    o = F().attention(q, k, v, variant=variant)
+    assert "attn_q64" in last_kernel(), last_kernel()
+    compare(f"attn q64 {case} v{variant} {dtype}", o, R.attention_ref(q, k, v), *tol(dtype), kernel=last_kernel())
+    # identical to rounding with the first-generation kernel on the same inputs (two independent implementations of one contract)
+    o32 = F().attention(q, k, v, variant=32)
+    assert "attn_fwd" in last_kernel()
+    assert rel(o, o32) < (2e-3 if dtype == torch.float16 else 1.5e-2)
+
+
+def test_attention_q64_on_fused_qkv_views_and_scale():
+    B, S, H, D = 2, 1024, 8, 80
+    C = H * D
+    qkv = rnd(B, S, 3 * C, seed=146)
+    q, k, v = (qkv[:, :, i * C:(i + 1) * C].unflatten(2, (H, D)) for i in range(3))
+    o = F().attention(q, k, v, variant=64)
+    assert "attn_q64" in last_kernel()
+    compare("attn q64 fused-qkv views", o, R.attention_ref(q, k, v), *tol(qkv.dtype), kernel=last_kernel())
+    o2 = F().attention(q, k, v, scale=0.05, variant=62)
+    compare("attn q64 scale", o2, R.attention_ref(q, k, v, 0.05), *tol(qkv.dtype), kernel=last_kernel())
+
+
+@pytest.mark.parametrize("variant", [32, 62, 64])
+def test_attention_reference_maximum_moves(variant):
+    """The 64-row kernel keeps a REFERENCE maximum per row that only moves when a tile's maximum exceeds it 64-fold (2^6); the
+    32-row kernel rescales whenever any row's maximum grows. Inputs that force the move at chosen tiles -- after O and the denominator
+    have accumulated -- for rows in both query blocks of a wave, once and repeatedly (scores growing tile after tile), plus rows that
+    never move. (Guide rule 26: a rare data-dependent branch needs an input that takes it and a full-tensor reference.)"""
+    B, H, S, D = 1, 2, 1024, 64
+    q, k, v = rnd(B, S, H, D, seed=150), rnd(B, S, H, D, seed=151), rnd(B, S, H, D, seed=152)
+    k[:, 300] = q[:, 5] * 4.0          # query 5 (first block of wave 0): jump at tile 4
+    k[:, 77] = q[:, 200] * 6.0         # query 200: jump at tile 1
+    k[:, 1000] = q[:, 40] * 8.0        # query 40 (second block of wave 0): jump at the last tile
+    for t in range(2, 16):             # query 700: a new, larger maximum in every tile from tile 2 on
+        k[:, 64 * t + 3] = q[:, 700] * (0.5 * t)
+    o = F().attention(q, k, v, variant=variant)
+    want = R.attention_ref(q, k, v)
+    compare(f"attn moving reference v{variant}", o, want, *tol(q.dtype), kernel=last_kernel())
+    for row in (5, 40, 200, 700):
+        assert float((o[0, row].float() - want[0, row].float()).abs().max()) < 2e-2
 
 
 def test_attention_bf16_and_scale():

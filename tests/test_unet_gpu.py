@@ -201,7 +201,9 @@ def test_compile_drop_in_surface():
     o2s = pipe.unet(lat2, torch.tensor(500, device=DEV), encoder_hidden_states=ehs[:, :40], cross_attention_kwargs={"scale": 0.5}, return_dict=False)[0]
     assert torch.equal(o2s, o2) and not pipe.unet.forward._warned and len(pipe.unet.forward._cached) == 2
     # unsupported call forms fall back to the original forward instead of computing something else
-    o3 = pipe.unet(lat2, 500, encoder_hidden_states=ehs[:, :40], cross_attention_kwargs={"ip_adapter_masks": None, "scale": 1.0}, return_dict=False)[0]
+    # (`attention_mask` -- the self-attention mask -- is not a plan input; the oracle module ignores it, so both eager runs agree)
+    o3 = pipe.unet(lat2, 500, encoder_hidden_states=ehs[:, :40], attention_mask=torch.ones(2, 1, 512, device=DEV, dtype=torch.float16),
+                   return_dict=False)[0]
     assert pipe.unet.forward._warned  # took the eager path (two eager fp16 runs differ by conv algorithm noise)
     assert rel_l2(o3, w2) < 1e-2 and len(pipe.unet.forward._cached) == 2
 

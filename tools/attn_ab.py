@@ -18,26 +18,39 @@ SHAPES = [  # (B, Sq, Skv, H, D)
 ]
 torch.manual_seed(0)
 out = []
+# `--variants 0,32,62,64`: the kernels to time per shape, interleaved rounds in ONE process (guide rule 24): 0 = the library's own choice,
+# 32 = first-generation kernel (32 query rows per wave), 62 / 64 = attention_q64.hip with 2 / 4 waves per workgroup
+VARIANTS = [0]
+if "--variants" in sys.argv:
+    VARIANTS = [int(x) for x in sys.argv[sys.argv.index("--variants") + 1].split(",")]
+if "--more-shapes" in sys.argv:
+    SHAPES += [(16, 4096, 4096, 8, 40), (2, 9216, 9216, 5, 64), (8, 2304, 2304, 10, 64), (2, 1024, 1024, 8, 40), (4, 1024, 1024, 10, 64)]
 for B, Sq, Skv, H, D in SHAPES:
     q = torch.randn(B, Sq, H, D, device="cuda", dtype=torch.float16)
     k = torch.randn(B, Skv, H, D, device="cuda", dtype=torch.float16)
     v = torch.randn(B, Skv, H, D, device="cuda", dtype=torch.float16)
-    for _ in range(5):
-        o = F.attention(q, k, v)
-    ref = torch.nn.functional.scaled_dot_product_attention(q.transpose(1, 2).float(), k.transpose(1, 2).float(),
-                                                           v.transpose(1, 2).float()).transpose(1, 2)
-    err = (o.float() - ref).abs().max().item()
-    best = 1e9
+    ref = torch.nn.functional.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2).float() \
+        if B * H * Sq * Skv > (1 << 31) else torch.nn.functional.scaled_dot_product_attention(
+            q.transpose(1, 2).float(), k.transpose(1, 2).float(), v.transpose(1, 2).float()).transpose(1, 2)
+    errs, names, best = {}, {}, {vr: 1e9 for vr in VARIANTS}
+    for vr in VARIANTS:
+        for _ in range(3):
+            o = F.attention(q, k, v, variant=vr)
+        names[vr] = L.last_kernel()
+        errs[vr] = (o.float() - ref).abs().max().item()
     for rep in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(40):
-            F.attention(q, k, v)
-        e1.record()
-        torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1) / 40 * 1e3)
+        for vr in VARIANTS:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                F.attention(q, k, v, variant=vr)
+            e1.record()
+            torch.cuda.synchronize()
+            best[vr] = min(best[vr], e0.elapsed_time(e1) / 20 * 1e3)
     fl = 4.0 * B * H * Sq * Skv * D
-    out.append(f"D={D:3d} Sq={Sq:4d} Skv={Skv:4d} H={H:2d}: {best:7.1f} us  {fl / best / 1e6:6.1f} TF  err {err:.1e}")
+    for vr in VARIANTS:
+        out.append(f"B={B:2d} D={D:3d} Sq={Sq:4d} Skv={Skv:4d} H={H:2d} variant={vr:2d} {names[vr]:24s}: {best[vr]:7.1f} us  {fl / best[vr] / 1e6:6.1f} TF  "
+                   f"({fl / best[vr] / 1e6 / 25.0:4.1f} % of 2.5 PF)  err {errs[vr]:.1e}")
 if "--trace" in sys.argv:
     import numpy as np
     lib = L.load()
