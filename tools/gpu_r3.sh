@@ -22,6 +22,12 @@ s1)  # review items: new parity tests, int8 binding, eager cliffs, smoke, defaul
   run smoke 600 python __graft_entry__.py smoke
   run bench 900 python bench.py --steps 50 --warmup 10 --dump-kernels gpurun_out/kernels.json
   ;;
+s2)  # attention_q64: parity + same-process A/B against the 32-row kernel; fixes of session 1
+  run t_attn 900 $PYT tests/test_ops_gpu.py -k "attention" --durations=5
+  run t_qlinear 600 $PYT tests/test_reference_api_gpu.py -k "linear_dynamic or qlinear"
+  run t_fix 600 $PYT tests/test_unet_gpu.py tests/test_parity_r3_gpu.py -k "compile_drop_in or peaked or tiny_trained" --durations=5
+  run attn_ab 600 python tools/attn_ab.py --variants 32,62,64 --more-shapes
+  ;;
 full)
   run t_all 1500 $PYT tests
   run smoke 600 python __graft_entry__.py smoke
