@@ -684,6 +684,12 @@ extern "C" int sfast_hip_attention_bias(const void *q, const void *k, const void
         // the chip has 1024 SIMDs, so below ~that many units the 32-row kernel (twice the units, half the work each) fills it better.
         // variant 64 / 62: forced, 4 / 2 waves per workgroup; variant 32 (and 2 / 4): the 32-row kernel.
         const int64_t units = (int64_t)ceil_div(p->Sq, 64) * p->H * p->B;
+        if (p->variant >= 1000 && p->variant < 2024) {  // timing-only ablations of the 64-row kernel (tools/attn_ablate.py)
+            set_kernel_name("attn_q64_ablation[%d]", p->variant - 1000);
+            const int rc = attention_q64_launch(a, p->dtype, 4 | (g_attn_xmap << 8) | ((p->variant - 1000) << 16), st);
+            if (rc != -1) return rc;
+            SFAST_REQUIRE(false, SFAST_ERR_UNSUPPORTED, "attention: no ablation instantiation %d", p->variant - 1000);
+        }
         int use = (p->variant == 64 || p->variant == 62) ? 1 : (p->variant != 0 ? 0 : (g_attn_q64 >= 0 ? g_attn_q64 : (units >= 768 ? 1 : 0)));
         if (use) {
             const int nw = p->variant == 62 ? 2 : (p->variant == 64 ? 4 : (p->Sq % 256 == 0 || p->Sq > 1024 ? 4 : 2));

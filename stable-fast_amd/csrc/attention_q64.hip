@@ -148,7 +148,10 @@ template <int D, int NW> struct Q64Plan {
     }
 };
 
-template <typename T, int D, int NW>
+// ABL: ablation bit mask of the TIMING-ONLY instantiations (tools/attn_ablate.py; results are garbage): 1 no v_exp, 2 no convert,
+// 4 no row maxima, 8 no V^T fragment reads, 16 no K fragment reads, 32 no staging stores, 64 no global prefetch, 128 no barrier,
+// 256 no QK^T MFMAs, 512 no PV MFMAs. ABL = 0 is the product kernel.
+template <typename T, int D, int NW, int ABL = 0>
 __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) {
     using vec8 = typename Elem<T>::vec8;
     using MA = MfmaAsm<T>;
@@ -265,6 +268,9 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
     auto prefetch_k = [&](u32x4 (&dst)[KTASK]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < KTASK; ++i) {
+            if constexpr ((ABL & 64) != 0) {
+                if (koff[i] != 0x12345u) continue;  // (never true: keeps the registers defined without issuing the load in the loop)
+            }
             dst[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ksrd, koff[i], 0, 0));
             koff[i] += ktile_bytes;
         }
@@ -274,6 +280,9 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
         for (int i = 0; i < VTASK; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
+                if constexpr ((ABL & 64) != 0) {
+                    if (voff[i][j] != 0x12345u) continue;
+                }
                 vreg[i][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vsrd, voff[i][j], 0, 0));
                 voff[i][j] += vtile_bytes;
             }
@@ -435,6 +444,12 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
             return u32x4{v0[0], v0[1], v1[0], v1[1]};
         };
         u32x4 vf[4][DB];
+        if constexpr ((ABL & 8) != 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int db = 0; db < DB; ++db) vf[g][db] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+        }
         u32x4 pf[2][4];  // f16 / bf16 probabilities: [query block][16-key group] = B operand of the PV MFMAs
         float mpart[2][4];
 
@@ -444,12 +459,14 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
             if constexpr (i < P::NA) {
                 constexpr int g = i / P::A_PER_G, w = i % P::A_PER_G;
                 if constexpr (w < DB) {
-                    vf[g][w] = v_frag(g, w);
+                    if constexpr ((ABL & 8) == 0) vf[g][w] = v_frag(g, w);
                 } else {
                     constexpr int j = (w - DB) >> 2, jj = (w - DB) & 3, kb = g >> 1, r0 = 8 * (g & 1) + 2 * jj;
-                    const float p0 = __builtin_amdgcn_exp2f(s[cur][j][kb][r0]);
-                    const float p1 = __builtin_amdgcn_exp2f(s[cur][j][kb][r0 + 1]);
-                    if constexpr (std::is_same<T, f16>::value) {
+                    const float p0 = (ABL & 1) ? s[cur][j][kb][r0] : __builtin_amdgcn_exp2f(s[cur][j][kb][r0]);
+                    const float p1 = (ABL & 1) ? s[cur][j][kb][r0 + 1] : __builtin_amdgcn_exp2f(s[cur][j][kb][r0 + 1]);
+                    if constexpr ((ABL & 2) != 0) {
+                        pf[j][g][jj] = __builtin_bit_cast(uint32_t, p0) ^ __builtin_bit_cast(uint32_t, p1);
+                    } else if constexpr (std::is_same<T, f16>::value) {
                         // round toward zero: numerator and denominator see the same rounded values (the ones row / block), the bias cancels
                         pf[j][g][jj] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(p0, p1));
                     } else {
@@ -462,7 +479,9 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
             } else if constexpr (i < P::I_KR) {
                 constexpr int m = i - P::I_MX, j = m >> 4, q = m & 15;
                 // volatile asm: a plain fmaxf is not ordered against sched_barrier and sinks behind the last MFMA
-                if constexpr (q < 4)
+                if constexpr ((ABL & 4) != 0) {
+                    if constexpr (q < 4) mpart[j][q] = 0.f;
+                } else if constexpr (q < 4)
                     asm volatile("v_max_f32 %0, %1, %2"
                                  : "=v"(mpart[j][q])
                                  : "v"(s[nxt][j][0][2 * q]), "v"(s[nxt][j][0][2 * q + 1]));
@@ -472,12 +491,12 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
                                  : "v"(s[nxt][j][q >> 3][2 * (q & 7)]), "v"(s[nxt][j][q >> 3][2 * (q & 7) + 1]));
             } else if constexpr (i < P::I_SV) {
                 constexpr int m = i - P::I_KR;
-                kf[m & 1][m >> 1] = qk_frag(Kn2, m & 1, m >> 1);
+                if constexpr ((ABL & 16) == 0) kf[m & 1][m >> 1] = qk_frag(Kn2, m & 1, m >> 1);
             } else if constexpr (i < P::I_SK) {
                 constexpr int m = i - P::I_SV;
-                stage_v_one(nxt, m >> 3, m & 7);
+                if constexpr ((ABL & 32) == 0) stage_v_one(nxt, m >> 3, m & 7);
             } else {
-                stage_k_one(nxt, i - P::I_SK, kreg);
+                if constexpr ((ABL & 32) == 0) stage_k_one(nxt, i - P::I_SK, kreg);
             }
         };
         auto gap = [&](auto K) __attribute__((always_inline)) {
@@ -492,7 +511,9 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
         static_for<0, P::NQK>([&](auto Gi) __attribute__((always_inline)) {
             constexpr int g = decltype(Gi)::value;
             constexpr int kd = g >> 2, kb = (g >> 1) & 1, j = g & 1;
-            if constexpr (kd == 0) {
+            if constexpr ((ABL & 256) != 0) {
+                if constexpr (kd == 0) asm volatile("" : "=v"(s[nxt][j][kb]));  // "defined" without an instruction
+            } else if constexpr (kd == 0) {
                 MA::qk_first(s[nxt][j][kb], kf[kb][0], qf[j][0], negm[j]);
             } else {
                 MA::qk_acc(s[nxt][j][kb], kf[kb][kd], qf[j][kd]);
@@ -503,7 +524,9 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
         static_for<0, P::NPV>([&](auto Gi) __attribute__((always_inline)) {
             constexpr int g = decltype(Gi)::value;
             constexpr int grp = g / P::GP, db = (g % P::GP) >> 1, j = g & 1;
-            if constexpr (db < DB) {
+            if constexpr ((ABL & 512) != 0) {
+                asm volatile("" ::"a"(vf[grp][db < DB ? db : 0]), "v"(pf[j][grp]));  // operands stay live, no MFMA
+            } else if constexpr (db < DB) {
                 MA::pv_acc(o[j][db], __builtin_bit_cast(vec8, vf[grp][db]), __builtin_bit_cast(vec8, pf[j][grp]));
             } else {
                 MA::pv_acc(o[j][db], ones8, __builtin_bit_cast(vec8, pf[j][grp]));  // denominator block: sum_k P[q][k] in every row
@@ -519,7 +542,7 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
             const float m4 = fmaxf(fmaxf(mpart[j][0], mpart[j][1]), fmaxf(mpart[j][2], mpart[j][3]));
             mloc[j] = fmaxf(m4, __shfl_xor(m4, 32, 64));
         }
-        __syncthreads();
+        if constexpr ((ABL & 128) == 0) __syncthreads();
     };
 
     int kt = 0;
@@ -586,6 +609,25 @@ template <typename T, int D> int q64_launch_d(AttnArgs &a, int nw, int xmap_enab
     return check_launch("attention_q64");
 }
 
+// timing-only ablations (f16, four waves): variant 1000 + mask, masks listed in kAblations
+#define SFAST_Q64_ABLATIONS(OP) OP(1) OP(3) OP(4) OP(7) OP(8) OP(16) OP(24) OP(32) OP(64) OP(96) OP(128) OP(224) OP(256) OP(512) OP(768) OP(255) OP(1023)
+template <int D> int q64_launch_abl(AttnArgs &a, int abl, int xmap_enabled, hipStream_t st) {
+    a.nqb = ceil_div(a.Sq, 256);
+    a.xmap = (xmap_enabled && (a.B * a.H) % 8 == 0) ? 1 : 0;
+    a.ppx = a.B * a.H / 8;
+    const dim3 grid = a.xmap ? dim3((unsigned)(a.nqb * a.B * a.H), 1, 1) : dim3((unsigned)a.nqb, (unsigned)a.H, (unsigned)a.B);
+#define ABL_OP(M)                                                                                                     \
+    if (abl == M) {                                                                                                   \
+        auto kern = attn_q64_kernel<f16, D, 4, M>;                                                                    \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, AttnGeom<D>::LDS_TOTAL); \
+        hipLaunchKernelGGL(kern, grid, dim3(256), AttnGeom<D>::LDS_TOTAL, st, a);                                      \
+        return check_launch("attention_q64_ablation");                                                                \
+    }
+    SFAST_Q64_ABLATIONS(ABL_OP)
+#undef ABL_OP
+    return -1;
+}
+
 template <typename T> int q64_launch_t(AttnArgs &a, int nw, int xmap_enabled, hipStream_t st) {
     switch (a.D) {
     case 40: return q64_launch_d<T, 40>(a, nw, xmap_enabled, st);
@@ -616,7 +658,13 @@ int attention_q64_init() {
 // nw: waves per workgroup (2 or 4). Caller guarantees: no bias, D in {40, 64, 80}, f16 / bf16, the vector-path alignment rules.
 int attention_q64_launch(const AttnArgs &a_in, int dtype, int nw_and_xmap, hipStream_t st) {
     AttnArgs a = a_in;
-    const int nw = nw_and_xmap & 0xff, xmap = (nw_and_xmap >> 8) & 1;
+    const int nw = nw_and_xmap & 0xff, xmap = (nw_and_xmap >> 8) & 1, abl = nw_and_xmap >> 16;
+    if (abl > 0) {
+        if (dtype != SFAST_F16 || a.bias != nullptr) return -1;
+        if (a.D == 40) return q64_launch_abl<40>(a, abl, xmap, st);
+        if (a.D == 64) return q64_launch_abl<64>(a, abl, xmap, st);
+        return -1;
+    }
     if (a.bias != nullptr || !(a.D == 40 || a.D == 64 || a.D == 80) || !(nw == 2 || nw == 4)) return -1;
     if (dtype == SFAST_F16) return q64_launch_t<f16>(a, nw, xmap, st);
     if (dtype == SFAST_BF16) return q64_launch_t<bf16>(a, nw, xmap, st);

@@ -28,6 +28,9 @@ s2)  # attention_q64: parity + same-process A/B against the 32-row kernel; fixes
   run t_fix 600 $PYT tests/test_unet_gpu.py tests/test_parity_r3_gpu.py -k "compile_drop_in or peaked or tiny_trained" --durations=5
   run attn_ab 600 python tools/attn_ab.py --variants 32,62,64 --more-shapes
   ;;
+s3)  # where the tile loop of attention_q64 spends its time
+  run attn_ablate 600 python tools/attn_ablate.py
+  ;;
 full)
   run t_all 1500 $PYT tests
   run smoke 600 python __graft_entry__.py smoke
