@@ -98,16 +98,21 @@ template <int D, int NW> struct Q64Plan {
     static constexpr int A_PER_G = DB + 8;                // per 16-key group g: DB V^T fragment reads, then 8 exp2-pair+convert items
     static constexpr int NA = 4 * A_PER_G;
     static constexpr int I_MX = NA;                       // 32 row-max items (v_max3) of tile t+1
-    static constexpr int I_KR = I_MX + 32;                // 2 * KD K-fragment reads of tile t+2
+    static constexpr int I_MG = I_MX + 32;                // 2 merges of the four partial maxima of a query block (v_max3 + v_max)
+    static constexpr int I_KR = I_MG + 2;                 // 2 * KD K-fragment reads of tile t+2
     static constexpr int I_SV = I_KR + 2 * KD;            // VTASK * 8 V^T staging items (v_perm + ds_write_b32)
     static constexpr int I_SK = I_SV + VTASK * 8;         // KTASK K staging stores
-    static constexpr int NI = I_SK + KTASK;
+    static constexpr int I_PK = I_SK + KTASK;             // KTASK global loads of K(t+4) (+ offset advance): the staging registers are free again
+    static constexpr int I_PV = I_PK + KTASK;             // 2 * VTASK global loads of V(t+2)
+    static constexpr int NI = I_PV + 2 * VTASK;
     static constexpr int weight(int i) {
         if (i < NA) return (i % A_PER_G) < DB ? 2 : 3;   // 2 ds_read_b64 | 2 v_exp + 1 v_cvt
-        if (i < I_KR) return 1;
+        if (i < I_MG) return 1;
+        if (i < I_KR) return 2;
         if (i < I_SV) return 1;
         if (i < I_SK) return 2;
-        return 3;                                          // ds_write_b128
+        if (i < I_PK) return 3;                            // ds_write_b128
+        return 2;                                          // buffer_load + v_add
     }
     static constexpr int total_weight() {
         int w = 0;
@@ -129,6 +134,7 @@ template <int D, int NW> struct Q64Plan {
             const int target = (W * (k + 1) + NG - 1) / NG;
             while (item < NI && cum < target) {
                 if (item >= I_MX && k < NQK + 1) break;
+                if (item >= I_MG && item < I_KR && k < NQK + 2) break;
                 cum += weight(item);
                 ++item;
             }
@@ -287,6 +293,20 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
                 voff[i][j] += vtile_bytes;
             }
     };
+    auto prefetch_k_one = [&](int i) __attribute__((always_inline)) {
+        if constexpr ((ABL & 64) != 0) {
+            if (koff[i] != 0x12345u) return;
+        }
+        kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ksrd, koff[i], 0, 0));
+        koff[i] += ktile_bytes;
+    };
+    auto prefetch_v_one = [&](int i, int j) __attribute__((always_inline)) {
+        if constexpr ((ABL & 64) != 0) {
+            if (voff[i][j] != 0x12345u) return;
+        }
+        vreg[i][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vsrd, voff[i][j], 0, 0));
+        voff[i][j] += vtile_bytes;
+    };
     auto stage_k_one = [&](int st, int i, const u32x4 (&src)[KTASK]) __attribute__((always_inline)) {
         *reinterpret_cast<u32x4 *>(smem + kdst[st][i]) = src[i];
     };
@@ -300,7 +320,7 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
     f32x16 o[2][DBX];     // O^T accumulators; the denominator is row D (ONES_ROW) or every row of block DB (constant ones fragment)
     f32x16 negm[2];       // -m_ref of the lane's query row in all 16 registers: C operand of the first QK^T MFMA of a tile
     f32x16 s[2][2][2];    // [tile parity][query block][key block]: S^T - m_ref in log2 units
-    float mloc[2];        // row maximum of the tile about to be exponentiated (relative to m_ref), both half-waves merged
+    float mloc[2];        // maximum of the tile about to be exponentiated (relative to m_ref) over the keys THIS half-wave holds of the row
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -411,7 +431,9 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
             }
         }
         // the reference maximum moves only when some row's tile maximum exceeds it by more than THR. Everything still at the old
-        // reference -- O (with the denominator inside), the pending tile, -m_ref itself -- moves by the same shift, once.
+        // reference -- O (with the denominator inside), the pending tile, -m_ref itself -- moves by the same shift, once. The test
+        // needs no cross-lane traffic (any lane of either half-wave over the threshold): the cross-half exchange of the first version
+        // sat, with its LDS round trip, on the serial path between two tiles (244 ns of a 1038 ns tile, profiles/r03_attn_q64_ablation_run3.log).
         if (__any(fmaxf(mloc[0], mloc[1]) > THR)) {
             mfma_drain();
 #pragma unroll
@@ -420,7 +442,7 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
                 for (int db = 0; db < DBX; ++db) pin_a(o[j][db]);
                 pin_v(s[cur][j][0]);
                 pin_v(s[cur][j][1]);
-                const float dlt = fmaxf(mloc[j], 0.f);
+                const float dlt = fmaxf(fmaxf(mloc[j], __shfl_xor(mloc[j], 32, 64)), 0.f);  // the row's maximum: both half-waves
                 const float alpha = __builtin_amdgcn_exp2f(-dlt);
 #pragma unroll
                 for (int db = 0; db < DBX; ++db)
@@ -489,14 +511,29 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
                     asm volatile("v_max3_f32 %0, %0, %1, %2"
                                  : "+v"(mpart[j][q & 3])
                                  : "v"(s[nxt][j][q >> 3][2 * (q & 7)]), "v"(s[nxt][j][q >> 3][2 * (q & 7) + 1]));
+            } else if constexpr (i < P::I_KR) {
+                constexpr int j = i - P::I_MG;
+                if constexpr ((ABL & 4) != 0) {
+                    mloc[j] = 0.f;
+                } else {
+                    asm volatile("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4"
+                                 : "=&v"(mloc[j])
+                                 : "v"(mpart[j][0]), "v"(mpart[j][1]), "v"(mpart[j][2]), "v"(mpart[j][3]));
+                }
             } else if constexpr (i < P::I_SV) {
                 constexpr int m = i - P::I_KR;
                 if constexpr ((ABL & 16) == 0) kf[m & 1][m >> 1] = qk_frag(Kn2, m & 1, m >> 1);
             } else if constexpr (i < P::I_SK) {
                 constexpr int m = i - P::I_SV;
                 if constexpr ((ABL & 32) == 0) stage_v_one(nxt, m >> 3, m & 7);
-            } else {
+            } else if constexpr (i < P::I_PK) {
                 if constexpr ((ABL & 32) == 0) stage_k_one(nxt, i - P::I_SK, kreg);
+            } else if constexpr (i < P::I_PV) {
+                // the staging registers are free again: global loads of K(kt+4), V(kt+2), staged by the NEXT iteration -- a full iteration
+                // of flight time. Tiles past the end are out of the descriptors' range and read 0 (unconditional: no branch here).
+                prefetch_k_one(i - P::I_PK);
+            } else {
+                prefetch_v_one((i - P::I_PV) >> 1, (i - P::I_PV) & 1);
             }
         };
         auto gap = [&](auto K) __attribute__((always_inline)) {
@@ -533,15 +570,6 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
             }
             gap(std::integral_constant<int, P::NQK + g>{});
         });
-        // the staging registers are free again: global loads of K(kt+4), V(kt+2), staged by the NEXT iteration -- a full iteration of
-        // flight time. Tiles past the end are out of the descriptors' range and read 0 (unconditional: no branch here).
-        prefetch_k(kreg);
-        prefetch_v();
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float m4 = fmaxf(fmaxf(mpart[j][0], mpart[j][1]), fmaxf(mpart[j][2], mpart[j][3]));
-            mloc[j] = fmaxf(m4, __shfl_xor(m4, 32, 64));
-        }
         if constexpr ((ABL & 128) == 0) __syncthreads();
     };
 
