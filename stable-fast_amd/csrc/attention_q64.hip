@@ -570,6 +570,10 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
             }
             gap(std::integral_constant<int, P::NQK + g>{});
         });
+        // The register allocator is free to move an O tile between AGPR tuples at a block boundary (seen: 16 v_accvgpr_read at the top
+        // of the second tile body); to it the asm MFMA above is complete. Leave the last PV MFMAs their 12 wait states before anything the
+        // compiler may have placed behind this point.
+        asm volatile("s_nop 9" ::: "memory");
         if constexpr ((ABL & 128) == 0) __syncthreads();
     };
 
