@@ -25,6 +25,7 @@ struct AttnArgs {
     // fabric once and then hit that XCD's L2. With the (q-block, head, batch) grid the query blocks of a head were spread over all
     // eight L2s: 53 MB of fabric traffic per SD1.5 self-attention launch against 16 MB of operands (profiles/r02_pmc_traffic_run8.log).
     int xmap, nqb, ppx;  // ppx = (batch, head) pairs per XCD
+    int o16;             // attention_q64: output rows are 16-byte addressable (staged epilogue)
 };
 
 __device__ __forceinline__ f32x16 amfma32(f16x8 a, f16x8 b, f32x16 c) {

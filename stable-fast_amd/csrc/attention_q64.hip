@@ -169,6 +169,7 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
     constexpr bool ONES_ROW = P::ONES_ROW;
     constexpr float THR = 6.0f;  // log2 units: the reference maximum moves when a row's tile maximum exceeds it 64-fold
     static_assert(D % 8 == 0, "head dim must be a multiple of 8");
+    static_assert(DBX == 2 || DBX == 3, "the slow-path fence lists the O tiles");
     static_assert(P::deadlines_ok(), "filler plan: probabilities / V fragments of a group are issued after the group's first PV MFMA");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -207,10 +208,10 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
         }
     }
 
-    // ---- Q fragments (B operand), pre-multiplied by scale * log2(e): scores arrive in log2 units -------------------------------
+    // ---- Q fragments (B operand): the loads go out first, the scaling happens behind the K / V prefetch of the prologue -----------------
     typedef const u32x4 __attribute__((address_space(1))) * gvec_ptr;
     const float c = a.scale_log2e;
-    vec8 qf[2][KD];
+    u32x4 qraw[2][KD];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int qrow = q0 + 32 * j + l31;
@@ -219,15 +220,10 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
             const int d0 = kd * 16 + hi * 8;
             const bool ok = d0 < D && qrow < a.Sq;
             const gvec_ptr src = ok ? (gvec_ptr)(const void *)(Qp + (int64_t)qrow * a.qs[1] + d0) : (gvec_ptr)(const void *)g_zero16;
-            const u32x4 raw = *src;
-            float f[8];
-            unpack8<T>(raw, f);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) f[i] *= c;
-            qf[j][kd] = __builtin_bit_cast(vec8, pack8<T>(f));
-            asm volatile("" : "+a"(qf[j][kd]));  // lives in the AGPR half from here on (every use is an MFMA operand)
+            qraw[j][kd] = *src;
         }
     }
+    vec8 qf[2][KD];
 
     // ---- staging: same tasks / LDS image as attention.hip ----------------------------------------------------------------------
     u32x4 kreg[KTASK];
@@ -368,6 +364,19 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
         prefetch_v();
         prefetch_k(k1);
         prefetch_k(k2);
+        // Q pre-multiplied by scale * log2(e): scores arrive in log2 units (one rounding to T, as every flash kernel that folds the
+        // scale into Q; the reference's xformers call scales in fp32 after the product)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kd = 0; kd < KD; ++kd) {
+                float f[8];
+                unpack8<T>(qraw[j][kd], f);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[i] *= c;
+                qf[j][kd] = __builtin_bit_cast(vec8, pack8<T>(f));
+                asm volatile("" : "+a"(qf[j][kd]));  // lives in the AGPR half from here on (every use is an MFMA operand)
+            }
 #pragma unroll
         for (int i = 0; i < KTASK; ++i) stage_k_one(0, i, kreg);
 #pragma unroll
@@ -403,6 +412,7 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
             for (int r = 0; r < 16; ++r) negm[j][r] = -m0;
             mloc[j] = 0.f;
         }
+        asm volatile("s_nop 7" : "+v"(negm[0]), "+v"(negm[1]), "+v"(s[0][0][0]), "+v"(s[0][0][1]), "+v"(s[0][1][0]), "+v"(s[0][1][1]));
         prefetch_k(kreg);  // K(3), V(1): staged by iteration 0
         prefetch_v();
         __syncthreads();  // every wave has read K(0) and K(1)
@@ -429,6 +439,7 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
                 mask_tail(s[cur][j], kt);
                 mloc[j] = row_max(s[cur][j]);
             }
+            asm volatile("s_nop 7" : "+v"(s[cur][0][0]), "+v"(s[cur][0][1]), "+v"(s[cur][1][0]), "+v"(s[cur][1][1]));
         }
         // the reference maximum moves only when some row's tile maximum exceeds it by more than THR. Everything still at the old
         // reference -- O (with the denominator inside), the pending tile, -m_ref itself -- moves by the same shift, once. The test
@@ -442,7 +453,10 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
                 for (int db = 0; db < DBX; ++db) pin_a(o[j][db]);
                 pin_v(s[cur][j][0]);
                 pin_v(s[cur][j][1]);
-                const float dlt = fmaxf(fmaxf(mloc[j], __shfl_xor(mloc[j], 32, 64)), 0.f);  // the row's maximum: both half-waves
+                // (the operand is re-defined INSIDE the branch: the cross-half exchange below must not be speculated into the loop header)
+                float mh = mloc[j];
+                asm volatile("" : "+v"(mh));
+                const float dlt = fmaxf(fmaxf(mh, __shfl_xor(mh, 32, 64)), 0.f);  // the row's maximum: both half-waves
                 const float alpha = __builtin_amdgcn_exp2f(-dlt);
 #pragma unroll
                 for (int db = 0; db < DBX; ++db)
@@ -455,7 +469,14 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) negm[j][r] -= dlt;
             }
-            asm volatile("s_nop 3" ::: "memory");  // VALU write -> MFMA C operand
+            // VALU write -> MFMA operand: every tile touched above is an INPUT of this statement (so its last write precedes the wait
+            // states) and an output of it (so no MFMA that reads it can be scheduled earlier)
+            if constexpr (DBX == 2)
+                asm volatile("s_nop 7" : "+v"(negm[0]), "+v"(negm[1]), "+v"(s[cur][0][0]), "+v"(s[cur][0][1]), "+v"(s[cur][1][0]), "+v"(s[cur][1][1]),
+                             "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[1][0]), "+a"(o[1][1]));
+            else
+                asm volatile("s_nop 7" : "+v"(negm[0]), "+v"(negm[1]), "+v"(s[cur][0][0]), "+v"(s[cur][0][1]), "+v"(s[cur][1][0]), "+v"(s[cur][1][1]),
+                             "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][DBX - 1]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[1][DBX - 1]));
         }
 
         auto v_frag = [&](int grp, int db) __attribute__((always_inline)) -> u32x4 {
@@ -584,8 +605,15 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
     }
     if (kt < ntiles) tile(kt, Buf0{});
 
-    // ---- epilogue: normalise and store 4 consecutive d per lane ----------------------------------------------------------------------
+    // ---- epilogue: normalise; whole output rows leave through LDS ------------------------------------------------------------------------
+    // A lane holds 4 consecutive d of ONE row per register group: stored directly, every store instruction touches 32 rows (32-64 cache
+    // lines, 8 bytes each). Each wave instead writes its 64 x D tile into its own LDS region (the K / V stages are idle now; row pitch
+    // D * 2 + 8 bytes: the 32 rows of a ds_write_b64 hit 32 different bank pairs) and streams it out as 16-byte chunks of contiguous rows.
     mfma_drain();
+    constexpr int ROWB = D * 2 + 8, CH = D / 8;
+    static_assert(NW * 64 * ROWB <= G::LDS_TOTAL, "output staging does not fit the K / V stages");
+    char *osm = smem + wave * (64 * ROWB);
+    const bool staged = a.o16 != 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -601,19 +629,32 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
         }
         const float inv = 1.0f / l_tot;
         const int qrow = q0 + 32 * j + l31;
-        if (qrow < a.Sq) {
-            T *Op = (T *)a.out + (int64_t)b * a.os[0] + (int64_t)qrow * a.os[1] + (int64_t)h * a.os[2];
+        T *Op = (T *)a.out + (int64_t)b * a.os[0] + (int64_t)qrow * a.os[1] + (int64_t)h * a.os[2];
 #pragma unroll
-            for (int db = 0; db < DB; ++db) {
+        for (int db = 0; db < DB; ++db) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d = db * 32 + 8 * g + 4 * hi;
-                    if (d < D) {
-                        *reinterpret_cast<u32x2 *>(Op + d) =
-                            pack4<T>(o[j][db][4 * g] * inv, o[j][db][4 * g + 1] * inv, o[j][db][4 * g + 2] * inv, o[j][db][4 * g + 3] * inv);
-                    }
+            for (int g = 0; g < 4; ++g) {
+                const int d = db * 32 + 8 * g + 4 * hi;
+                if (d < D) {
+                    const u32x2 v4 = pack4<T>(o[j][db][4 * g] * inv, o[j][db][4 * g + 1] * inv, o[j][db][4 * g + 2] * inv, o[j][db][4 * g + 3] * inv);
+                    if (staged)
+                        *reinterpret_cast<u32x2 *>(osm + (32 * j + l31) * ROWB + d * 2) = v4;
+                    else if (qrow < a.Sq)
+                        *reinterpret_cast<u32x2 *>(Op + d) = v4;
                 }
             }
+        }
+    }
+    if (staged) {
+        // (only this wave reads this region: its own LDS writes are ordered by the wait the compiler places before the reads)
+        T *Ob = (T *)a.out + (int64_t)b * a.os[0] + (int64_t)h * a.os[2];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int id = lane + 64 * i;
+            const int row = id / CH, cc = id - row * CH;
+            const char *src = osm + row * ROWB + cc * 16;
+            const u32x2 lo = *reinterpret_cast<const u32x2 *>(src), hi2 = *reinterpret_cast<const u32x2 *>(src + 8);
+            if (q0 + row < a.Sq) *reinterpret_cast<u32x4 *>(Ob + (int64_t)(q0 + row) * a.os[1] + cc * 8) = u32x4{lo[0], lo[1], hi2[0], hi2[1]};
         }
     }
 }
@@ -630,6 +671,7 @@ template <typename T, int D, int NW> int q64_set_attr() {
 
 template <typename T, int D> int q64_launch_d(AttnArgs &a, int nw, int xmap_enabled, hipStream_t st) {
     const int rows = nw * 64;
+    a.o16 = (aligned16(a.out) && a.os[0] % 8 == 0 && a.os[1] % 8 == 0 && a.os[2] % 8 == 0) ? 1 : 0;  // 16-byte row chunks storable
     a.nqb = ceil_div(a.Sq, rows);
     a.xmap = (xmap_enabled && (a.B * a.H) % 8 == 0 && (int64_t)a.nqb * a.B * a.H < (1 << 22)) ? 1 : 0;
     a.ppx = a.B * a.H / 8;
@@ -645,6 +687,7 @@ template <typename T, int D> int q64_launch_d(AttnArgs &a, int nw, int xmap_enab
 #define SFAST_Q64_ABLATIONS(OP) OP(1) OP(3) OP(4) OP(7) OP(8) OP(16) OP(24) OP(32) OP(64) OP(96) OP(128) OP(224) OP(256) OP(512) OP(768) OP(255) OP(1023)
 template <int D> int q64_launch_abl(AttnArgs &a, int abl, int xmap_enabled, hipStream_t st) {
     a.nqb = ceil_div(a.Sq, 256);
+    a.o16 = (aligned16(a.out) && a.os[0] % 8 == 0 && a.os[1] % 8 == 0 && a.os[2] % 8 == 0) ? 1 : 0;
     a.xmap = (xmap_enabled && (a.B * a.H) % 8 == 0) ? 1 : 0;
     a.ppx = a.B * a.H / 8;
     const dim3 grid = a.xmap ? dim3((unsigned)(a.nqb * a.B * a.H), 1, 1) : dim3((unsigned)a.nqb, (unsigned)a.H, (unsigned)a.B);

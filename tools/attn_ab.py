@@ -23,6 +23,8 @@ out = []
 VARIANTS = [0]
 if "--variants" in sys.argv:
     VARIANTS = [int(x) for x in sys.argv[sys.argv.index("--variants") + 1].split(",")]
+if "--fixed-cost" in sys.argv:  # same query set, 2 .. 64 key tiles: the intercept is launch + prologue + epilogue, the slope the tile loop
+    SHAPES = [(2, 4096, skv, 8, d) for d in (40, 64) for skv in (128, 512, 2048, 4096)]
 if "--more-shapes" in sys.argv:
     SHAPES += [(16, 4096, 4096, 8, 40), (2, 9216, 9216, 5, 64), (8, 2304, 2304, 10, 64), (2, 1024, 1024, 8, 40), (4, 1024, 1024, 10, 64)]
 for B, Sq, Skv, H, D in SHAPES:

@@ -31,7 +31,8 @@ s2)  # attention_q64: parity + same-process A/B against the 32-row kernel; fixes
 s3)  # where the tile loop of attention_q64 spends its time
   run attn_ablate 600 python tools/attn_ablate.py
   run attn_ab 600 python tools/attn_ab.py --variants 32,64
-  run t_attn 900 $PYT tests/test_ops_gpu.py -k "attention_q64 or reference_maximum"
+  run attn_fixed 600 python tools/attn_ab.py --variants 32,64 --fixed-cost
+  run t_attn 900 $PYT tests/test_ops_gpu.py tests/test_parity_r3_gpu.py -k "attention or peaked"
   ;;
 full)
   run t_all 1500 $PYT tests
