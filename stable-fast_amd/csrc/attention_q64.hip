@@ -95,7 +95,8 @@ template <int D, int NW> struct Q64Plan {
     static constexpr int NPV = 4 * GP;
     static constexpr int NG = NQK + NPV;                  // MFMA gaps per tile
     // filler items, in issue order
-    static constexpr int A_PER_G = DB + 8;                // per 16-key group g: DB V^T fragment reads, then 8 exp2-pair+convert items
+    static constexpr int A_PER_G = DB + 4;                // per 16-key group g: DB V^T fragment reads, then 4 items of 4 exp2 + 2 converts
+                                                          // (four v_exp ahead of the first convert: no wait state behind the transcendental)
     static constexpr int NA = 4 * A_PER_G;
     static constexpr int I_MX = NA;                       // 32 row-max items (v_max3) of tile t+1
     static constexpr int I_MG = I_MX + 32;                // 2 merges of the four partial maxima of a query block (v_max3 + v_max)
@@ -106,7 +107,7 @@ template <int D, int NW> struct Q64Plan {
     static constexpr int I_PV = I_PK + KTASK;             // 2 * VTASK global loads of V(t+2)
     static constexpr int NI = I_PV + 2 * VTASK;
     static constexpr int weight(int i) {
-        if (i < NA) return (i % A_PER_G) < DB ? 2 : 3;   // 2 ds_read_b64 | 2 v_exp + 1 v_cvt
+        if (i < NA) return (i % A_PER_G) < DB ? 2 : 6;   // 2 ds_read_b64 | 4 v_exp + 2 v_cvt
         if (i < I_MG) return 1;
         if (i < I_KR) return 2;
         if (i < I_SV) return 1;
@@ -504,23 +505,32 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_q64_kernel(const AttnArgs a) 
                 if constexpr (w < DB) {
                     if constexpr ((ABL & 8) == 0) vf[g][w] = v_frag(g, w);
                 } else {
-                    constexpr int j = (w - DB) >> 2, jj = (w - DB) & 3, kb = g >> 1, r0 = 8 * (g & 1) + 2 * jj;
-                    const float p0 = (ABL & 1) ? s[cur][j][kb][r0] : __builtin_amdgcn_exp2f(s[cur][j][kb][r0]);
-                    const float p1 = (ABL & 1) ? s[cur][j][kb][r0 + 1] : __builtin_amdgcn_exp2f(s[cur][j][kb][r0 + 1]);
-                    if constexpr ((ABL & 2) != 0) {
-                        pf[j][g][jj] = __builtin_bit_cast(uint32_t, p0) ^ __builtin_bit_cast(uint32_t, p1);
-                    } else if constexpr (std::is_same<T, f16>::value) {
-                        // round toward zero: numerator and denominator see the same rounded values (the ones row / block), the bias cancels
-                        pf[j][g][jj] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(p0, p1));
-                    } else {
-                        typename Elem<T>::vec2 pr;
-                        pr[0] = Elem<T>::from_f32(p0);
-                        pr[1] = Elem<T>::from_f32(p1);
-                        pf[j][g][jj] = __builtin_bit_cast(uint32_t, pr);
+                    constexpr int j = (w - DB) >> 1, kb = g >> 1;
+                    float pr[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int r = 8 * (g & 1) + 4 * ((w - DB) & 1) + u;
+                        pr[u] = (ABL & 1) ? s[cur][j][kb][r] : __builtin_amdgcn_exp2f(s[cur][j][kb][r]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int jj = 2 * ((w - DB) & 1) + u;
+                        if constexpr ((ABL & 2) != 0) {
+                            pf[j][g][jj] = __builtin_bit_cast(uint32_t, pr[2 * u]) ^ __builtin_bit_cast(uint32_t, pr[2 * u + 1]);
+                        } else if constexpr (std::is_same<T, f16>::value) {
+                            // round toward zero: numerator and denominator see the same rounded values (the ones row / block), the bias cancels
+                            pf[j][g][jj] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(pr[2 * u], pr[2 * u + 1]));
+                        } else {
+                            typename Elem<T>::vec2 pq;
+                            pq[0] = Elem<T>::from_f32(pr[2 * u]);
+                            pq[1] = Elem<T>::from_f32(pr[2 * u + 1]);
+                            pf[j][g][jj] = __builtin_bit_cast(uint32_t, pq);
+                        }
                     }
                 }
-            } else if constexpr (i < P::I_KR) {
+            } else if constexpr (i < P::I_MG) {
                 constexpr int m = i - P::I_MX, j = m >> 4, q = m & 15;
+                static_assert(j < 2, "row-max item index");
                 // volatile asm: a plain fmaxf is not ordered against sched_barrier and sinks behind the last MFMA
                 if constexpr ((ABL & 4) != 0) {
                     if constexpr (q < 4) mpart[j][q] = 0.f;
