@@ -680,10 +680,17 @@ extern "C" int sfast_hip_attention_bias(const void *q, const void *k, const void
         a.bspan = (uint32_t)bspan;
     }
     if (vec && p->variant != 100 && p->scale > 0.f && !bias && (p->D == 40 || p->D == 64 || p->D == 80) && p->Skv >= 128) {
-        // second-generation kernel (attention_q64.hip): 64 query rows per wave, one wave per SIMD. A work unit is one wave's 64 rows;
-        // the chip has 1024 SIMDs, so below ~that many units the 32-row kernel (twice the units, half the work each) fills it better.
+        // second-generation kernel (attention_q64.hip): 64 query rows per wave, one wave per SIMD. A work unit is one wave's 64 rows and the
+        // chip runs 1024 of them at a time (one per SIMD), every unit taking the same time T whatever the grid:
+        //   * up to 1024 units the launch takes T; the 32-row kernel does half the work per wave, twice the waves -- it wins below ~half a
+        //     chip of units (measured, profiles/r03_attn_q64_ab_*.log: D=40 at 256 units 15.9 vs 19.6 us, D=64 at 640 units 25.6 vs 21.8 us);
+        //   * beyond 1024 units the launch takes ceil(units / 1024) rounds: a last round that is less than half full costs a whole T
+        //     (SDXL's 10-head 64x64 level: 1280 units = 2 rounds, 137 vs 132 us) unless there are many rounds to spread it over.
         // variant 64 / 62: forced, 4 / 2 waves per workgroup; variant 32 (and 2 / 4): the 32-row kernel.
         const int64_t units = (int64_t)ceil_div(p->Sq, 64) * p->H * p->B;
+        const int64_t tail = units % 1024;
+        const bool fills = units <= 1024 ? units >= (p->D == 80 ? 1024 : 512) : (units >= 3072 || tail == 0 || tail >= 512);
+        int use = (p->variant == 64 || p->variant == 62) ? 1 : (p->variant != 0 ? 0 : (g_attn_q64 >= 0 ? g_attn_q64 : (fills ? 1 : 0)));
         if (p->variant >= 1000 && p->variant < 2024) {  // timing-only ablations of the 64-row kernel (tools/attn_ablate.py)
             set_kernel_name("attn_q64_ablation[%d]", p->variant - 1000);
             const int rc = attention_q64_launch(a, p->dtype, 4 | (g_attn_xmap << 8) | ((p->variant - 1000) << 16), st);
