@@ -697,7 +697,6 @@ extern "C" int sfast_hip_attention_bias(const void *q, const void *k, const void
             if (rc != -1) return rc;
             SFAST_REQUIRE(false, SFAST_ERR_UNSUPPORTED, "attention: no ablation instantiation %d", p->variant - 1000);
         }
-        int use = (p->variant == 64 || p->variant == 62) ? 1 : (p->variant != 0 ? 0 : (g_attn_q64 >= 0 ? g_attn_q64 : (units >= 768 ? 1 : 0)));
         if (use) {
             const int nw = p->variant == 62 ? 2 : (p->variant == 64 ? 4 : (p->Sq % 256 == 0 || p->Sq > 1024 ? 4 : 2));
             set_kernel_name("attn_q64[D=%d,BQ=%d]", p->D, nw * 64);
