@@ -351,6 +351,12 @@ int sfast_hip_cfg_ddim_step(const void *eps_uc, const void *latents, void *laten
                             void *unet_in, const float *coef, float guidance, int64_t numel,
                             int32_t dtype, sfast_stream_t stream);
 
+/* ---- what sfast_hip_conv2d would run for this problem under a forced (variant, split_k) ---------------------
+ * out = {tile rows, tile columns, K-splits, K-tiles per split, variant id}: the measured kernel selection (the reference's cuDNN
+ * benchmark cache, cudnn_convolution_impl.cc:344-370) asks this before timing a candidate -- a variant the problem cannot take
+ * (the LDS-patch pipe needs 3x3 / stride 1 / pad 1 / 64-channel slices / tiles of whole image rows) comes back as another id.   */
+int sfast_hip_conv2d_plan(const sfast_conv_params *p, int32_t variant, int32_t split_k, int32_t out[5]);
+
 /* ---- device-side schedule cursor ---------------------------------------------------------------------------
  * idx = *cursor mod n_steps; ts_out[0:ts_cols] = ts_table[idx][:]; coef_out[0:coef_cols] = coef_table[idx][:]; *cursor = idx + 1
  * (mod n_steps). Recorded as the first node of the step's hipGraph it replaces the per-step host-issued copies of the timestep

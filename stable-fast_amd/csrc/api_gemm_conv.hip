@@ -168,7 +168,29 @@ void fill_small_conv(SmallConvArgs &a, const void *x, const void *x2, const void
     a.alpha = p->alpha;
 }
 
+// planning capabilities of a conv problem (igemm.h igemm_caps): LDS-DMA pipes need 64-channel slices per source and uniform taps per
+// K-tile; the patch pipe (conv_patch.hip) additionally 3x3 / stride 1 / padding 1 / no dilation / no fused upsample
+static int conv_caps(const sfast_conv_params *p) {
+    const int C2 = p->Cin - p->C1;
+    const bool glds_ok = !p->upsample2x && p->C1 % 64 == 0 && C2 % 64 == 0 && p->KH * p->KW <= 32;
+    const bool patch = glds_ok && p->KH == 3 && p->KW == 3 && p->stride_h == 1 && p->stride_w == 1 && p->pad_h == 1 && p->pad_w == 1 &&
+                       p->pad_h_extra == 0 && p->pad_w_extra == 0 && p->dil_h == 1 && p->dil_w == 1;
+    return igemm_caps(glds_ok, patch ? p->H : 0, patch ? p->W : 0);
+}
+
 }  // namespace
+
+// what igemm_run would choose for this conv under a forced (variant, split): out = {BM, BN, splits, K-tiles per split, variant id}
+extern "C" int sfast_hip_conv2d_plan(const sfast_conv_params *p, int32_t variant, int32_t split_k, int32_t out[5]) {
+    if (!p || !out) return SFAST_ERR_INVALID;
+    const ConvGeom g = conv_geom(p, nullptr);
+    const int64_t M = (int64_t)p->B * g.Ho * g.Wo;
+    if (M <= 0 || M > INT32_MAX) return SFAST_ERR_INVALID;
+    int o[5];
+    igemm_plan_query((int)M, p->Cout, p->KH * p->KW * p->Cin, false, variant < 100 ? variant : 0, split_k, conv_caps(p), o);
+    for (int i = 0; i < 5; ++i) out[i] = o[i];
+    return SFAST_OK;
+}
 
 extern "C" int sfast_hip_igemm_plan(int32_t M, int32_t N, int32_t K, int32_t geglu, int32_t variant, int32_t split_k,
                                     int32_t out[5]) {
@@ -352,9 +374,7 @@ extern "C" size_t sfast_hip_conv2d_workspace_bytes(const sfast_conv_params *p) {
     const int64_t M = (int64_t)p->B * g.Ho * g.Wo;
     const int K = p->KH * p->KW * p->Cin;
     if (M <= 0 || M > INT32_MAX || K % 8 != 0) return 0;
-    const int C2 = p->Cin - p->C1;
-    const bool glds_ok = !p->upsample2x && p->C1 % 64 == 0 && C2 % 64 == 0 && p->KH * p->KW <= 32;
-    return igemm_workspace_bytes((int)M, p->Cout, K, false, p->variant < 100 ? p->variant : 0, p->split_k, glds_ok);
+    return igemm_workspace_bytes((int)M, p->Cout, K, false, p->variant < 100 ? p->variant : 0, p->split_k, conv_caps(p));
 }
 
 extern "C" int sfast_hip_conv2d(const void *x, const void *x2, const void *w, const void *bias, const void *rowbias,
@@ -372,9 +392,8 @@ extern "C" int sfast_hip_conv2d_stats_layout(const sfast_conv_params *p, const s
     // the conditions of conv_route()'s MFMA branch that do not depend on pointers (dense NHWC activations, K-contiguous weights)
     const bool igemm = is_half(p->dtype) && p->Cout >= 16 && p->Cout % 8 == 0 && M > 0 && M <= INT32_MAX && K % 8 == 0 && p->C1 % 8 == 0 &&
                        C2 % 8 == 0 && g.x_dense && g.x2_dense && g.w_kcontig && g.out_dense && g.ldo % 8 == 0 && p->variant < 100;
-    const bool glds_ok = !p->upsample2x && p->C1 % 64 == 0 && C2 % 64 == 0 && p->KH * p->KW <= 32;
     StatsLayout l{};
-    if (!igemm || !igemm_stats_layout((int)M, p->Cout, K, false, p->variant, p->split_k, glds_ok, ext->gn_unit, ext->gn_rows_per_sample, l)) {
+    if (!igemm || !igemm_stats_layout((int)M, p->Cout, K, false, p->variant, p->split_k, conv_caps(p), ext->gn_unit, ext->gn_rows_per_sample, l)) {
         set_error("conv2d_stats_layout: this problem / kernel choice cannot emit GroupNorm statistics");
         return SFAST_ERR_UNSUPPORTED;
     }

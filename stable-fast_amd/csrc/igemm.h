@@ -42,6 +42,15 @@ static inline dim3 igemm_grid(const IgemmArgs &a) {
 // statistics slots a tile of `bno` output columns can overlap: units are `unit` channels wide, tile origins multiples of bno
 static inline int stats_slots(int bno, int unit) { return (bno - 1) / unit + 2; }
 
+// `caps` of a problem (the `glds_ok` argument of the planning functions below, an int): bit 0 = the LDS-DMA pipes may be chosen;
+// for convs the patch pipe (conv_patch.hip) may be chosen can: 3x3, stride 1, padding 1, dense NHWC, C1 / C2 multiples of 64 -- then
+// bits 8..19 = image width W, bits 20..31 = image height H (the tile has to cover whole image rows).
+static inline int igemm_caps(bool glds_ok, int patch_h, int patch_w) {
+    return (glds_ok ? 1 : 0) | ((patch_h > 0 && patch_w > 0 && patch_h < 4096 && patch_w < 4096) ? ((patch_w << 8) | (patch_h << 20)) : 0);
+}
+bool conv_patch_fits(int H, int W, int M, int BM, int BN);                                 // conv_patch.hip
+int conv_patch_launch(const IgemmArgs &a, int dtype, int BM, int BN, hipStream_t st);       // conv_patch.hip
+
 // mode: 0 = linear (x row m at x + m*ldx), 1 = conv (implicit im2col over dense NHWC x / x2).
 // Fills the plan fields of `a` (tiles, split) and launches on `st`.
 int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int split, void *ws, size_t ws_bytes,
@@ -51,11 +60,11 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
 struct StatsLayout {
     int rb_rows, bno, slots, tiles_n, n_rb;
 };
-bool igemm_stats_layout(int M, int N, int K, bool geglu, int variant, int split, bool glds_ok, int unit, int rows_per_sample,
+bool igemm_stats_layout(int M, int N, int K, bool geglu, int variant, int split, int glds_ok, int unit, int rows_per_sample,
                         StatsLayout &out);
 // glds_ok: whether the LDS-DMA pipe may be chosen for this problem (see igemm_glds_eligible)
-void igemm_plan_query(int M, int N, int K, bool geglu, int variant, int split, bool glds_ok, int out[5]);
-size_t igemm_workspace_bytes(int M, int N, int K, bool geglu, int variant, int split, bool glds_ok);
+void igemm_plan_query(int M, int N, int K, bool geglu, int variant, int split, int glds_ok, int out[5]);
+size_t igemm_workspace_bytes(int M, int N, int K, bool geglu, int variant, int split, int glds_ok);
 bool igemm_glds_eligible(const IgemmArgs &a, int mode);
 // weight-only int8 linear (sfast::cutlass_qlinear_dynamic): register-staged pipe, no split-K
 int igemm_run_w8(IgemmArgs &a, int dtype, hipStream_t st);

@@ -533,6 +533,8 @@ static const Variant kVariants[] = {
     {21, 128, 128, 2, 2, 2, 4, 1.00f}, {22, 128, 160, 4, 1, 2, 4, 1.00f}, {23, 64, 64, 2, 2, 2, 4, 0.60f},
     {24, 128, 64, 2, 2, 2, 3, 0.80f},  {25, 64, 128, 2, 2, 2, 3, 0.80f},  // autotuner candidates (ids >= 16 are skipped by the analytic planner)
     {26, 64, 64, 2, 2, 2, 3, 0.60f},   // 48 KB ring: three workgroups per CU
+    // pipe 3: LDS-resident input patch for 3x3 / stride 1 / pad 1 convs (conv_patch.hip); autotuner candidates
+    {31, 128, 160, 4, 1, 3, 3, 1.00f}, {32, 128, 128, 2, 2, 3, 3, 1.00f}, {34, 128, 64, 2, 2, 3, 4, 0.80f},
 };
 static const Variant kGegluVariants[] = {
     {1, 128, 128, 2, 2, 0, 2, 1.00f},  {3, 64, 128, 2, 2, 0, 2, 0.75f},  {11, 128, 128, 2, 2, 1, 4, 1.00f},
@@ -654,7 +656,9 @@ static int staged_variant(int id) {
     }
 }
 
-static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, int force_split, bool glds_ok) {
+static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, int force_split, int caps) {
+    const bool glds_ok = (caps & 1) != 0;
+    const int patch_w = (caps >> 8) & 0xfff, patch_h = (caps >> 20) & 0xfff;
     const Variant *vs = geglu ? kGegluVariants : kVariants;
     const int nv = geglu ? (int)(sizeof(kGegluVariants) / sizeof(Variant)) : (int)(sizeof(kVariants) / sizeof(Variant));
     const int ktiles = ceil_div(K, 64);
@@ -672,6 +676,7 @@ static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, 
             if (v.pipe == 0 && glds_ok && g_pipe_pref == 1) continue;
         }
         if (v.pipe >= 1 && !glds_ok) continue;
+        if (v.pipe == 3 && !(patch_w > 0 && K % 576 == 0 && conv_patch_fits(patch_h, patch_w, M, v.BM, v.BN))) continue;
         const int bno = geglu ? v.BN / 2 : v.BN;
         const int tm = ceil_div(M, v.BM), tn = ceil_div(N, bno);
         const int tiles = tm * tn;
@@ -687,7 +692,8 @@ static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, 
             int s = force_split ? force_split : kSplitCand[ci];
             if (s > ktiles) s = ktiles;
             if (s < 1) s = 1;
-            const int ktps = ceil_div(ktiles, s);
+            int ktps = ceil_div(ktiles, s);
+            if (v.pipe == 3) ktps = 9 * ceil_div(ktiles / 9, s);  // the patch pipe cuts K between 64-channel slices (9 taps each)
             const int splits = ceil_div(ktiles, ktps);
             if (splits == last_splits) continue;
             last_splits = splits;
@@ -732,7 +738,7 @@ static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, 
     return best;
 }
 
-bool igemm_stats_layout(int M, int N, int K, bool geglu, int variant, int split, bool glds_ok, int unit, int rows_per_sample,
+bool igemm_stats_layout(int M, int N, int K, bool geglu, int variant, int split, int glds_ok, int unit, int rows_per_sample,
                         StatsLayout &out) {
     if (geglu || unit < 8 || rows_per_sample <= 0 || M % rows_per_sample != 0 || N % 8 != 0) return false;
     IgemmPlan p = igemm_plan(M, N, K, geglu, variant, split, glds_ok);
@@ -757,7 +763,7 @@ bool igemm_stats_layout(int M, int N, int K, bool geglu, int variant, int split,
     return true;
 }
 
-void igemm_plan_query(int M, int N, int K, bool geglu, int variant, int split, bool glds_ok, int out[5]) {
+void igemm_plan_query(int M, int N, int K, bool geglu, int variant, int split, int glds_ok, int out[5]) {
     IgemmPlan p = igemm_plan(M, N, K, geglu, variant, split, glds_ok);
     out[0] = p.v.BM;
     out[1] = p.v.BN;
@@ -766,7 +772,7 @@ void igemm_plan_query(int M, int N, int K, bool geglu, int variant, int split, b
     out[4] = p.v.id;
 }
 
-size_t igemm_workspace_bytes(int M, int N, int K, bool geglu, int variant, int split, bool glds_ok) {
+size_t igemm_workspace_bytes(int M, int N, int K, bool geglu, int variant, int split, int glds_ok) {
     IgemmPlan p = igemm_plan(M, N, K, geglu, variant, split, glds_ok);
     if (p.splits <= 1) return 0;
     return (size_t)p.splits * M * (geglu ? 2 * (size_t)N : (size_t)N) * sizeof(float);
@@ -904,7 +910,10 @@ static void choose_xcd_map(IgemmArgs &a, int mode, bool geglu) {
 // entry used by api_gemm_conv.hip. mode: 0 linear, 1 conv. Fills plan fields of `a`.
 int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int split, void *ws, size_t ws_bytes,
               hipStream_t st) {
-    const bool glds_ok = igemm_glds_eligible(a, mode);
+    const bool glds_elig = igemm_glds_eligible(a, mode);
+    const bool patch_elig = mode == 1 && glds_elig && a.KH == 3 && a.KW == 3 && a.stride_h == 1 && a.stride_w == 1 && a.pad_h == 1 && a.pad_w == 1 &&
+                            a.dil_h == 1 && a.dil_w == 1 && !a.ups && a.Ho == a.H && a.Wo == a.W;
+    const int glds_ok = igemm_caps(glds_elig, patch_elig ? a.H : 0, patch_elig ? a.W : 0);
     IgemmPlan p = igemm_plan(a.M, a.N, a.K, geglu, variant, split, glds_ok);
     const bool want_staged = !geglu && (a.gn_stats != nullptr || g_stage_pref > 0);
     if (want_staged && p.v.pipe == 1 && p.splits == 1) p = igemm_plan(a.M, a.N, a.K, geglu, staged_variant(p.v.id), p.splits, glds_ok);
@@ -941,13 +950,15 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
         a.partial = (float *)ws;
     }
     char pipe[8];
-    snprintf(pipe, sizeof(pipe), p.v.pipe == 2 ? "ws%d" : p.v.pipe ? "dma%d" : "reg", p.v.ns);
+    snprintf(pipe, sizeof(pipe), p.v.pipe == 3 ? "patch%d" : p.v.pipe == 2 ? "ws%d" : p.v.pipe ? "dma%d" : "reg", p.v.ns);
     char xmap[24] = "";
     if (a.xmap) snprintf(xmap, sizeof(xmap), "@xcd%dx%dx%d", 8 >> (a.x_lxm + a.x_lxn), 1 << a.x_lxm, 1 << a.x_lxn);  // K-split x row x column boxes
     set_kernel_name("igemm_%s_%s%s[%dx%d,split=%d,%s]%s%s", mode ? "conv" : "lin", dtype == SFAST_F16 ? "f16" : "bf16",
                     geglu ? "_geglu" : "", p.v.BM, p.v.BN, p.splits, pipe, a.gn_stats ? "+gnstats" : (a.stage_out ? "+staged" : ""), xmap);
     int rc;
-    if (p.v.pipe == 2)
+    if (p.v.pipe == 3)
+        rc = conv_patch_launch(a, dtype, p.v.BM, p.v.BN, st);
+    else if (p.v.pipe == 2)
         rc = igemm_glds_ws_launch(a, dtype, mode, geglu, p.v.BM, p.v.BN, p.v.ns, st);
     else if (p.v.pipe == 1)
         rc = igemm_glds_launch(a, dtype, mode, geglu, p.v.BM, p.v.BN, p.v.ns, st);

@@ -22,9 +22,10 @@ _cache = {}
 _cache_lock = threading.Lock()
 _loaded_files = set()
 
-SPLITS = (1, 2, 3, 4, 6, 8, 12, 16, 24)
+SPLITS = (1, 2, 3, 4, 5, 6, 8, 10, 12, 15, 16, 20, 24)
 VARIANTS = (1, 2, 3, 5, 11, 12, 13, 15, 16, 17, 18, 21, 22, 23, 24, 25, 26)
 GEGLU_VARIANTS = (1, 3, 11, 13, 16, 18, 21, 23)
+CONV_PATCH_VARIANTS = (31, 32, 34)   # conv_patch.hip: 3x3 / stride 1 / pad 1 convs only (sfast_hip_conv2d_plan says whether a problem fits)
 MAX_SLAB_BYTES = 192 << 20
 
 
@@ -149,13 +150,18 @@ def tune_plan(plan, device, dtype_tag="f16", verbose=False):
         ktiles = (K + 63) // 64
         wrows = 2 * N if geglu else N
         best = None
-        for v in (GEGLU_VARIANTS if geglu else VARIANTS):
+        is_conv = not isinstance(p, L.GemmParams)
+        cands = GEGLU_VARIANTS if geglu else (VARIANTS + CONV_PATCH_VARIANTS if is_conv else VARIANTS)
+        for v in cands:
             for s in SPLITS:
                 if s > 1 and ktiles // s < 2:
                     continue
                 if s > 1 and s * M * wrows * 4 > MAX_SLAB_BYTES:
                     continue
-                lib.sfast_hip_igemm_plan(M, N, K, int(geglu), v, s, C.byref(o))
+                if is_conv:
+                    lib.sfast_hip_conv2d_plan(C.byref(p), v, s, o)
+                else:
+                    lib.sfast_hip_igemm_plan(M, N, K, int(geglu), v, s, C.byref(o))
                 bm, bn, splits, _, vid = list(o)
                 if splits != s or vid != v:
                     continue
@@ -167,7 +173,7 @@ def tune_plan(plan, device, dtype_tag="f16", verbose=False):
                 if launch_with(sp, ws.data_ptr(), ws.numel()) != 0:
                     continue
                 k = L.last_kernel()
-                if ("ws" if v >= 20 else "dma" if v >= 10 else "reg") not in k.split(",")[-1]:
+                if ("patch" if v >= 30 else "ws" if v >= 20 else "dma" if v >= 10 else "reg") not in k.split(",")[-1]:
                     continue  # pipe not applicable to this problem: the library substituted another
                 t = _time(lambda: launch_with(sp, ws.data_ptr(), ws.numel()), stream)
                 if best is None or t < best[0]:

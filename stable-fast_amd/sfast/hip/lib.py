@@ -31,7 +31,7 @@ EXPORTS = [
     "sfast_hip_group_norm_apply",
     "sfast_hip_attention", "sfast_hip_attention_bias", "sfast_hip_strided_copy", "sfast_hip_timestep_embedding",
     "sfast_hip_gemv_grouped", "sfast_hip_gemm_grouped", "sfast_hip_qlinear_w8", "sfast_hip_cfg_ddim_step", "sfast_hip_linear_step", "sfast_hip_mix_rows", "sfast_hip_igemm_plan", "sfast_hip_set_trace", "sfast_hip_image_postprocess", "sfast_hip_add_strided",
-    "sfast_hip_schedule_advance",
+    "sfast_hip_schedule_advance", "sfast_hip_conv2d_plan",
 ]
 
 
@@ -190,6 +190,8 @@ def _declare(lib):
     lib.sfast_hip_mix_rows.argtypes = [vp, vp, vp, vp, vp, C.POINTER(MixParams), vp]
     lib.sfast_hip_linear_step.restype = C.c_int
     lib.sfast_hip_linear_step.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int64, C.c_int64, C.c_int32, vp]
+    lib.sfast_hip_conv2d_plan.restype = C.c_int
+    lib.sfast_hip_conv2d_plan.argtypes = [C.POINTER(ConvParams), C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     lib.sfast_hip_schedule_advance.restype = C.c_int
     lib.sfast_hip_schedule_advance.argtypes = [vp, vp, C.c_int32, vp, vp, C.c_int32, vp, C.c_int32, vp]
     lib.sfast_hip_cfg_ddim_step.restype = C.c_int

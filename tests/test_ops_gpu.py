@@ -350,6 +350,75 @@ def test_conv_igemm(case, variant):
     compare(f"conv {name} v{variant}", y, want, *tol(x.dtype, 2.0), kernel=last_kernel())
 
 
+PATCH_CASES = [
+    # name, B, Cin, H, W, Cout, extras: every image size of the UNet levels (a 128-pixel tile = 2 rows at 64 wide ... two whole images at
+    # 8x8), odd batch, two-source concat (slices of both sources), non-square images, Cout that leaves a ragged last column tile
+    ("320@64", 2, 320, 64, 64, 320, dict(rowbias=True)),
+    ("320@64 +z", 1, 320, 64, 64, 320, dict(z=True)),
+    ("640@32", 2, 640, 32, 32, 640, dict(z=True)),
+    ("1280@16", 2, 1280, 16, 16, 1280, dict(rowbias=True)),
+    ("1280@8 two images per tile", 2, 1280, 8, 8, 1280, dict(z=True)),
+    ("1280@8 B=4", 4, 1280, 8, 8, 640, {}),
+    ("cat 640+320@64", 1, 640, 64, 64, 320, dict(c2=320)),
+    ("cat 1280+1280@16", 2, 1280, 16, 16, 1280, dict(c2=1280, z=True)),
+    ("64@32x16", 3, 64, 32, 16, 96, dict(z=True)),
+    ("128@16x32", 2, 128, 16, 32, 200, {}),
+]
+
+
+@pytest.mark.parametrize("case", PATCH_CASES, ids=[c[0] for c in PATCH_CASES])
+@pytest.mark.parametrize("variant,split", [(31, 1), (32, 1), (34, 1), (31, 2), (32, 5), (34, 4), (31, 20)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_conv_patch_pipe(case, variant, split, dtype):
+    """conv_patch.hip (pipe 3): the input patch of a 64-channel slice stays in LDS for all nine taps. Same results as the implicit-
+    im2col pipes (and the oracle) for every tile / split / image geometry; a problem the pipe cannot take is planned on another one."""
+    name, B, Cin, H, W, Cout, ex = case
+    x = cl(rnd(B, Cin, H, W, seed=80, dtype=dtype))
+    c2 = ex.get("c2", 0)
+    x2 = cl(rnd(B, c2, H, W, seed=81, dtype=dtype)) if c2 else None
+    w = cl(rnd(Cout, Cin + c2, 3, 3, seed=82, scale=((Cin + c2) * 9) ** -0.5, dtype=dtype))
+    b = rnd(Cout, seed=83, scale=0.1, dtype=dtype)
+    z = cl(rnd(B, Cout, H, W, seed=84, dtype=dtype)) if ex.get("z") else None
+    rb = rnd(B, Cout, seed=85, dtype=dtype) if ex.get("rowbias") else None
+    nslices = (Cin + c2) // 64
+    y = F().conv2d(x, w, b, z=z, padding=1, x2=x2, rowbias=rb, variant=variant, split_k=split)
+    k = last_kernel()
+    assert "igemm_conv" in k
+    bm = 128
+    fits = (B * H * W) % bm == 0 and bm % W == 0 and ((H * W) % bm == 0 or bm % (H * W) == 0)
+    if fits:
+        assert "patch" in k, k
+        if split <= nslices:
+            assert f"split={-(-nslices // -(-nslices // split))}" in k, k   # K is cut between 64-channel slices
+    else:
+        assert "patch" not in k, k
+    want = R.conv2d_ref(x, w, b, z, 1.0, 1, 1, x2=x2, rowbias=rb)
+    compare(f"conv patch {name} v{variant} s{split} {dtype}", y, want, *tol(dtype, 2.0), kernel=k)
+
+
+@pytest.mark.parametrize("variant,split", [(31, 1), (32, 1), (34, 1), (31, 5), (32, 2)])
+@pytest.mark.parametrize("cin,cout,hw,unit", [(320, 320, 32, 10), (640, 1280, 16, 20)])
+def test_conv_patch_pipe_emits_groupnorm_statistics(variant, split, cin, cout, hw, unit):
+    import numpy as np
+    x = rnd(2, cin, hw, hw, seed=200, shift=0.5).contiguous(memory_format=torch.channels_last)
+    w = rnd(cout, cin, 3, 3, seed=201, scale=(9 * cin) ** -0.5).contiguous(memory_format=torch.channels_last)
+    b = rnd(cout, seed=202, shift=2.0)
+    z = rnd(2, cout, hw, hw, seed=203).contiguous(memory_format=torch.channels_last)
+    y, stats, lay = F().conv2d(x, w, b, z=z, padding=1, variant=variant, split_k=split, gn_unit=unit)
+    k = last_kernel()
+    assert "patch" in k and "+gnstats" in k, k
+    plain = F().conv2d(x, w, b, z=z, padding=1, variant=variant, split_k=split)
+    assert torch.equal(y, plain), k
+    want = _stats_reference(y.permute(0, 2, 3, 1).reshape(-1, cout), lay)
+    got = stats.double().cpu().numpy().reshape(want.shape)
+    used = ~np.isnan(want)
+    assert np.allclose(got[..., 0][used[..., 0]], want[..., 0][used[..., 0]], rtol=1e-4, atol=1e-4), k
+    assert np.allclose(got[..., 1][used[..., 1]], want[..., 1][used[..., 1]], rtol=2e-3, atol=1e-2), k
+    gam, bet = rnd(cout, seed=204, shift=1.0, scale=0.2), rnd(cout, seed=205, scale=0.2)
+    yn = F().group_norm_apply(y, 32, gam, bet, 1e-5, "silu", stats, lay)
+    compare(f"gn_apply conv patch {cin}->{cout}@{hw} v{variant} s{split}", yn, R.group_norm_ref(y, 32, gam, bet, 1e-5, True), *tol(y.dtype, 2.0), kernel=k)
+
+
 @pytest.mark.parametrize("split", [2, 4, 12])
 def test_conv_split_k(split):
     x, w, b = cl(rnd(2, 1280, 8, 8, seed=76)), cl(rnd(1280, 1280, 3, 3, seed=77, scale=11520 ** -0.5)), rnd(1280, seed=78)

@@ -34,6 +34,10 @@ s3)  # where the tile loop of attention_q64 spends its time
   run attn_fixed 600 python tools/attn_ab.py --variants 32,64 --fixed-cost
   run t_attn 900 $PYT tests/test_ops_gpu.py tests/test_parity_r3_gpu.py -k "attention or peaked"
   ;;
+s4)  # conv_patch.hip: parity + A/B against the implicit-im2col pipes
+  run t_patch 900 $PYT tests/test_ops_gpu.py -k "conv_patch" --durations=3
+  run conv_ab 900 python tools/conv_ab.py
+  ;;
 full)
   run t_all 1500 $PYT tests
   run smoke 600 python __graft_entry__.py smoke
