@@ -14,14 +14,13 @@
 //
 //   K order of a workgroup: channel slice major, tap minor (unit u = slice * 9 + tap; weights stay [Cout][kh][kw][Cin], so unit u reads
 //   weight columns tap * Cin + slice * 64 ...). Split-K cuts between slices.
-//   LDS: two patch buffers (slice s is computed while slice s + 1 lands) + an NSW-deep ring of weight tiles (BN rows x 128 B) + a
-//   1 KiB sink per producer wave. Patch rows are 128 B per pixel, XOR-swizzled by the pixel index exactly like the tile rows of the
-//   other pipes; image borders (and the two padding rows between images when a tile spans images) are patch pixels loaded from the
-//   device zero block, so the consumers never test a border.
-//   Waves: PW producer waves issue LDS-DMA only (per unit: the weight tile of unit u + NSW - 1 and a share of the next slice's
-//   patch; always the same number of requests, unused ones go to the sink, so one counted vmcnt serves every unit); WM x WN consumer
-//   waves read fragments and issue MFMAs; one barrier per unit -- the structure of igemm_glds_ws.hip. Same fragment layout, same
-//   epilogue (igemm_device.h: bias / row bias / residual / activation, staged stores, GroupNorm statistics, split-K slabs).
+//   LDS: two patch buffers (slice s is computed while slice s + 1 lands) + a ring of weight tiles (BN rows x 128 B), as deep as the
+//   rest of the 160 KiB allows (3 .. 5 stages). Patch rows are 128 B per pixel, XOR-swizzled by the pixel index exactly like the tile
+//   rows of the other pipes; image borders (and the two padding rows between images when a tile spans images) are patch pixels loaded
+//   from the device zero block, so the consumers never test a border.
+//   Waves: two weight-producer and two patch-producer waves issue LDS-DMA only; WM x WN consumer waves read fragments and issue MFMAs;
+//   one barrier per unit -- the structure of igemm_glds_ws.hip. Same fragment layout, same epilogue (igemm_device.h: bias / row bias /
+//   residual / activation, staged stores, GroupNorm statistics, split-K slabs).
 #include "igemm_device.h"
 
 namespace sfast {
@@ -40,26 +39,30 @@ template <int N> __device__ __forceinline__ void cp_wait_vmcnt() { asm volatile(
 typedef const u32x4 __attribute__((address_space(1))) * cp_src_t;
 typedef __attribute__((address_space(3))) void *cp_dst_t;
 
-constexpr int CP_MAXPI = 16;   // patch LDS-DMA instructions per producer wave and slice (<= 64 per workgroup: patches up to 512 pixels)
+constexpr int CP_MAXPI = 32;   // patch LDS-DMA instructions per patch-producer wave and slice (two such waves: patches up to 512 pixels)
 constexpr int CP_SPREAD = 7;   // the next slice's patch is requested during taps 0 .. 6 of the current one
 
-template <typename T, int BM, int BN, int WM, int WN, int PW, int NSW, bool STAGED>
-__global__ void __launch_bounds__((WM * WN + PW) * 64, (WM * WN + PW) / 4) conv_patch_kernel(const IgemmArgs a, const PatchGeom g) {
+// PWW weight-producer waves + PWP patch-producer waves. They are separate waves on purpose: a weight producer issues the SAME number of
+// requests for every unit, so one counted vmcnt tells it that unit u's tile has landed; the patch producers have requests in taps
+// 0 .. 6 only and simply drain (vmcnt(0)) at a slice change, two or more units after their last request. (The first version let every
+// producer wave carry both kinds and padded the patch share of every unit with requests into a sink to keep the count constant:
+// 72 requests per slice and wave against the 81 of the implicit-im2col kernel, a ring one stage shallower -- and 0.73-0.82x its speed,
+// profiles/r03_conv_patch_ab_run4.log. A CU retires one 1-KiB LDS-DMA request per ~28 cycles: requests are the currency.)
+template <typename T, int BM, int BN, int WM, int WN, int PWW, int PWP, int NSW, bool STAGED>
+__global__ void __launch_bounds__((WM * WN + PWW + PWP) * 64, (WM * WN + PWW + PWP) / 4) conv_patch_kernel(const IgemmArgs a, const PatchGeom g) {
     using vec8 = typename Elem<T>::vec8;
-    constexpr int NC = WM * WN * 64, NP = PW * 64;
+    constexpr int NC = WM * WN * 64, NPW = PWW * 64;
     constexpr int FM = BM / (WM * 32), FN = BN / (WN * 32);
-    constexpr int WCH = BN * 8 / NP;   // weight chunks per producer thread and unit
-    constexpr int RPP = NP / 8;
+    constexpr int WCH = BN * 8 / NPW;  // weight chunks per weight-producer thread and unit
+    constexpr int RPP = NPW / 8;
     constexpr int WNB = FN * 32;
-    constexpr int PPT = (CP_MAXPI + CP_SPREAD - 1) / CP_SPREAD;  // patch requests per producer wave and unit (3)
-    constexpr int L = WCH + PPT;       // LDS-DMA requests per producer thread and unit: constant
-    static_assert((BN * 8) % NP == 0 && RPP % 16 == 0, "weight staging mismatch");
-    static_assert(NSW >= 3 && NSW <= 4 && L * (NSW - 2) <= 63, "ring depth / vmcnt field");
+    constexpr int PPT = (CP_MAXPI + CP_SPREAD - 1) / CP_SPREAD;  // patch requests per patch-producer wave and unit
+    static_assert((BN * 8) % NPW == 0 && RPP % 16 == 0, "weight staging mismatch");
+    static_assert(NSW >= 3 && NSW <= 5 && WCH * (NSW - 2) <= 63, "ring depth / vmcnt field");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *const pbuf0 = smem;
     char *const wring = smem + 2 * g.patch_bytes;
-    char *const sink = wring + NSW * (BN * 128);
 
     touch_args(a);
     touch_conv_args(a);
@@ -74,19 +77,18 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, (WM * WN + PW) / 4) conv_
     const int gy0 = fdiv22(m0, a.W, g.r_W);             // global output row of the tile's first pixel (tiles are whole rows)
     const int b0 = fdiv22(gy0, a.H, g.r_H);
     const int pg_first = b0 * g.H2 + (gy0 - b0 * a.H);  // = padded row of the first output row, minus 1
+    const cp_src_t zero_src = (cp_src_t)(const void *)g_zero16;
 
-    if (wave >= WM * WN) {
-        // =============================== producer wave ===============================================
-        const int ptid = tid - NC;
-        const int pwave = wave - WM * WN;
-        const cp_src_t zero_src = (cp_src_t)(const void *)g_zero16;
+    if (wave >= WM * WN + PWW) {
+        // =============================== patch-producer wave ==========================================
+        const int pwave = wave - (WM * WN + PWW);
         const int nbatch = a.M / (a.H * a.W);
-        // this lane's share of the patch: instruction ii = pwave + PW * j covers patch pixels ii * 8 .. + 7, lane -> (pixel, 16-byte slot);
-        // packed: source pixel index * 8 + channel chunk, or -1 for a border / padding / unused pixel
+        // this lane's share of the patch: instruction ii = pwave + PWP * j covers patch pixels ii * 8 .. + 7, lane -> (pixel, 16-byte slot);
+        // packed: source pixel index * 8 + channel chunk, or -1 for a border / padding pixel
         int ppix[CP_MAXPI];
 #pragma unroll
         for (int j = 0; j < CP_MAXPI; ++j) {
-            const int ii = pwave + PW * j;
+            const int ii = pwave + PWP * j;
             const int pp = ii * 8 + (lane >> 3);
             const int chunk = (lane & 7) ^ ((pp >> 1) & 7);  // source-side swizzle: LDS-DMA writes lane-linearly
             const int prow = fdiv22(pp, g.W2, g.r_W2);
@@ -94,10 +96,49 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, (WM * WN + PW) / 4) conv_
             const int pgr = pg_first + prow;
             const int b = fdiv22(pgr, g.H2, g.r_H2);
             const int yy = pgr - b * g.H2 - 1, xx = pcol - 1;
-            const bool ok = ii < g.npi && pp < g.pp && b < nbatch && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+            const bool ok = pp < g.pp && b < nbatch && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
             ppix[j] = ok ? (((b * a.H + yy) * a.W + xx) << 3) + chunk : -1;
         }
-        // weight rows of this thread (as in igemm_glds_ws.hip)
+        // request of patch instruction j for channel slice `cs` into patch buffer cs & 1 (nothing for instructions past the patch)
+        auto issue_patch = [&](int j, int cs) __attribute__((always_inline)) {
+            const int ii = pwave + PWP * j;
+            if (ii >= g.npi) return;  // wave-uniform
+            const int c0 = cs * 64;
+            const bool first = c0 < a.C1;
+            const T *src = first ? (const T *)a.x : (const T *)a.x2;
+            const int pitch = first ? a.C1 : a.C2, cc = first ? c0 : c0 - a.C1;
+            const int v = ppix[j];
+            const cp_src_t s = (v >= 0) ? (cp_src_t)(const void *)(src + (int64_t)(v >> 3) * pitch + cc + (v & 7) * 8) : zero_src;
+            __builtin_amdgcn_global_load_lds(s, (cp_dst_t)(pbuf0 + (cs & 1) * g.patch_bytes + ii * 1024), 16, 0, 0);
+        };
+        int cs = fdiv22(u_begin, 9, 0.11111111938953400f), tap = u_begin - cs * 9;
+#pragma unroll
+        for (int j = 0; j < CP_MAXPI; ++j) issue_patch(j, cs);
+        cp_wait_vmcnt<0>();  // the first patch
+        for (int u = u_begin; u < u_end; ++u) {
+            if (tap == 0 && u != u_begin) cp_wait_vmcnt<0>();  // slice change: this slice's patch, requested during taps 0 .. 6 of the last one
+            __builtin_amdgcn_s_barrier();
+            const bool more = (cs + 1) * 9 < u_end;
+#pragma unroll
+            for (int t = 0; t < CP_SPREAD; ++t) {   // (static indices into ppix: one uniform branch per tap)
+                if (tap == t && more) {
+#pragma unroll
+                    for (int j = 0; j < PPT; ++j)
+                        if (t * PPT + j < CP_MAXPI) issue_patch(t * PPT + j, cs + 1);
+                }
+            }
+            if (++tap == 9) {
+                tap = 0;
+                ++cs;
+            }
+        }
+        cp_wait_vmcnt<0>();
+        return;
+    }
+    if (wave >= WM * WN) {
+        // =============================== weight-producer wave =========================================
+        const int ptid = tid - NC;
+        const int pwave = wave - WM * WN;
         const int rbase = ptid >> 3;
         const int kc = (ptid & 7) ^ ((rbase >> 1) & 7);
         const T *wrow[WCH];
@@ -106,19 +147,6 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, (WM * WN + PW) / 4) conv_
             const int n = n0 + rbase + i * RPP;
             wrow[i] = (n < a.N) ? (const T *)a.w[0] + (int64_t)n * a.ldw + kc * 8 : nullptr;
         }
-        // requests of patch instruction j for channel slice `cs` into patch buffer cs & 1
-        auto issue_patch = [&](int j, int cs) __attribute__((always_inline)) {
-            const int c0 = cs * 64;
-            const bool first = c0 < a.C1;
-            const T *src = first ? (const T *)a.x : (const T *)a.x2;
-            const int pitch = first ? a.C1 : a.C2, cc = first ? c0 : c0 - a.C1;
-            const int ii = pwave + PW * j;
-            const bool live = ii < g.npi;
-            const int v = ppix[j];
-            const cp_src_t s = (v >= 0) ? (cp_src_t)(const void *)(src + (int64_t)(v >> 3) * pitch + cc + (v & 7) * 8) : zero_src;
-            char *dst = live ? pbuf0 + (cs & 1) * g.patch_bytes + ii * 1024 : sink + pwave * 1024;
-            __builtin_amdgcn_global_load_lds(s, (cp_dst_t)dst, 16, 0, 0);
-        };
         int wstage = 0;
         auto issue_weights = [&](int u) __attribute__((always_inline)) {
             const bool ok_u = u < u_end;
@@ -133,52 +161,12 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, (WM * WN + PW) / 4) conv_
             }
             wstage = (wstage + 1 == NSW) ? 0 : wstage + 1;
         };
-        auto issue_sink = [&]() __attribute__((always_inline)) {
-            __builtin_amdgcn_global_load_lds(zero_src, (cp_dst_t)(sink + pwave * 1024), 16, 0, 0);
-        };
-
-        // prologue: the whole first patch and NSW - 1 weight tiles; everything must have landed before the first unit
-        const int cs_first = fdiv22(u_begin, 9, 0.11111111938953400f);
 #pragma unroll
-        for (int j = 0; j < CP_MAXPI; ++j) issue_patch(j, cs_first);
-#pragma unroll
-        for (int s = 0; s < NSW - 1; ++s) {
-            issue_weights(u_begin + s);
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) issue_sink();  // (keeps the per-unit request count constant from the first unit on)
-        }
-        int cs = cs_first, tap = u_begin - cs_first * 9;
+        for (int s = 0; s < NSW - 1; ++s) issue_weights(u_begin + s);
         for (int u = u_begin; u < u_end; ++u) {
-            // unit u's weight tile has landed (requests retire in order: in the first iteration that includes the whole first patch, at a
-            // slice change the patch shares requested >= NSW - 1 units ago)
-            cp_wait_vmcnt<L *(NSW - 2)>();
-            __builtin_amdgcn_s_barrier();       // consumers finished unit u - 1: its weight stage (and the other patch buffer) is free
+            cp_wait_vmcnt<WCH *(NSW - 2)>();  // unit u's tile has landed (this wave's share; requests retire in order)
+            __builtin_amdgcn_s_barrier();     // consumers finished unit u - 1: its stage is free
             issue_weights(u + NSW - 1);
-            // taps 0 .. CP_SPREAD - 1 carry the next slice's patch (PPT requests each); the registers holding this lane's patch addresses
-            // are indexed statically: one uniform branch per tap
-            const bool more = (cs + 1) * 9 < u_end;
-            bool sent = false;
-#pragma unroll
-            for (int t = 0; t < CP_SPREAD; ++t) {
-                if (tap == t && more) {
-#pragma unroll
-                    for (int j = 0; j < PPT; ++j) {
-                        if (t * PPT + j < CP_MAXPI)
-                            issue_patch(t * PPT + j, cs + 1);
-                        else
-                            issue_sink();
-                    }
-                    sent = true;
-                }
-            }
-            if (!sent) {
-#pragma unroll
-                for (int j = 0; j < PPT; ++j) issue_sink();
-            }
-            if (++tap == 9) {
-                tap = 0;
-                ++cs;
-            }
         }
         cp_wait_vmcnt<0>();  // nothing may still be landing when the LDS is released / re-used by the epilogue
         return;
@@ -188,7 +176,7 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, (WM * WN + PW) / 4) conv_
     const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    constexpr bool EPI_EARLY = FN * FM <= 4 && (WM * WN + PW) <= 8;  // (12-wave tiles have 168 registers per lane: operands fetched late)
+    constexpr bool EPI_EARLY = FN * FM <= 4 && (WM * WN + PWW + PWP) <= 8;  // (12-wave tiles have 168 registers per lane: operands fetched late)
     EpiOperands<(EPI_EARLY ? FN : 1), (EPI_EARLY ? FM : 1)> epi;
     if constexpr (EPI_EARLY) epilogue_prefetch<T, FN, FM, false>(a, epi, m0 + wm * (FM * 32), n0 + wn * WNB, l31, hi);
 
@@ -216,43 +204,58 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, (WM * WN + PW) / 4) conv_
     int cs = fdiv22(u_begin, 9, 0.11111111938953400f), tap = u_begin - cs * 9;
     cs = __builtin_amdgcn_readfirstlane(cs);
     tap = __builtin_amdgcn_readfirstlane(tap);
-    for (int u = u_begin; u < u_end; ++u) {
-        __builtin_amdgcn_s_barrier();
-        const char *ws = wring + cstage * (BN * 128);
-        const char *ps = pbuf0 + (cs & 1) * g.patch_bytes;
+    vec8 af[2][FN], bf[2][FM];
+    int prow[FM], pswz[FM];
+    const char *ws, *ps;
+    // addresses of unit (cs, tap) in ring stage `cstage`
+    auto enter_unit = [&]() {
+        ws = wring + cstage * (BN * 128);
+        ps = pbuf0 + (cs & 1) * g.patch_bytes;
         const int tr = (tap >= 6) ? 2 : (tap >= 3 ? 1 : 0);
         const int toff = tr * g.W2 + (tap - 3 * tr);
-        int prow[FM], pswz[FM];
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm) {
             const int pp = pbase[fm] + toff;
             prow[fm] = pp << 7;
             pswz[fm] = (pp >> 1) & 7;
         }
-        vec8 af[2][FN], bf[2][FM];
-        auto read_frags = [&](int ks, int set) {
-            const int chunk = ks * 2 + hi;
+    };
+    auto read_frags = [&](int ks, int set) {
+        const int chunk = ks * 2 + hi;
 #pragma unroll
-            for (int fn = 0; fn < FN; ++fn)
-                af[set][fn] = *reinterpret_cast<const vec8 *>(ws + lds_off(wn * WNB + fn * 32 + l31, chunk));
+        for (int fn = 0; fn < FN; ++fn)
+            af[set][fn] = *reinterpret_cast<const vec8 *>(ws + lds_off(wn * WNB + fn * 32 + l31, chunk));
 #pragma unroll
-            for (int fm = 0; fm < FM; ++fm)
-                bf[set][fm] = *reinterpret_cast<const vec8 *>(ps + prow[fm] + ((chunk ^ pswz[fm]) << 4));
-        };
-        read_frags(0, 0);
+        for (int fm = 0; fm < FM; ++fm)
+            bf[set][fm] = *reinterpret_cast<const vec8 *>(ps + prow[fm] + ((chunk ^ pswz[fm]) << 4));
+    };
+    // fragment reads one k-step ahead of the MFMAs across the unit boundary, the barrier before the last k-step's MFMAs
+    // (igemm_glds_ws.hip, consumer loop)
+    __builtin_amdgcn_s_barrier();
+    enter_unit();
+    read_frags(0, 0);
+    for (int u = u_begin; u < u_end; ++u) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (ks + 1 < 4) read_frags(ks + 1, (ks + 1) & 1);
+            if (ks + 1 < 4) {
+                read_frags(ks + 1, (ks + 1) & 1);
+            } else if (u + 1 < u_end) {
+                cstage = (cstage + 1 == NSW) ? 0 : cstage + 1;
+                if (++tap == 9) {
+                    tap = 0;
+                    ++cs;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");  // (the reads below stay below)
+                enter_unit();
+                read_frags(0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
                 for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = mfma32(af[ks & 1][fn], bf[ks & 1][fm], acc[fn][fm]);
-        }
-        cstage = (cstage + 1 == NSW) ? 0 : cstage + 1;
-        if (++tap == 9) {
-            tap = 0;
-            ++cs;
         }
     }
 
@@ -261,12 +264,21 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, (WM * WN + PW) / 4) conv_
 
 // ---- host side ------------------------------------------------------------------------------------------
 // variant ids 31.. (igemm.hip kVariants, pipe 3): tile, consumer waves WM x WN, producer waves, weight ring depth
+// variant ids 31.. (igemm.hip kVariants, pipe 3): tile, consumer waves WM x WN; two weight-producer + two patch-producer waves; the
+// weight ring takes what the patch buffers leave of the 160 KiB (3 .. 5 stages)
 #define SFAST_FOR_PATCH_VARIANTS(T, OP) \
-    OP(T, 128, 160, 4, 1, 4, 3)         \
-    OP(T, 128, 128, 2, 2, 4, 3)         \
-    OP(T, 128, 64, 2, 2, 4, 4)
+    OP(T, 128, 160, 4, 1)               \
+    OP(T, 128, 128, 2, 2)               \
+    OP(T, 128, 64, 2, 2)
 
-static size_t patch_lds_bytes(int BN, int PW, int NSW, int patch_bytes) { return (size_t)2 * patch_bytes + (size_t)NSW * BN * 128 + (size_t)PW * 1024; }
+static size_t patch_lds_bytes(int BN, int NSW, int patch_bytes) { return (size_t)2 * patch_bytes + (size_t)NSW * BN * 128; }
+static int patch_ring_depth(int BM, int BN, int patch_bytes, bool staged) {
+    for (int n = 5; n >= 3; --n) {
+        const size_t need = staged ? (size_t)BM * (BN * 2 + 8) + 16 + 256 * 16 : 0;
+        if (patch_lds_bytes(BN, n, patch_bytes) <= 160 * 1024 && need <= 160 * 1024) return n;
+    }
+    return 0;
+}
 
 // patch rows of a BM-pixel tile of whole image rows: inside one image rows + 2, over whole images (H + 2) each; 0 = not tileable
 int conv_patch_rows(int H, int W, int BM) {
@@ -282,30 +294,28 @@ bool conv_patch_fits(int H, int W, int M, int BM, int BN) {
     const int pr = conv_patch_rows(H, W, BM);
     if (!pr || M % BM != 0) return false;
     const int pp = pr * (W + 2), npi = (pp + 7) / 8;
-    int nsw = 3, pw = 4;
-    if (BM == 128 && BN == 64) nsw = 4;
-    return npi <= pw * CP_MAXPI && patch_lds_bytes(BN, pw, nsw, npi * 1024) <= 160 * 1024;
+    return npi <= 2 * CP_MAXPI && patch_ring_depth(BM, BN, npi * 1024, false) >= 3;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int PW, int NSW>
+template <typename T, int BM, int BN, int WM, int WN, int NSW>
 static int patch_launch_one(const IgemmArgs &a, const PatchGeom &g, hipStream_t st) {
-    const size_t smem = patch_lds_bytes(BN, PW, NSW, g.patch_bytes);
-    const dim3 block((WM * WN + PW) * 64);
+    const size_t smem = patch_lds_bytes(BN, NSW, g.patch_bytes);
+    const dim3 block((WM * WN + 4) * 64);
     static bool attr_done = false;  // per instantiation, idempotent: the kernels may use the whole 160 KiB (the size depends on the image width)
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(conv_patch_kernel<T, BM, BN, WM, WN, PW, NSW, true>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(conv_patch_kernel<T, BM, BN, WM, WN, 2, 2, NSW, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(conv_patch_kernel<T, BM, BN, WM, WN, PW, NSW, false>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(conv_patch_kernel<T, BM, BN, WM, WN, 2, 2, NSW, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     if (a.stage_out) {
         const size_t need = (size_t)BM * (BN * 2 + 8) + 16 + (size_t)WM * WN * 64 * 16;
         const size_t sm = smem > need ? smem : need;
-        hipLaunchKernelGGL((conv_patch_kernel<T, BM, BN, WM, WN, PW, NSW, true>), igemm_grid(a), block, sm, st, a, g);
+        hipLaunchKernelGGL((conv_patch_kernel<T, BM, BN, WM, WN, 2, 2, NSW, true>), igemm_grid(a), block, sm, st, a, g);
         return check_launch("conv_patch_staged");
     }
-    hipLaunchKernelGGL((conv_patch_kernel<T, BM, BN, WM, WN, PW, NSW, false>), igemm_grid(a), block, smem, st, a, g);
+    hipLaunchKernelGGL((conv_patch_kernel<T, BM, BN, WM, WN, 2, 2, NSW, false>), igemm_grid(a), block, smem, st, a, g);
     return check_launch("conv_patch");
 }
 
@@ -324,8 +334,14 @@ int conv_patch_launch(const IgemmArgs &a, int dtype, int BM, int BN, hipStream_t
     g.r_W2 = 1.0f / (float)g.W2;
     g.r_H2 = 1.0f / (float)g.H2;
     SFAST_REQUIRE(g.pp > 0 && a.ktiles_per_split % 9 == 0 && (a.C1 + a.C2) * 9 == a.K, SFAST_ERR_UNSUPPORTED, "conv_patch: plan does not fit the patch kernel");
-#define PATCH_OP(T, BM_, BN_, WM_, WN_, PW_, NSW_) \
-    if (BM == BM_ && BN == BN_) return patch_launch_one<T, BM_, BN_, WM_, WN_, PW_, NSW_>(a, g, st);
+    const int nsw = patch_ring_depth(BM, BN, g.patch_bytes, a.stage_out != 0);
+    SFAST_REQUIRE(nsw >= 3, SFAST_ERR_UNSUPPORTED, "conv_patch: the patch leaves no room for a weight ring");
+#define PATCH_OP(T, BM_, BN_, WM_, WN_)                                                              \
+    if (BM == BM_ && BN == BN_) {                                                                    \
+        if (nsw == 5) return patch_launch_one<T, BM_, BN_, WM_, WN_, 5>(a, g, st);                   \
+        if (nsw == 4) return patch_launch_one<T, BM_, BN_, WM_, WN_, 4>(a, g, st);                   \
+        return patch_launch_one<T, BM_, BN_, WM_, WN_, 3>(a, g, st);                                 \
+    }
     if (dtype == SFAST_F16) {
         SFAST_FOR_PATCH_VARIANTS(f16, PATCH_OP)
     } else {

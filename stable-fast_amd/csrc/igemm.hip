@@ -534,7 +534,7 @@ static const Variant kVariants[] = {
     {24, 128, 64, 2, 2, 2, 3, 0.80f},  {25, 64, 128, 2, 2, 2, 3, 0.80f},  // autotuner candidates (ids >= 16 are skipped by the analytic planner)
     {26, 64, 64, 2, 2, 2, 3, 0.60f},   // 48 KB ring: three workgroups per CU
     // pipe 3: LDS-resident input patch for 3x3 / stride 1 / pad 1 convs (conv_patch.hip); autotuner candidates
-    {31, 128, 160, 4, 1, 3, 3, 1.00f}, {32, 128, 128, 2, 2, 3, 3, 1.00f}, {34, 128, 64, 2, 2, 3, 4, 0.80f},
+    {31, 128, 160, 4, 1, 3, 5, 1.00f}, {32, 128, 128, 2, 2, 3, 5, 1.00f}, {34, 128, 64, 2, 2, 3, 5, 0.80f},  // (ring: 3 .. 5, by LDS left)
 };
 static const Variant kGegluVariants[] = {
     {1, 128, 128, 2, 2, 0, 2, 1.00f},  {3, 64, 128, 2, 2, 0, 2, 0.75f},  {11, 128, 128, 2, 2, 1, 4, 1.00f},

@@ -225,33 +225,45 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, ws_min_waves((WM * WN + P
 
     trace_mark(a, 1);
     trace_mark(a, 2);
+    // The fragment reads run one k-step ahead of the MFMAs ACROSS the tile boundary: before the last k-step's MFMAs of tile kt the
+    // wave has every fragment of the tile in registers (lgkmcnt(0)), so it meets the producers at the barrier there -- tile kt + 1
+    // has landed, stage kt is released -- and the first fragments of tile kt + 1 are fetched under those MFMAs. (With the barrier at
+    // the top of a tile every tile began with an exposed LDS round trip, ~1/6 of the loop: profiles/r03_conv_patch_ab_run5.log
+    // showed the loop indifferent to a third less LDS-DMA traffic, i.e. not bound by it.)
     int cstage = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        __builtin_amdgcn_s_barrier();
-        if (kt == kt_begin) trace_mark(a, 3);
-        const char *xs = smem + cstage * STAGE;
+    vec8 af[2][FN], bf[2][FM];
+    auto read_frags = [&](const char *xs, int ks, int set) {
         const char *ws = xs + BM * 128;
-        vec8 af[2][FN], bf[2][FM];
-        auto read_frags = [&](int ks, int set) {
-            const int chunk = ks * 2 + hi;
+        const int chunk = ks * 2 + hi;
 #pragma unroll
-            for (int fn = 0; fn < FN; ++fn)
-                af[set][fn] = *reinterpret_cast<const vec8 *>(ws + lds_off(wn * WNB + fn * 32 + l31, chunk));
+        for (int fn = 0; fn < FN; ++fn)
+            af[set][fn] = *reinterpret_cast<const vec8 *>(ws + lds_off(wn * WNB + fn * 32 + l31, chunk));
 #pragma unroll
-            for (int fm = 0; fm < FM; ++fm)
-                bf[set][fm] = *reinterpret_cast<const vec8 *>(xs + lds_off(wm * (FM * 32) + fm * 32 + l31, chunk));
-        };
-        read_frags(0, 0);
+        for (int fm = 0; fm < FM; ++fm)
+            bf[set][fm] = *reinterpret_cast<const vec8 *>(xs + lds_off(wm * (FM * 32) + fm * 32 + l31, chunk));
+    };
+    __builtin_amdgcn_s_barrier();  // tile kt_begin has landed
+    trace_mark(a, 3);
+    read_frags(smem, 0, 0);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const char *xs = smem + cstage * STAGE;
+        cstage = (cstage + 1 == NS) ? 0 : cstage + 1;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (ks + 1 < 4) read_frags(ks + 1, (ks + 1) & 1);
+            if (ks + 1 < 4) {
+                read_frags(xs, ks + 1, (ks + 1) & 1);
+            } else if (kt + 1 < kt_end) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");  // (the reads below stay below)
+                read_frags(smem + cstage * STAGE, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs (the scheduler sinks them otherwise)
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
                 for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = mfma32(af[ks & 1][fn], bf[ks & 1][fm], acc[fn][fm]);
         }
-        cstage = (cstage + 1 == NS) ? 0 : cstage + 1;
     }
 
     trace_mark(a, 4);

@@ -27,7 +27,7 @@ class SVDUNetEngine(UNet2DEngine):
 
     # ------------------------------------------------------------------------------------------
     @classmethod
-    def from_module(cls, m, _lib=None):
+    def from_module(cls, m, _host=None):
         cfg = getattr(m, "config", None)
         if cfg is None:
             raise UnsupportedUNet("module has no .config")
@@ -41,7 +41,7 @@ class SVDUNetEngine(UNet2DEngine):
                     # Conv3d (3,1,1): [Cout][kt][1][1][Cin] physical order = the K-contiguous image of a 3 x 1 conv
                     p.data = d = d.contiguous(memory_format=torch.channels_last_3d)
                 params[name] = d
-        eng = cls(cfg, params, _lib=_lib)
+        eng = cls(cfg, params, _host=_host)
         eng.norm_eps = live_norm_eps(m)
         return eng
 
@@ -239,8 +239,7 @@ class SVDUNetEngine(UNet2DEngine):
 
     # ------------------------------------------------------------------------------------------
     def build_plan(self, B, Fr, H, W):
-        if not self._emulated:
-            L.init_device(self.device)
+        self.host.init_device(self.device)
         nlev = len(self.boc)
         if H % (1 << (nlev - 1)) or W % (1 << (nlev - 1)):
             raise UnsupportedUNet(f"latent {H}x{W} not divisible by {1 << (nlev - 1)}")
@@ -418,5 +417,5 @@ class SVDUNetEngine(UNet2DEngine):
             raise UnsupportedUNet("the spatio-temporal plan takes one context token per video (CLIP image embedding)")
         plan = self.get_plan(B, Fr, H, W)
         self.load_inputs(plan, sample, timestep, encoder_hidden_states, added_time_ids)
-        plan.run(None if self._emulated else torch.cuda.current_stream(self.device).cuda_stream)
+        plan.run(self.host.stream_ptr(self.device))
         return plan.static_out.clone()

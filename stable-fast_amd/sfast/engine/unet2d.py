@@ -120,9 +120,15 @@ class UNetPlan:
         self.pool = None
         self.keep = []  # ctypes objects / tensors that must outlive the launches
         self.kv_requests = []  # (name, Wk, Wv, kv buffer, C) of every cross-attention block, grouped at the end of build_plan
-        self.writer = {}       # id(buffer) -> producer record of the op that last wrote the whole buffer (GroupNorm statistics hand-over)
+        # id(buffer) -> producer record of the op that last wrote the whole buffer (GroupNorm statistics hand-over). A record holds its
+        # buffer (`buf`), so the id cannot be recycled by another tensor while the record exists, and writer_of() checks identity.
+        self.writer = {}
         self.gn_candidates = []
         self.gn_fused = 0      # GroupNorms that run as ONE normalisation pass over statistics their producers emit
+
+    def writer_of(self, t):
+        rec = self.writer.get(id(t)) if t is not None else None
+        return rec if rec is not None and rec["buf"] is t else None
 
     def run(self, stream_ptr):
         """Serial execution in program order on one stream (eager mode, tuning, per-op timing)."""
@@ -226,15 +232,39 @@ def capture_plan_graph(plan, stream, pool=None, tail=None, calibrate=True):
     return best[2], best[1]
 
 
+class DeviceHost:
+    """What an engine asks of its surroundings: the C-ABI library, a ROCm device, streams, whether to measure kernel choices.
+    This is the only implementation the package has -- the real library on a real device, no CPU path. (The planner tests replace
+    it from outside: tests/abi_emulator.EmuHost hands the engines a host emulator of the C ABI so that pointer / stride /
+    buffer-reuse logic can be checked without a GPU.)"""
+
+    def library(self):
+        return L.load()
+
+    def require_device(self, device, who):
+        if device.type != "cuda":
+            raise L.SfastHipError(f"{who} needs parameters on a ROCm device; there is no CPU path")
+
+    def init_device(self, device):
+        L.init_device(device)
+
+    def stream_ptr(self, device):
+        return torch.cuda.current_stream(device).cuda_stream
+
+    def new_stream(self, device):
+        return torch.cuda.Stream(device=device)
+
+    def tuning(self):
+        from . import autotune
+        return autotune.enabled()
+
+
 class UNet2DEngine:
     """Executor for SD1.5 / SD2.x / SDXL-family `UNet2DConditionModel` parameter sets."""
 
-    def __init__(self, config, params, device=None, dtype=None, _lib=None):
-        # `_lib` is a test hook: tests/abi_emulator.py injects a host emulator of the C ABI so the
-        # planner's pointer / stride / buffer-reuse logic can be checked on CPU. Product code never
-        # passes it; without it the real library and a ROCm device are mandatory.
-        self._emulated = _lib is not None
-        self.lib = _lib if _lib is not None else L.load()
+    def __init__(self, config, params, device=None, dtype=None, _host=None):
+        self.host = _host if _host is not None else DeviceHost()
+        self.lib = self.host.library()
         self.cfg = config
         self.params = params
         first = params["conv_in.weight"]
@@ -242,8 +272,7 @@ class UNet2DEngine:
         self.dtype = dtype or first.dtype
         if self.dtype not in (torch.float16, torch.bfloat16):
             raise UnsupportedUNet(f"UNet2DEngine runs f16/bf16 parameters, got {self.dtype}")
-        if self.device.type != "cuda" and not self._emulated:
-            raise L.SfastHipError("UNet2DEngine needs parameters on a ROCm device; there is no CPU path")
+        self.host.require_device(self.device, type(self).__name__)
         self.dt = L.F16 if self.dtype == torch.float16 else L.BF16
         self.esize = 2
         self.norm_eps = {}  # module path -> eps of the live normalisation layer (from_module); empty: the planner's defaults
@@ -253,7 +282,7 @@ class UNet2DEngine:
 
     # ------------------------------------------------------------------------------------------
     @classmethod
-    def from_module(cls, m, _lib=None):
+    def from_module(cls, m, _host=None):
         """Build from a diffusers-style module: `m.config` + `m.named_parameters()` (live storage)."""
         cfg = getattr(m, "config", None)
         if cfg is None:
@@ -273,7 +302,7 @@ class UNet2DEngine:
                     else:
                         p.data = d = d.contiguous(memory_format=torch.channels_last)
                 params[name] = d
-        eng = cls(cfg, params, _lib=_lib)
+        eng = cls(cfg, params, _host=_host)
         eng.norm_eps = live_norm_eps(m)
         return eng
 
@@ -452,7 +481,7 @@ class UNet2DEngine:
             L.check(lib.sfast_hip_group_norm(xp, x2p, gp, bp, yp, C.byref(p), ws[0].data_ptr() if ws[0] is not None else None, ws[1], stream), name)
 
         self._add(plan, "gn_silu" if silu else "gn", name, 0.0, (2.0 * N * HW * Ctot + 2 * Ctot) * self.esize, launch)
-        plan.gn_candidates.append(dict(name=name, p=p, pre=pre, xw=plan.writer.get(id(x)), x2w=plan.writer.get(id(x2)) if x2 is not None else None,
+        plan.gn_candidates.append(dict(name=name, p=p, pre=pre, xw=plan.writer_of(x), x2w=plan.writer_of(x2),
                                        concat=x2 is not None, HW=HW))
         plan.writer.pop(id(y), None)
 
@@ -499,7 +528,7 @@ class UNet2DEngine:
             return lib.sfast_hip_gemm(xp, segs, bp, None, rp, op, C.byref(p), ws_ptr, ws_bytes, stream)
 
         if out_offset == 0 and ldo == N and lane == LANE_MAIN:
-            plan.writer[id(out)] = dict(name=name, p=p, ext=ext, stats=stats, conv=False, lane=lane)
+            plan.writer[id(out)] = dict(buf=out, name=name, p=p, ext=ext, stats=stats, conv=False, lane=lane)
         else:
             plan.writer.pop(id(out), None)
 
@@ -575,7 +604,7 @@ class UNet2DEngine:
             return lib.sfast_hip_conv2d(xp, x2p, wp, bp, rbp, zp, op, C.byref(p), ws_ptr, ws_bytes, stream)
 
         if os_ is None:
-            plan.writer[id(out)] = dict(name=name, p=p, ext=ext, stats=stats, conv=True, lane=LANE_MAIN)
+            plan.writer[id(out)] = dict(buf=out, name=name, p=p, ext=ext, stats=stats, conv=True, lane=LANE_MAIN)
         else:
             plan.writer.pop(id(out), None)
 
@@ -779,8 +808,7 @@ class UNet2DEngine:
         `tcond`: the plan takes `timestep_cond` [B, time_cond_proj_dim] (LCM-distilled UNets)."""
         if tcond and self.tcond_dim is None:
             raise UnsupportedUNet("timestep_cond given, but the UNet has no time_embedding.cond_proj (time_cond_proj_dim is None)")
-        if not self._emulated:
-            L.init_device(self.device)
+        self.host.init_device(self.device)
         nlev = len(self.boc)
         if H % (1 << (nlev - 1)) or W % (1 << (nlev - 1)):
             raise UnsupportedUNet(f"latent {H}x{W} not divisible by {1 << (nlev - 1)}")
@@ -1114,7 +1142,7 @@ class UNet2DEngine:
         # measured tile / pipe / split-K selection per distinct GEMM / conv problem (cuDNN-benchmark style)
         from . import autotune
         lib, dev = self.lib, self.device
-        if not self._emulated and autotune.enabled():
+        if self.host.tuning():
             autotune.tune_plan(plan, dev, "f16" if self.dtype == torch.float16 else "bf16")
             for op in plan.ops:
                 if op.tune is not None:
@@ -1126,8 +1154,7 @@ class UNet2DEngine:
             plan.ws[0] = torch.empty(plan.ws[1], dtype=torch.uint8, device=dev)
         if plan.ws_side[1]:
             plan.ws_side[0] = torch.empty(plan.ws_side[1], dtype=torch.uint8, device=dev)
-        if not self._emulated:
-            plan.side_stream = torch.cuda.Stream(device=dev)
+        plan.side_stream = self.host.new_stream(dev)
 
     def _controlnet_cond_embedding(self, plan, h, B, H, W, c0):
         """ControlNetConditioningEmbedding on the NCHW conditioning image; its conv_out is fused with the add onto
@@ -1240,7 +1267,7 @@ class UNet2DEngine:
         plan = self.get_plan(B, H, W, encoder_hidden_states.shape[1], ctrl, encoder_attention_mask is not None, timestep_cond is not None)
         self.load_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs, down_block_additional_residuals,
                          mid_block_additional_residual, encoder_attention_mask, timestep_cond, class_labels)
-        plan.run(None if self._emulated else torch.cuda.current_stream(self.device).cuda_stream)
+        plan.run(self.host.stream_ptr(self.device))
         return plan.static_out.clone()
 
 
@@ -1248,8 +1275,8 @@ class ControlNetEngine(UNet2DEngine):
     """Executor for diffusers `ControlNetModel` parameter sets: the UNet's down path + mid block, the conditioning
     embedding and the 1x1 output convs, as one plan of the same C-ABI launches."""
 
-    def __init__(self, config, params, device=None, dtype=None, _lib=None):
-        super().__init__(config, params, device=device, dtype=dtype, _lib=_lib)
+    def __init__(self, config, params, device=None, dtype=None, _host=None):
+        super().__init__(config, params, device=device, dtype=dtype, _host=_host)
         if not self.is_controlnet:
             raise UnsupportedUNet("parameters do not look like a ControlNetModel (no controlnet_mid_block)")
         if self.add_type is not None:
@@ -1267,7 +1294,7 @@ class ControlNetEngine(UNet2DEngine):
         B, _, H, W = sample.shape
         plan = self.get_plan(B, H, W, encoder_hidden_states.shape[1])
         self.load_inputs(plan, sample, timestep, encoder_hidden_states, controlnet_cond)
-        plan.run(None if self._emulated else torch.cuda.current_stream(self.device).cuda_stream)
+        plan.run(self.host.stream_ptr(self.device))
         return self.outputs(plan, conditioning_scale)
 
     @staticmethod

@@ -22,7 +22,7 @@ import threading
 import torch
 
 from ..hip import lib as L
-from .unet2d import UNet2DEngine, UNetPlan, UnsupportedUNet, _Pool, _as2d, _cfg_get, live_norm_eps
+from .unet2d import DeviceHost, UNet2DEngine, UNetPlan, UnsupportedUNet, _Pool, _as2d, _cfg_get, live_norm_eps
 
 
 class UnsupportedVae(UnsupportedUNet):
@@ -32,9 +32,9 @@ class UnsupportedVae(UnsupportedUNet):
 class VaeDecoderEngine(UNet2DEngine):
     """Executor for `AutoencoderKL.decoder` parameter sets (SD1.x / SD2.x / SDXL VAE family)."""
 
-    def __init__(self, config, params, device=None, dtype=None, _lib=None):
-        self._emulated = _lib is not None
-        self.lib = _lib if _lib is not None else L.load()
+    def __init__(self, config, params, device=None, dtype=None, _host=None):
+        self.host = _host if _host is not None else DeviceHost()
+        self.lib = self.host.library()
         self.cfg = config
         self.params = params
         first = params["conv_in.weight"]
@@ -42,8 +42,7 @@ class VaeDecoderEngine(UNet2DEngine):
         self.dtype = dtype or first.dtype
         if self.dtype not in (torch.float16, torch.bfloat16):
             raise UnsupportedVae(f"VaeDecoderEngine runs f16/bf16 parameters, got {self.dtype}")
-        if self.device.type != "cuda" and not self._emulated:
-            raise L.SfastHipError("VaeDecoderEngine needs parameters on a ROCm device; there is no CPU path")
+        self.host.require_device(self.device, type(self).__name__)
         self.dt = L.F16 if self.dtype == torch.float16 else L.BF16
         self.esize = 2
         self.norm_eps = {}
@@ -52,7 +51,7 @@ class VaeDecoderEngine(UNet2DEngine):
         self._lock = threading.Lock()
 
     @classmethod
-    def from_module(cls, m, config=None, _lib=None):
+    def from_module(cls, m, config=None, _host=None):
         """Build from a diffusers-style `Decoder` module (live parameter storage). `config` may be the owning
         AutoencoderKL's config (only `norm_num_groups` is read; the layout comes from the parameter shapes)."""
         cfg = config if config is not None else getattr(m, "config", None)
@@ -65,7 +64,7 @@ class VaeDecoderEngine(UNet2DEngine):
                 if p.ndim == 4 and not p.data.is_contiguous(memory_format=torch.channels_last):
                     p.data = p.data.contiguous(memory_format=torch.channels_last)
                 params[name] = p.data
-        eng = cls(cfg, params, _lib=_lib)
+        eng = cls(cfg, params, _host=_host)
         eng.norm_eps = live_norm_eps(m)
         return eng
 
@@ -217,8 +216,7 @@ class VaeDecoderEngine(UNet2DEngine):
 
     # ------------------------------------------------------------------------------------------
     def build_plan(self, B, H, W, S_ctx=0):
-        if not self._emulated:
-            L.init_device(self.device)
+        self.host.init_device(self.device)
         P = self.params
         dev, dt = self.device, self.dtype
         plan = UNetPlan(self, B, H, W, 0)
@@ -282,7 +280,7 @@ class VaeDecoderEngine(UNet2DEngine):
         B, _, H, W = z.shape
         plan = self.get_plan(B, H, W)
         self.load_inputs(plan, z)
-        plan.run(None if self._emulated else torch.cuda.current_stream(self.device).cuda_stream)
+        plan.run(self.host.stream_ptr(self.device))
         return plan.static_out.clone()
 
 
@@ -321,8 +319,7 @@ class VaeEncoderEngine(VaeDecoderEngine):
                 raise UnsupportedVae(f"channel count {c} (needs a multiple of 8 and of the group count)")
 
     def build_plan(self, B, H, W, S_ctx=0):
-        if not self._emulated:
-            L.init_device(self.device)
+        self.host.init_device(self.device)
         P = self.params
         dev, dt = self.device, self.dtype
         n_ds = sum(1 for i in range(self.n_down) if f"down_blocks.{i}.downsamplers.0.conv.weight" in P)

@@ -173,20 +173,21 @@ def cublas_lowp_mm(self, mat2):
 
 
 def _addmm(self, mat1, mat2, beta, alpha, act=None, other=None, gamma=1.0):
-    beta, alpha = float(beta), float(alpha)
+    """act(alpha * mat1 @ mat2 + beta * self) [+ gamma * other] as ONE GEMM launch: alpha is the accumulator scale of the epilogue
+    (`out_scale`); `self` is the bias operand when it is a [N] vector with beta == 1, and otherwise the epilogue's scaled residual
+    operand, added before the activation (a [N] or [1, N] `self` is a residual with row stride 0 -- no expanded copy is made).
+    Reference: csrc/operators/cublas/cublas_gemm.cc:206-330 (cublasGemmEx alpha / beta, then the bias / activation epilogue)."""
+    beta, alpha, gamma = float(beta), float(alpha), float(gamma)
     w = _as_weight(mat2)
     n = w.shape[0]
-    if alpha == 1.0 and beta == 1.0 and self.ndim == 1 and self.shape[0] == n:
-        return F.linear(mat1, w, self, act=act, residual=other, alpha=float(gamma))
-    out = F.linear(mat1, w)
-    out = out * alpha + self * beta
-    if act == "relu":
-        out = torch.relu(out)
-    elif act == "gelu":
-        out = torch.nn.functional.gelu(out)
-    if other is not None:
-        out = out + other * float(gamma)
-    return out
+    if beta == 1.0 and self.ndim == 1 and self.shape[0] == n:
+        return F.linear(mat1, w, self, act=act, residual=other, alpha=gamma, out_scale=alpha)
+    if other is None:
+        return F.linear(mat1, w, None, act=act, residual=self, alpha=beta, res_before_act=True, out_scale=alpha)
+    # two scaled addends besides the product (addmm_add with a general `self`; the reference's fuser never emits it): the epilogue has
+    # one residual slot, so beta * self rides in the GEMM and gamma * other in a second pass over the output
+    out = F.linear(mat1, w, None, act=act, residual=self, alpha=beta, res_before_act=True, out_scale=alpha)
+    return out.add_(other, alpha=gamma)
 
 
 def cublas_lowp_addmm(self, mat1, mat2, beta=1, alpha=1):

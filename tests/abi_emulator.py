@@ -379,6 +379,32 @@ class EmuLib:
         return 0
 
 
+class EmuHost:
+    """Stands where `sfast.engine.unet2d.DeviceHost` stands in product code: hands an engine the emulator as its library, accepts CPU
+    parameters, and has no device, no streams and no measured tuning. The engines themselves carry no emulation branch."""
+
+    def __init__(self, lib=None):
+        self.lib = lib if lib is not None else EmuLib()
+
+    def library(self):
+        return self.lib
+
+    def require_device(self, device, who):
+        pass
+
+    def init_device(self, device):
+        pass
+
+    def stream_ptr(self, device):
+        return None
+
+    def new_stream(self, device):
+        return None
+
+    def tuning(self):
+        return False
+
+
 def emulated_denoise_loop(engine, **kw):
     """`sfast.engine.denoise.DenoiseLoop` driven through the host emulator: the product class knows nothing about emulation (it always
     takes the real library and the device's current stream); the two seams it exposes are overridden HERE, in test code."""

@@ -4,7 +4,7 @@ concat / upsample bookkeeping, op counts. No GPU, no kernel launches."""
 import pytest
 import torch
 
-from abi_emulator import EmuLib
+from abi_emulator import EmuLib, EmuHost
 from oracle import unet_ref as U
 from parity import rel_l2
 from sfast.engine import UNet2DEngine, UnsupportedUNet
@@ -21,7 +21,7 @@ def test_plan_executes_tiny_sd15_topology(built_lib):
     cfg = U.tiny_config()
     m16, m32 = _pair(cfg, 3)
     emu = EmuLib()
-    eng = UNet2DEngine.from_module(m16, _lib=emu)
+    eng = UNet2DEngine.from_module(m16, _host=EmuHost(emu))
     g = torch.Generator().manual_seed(0)
     s = torch.randn(2, 4, 16, 16, generator=g).half()
     e = torch.randn(2, 77, 64, generator=g).half()
@@ -48,7 +48,7 @@ def test_live_unet_parameters_are_read_at_every_run(built_lib):
     # QKV-segment and cross-attention weights shows up in the next run of the SAME plan, nothing is re-packed or re-built
     cfg = U.tiny_config()
     m16, m32 = _pair(cfg, 9)
-    eng = UNet2DEngine.from_module(m16, _lib=EmuLib())
+    eng = UNet2DEngine.from_module(m16, _host=EmuHost())
     g = torch.Generator().manual_seed(4)
     s = torch.randn(2, 4, 16, 16, generator=g).half()
     e = torch.randn(2, 77, 64, generator=g).half()
@@ -69,7 +69,7 @@ def test_plan_executes_tiny_sd2_topology(built_lib):
     # SD2.x = the SD1.5 block layout with Linear proj_in / proj_out and a per-level head count
     cfg = U.tiny_config(use_linear_projection=True, attention_head_dim=(2, 4, 4), cross_attention_dim=48)
     m16, m32 = _pair(cfg, 5)
-    eng = UNet2DEngine.from_module(m16, _lib=EmuLib())
+    eng = UNet2DEngine.from_module(m16, _host=EmuHost())
     g = torch.Generator().manual_seed(1)
     s = torch.randn(2, 4, 16, 16, generator=g).half()
     e = torch.randn(2, 77, 48, generator=g).half()
@@ -86,7 +86,7 @@ def test_plan_executes_tiny_sdxl_topology(built_lib):
                         addition_embed_type="text_time", addition_time_embed_dim=32,
                         projection_class_embeddings_input_dim=64 + 6 * 32, layers_per_block=2)
     m16, m32 = _pair(cfg, 4)
-    eng = UNet2DEngine.from_module(m16, _lib=EmuLib())
+    eng = UNet2DEngine.from_module(m16, _host=EmuHost())
     g = torch.Generator().manual_seed(1)
     s = torch.randn(2, 4, 16, 16, generator=g).half()
     e = torch.randn(2, 20, 64, generator=g).half()
@@ -112,7 +112,7 @@ def _shape_params(cfg):
 def test_sd15_plan_op_inventory(built_lib):
     """The SD1.5 plan matches the per-forward op inventory of SURVEY.md section 3.3 / 8d."""
     config, params = _shape_params(U.SD15_CONFIG)
-    eng = UNet2DEngine(config, params, _lib=EmuLib())
+    eng = UNet2DEngine(config, params, _host=EmuHost())
     plan = eng.build_plan(2, 64, 64, 77)
     s = plan.summary()
     assert s["gn_silu"]["count"] == 45 and s["gn"]["count"] == 16 and s["ln"]["count"] == 48
@@ -133,7 +133,7 @@ def test_sd15_plan_op_inventory(built_lib):
 
 def test_sdxl_plan_builds(built_lib):
     config, params = _shape_params(U.SDXL_CONFIG)
-    eng = UNet2DEngine(config, params, _lib=EmuLib())
+    eng = UNet2DEngine(config, params, _host=EmuHost())
     plan = eng.build_plan(1, 128, 128, 77)
     s = plan.summary()
     assert s["attn_self"]["count"] == 70 and s["geglu"]["count"] == 70
@@ -145,12 +145,12 @@ def test_unsupported_configs_are_rejected(built_lib):
     config, params = _shape_params(U.tiny_config())
     config.class_embed_type = "timestep"
     with pytest.raises(UnsupportedUNet):
-        UNet2DEngine(config, params, _lib=EmuLib())
+        UNet2DEngine(config, params, _host=EmuHost())
     config, params = _shape_params(U.tiny_config())
     with pytest.raises(UnsupportedUNet):
-        UNet2DEngine(config, {k: v.float() for k, v in params.items()}, _lib=EmuLib())
+        UNet2DEngine(config, {k: v.float() for k, v in params.items()}, _host=EmuHost())
     config, params = _shape_params(U.tiny_config())
-    eng = UNet2DEngine(config, params, _lib=EmuLib())
+    eng = UNet2DEngine(config, params, _host=EmuHost())
     with pytest.raises(UnsupportedUNet):
         eng.build_plan(1, 18, 16, 77)  # not divisible by 4
 
@@ -182,7 +182,7 @@ def test_controlnet_residuals_through_the_plan(built_lib):
     cfg = U.tiny_config()
     m16, m32 = _pair(cfg, 9)
     emu = EmuLib()
-    eng = UNet2DEngine.from_module(m16, _lib=emu)
+    eng = UNet2DEngine.from_module(m16, _host=EmuHost(emu))
     g = torch.Generator().manual_seed(4)
     s = torch.randn(2, 4, 16, 16, generator=g).half()
     e = torch.randn(2, 77, 64, generator=g).half()
@@ -215,7 +215,7 @@ def test_controlnet_engine_on_the_emulator(built_lib):
     c32 = CN.build(ccfg, seed=21)
     c32.load_state_dict({k: v.float() for k, v in c16.state_dict().items()})
     emu = EmuLib()
-    ceng = ControlNetEngine.from_module(c16, _lib=emu)
+    ceng = ControlNetEngine.from_module(c16, _host=EmuHost(emu))
     g = torch.Generator().manual_seed(7)
     s = torch.randn(2, 4, 16, 16, generator=g).half()
     e = torch.randn(2, 77, 64, generator=g).half()
@@ -229,13 +229,13 @@ def test_controlnet_engine_on_the_emulator(built_lib):
     assert rel_l2(d2[0], 0.5 * wd[0]) < 3e-3 and rel_l2(m2, 0.5 * wm) < 3e-3
     # chain into the UNet plan
     m16, m32 = _pair(U.tiny_config(), 22)
-    ueng = UNet2DEngine.from_module(m16, _lib=EmuLib())
+    ueng = UNet2DEngine.from_module(m16, _host=EmuHost())
     y = ueng.forward(s, 300, e, down_block_additional_residuals=down, mid_block_additional_residual=mid)
     with torch.no_grad():
         want = m32(s.float(), 300, e.float(), down_block_additional_residuals=wd, mid_block_additional_residual=wm).sample
     assert rel_l2(y, want) < 4e-3
     with pytest.raises(UnsupportedUNet):
-        ControlNetEngine.from_module(m16, _lib=EmuLib())  # a UNet is not a ControlNet
+        ControlNetEngine.from_module(m16, _host=EmuHost())  # a UNet is not a ControlNet
 
 
 def test_groupnorm_statistics_come_from_the_producers(built_lib):
@@ -247,7 +247,7 @@ def test_groupnorm_statistics_come_from_the_producers(built_lib):
                         up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), attention_head_dim=8, norm_num_groups=32)
     m = U.build(cfg, seed=21, dtype=torch.float16)
     emu = EmuLib()
-    eng = UNet2DEngine.from_module(m, _lib=emu)
+    eng = UNet2DEngine.from_module(m, _host=EmuHost(emu))
     g = torch.Generator().manual_seed(22)
     sample = torch.randn(1, 4, 64, 64, generator=g).half()
     ehs = torch.randn(1, 20, cfg["cross_attention_dim"], generator=g).half()
@@ -277,7 +277,7 @@ def test_encoder_attention_mask_is_a_plan_input(built_lib):
     """Text-padding mask -> additive key bias of every cross-attention launch (diffusers' (1 - mask) * -10000); own plan-cache key."""
     cfg = U.tiny_config()
     m = U.build(cfg, seed=31, dtype=torch.float16)
-    eng = UNet2DEngine.from_module(m, _lib=EmuLib())
+    eng = UNet2DEngine.from_module(m, _host=EmuHost())
     g = torch.Generator().manual_seed(32)
     sample = torch.randn(2, 4, 16, 16, generator=g).half()
     ehs = torch.randn(2, 20, cfg["cross_attention_dim"], generator=g).half()
@@ -305,7 +305,7 @@ def test_plan_takes_timestep_cond_like_an_lcm_unet(built_lib):
     cfg = U.tiny_config(time_cond_proj_dim=32)
     m16, m32 = _pair(cfg, 6)
     assert "time_embedding.cond_proj.weight" in dict(m16.named_parameters())
-    eng = UNet2DEngine.from_module(m16, _lib=EmuLib())
+    eng = UNet2DEngine.from_module(m16, _host=EmuHost())
     g = torch.Generator().manual_seed(2)
     s = torch.randn(2, 4, 16, 16, generator=g).half()
     e = torch.randn(2, 77, 64, generator=g).half()
@@ -320,7 +320,7 @@ def test_plan_takes_timestep_cond_like_an_lcm_unet(built_lib):
     names = [op.name for op in eng.get_plan(2, 16, 16, 77, False, False, True).ops]
     assert "time_embedding.cond_proj" in names and names.index("time_embedding.cond_proj") < names.index("time_embedding.linear_1")
     # a UNet without cond_proj refuses the input instead of ignoring it
-    eng2 = UNet2DEngine.from_module(U.build(U.tiny_config(), seed=1, dtype=torch.float16), _lib=EmuLib())
+    eng2 = UNet2DEngine.from_module(U.build(U.tiny_config(), seed=1, dtype=torch.float16), _host=EmuHost())
     with pytest.raises(UnsupportedUNet):
         eng2.forward(s, 700, e, timestep_cond=w)
 
@@ -332,7 +332,7 @@ def test_plan_takes_class_labels(built_lib, cet):
         over["projection_class_embeddings_input_dim"] = 40
     cfg = U.tiny_config(**over)
     m16, m32 = _pair(cfg, 8)
-    eng = UNet2DEngine.from_module(m16, _lib=EmuLib())
+    eng = UNet2DEngine.from_module(m16, _host=EmuHost())
     g = torch.Generator().manual_seed(3)
     s = torch.randn(2, 4, 16, 16, generator=g).half()
     e = torch.randn(2, 77, 64, generator=g).half()
@@ -351,7 +351,7 @@ def test_class_embedding_and_text_time_stack(built_lib):
     cfg = U.tiny_config(class_embed_type="timestep", addition_embed_type="text_time", addition_time_embed_dim=32,
                         projection_class_embeddings_input_dim=64 + 6 * 32, time_cond_proj_dim=16)
     m16, m32 = _pair(cfg, 10)
-    eng = UNet2DEngine.from_module(m16, _lib=EmuLib())
+    eng = UNet2DEngine.from_module(m16, _host=EmuHost())
     g = torch.Generator().manual_seed(4)
     s = torch.randn(2, 4, 16, 16, generator=g).half()
     e = torch.randn(2, 20, 64, generator=g).half()
@@ -369,11 +369,11 @@ def test_unknown_class_embedding_types_stay_unsupported(built_lib):
     config, params = _shape_params(U.tiny_config())
     config.class_embed_type = "identity"
     with pytest.raises(UnsupportedUNet):
-        UNet2DEngine(config, params, _lib=EmuLib())
+        UNet2DEngine(config, params, _host=EmuHost())
     config.class_embed_type = None
     config.num_class_embeds = 10
     with pytest.raises(UnsupportedUNet):
-        UNet2DEngine(config, params, _lib=EmuLib())
+        UNet2DEngine(config, params, _host=EmuHost())
 
 
 def test_norm_eps_is_read_from_the_live_module(built_lib):
@@ -385,7 +385,7 @@ def test_norm_eps_is_read_from_the_live_module(built_lib):
         m.down_blocks[0].resnets[0].norm1.eps = 0.3          # GroupNorm + SiLU
         m.mid_block.attentions[0].norm.eps = 0.2             # transformer GroupNorm
         m.up_blocks[1].attentions[0].transformer_blocks[0].norm2.eps = 0.5   # LayerNorm
-    eng = UNet2DEngine.from_module(m16, _lib=EmuLib())
+    eng = UNet2DEngine.from_module(m16, _host=EmuHost())
     assert eng.norm_eps["down_blocks.0.resnets.0.norm1"] == 0.3 and eng.norm_eps["conv_norm_out"] == 1e-5
     g = torch.Generator().manual_seed(5)
     s = torch.randn(2, 4, 16, 16, generator=g).half()

@@ -185,7 +185,7 @@ def _loop_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from abi_emulator import EmuLib, emulated_denoise_loop
+        from abi_emulator import EmuLib, emulated_denoise_loop, EmuHost
         from oracle import unet_ref as U
         from sfast.engine import UNet2DEngine, autotune
         from sfast.engine.replicas import broadcast_parameters, gather_latents, share_tune_cache
@@ -196,7 +196,7 @@ def _loop_worker(rank, world, port, q):
         if rank == 0:
             autotune.import_cache({"gfx950|f16|gemm|1x2x3|(0, 0, 1)": [3, 1]})
         got = share_tune_cache(src=0)
-        eng = UNet2DEngine(m.config, params, device=torch.device("cpu"), dtype=torch.float16, _lib=EmuLib())
+        eng = UNet2DEngine(m.config, params, device=torch.device("cpu"), dtype=torch.float16, _host=EmuHost())
         loop = emulated_denoise_loop(eng, images=1, height=16, width=16, ctx_len=20, guidance=7.5, num_steps=50)
         g = torch.Generator().manual_seed(1234 + rank)
         lat = torch.randn(1, 4, 16, 16, generator=g).half()
@@ -223,13 +223,13 @@ def test_denoise_loop_replicas_gloo_world2(built_lib):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[1][1] >= 1 and res[1][3] == [3, 1]  # rank 1 received rank 0's kernel choices
-    from abi_emulator import EmuLib
+    from abi_emulator import EmuHost, EmuLib
     from oracle import unet_ref as U
     from oracle.ops_ref import cfg_ddim_ref, ddim_schedule
     from sfast.engine import UNet2DEngine
     cfg = U.tiny_config()
     m = U.build(cfg, seed=50, dtype=torch.float16)
-    eng = UNet2DEngine.from_module(m, _lib=EmuLib())
+    eng = UNet2DEngine.from_module(m, _host=EmuHost())
     ts, coefs = ddim_schedule(50)
     for r in range(2):
         g = torch.Generator().manual_seed(1234 + r)

@@ -148,6 +148,32 @@ def test_lowp_linear_family():
         torch.testing.assert_close(torch.ops.sfast.cublas_lowp_bmm(a, b), torch.bmm(a, b), rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("self_shape", ["n", "1n", "mn"])
+@pytest.mark.parametrize("m", [300, 7, 4096])
+def test_lowp_addmm_general_alpha_beta(self_shape, m):
+    """cublas_lowp_addmm / _addmm_add / _addmm_activation with alpha, beta, gamma != 1 (reference cublas_gemm.cc:206-330): the scales
+    are epilogue parameters of the one GEMM launch, checked against fp32 torch.addmm of the same f16 operands."""
+    torch.manual_seed(3)
+    k, n = 320, 640
+    x = torch.randn(m, k, device="cuda", dtype=torch.float16)
+    w = torch.randn(k, n, device="cuda", dtype=torch.float16) * k ** -0.5
+    shape = {"n": (n,), "1n": (1, n), "mn": (m, n)}[self_shape]
+    bias = torch.randn(shape, device="cuda", dtype=torch.float16)
+    other = torch.randn(m, n, device="cuda", dtype=torch.float16)
+    alpha, beta, gamma = 0.75, -1.5, 0.25
+    ref = torch.addmm(bias.float(), x.float(), w.float(), beta=beta, alpha=alpha)
+    tol = dict(rtol=4e-3, atol=4e-3)
+    torch.testing.assert_close(torch.ops.sfast.cublas_lowp_addmm(bias, x, w, beta, alpha).float(), ref, **tol)
+    torch.testing.assert_close(torch.ops.sfast.cublas_lowp_addmm(bias, x, w, 1, alpha).float(),
+                               torch.addmm(bias.float(), x.float(), w.float(), alpha=alpha), **tol)
+    torch.testing.assert_close(torch.ops.sfast.cublas_lowp_addmm_activation(bias, x, w, beta, alpha, True).float(), F.gelu(ref), **tol)
+    torch.testing.assert_close(torch.ops.sfast.cublas_lowp_addmm_activation(bias, x, w, beta, alpha, False).float(), F.relu(ref), **tol)
+    torch.testing.assert_close(torch.ops.sfast.cublas_lowp_addmm_add(bias, x, w, other, beta, alpha, gamma).float(),
+                               ref + gamma * other.float(), **tol)
+    torch.testing.assert_close(torch.ops.sfast.cublas_lowp_addmm_add(bias, x, w, other, 1, alpha, gamma).float(),
+                               torch.addmm(bias.float(), x.float(), w.float(), alpha=alpha) + gamma * other.float(), **tol)
+
+
 def test_triton_namespace_norms():
     x = torch.randn(2, 320, 32, 32, device="cuda", dtype=torch.float16).contiguous(memory_format=torch.channels_last)
     gn = nn.GroupNorm(32, 320).cuda().half()

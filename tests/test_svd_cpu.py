@@ -3,7 +3,7 @@ published parameter count, the engine's parameter inventory against the oracle, 
 reshaped 2-D ops, strided temporal attention, single-key cross-attention as a row bias, AlphaBlender) executed on the ABI emulator."""
 import torch
 
-from abi_emulator import EmuLib
+from abi_emulator import EmuLib, EmuHost
 from oracle import svd_ref as S
 from sfast.engine import SVDUNetEngine
 from sfast.engine.unet_spec import SVD_CONFIG, svd_param_shapes
@@ -38,7 +38,7 @@ def test_svd_plan_executes_tiny_topology(built_lib):
     cfg = S.tiny_svd_config()
     m = S.build(cfg, seed=41, dtype=torch.float16)
     emu = EmuLib()
-    eng = SVDUNetEngine.from_module(m, _lib=emu)
+    eng = SVDUNetEngine.from_module(m, _host=EmuHost(emu))
     g = torch.Generator().manual_seed(42)
     B, Fr = 2, cfg["num_frames"]
     sample = torch.randn(B, Fr, 8, 16, 16, generator=g).half()

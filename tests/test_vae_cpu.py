@@ -5,7 +5,7 @@ import os
 import pytest
 import torch
 
-from abi_emulator import EmuLib
+from abi_emulator import EmuLib, EmuHost
 from oracle import vae_ref as V
 from parity import rel_l2
 from sfast.engine import UnsupportedVae, VaeDecoderEngine
@@ -47,7 +47,7 @@ def _pair(seed, **cfg):
 def test_plan_executes_tiny_decoder(built_lib):
     m16, m32 = _pair(5, **TINY)
     emu = EmuLib()
-    eng = VaeDecoderEngine.from_module(m16, _lib=emu)
+    eng = VaeDecoderEngine.from_module(m16, _host=EmuHost(emu))
     z = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(0)).half()
     y = eng.forward(z)
     with torch.no_grad():
@@ -67,7 +67,7 @@ def test_plan_executes_tiny_decoder(built_lib):
 
 def test_live_parameters_are_read_at_every_run(built_lib):
     m16, m32 = _pair(6, **TINY)
-    eng = VaeDecoderEngine.from_module(m16, _lib=EmuLib())
+    eng = VaeDecoderEngine.from_module(m16, _host=EmuHost())
     z = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(2)).half()
     y0 = eng.forward(z)
     with torch.no_grad():
@@ -83,10 +83,10 @@ def test_live_parameters_are_read_at_every_run(built_lib):
 def test_unsupported_decoders_are_rejected(built_lib):
     m32 = V.build("tiny", **TINY)
     with pytest.raises(UnsupportedVae):
-        VaeDecoderEngine.from_module(m32, _lib=EmuLib())  # fp32 parameters
+        VaeDecoderEngine.from_module(m32, _host=EmuHost())  # fp32 parameters
     bad = V.build("tiny", dtype=torch.float16, block_out_channels=(36, 72), norm_num_groups=4, layers_per_block=1)
     with pytest.raises(UnsupportedVae):
-        VaeDecoderEngine.from_module(bad, _lib=EmuLib())  # channel counts not multiples of 8
+        VaeDecoderEngine.from_module(bad, _host=EmuHost())  # channel counts not multiples of 8
 
 
 class _FakeProcessor:
@@ -135,7 +135,7 @@ def test_encoder_topology_and_plan(built_lib):
     m32 = V.build_encoder("tiny", seed=8, **cfg)
     m32.load_state_dict({k: v.float() for k, v in m16.state_dict().items()})
     emu = EmuLib()
-    eng = VaeEncoderEngine.from_module(m16, _lib=emu)
+    eng = VaeEncoderEngine.from_module(m16, _host=EmuHost(emu))
     x = torch.randn(2, 3, 16, 24, generator=torch.Generator().manual_seed(3)).half()
     y = eng.forward(x)
     with torch.no_grad():

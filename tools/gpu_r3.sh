@@ -38,6 +38,17 @@ s4)  # conv_patch.hip: parity + A/B against the implicit-im2col pipes
   run t_patch 900 $PYT tests/test_ops_gpu.py -k "conv_patch" --durations=3
   run conv_ab 900 python tools/conv_ab.py
   ;;
+s5)  # conv_patch with separate weight / patch producer waves and the deeper ring; attention PMC pass (32-row kernel vs attention_q64)
+  run t_patch 900 $PYT tests/test_ops_gpu.py -k "conv_patch" --durations=3
+  run conv_ab 900 python tools/conv_ab.py
+  run pmc_attn 700 bash tools/gpu_pmc_attn.sh
+  ;;
+s6)  # fragment reads pipelined across the tile barrier (igemm_glds_ws + conv_patch): parity, conv A/B, bench with the packaged choices and with a fresh tune
+  run t_gemm 900 $PYT tests/test_ops_gpu.py -k "gemm or conv or linear or geglu"
+  run conv_ab 900 python tools/conv_ab.py
+  run bench_pk 600 python bench.py --steps 50 --warmup 10 --no-end-to-end --no-cpu-baseline
+  SFAST_TUNE_PACKAGED=0 SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_cache.json run bench_tuned 900 python bench.py --steps 50 --warmup 10 --no-end-to-end --no-cpu-baseline --dump-kernels gpurun_out/kernels.json
+  ;;
 full)
   run t_all 1500 $PYT tests
   run smoke 600 python __graft_entry__.py smoke
