@@ -174,7 +174,7 @@ def kernel_symbol(variant):
     of one tile shape share a symbol, so the split factor is dropped. A trailing "+staged" / "+gnstats" marks the
     instantiation with LDS-staged stores (last template argument)."""
     import re
-    m = re.match(r"igemm_(conv|lin)_(f16|bf16)(_geglu)?\[(\d+x\d+),split=(\d+),(reg|dma(\d)|ws(\d))\](\+staged|\+gnstats)?", variant)
+    m = re.match(r"igemm_(conv|lin)_(f16|bf16)(_geglu)?\[(\d+x\d+),split=(\d+),(reg|dma(\d)|ws(\d))\](\+staged|\+gnstats)?(\+join)?", variant)
     if not m:
         ma = re.match(r"attn_fwd\[D=(\d+),BQ=(\d+)\](\+bias)?", variant)
         if ma:  # attn_fwd_kernel<T, D, NW, TRACE = 0, BIAS = false>: one wave per 32 queries
@@ -185,13 +185,13 @@ def kernel_symbol(variant):
     geglu = m.group(3) is not None
     bm, bn = m.group(4).split("x")
     wm, wn = _IGEMM_WAVES[(m.group(4), geglu)]
-    # staged stores (and statistics from the tile flush) only without split-K: a split GEMM writes fp32 slabs and the
-    # statistics come from splitk_reduce_rows_kernel behind it (igemm.hip igemm_run)
-    staged = int(m.group(9) is not None and int(m.group(5)) == 1)
+    # staged stores (and statistics from the tile flush) only when the GEMM kernel itself finishes the tile: unsplit, or split-K joined
+    # inside the kernel ("+join"); otherwise a split GEMM writes fp32 slabs and splitk_reduce[_rows]_kernel finishes (igemm.hip igemm_run)
+    staged = int(m.group(9) is not None and (int(m.group(5)) == 1 or m.group(10) is not None))
     if m.group(6) == "reg":
         return f"_ZN5sfast12igemm_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi{mode}ELb{int(geglu)}ELb{staged}EEEvNS_9IgemmArgsE"
     if m.group(6).startswith("ws"):
-        return (f"_ZN5sfast20igemm_glds_ws_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi4ELi{m.group(8)}ELi{mode}ELb{int(geglu)}ELb{staged}EEE"
+        return (f"_ZN5sfast20igemm_glds_ws_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi4ELi{m.group(8)}ELi{mode}ELb{int(geglu)}ELb{staged}ELi0EEE"
                 "vNS_9IgemmArgsE")
     return f"_ZN5sfast17igemm_glds_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi{m.group(7)}ELi{mode}ELb{int(geglu)}ELi0ELb0EEEvNS_9IgemmArgsE"
 

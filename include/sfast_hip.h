@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define SFAST_HIP_ABI_VERSION 4
+#define SFAST_HIP_ABI_VERSION 5
 
 typedef void *sfast_stream_t; /* hipStream_t */
 
@@ -248,13 +248,27 @@ int sfast_hip_conv2d(const void *x, const void *x2, const void *w, const void *b
  *             kernel plus a normalisation kernel (reference: triton/ops/group_norm.py:111-165 + :272-349, two launches).
  *             gn_unit = channels per statistics unit: >= 8, a divisor of every consumer's C/G (and of the channel offset at
  *             which the tensor sits inside a virtual concat); gn_rows_per_sample = H*W of the output. The records of one tensor
- *             can serve several consumers (e.g. a skip connection normalised alone and again inside a concat).            */
+ *             can serve several consumers (e.g. a skip connection normalised alone and again inside a concat).
+ * flags & SFAST_EXT_WS_TICKETS: split-K problems are finished INSIDE the GEMM kernel instead of by a second (reduce + epilogue)
+ *             launch: the workgroups of a tile leave fp32 partials in the workspace, draw a ticket from the tile's counter, and the
+ *             one that draws the last ticket sums the partials in split order (bitwise reproducible, same order as the reduce
+ *             kernel) and runs the epilogue. The caller promises that the LAST SFAST_WS_TICKET_BYTES of
+ *             [workspace, workspace + workspace_bytes) are ticket counters: zeroed once (sfast_hip_workspace_init), never written
+ *             by anybody else, and that every call sharing the workspace passes the same workspace_bytes. The library leaves
+ *             them zero after every launch. sfast_hip_*_workspace_bytes already includes the block for split-K problems; a
+ *             workspace shared with other operators should be sized max(needs) + SFAST_WS_TICKET_BYTES so that no operator's
+ *             scratch reaches into it. Without the flag nothing changes (row-major slabs + reduce kernel).                    */
+#define SFAST_WS_TICKET_BYTES 65536
+#define SFAST_EXT_WS_TICKETS 1
 typedef struct {
     float out_scale;
     int32_t gn_unit;
     int32_t gn_rows_per_sample;
-    int32_t reserved;
+    int32_t flags;
 } sfast_epilogue_ext;
+
+/* zero the ticket block of a fresh workspace (asynchronous, on `stream`) */
+int sfast_hip_workspace_init(void *workspace, size_t workspace_bytes, sfast_stream_t stream);
 
 typedef struct {
     int32_t rb_rows; /* rows per row block (a tile's BM, or the rows a split-K reduce workgroup owns) */

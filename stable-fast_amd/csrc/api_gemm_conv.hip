@@ -207,6 +207,24 @@ extern "C" size_t sfast_hip_gemm_workspace_bytes(const sfast_gemm_params *p) {
 }
 
 static float ext_scale(const sfast_epilogue_ext *ext) { return (ext && ext->out_scale != 0.0f) ? ext->out_scale : 1.0f; }
+static bool ext_tickets(const sfast_epilogue_ext *ext) { return ext && (ext->flags & SFAST_EXT_WS_TICKETS) != 0; }
+
+// SFAST_EXT_WS_TICKETS: the last SFAST_WS_TICKET_BYTES of the workspace are the split-K ticket counters; the rest is scratch
+static void split_workspace(const sfast_epilogue_ext *ext, void *workspace, size_t &workspace_bytes, IgemmArgs &a) {
+    a.tickets = nullptr;
+    if (ext_tickets(ext) && workspace && workspace_bytes >= SFAST_WS_TICKET_BYTES && (workspace_bytes % 4) == 0) {
+        workspace_bytes -= SFAST_WS_TICKET_BYTES;
+        a.tickets = (unsigned *)((char *)workspace + workspace_bytes);
+    }
+}
+
+extern "C" int sfast_hip_workspace_init(void *workspace, size_t workspace_bytes, sfast_stream_t stream) {
+    SFAST_REQUIRE(workspace && workspace_bytes >= SFAST_WS_TICKET_BYTES && workspace_bytes % 4 == 0, SFAST_ERR_WORKSPACE,
+                  "workspace_init: needs a workspace of at least %d bytes (a multiple of 4)", SFAST_WS_TICKET_BYTES);
+    hipError_t e = hipMemsetAsync((char *)workspace + workspace_bytes - SFAST_WS_TICKET_BYTES, 0, SFAST_WS_TICKET_BYTES, (hipStream_t)stream);
+    SFAST_REQUIRE(e == hipSuccess, SFAST_ERR_LAUNCH, "workspace_init: %s", hipGetErrorString(e));
+    return SFAST_OK;
+}
 
 extern "C" int sfast_hip_gemm(const void *x, const void *const *w_segs, const void *bias, const void *rowbias,
                               const void *residual, void *out, const sfast_gemm_params *p, void *workspace,
@@ -218,7 +236,7 @@ extern "C" int sfast_hip_gemm_stats_layout(const sfast_gemm_params *p, const sfa
     SFAST_REQUIRE(p && ext && out, SFAST_ERR_INVALID, "gemm_stats_layout: null argument");
     StatsLayout l{};
     const bool igemm = is_half(p->dtype) && p->K % 8 == 0 && !(p->M <= 16 && p->variant == 0) && p->variant < 100 && p->N % 8 == 0 && p->ldo % 8 == 0;
-    if (!igemm || !igemm_stats_layout(p->M, p->N, p->K, p->geglu != 0, p->variant, p->split_k, true, ext->gn_unit, ext->gn_rows_per_sample, l)) {
+    if (!igemm || !igemm_stats_layout(p->M, p->N, p->K, p->geglu != 0, p->variant, p->split_k, true, ext->gn_unit, ext->gn_rows_per_sample, ext_tickets(ext), l)) {
         set_error("gemm_stats_layout: this problem / kernel choice cannot emit GroupNorm statistics");
         return SFAST_ERR_UNSUPPORTED;
     }
@@ -266,6 +284,7 @@ extern "C" int sfast_hip_gemm_ex(const void *x, const void *const *w_segs, const
         a.gn_stats = (float *)gn_stats;
         a.gn_unit = ext ? ext->gn_unit : 0;
         a.gn_rows_per_sample = ext ? ext->gn_rows_per_sample : 0;
+        split_workspace(ext, workspace, workspace_bytes, a);
         return igemm_run(a, p->dtype, 0, p->geglu != 0, p->variant < 100 ? p->variant : 0, p->split_k, workspace, workspace_bytes, st);
     }
     SmallGemmArgs a{};
@@ -393,7 +412,7 @@ extern "C" int sfast_hip_conv2d_stats_layout(const sfast_conv_params *p, const s
     const bool igemm = is_half(p->dtype) && p->Cout >= 16 && p->Cout % 8 == 0 && M > 0 && M <= INT32_MAX && K % 8 == 0 && p->C1 % 8 == 0 &&
                        C2 % 8 == 0 && g.x_dense && g.x2_dense && g.w_kcontig && g.out_dense && g.ldo % 8 == 0 && p->variant < 100;
     StatsLayout l{};
-    if (!igemm || !igemm_stats_layout((int)M, p->Cout, K, false, p->variant, p->split_k, conv_caps(p), ext->gn_unit, ext->gn_rows_per_sample, l)) {
+    if (!igemm || !igemm_stats_layout((int)M, p->Cout, K, false, p->variant, p->split_k, conv_caps(p), ext->gn_unit, ext->gn_rows_per_sample, ext_tickets(ext), l)) {
         set_error("conv2d_stats_layout: this problem / kernel choice cannot emit GroupNorm statistics");
         return SFAST_ERR_UNSUPPORTED;
     }
@@ -461,6 +480,7 @@ extern "C" int sfast_hip_conv2d_ex(const void *x, const void *x2, const void *w,
         a.gn_stats = (float *)gn_stats;
         a.gn_unit = ext ? ext->gn_unit : 0;
         a.gn_rows_per_sample = ext ? ext->gn_rows_per_sample : 0;
+        split_workspace(ext, workspace, workspace_bytes, a);
         return igemm_run(a, p->dtype, 1, false, p->variant < 100 ? p->variant : 0, p->split_k, workspace, workspace_bytes, st);
     }
     SmallConvArgs a{};

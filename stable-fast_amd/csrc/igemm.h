@@ -10,6 +10,7 @@ struct IgemmArgs {
     const void *bias, *rowbias, *res;
     void *out;
     float *partial;
+    unsigned *tickets;  // split-K ticket counters, one per output tile (zero between launches), or nullptr: separate reduce kernel
     int M, N, K;
     int64_t ldx, ldw, ldo, ldr, ld_rowbias;
     int rows_per_seg, rows_per_batch;
@@ -61,7 +62,7 @@ struct StatsLayout {
     int rb_rows, bno, slots, tiles_n, n_rb;
 };
 bool igemm_stats_layout(int M, int N, int K, bool geglu, int variant, int split, int glds_ok, int unit, int rows_per_sample,
-                        StatsLayout &out);
+                        bool tickets, StatsLayout &out);
 // glds_ok: whether the LDS-DMA pipe may be chosen for this problem (see igemm_glds_eligible)
 void igemm_plan_query(int M, int N, int K, bool geglu, int variant, int split, int glds_ok, int out[5]);
 size_t igemm_workspace_bytes(int M, int N, int K, bool geglu, int variant, int split, int glds_ok);

@@ -738,12 +738,17 @@ static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, 
     return best;
 }
 
+// whether a split-K plan finishes its tiles inside the GEMM kernel (splitk_join, igemm_device.h) instead of a second launch
+static bool splitk_joins(const IgemmPlan &p, bool tickets, bool stats, int rows_per_sample) {
+    return p.splits > 1 && tickets && p.v.pipe != 1 && (int64_t)p.tiles_m * p.tiles_n <= SFAST_WS_TICKET_BYTES / 4 && (!stats || rows_per_sample % p.v.BM == 0);
+}
+
 bool igemm_stats_layout(int M, int N, int K, bool geglu, int variant, int split, int glds_ok, int unit, int rows_per_sample,
-                        StatsLayout &out) {
+                        bool tickets, StatsLayout &out) {
     if (geglu || unit < 8 || rows_per_sample <= 0 || M % rows_per_sample != 0 || N % 8 != 0) return false;
     IgemmPlan p = igemm_plan(M, N, K, geglu, variant, split, glds_ok);
     if (p.v.pipe == 1 && p.splits == 1) p = igemm_plan(M, N, K, geglu, staged_variant(p.v.id), p.splits, glds_ok);
-    if (p.splits == 1) {
+    if (p.splits == 1 || splitk_joins(p, tickets, true, rows_per_sample)) {
         if (rows_per_sample % p.v.BM != 0) return false;
         out.rb_rows = p.v.BM;
         out.bno = p.v.BN;
@@ -775,7 +780,11 @@ void igemm_plan_query(int M, int N, int K, bool geglu, int variant, int split, i
 size_t igemm_workspace_bytes(int M, int N, int K, bool geglu, int variant, int split, int glds_ok) {
     IgemmPlan p = igemm_plan(M, N, K, geglu, variant, split, glds_ok);
     if (p.splits <= 1) return 0;
-    return (size_t)p.splits * M * (geglu ? 2 * (size_t)N : (size_t)N) * sizeof(float);
+    // row-major slabs for the reduce kernel, or whole-tile slabs in fragment order + the ticket block at the end (whichever the
+    // caller's flags select at launch time)
+    const size_t rows = (size_t)p.splits * M * (geglu ? 2 * (size_t)N : (size_t)N) * sizeof(float);
+    const size_t tiles = (size_t)p.splits * p.tiles_m * p.tiles_n * p.v.BM * p.v.BN * sizeof(float);
+    return (rows > tiles ? rows : tiles) + SFAST_WS_TICKET_BYTES;
 }
 
 // The LDS-DMA pipe takes every linear problem; conv problems need uniform taps per K-tile.
@@ -930,10 +939,12 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
     const int bno_sel = geglu ? p.v.BN / 2 : p.v.BN;
     const bool stage_ok = a.N % 8 == 0 && a.ldo % 8 == 0 && aligned16(a.out);
     int red_ty = 0, red_rt = 0;
+    const bool joins = splitk_joins(p, a.tickets != nullptr, a.gn_stats != nullptr, a.gn_rows_per_sample);
+    if (!joins) a.tickets = nullptr;
     if (a.gn_stats) {
         SFAST_REQUIRE(!geglu && stage_ok && a.gn_unit >= 8 && a.gn_rows_per_sample > 0 && a.M % a.gn_rows_per_sample == 0, SFAST_ERR_UNSUPPORTED,
                       "igemm: GroupNorm statistics need a non-GEGLU problem with 16-byte aligned output rows and unit >= 8");
-        if (p.splits == 1) {
+        if (p.splits == 1 || joins) {
             SFAST_REQUIRE(a.gn_rows_per_sample % p.v.BM == 0, SFAST_ERR_UNSUPPORTED, "igemm: %d rows per sample do not tile by BM=%d",
                           a.gn_rows_per_sample, p.v.BM);
             a.gn_slots = stats_slots(bno_sel, a.gn_unit);
@@ -943,9 +954,10 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
             a.gn_slots = ceil_div(a.N, a.gn_unit);
         }
     }
-    a.stage_out = (p.splits == 1 && !geglu && stage_ok && (a.gn_stats != nullptr || g_stage_pref > 0)) ? 1 : 0;
+    a.stage_out = ((p.splits == 1 || joins) && !geglu && stage_ok && (a.gn_stats != nullptr || g_stage_pref > 0)) ? 1 : 0;
     if (p.splits > 1) {
-        const size_t need = (size_t)p.splits * a.M * (geglu ? 2 * (size_t)a.N : (size_t)a.N) * sizeof(float);
+        const size_t need = joins ? (size_t)p.splits * p.tiles_m * p.tiles_n * p.v.BM * p.v.BN * sizeof(float)
+                                  : (size_t)p.splits * a.M * (geglu ? 2 * (size_t)a.N : (size_t)a.N) * sizeof(float);
         SFAST_REQUIRE(ws && ws_bytes >= need, SFAST_ERR_WORKSPACE, "igemm: workspace %zu < %zu", ws_bytes, need);
         a.partial = (float *)ws;
     }
@@ -953,8 +965,9 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
     snprintf(pipe, sizeof(pipe), p.v.pipe == 3 ? "patch%d" : p.v.pipe == 2 ? "ws%d" : p.v.pipe ? "dma%d" : "reg", p.v.ns);
     char xmap[24] = "";
     if (a.xmap) snprintf(xmap, sizeof(xmap), "@xcd%dx%dx%d", 8 >> (a.x_lxm + a.x_lxn), 1 << a.x_lxm, 1 << a.x_lxn);  // K-split x row x column boxes
-    set_kernel_name("igemm_%s_%s%s[%dx%d,split=%d,%s]%s%s", mode ? "conv" : "lin", dtype == SFAST_F16 ? "f16" : "bf16",
-                    geglu ? "_geglu" : "", p.v.BM, p.v.BN, p.splits, pipe, a.gn_stats ? "+gnstats" : (a.stage_out ? "+staged" : ""), xmap);
+    set_kernel_name("igemm_%s_%s%s[%dx%d,split=%d,%s]%s%s%s", mode ? "conv" : "lin", dtype == SFAST_F16 ? "f16" : "bf16",
+                    geglu ? "_geglu" : "", p.v.BM, p.v.BN, p.splits, pipe, a.gn_stats ? "+gnstats" : (a.stage_out ? "+staged" : ""),
+                    joins ? "+join" : "", xmap);  // +join: split-K finished inside this kernel (no reduce launch)
     int rc;
     if (p.v.pipe == 3)
         rc = conv_patch_launch(a, dtype, p.v.BM, p.v.BN, st);
@@ -966,7 +979,7 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
         rc = mode ? dispatch_variant<f16, 1>(a, p.v, geglu, st) : dispatch_variant<f16, 0>(a, p.v, geglu, st);
     else
         rc = mode ? dispatch_variant<bf16, 1>(a, p.v, geglu, st) : dispatch_variant<bf16, 0>(a, p.v, geglu, st);
-    if (rc) return rc;
+    if (rc || joins) return rc;
     if (p.splits > 1 && a.gn_stats) {
         const int R = red_ty * red_rt, CPR = a.N / 8;
         const dim3 grid((unsigned)ceil_div(a.M, R)), block((unsigned)(((CPR * red_ty + 63) / 64) * 64));

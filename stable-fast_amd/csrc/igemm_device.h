@@ -195,9 +195,10 @@ template <int FH, int FM> struct EpiOperands {
 
 template <typename T, int FN, int FM, bool GEGLU>
 __device__ __forceinline__ void epilogue_prefetch(const IgemmArgs &a, EpiOperands<(GEGLU ? FN / 2 : FN), FM> &e, int mbase, int nbase,
-                                                  int l31, int hi) {
+                                                  int l31, int hi, bool whole = false) {
+    // whole: this workgroup holds the sum over all K-splits (splitk_join) -- the epilogue runs although a.splits > 1
     constexpr int FH = GEGLU ? FN / 2 : FN;
-    if (a.splits > 1) return;
+    if (a.splits > 1 && !whole) return;
     const EpiRow<T> bias(a.bias, 0, true), bias_g(a.bias, a.N, true);
 #pragma unroll
     for (int fh = 0; fh < FH; ++fh)
@@ -345,8 +346,8 @@ __device__ __forceinline__ void epilogue_act_tail(const IgemmArgs &a, const Stag
 template <typename T, int FN, int FM, bool GEGLU, bool STAGED>
 __device__ __forceinline__ void epilogue_finish(const IgemmArgs &a, const StageCtx &sc, f32x16 (&acc)[FN][FM],
                                                 const EpiOperands<(GEGLU ? FN / 2 : FN), FM> &e, int mbase, int nbase, int l31, int hi,
-                                                int split_idx) {
-    if (a.splits > 1) {
+                                                int split_idx, bool whole) {
+    if (a.splits > 1 && !whole) {
         store_partial<FN, FM, GEGLU>(a, acc, mbase, nbase, l31, hi, split_idx);
         return;
     }
@@ -389,10 +390,10 @@ __device__ __forceinline__ void epilogue_finish(const IgemmArgs &a, const StageC
 // (Program order = load(f+1), store(f): legal for in-place residuals because fragments never overlap.)
 template <typename T, int FN, int FM, bool STAGED>
 __device__ __forceinline__ void epilogue_late(const IgemmArgs &a, const StageCtx &sc, f32x16 (&acc)[FN][FM], int mbase, int nbase, int l31,
-                                              int hi, int split_idx) {
+                                              int hi, int split_idx, bool whole) {
     typedef const u32x2 __attribute__((address_space(1))) * g2_ptr;
     const g2_ptr zero = (g2_ptr)(const void *)g_zero16;
-    if (a.splits > 1) {
+    if (a.splits > 1 && !whole) {
         store_partial<FN, FM, false>(a, acc, mbase, nbase, l31, hi, split_idx);
         return;
     }
@@ -535,23 +536,98 @@ __device__ __forceinline__ void flush_staged_tile(const IgemmArgs &a, char *lds,
 // One entry for the three kernel files: split-K slab store, or the fused epilogue with direct (STAGED = false) or staged stores.
 // STAGED is a KERNEL template parameter (separate instantiations, chosen on the host from IgemmArgs::stage_out): with both store
 // paths in one kernel the 128-wide tiles ran out of their 256 registers and spilled.
-template <typename T, int BM, int BNO, int FN, int FM, bool GEGLU, bool EPI_EARLY, int NTC, bool STAGED>
+// ---- split-K without a second kernel ----------------------------------------------------------------------------------------
+// Every workgroup of a split tile leaves its fp32 partial accumulators in the workspace IN FRAGMENT ORDER (thread-linear 16-byte
+// groups: the slab layout is private to this function, every access a fully coalesced 1 KiB per wave), publishes them (agent-scope
+// fence) and draws a ticket from the tile's counter; the workgroup that draws the last ticket re-reads ALL the slabs in split order
+// 0 .. splits-1 (so the sum does not depend on which workgroup happened to finish last: bitwise reproducible, and the same order as
+// splitk_reduce_kernel) and goes on into the ordinary epilogue -- bias / residual / activation / staged stores / GroupNorm
+// statistics -- as if it had computed the whole K range. atomicInc wraps the counter back to 0 with the last ticket: the counters
+// are zero again when the launch ends (sfast_hip.h, SFAST_EXT_WS_TICKETS).
+// Measured reason (tools/ws_loop_probe.py, profiles/r03_ws_loop_probe_run7.log): with the reduce as a second launch the part of a
+// split conv that is NOT its K loop costs 20-24 us against 10 us for an unsplit one.
+// Agent-scope accesses of the slabs: relaxed ATOMIC 8-byte stores / loads at agent scope compile to sc1 accesses -- the stores write
+// through this XCD's L2, the loads do not hit in the L1 or in a stale L2 line -- and are ordinary compiler-visible memory operations
+// (the compiler tracks their vmcnt; a first attempt with inline-asm dwordx4 loads carried not-yet-landed registers across the loop
+// back edge). With them no fence is needed around the ticket: a release / acquire fence at agent scope is buffer_wbl2 / buffer_inv,
+// a write-back resp. invalidation of the whole 4 MiB L2 per workgroup -- the fenced version made a joined launch 20-30 us SLOWER than
+// the two-launch form (profiles/r03_splitk_join_fenced_run8.json.log: 157 it/s against 183).
+typedef unsigned long long slab_word;  // two floats
+__device__ __forceinline__ void store_agent(slab_word *p, float x, float y) {
+    __hip_atomic_store(p, (slab_word)__float_as_uint(x) | ((slab_word)__float_as_uint(y) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ slab_word load_agent(const slab_word *p) {
+    return __hip_atomic_load(const_cast<slab_word *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int FN, int FM, int NTC>
+__device__ __forceinline__ bool splitk_join(const IgemmArgs &a, f32x16 (&acc)[FN][FM], char *smem, int tile_id, int split_idx, int ctid) {
+    constexpr int Q = FN * FM * 8;              // 8-byte words per thread (accumulator registers r, r + 1 of a fragment)
+    constexpr int64_t SLAB = (int64_t)Q * NTC;  // words per (tile, split); word q of thread t at q * NTC + t: 512 contiguous bytes per wave
+    slab_word *const tile0 = reinterpret_cast<slab_word *>(a.partial) + (int64_t)tile_id * a.splits * SLAB + ctid;
+    slab_word *const mine = tile0 + split_idx * SLAB;
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) store_agent(mine + ((fn * FM + fm) * 8 + r) * NTC, acc[fn][fm][2 * r], acc[fn][fm][2 * r + 1]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's part of the slab has been written through
+    __syncthreads();                                   // ... every thread's; and nobody reads or lands anything in the LDS ring any more
+    if (ctid == 0)
+        *reinterpret_cast<volatile unsigned *>(smem) = __builtin_amdgcn_atomic_inc32(a.tickets + tile_id, (unsigned)(a.splits - 1), __ATOMIC_RELAXED, "agent");
+    __syncthreads();
+    const unsigned ticket = *reinterpret_cast<volatile unsigned *>(smem);
+    if (ticket != (unsigned)(a.splits - 1)) return false;
+    // the last ticket: sum all slabs in split order 0 .. S-1 (its own included: read back, so that the order never depends on who is last)
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[fn][fm][r] = 0.f;
+    for (int sp = 0; sp < a.splits; ++sp) {
+        const slab_word *src = tile0 + sp * SLAB;
+        slab_word v[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) v[q] = load_agent(src + q * NTC);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            acc[(q / 8) / FM][(q / 8) % FM][2 * (q % 8)] += __uint_as_float((unsigned)v[q]);
+            acc[(q / 8) / FM][(q / 8) % FM][2 * (q % 8) + 1] += __uint_as_float((unsigned)(v[q] >> 32));
+        }
+    }
+    __syncthreads();  // the ticket word sits in the LDS the staged epilogue is about to use
+    return true;
+}
+
+// JOIN = false compiles the in-kernel split-K join out (the single-stream LDS-DMA kernels of igemm_glds.hip sit at the SGPR limit;
+// igemm_run never hands them tickets)
+template <typename T, int BM, int BNO, int FN, int FM, bool GEGLU, bool EPI_EARLY, int NTC, bool STAGED, bool JOIN = true>
 __device__ __forceinline__ void run_epilogue(const IgemmArgs &a, f32x16 (&acc)[FN][FM],
-                                             const EpiOperands<(EPI_EARLY ? (GEGLU ? FN / 2 : FN) : 1), (EPI_EARLY ? FM : 1)> &epi, char *smem,
+                                             EpiOperands<(EPI_EARLY ? (GEGLU ? FN / 2 : FN) : 1), (EPI_EARLY ? FM : 1)> &epi, char *smem,
                                              int m0, int n0, int mbase, int nbase, int l31, int hi, int ctid, int split_idx) {
+    bool whole = false;
+    if (JOIN && a.splits > 1 && a.tickets != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA request of this wave is still on its way into the ring
+        const int tile_id = (m0 / BM) * a.tiles_n + n0 / BNO;
+        if (!splitk_join<FN, FM, NTC>(a, acc, smem, tile_id, split_idx, ctid)) return;
+        whole = true;  // from here on: the workgroup that owns the finished tile
+        if constexpr (EPI_EARLY) epilogue_prefetch<T, FN, FM, GEGLU>(a, epi, mbase, nbase, l31, hi, true);
+    }
     StageCtx sc{smem, m0, n0, BNO * 2 + 8};
     if constexpr (STAGED) {
         __syncthreads();  // LDS ring is free: every wave is past its last fragment read and its last LDS-DMA has landed
         if constexpr (EPI_EARLY)
-            epilogue_finish<T, FN, FM, GEGLU, true>(a, sc, acc, epi, mbase, nbase, l31, hi, split_idx);
+            epilogue_finish<T, FN, FM, GEGLU, true>(a, sc, acc, epi, mbase, nbase, l31, hi, split_idx, whole);
         else
-            epilogue_late<T, FN, FM, true>(a, sc, acc, mbase, nbase, l31, hi, split_idx);
+            epilogue_late<T, FN, FM, true>(a, sc, acc, mbase, nbase, l31, hi, split_idx, whole);
         flush_staged_tile<T, BM, BNO, NTC>(a, smem, m0, n0, ctid);
     } else {
         if constexpr (EPI_EARLY)
-            epilogue_finish<T, FN, FM, GEGLU, false>(a, sc, acc, epi, mbase, nbase, l31, hi, split_idx);
+            epilogue_finish<T, FN, FM, GEGLU, false>(a, sc, acc, epi, mbase, nbase, l31, hi, split_idx, whole);
         else
-            epilogue_late<T, FN, FM, false>(a, sc, acc, mbase, nbase, l31, hi, split_idx);
+            epilogue_late<T, FN, FM, false>(a, sc, acc, mbase, nbase, l31, hi, split_idx, whole);
     }
 }
 

@@ -32,7 +32,9 @@ constexpr int ws_min_waves(int threads, int lds_bytes) {
     return (threads == 512 && lds_bytes <= 48 * 1024) ? 6 : igemm_min_waves(threads, lds_bytes);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int PW, int NS, int MODE, bool GEGLU, bool STAGED = false>
+// EXP != 0: timing-only experiment instantiations (tools/ws_loop_probe.py; results are garbage): bit 0 no MFMAs, bit 1 no fragment
+// reads, bit 2 no LDS-DMA requests inside the loop (the producers only wait and meet the barrier), bit 3 weight requests only.
+template <typename T, int BM, int BN, int WM, int WN, int PW, int NS, int MODE, bool GEGLU, bool STAGED = false, int EXP = 0>
 __global__ void __launch_bounds__((WM * WN + PW) * 64, ws_min_waves((WM * WN + PW) * 64, NS *(BM + BN) * 128))
     igemm_glds_ws_kernel(const IgemmArgs a) {
     using vec8 = typename Elem<T>::vec8;
@@ -155,7 +157,10 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, ws_min_waves((WM * WN + P
             char *sw = sx + BM * 128;
             const bool tile_ok = issued < kt_end;
             const int k = issued * 64;
-            if (MODE == 0) {
+            if constexpr ((EXP & 8) != 0) {
+#pragma unroll
+                for (int i = 0; i < XCH; ++i) __builtin_amdgcn_global_load_lds(zero_src, (ws_dst_t)(sx + i * (RPP * 128)), 16, 0, 0);
+            } else if (MODE == 0) {
 #pragma unroll
                 for (int i = 0; i < XCH; ++i) {
                     const bool ok = tile_ok & (xrow[i] != nullptr) & (k + kc * 8 < a.K);
@@ -199,9 +204,9 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, ws_min_waves((WM * WN + P
 #pragma unroll
         for (int s = 0; s < NS - 1; ++s) issue_tile();
         for (int kt = kt_begin; kt < kt_end; ++kt) {
-            ws_wait_vmcnt<L *(NS - 2)>();     // tile kt has landed (this wave's share)
+            ws_wait_vmcnt<((EXP & 4) ? 0 : L *(NS - 2))>();  // tile kt has landed (this wave's share)
             __builtin_amdgcn_s_barrier();     // consumers finished tile kt-1: its stage is free
-            issue_tile();                     // tile kt+NS-1 -> that stage
+            if constexpr ((EXP & 4) == 0) issue_tile();  // tile kt+NS-1 -> that stage
         }
         ws_wait_vmcnt<0>();  // the zero-filled tail requests must have landed before the LDS is released
         return;
@@ -232,7 +237,17 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, ws_min_waves((WM * WN + P
     // showed the loop indifferent to a third less LDS-DMA traffic, i.e. not bound by it.)
     int cstage = 0;
     vec8 af[2][FN], bf[2][FM];
+    if constexpr ((EXP & 2) != 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) af[q][fn] = vec8{};
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) bf[q][fm] = vec8{};
+        }
+    }
     auto read_frags = [&](const char *xs, int ks, int set) {
+        if constexpr ((EXP & 2) != 0) return;
         const char *ws = xs + BM * 128;
         const int chunk = ks * 2 + hi;
 #pragma unroll
@@ -262,7 +277,13 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, ws_min_waves((WM * WN + P
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
-                for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = mfma32(af[ks & 1][fn], bf[ks & 1][fm], acc[fn][fm]);
+                for (int fm = 0; fm < FM; ++fm) {
+                    if constexpr ((EXP & 1) == 0) {
+                        acc[fn][fm] = mfma32(af[ks & 1][fn], bf[ks & 1][fm], acc[fn][fm]);
+                    } else {
+                        asm volatile("" ::"v"(af[ks & 1][fn]), "v"(bf[ks & 1][fm]));  // the fragment reads stay
+                    }
+                }
         }
     }
 
@@ -316,6 +337,7 @@ int igemm_glds_ws_init() {
 }
 
 extern unsigned long long *g_igemm_trace;  // igemm_glds.hip
+extern int g_igemm_exp;                     // igemm_glds.hip (SFAST_IGEMM_EXP, latched by sfast_hip_set_trace)
 
 template <typename T, int MODE>
 static int ws_dispatch(const IgemmArgs &a, int BM_, int BN_, int NS_, bool geglu, hipStream_t st) {
@@ -331,6 +353,22 @@ static int ws_dispatch(const IgemmArgs &a, int BM_, int BN_, int NS_, bool geglu
         auto kern = igemm_glds_ws_kernel<TT, BM, BN, WM, WN, PW, NS, MODE_, G_>;                                               \
         hipLaunchKernelGGL(kern, igemm_grid(a), dim3((WM * WN + PW) * 64), NS *(BM + BN) * 128, st, a); \
         return check_launch("igemm_glds_ws");                                                                                  \
+    }
+    if constexpr (std::is_same<T, f16>::value && MODE == 1) {
+        if (g_igemm_exp != 0 && !geglu && !a.stage_out) {  // timing experiments: two conv tiles only
+#define LAUNCH_EXP(BM, BN, WM, WN, NS, E)                                                                                      \
+    if (BM_ == BM && BN_ == BN && NS_ == NS && g_igemm_exp == E) {                                                             \
+        auto kern = igemm_glds_ws_kernel<f16, BM, BN, WM, WN, 4, NS, 1, false, false, E>;                                      \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, NS *(BM + BN) * 128); \
+        hipLaunchKernelGGL(kern, igemm_grid(a), dim3((WM * WN + 4) * 64), NS *(BM + BN) * 128, st, a);                         \
+        return check_launch("igemm_glds_ws_exp");                                                                              \
+    }
+            LAUNCH_EXP(128, 128, 2, 2, 4, 1) LAUNCH_EXP(128, 128, 2, 2, 4, 2) LAUNCH_EXP(128, 128, 2, 2, 4, 3)
+            LAUNCH_EXP(128, 128, 2, 2, 4, 4) LAUNCH_EXP(128, 128, 2, 2, 4, 7) LAUNCH_EXP(128, 128, 2, 2, 4, 8)
+            LAUNCH_EXP(128, 160, 4, 1, 4, 1) LAUNCH_EXP(128, 160, 4, 1, 4, 2) LAUNCH_EXP(128, 160, 4, 1, 4, 3)
+            LAUNCH_EXP(128, 160, 4, 1, 4, 4) LAUNCH_EXP(128, 160, 4, 1, 4, 7) LAUNCH_EXP(128, 160, 4, 1, 4, 8)
+#undef LAUNCH_EXP
+        }
     }
     if (!geglu) {
         SFAST_FOR_WS_VARIANTS(T, MODE, LAUNCH_OP)

@@ -138,6 +138,7 @@ def tune_plan(plan, device, dtype_tag="f16", verbose=False):
     if not todo:
         return 0
     ws = torch.empty(MAX_SLAB_BYTES, dtype=torch.uint8, device=device)
+    L.check(lib.sfast_hip_workspace_init(ws.data_ptr(), ws.numel(), torch.cuda.current_stream(device).cuda_stream), "sfast_hip_workspace_init")
     for t in plan.pool.all:
         t.zero_()
     stream = torch.cuda.current_stream(device)
@@ -170,6 +171,8 @@ def tune_plan(plan, device, dtype_tag="f16", verbose=False):
                 if (s > 1 and wgs > 2048) or (s == 1 and wgs > 8192 and bm * bn < 128 * 128):
                     continue  # no split-K once the tiles alone fill the chip; no 64-wide tiles on problems of > 8192 of them
                 p.variant, p.split_k = v, s
+                if (lib.sfast_hip_conv2d_workspace_bytes if is_conv else lib.sfast_hip_gemm_workspace_bytes)(C.byref(p)) > ws.numel():
+                    continue
                 if launch_with(sp, ws.data_ptr(), ws.numel()) != 0:
                     continue
                 k = L.last_kernel()

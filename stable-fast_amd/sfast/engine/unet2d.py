@@ -232,6 +232,12 @@ def capture_plan_graph(plan, stream, pool=None, tail=None, calibrate=True):
     return best[2], best[1]
 
 
+# sfast_epilogue_ext.flags of every GEMM / conv launch of a plan. SFAST_SPLITK_JOIN=1: split-K problems finish inside the GEMM kernel
+# (ticket counters at the end of the plan's workspace) instead of a reduce launch -- off by default, it measured slower on the SD1.5
+# step (one workgroup per tile re-reads all slabs; DESIGN.md round 3, profiles/r03_splitk_join_*.json.log)
+EXT_FLAGS = L.EXT_WS_TICKETS if os.environ.get("SFAST_SPLITK_JOIN", "0") not in ("0", "false", "off", "") else 0
+
+
 class DeviceHost:
     """What an engine asks of its surroundings: the C-ABI library, a ROCm device, streams, whether to measure kernel choices.
     This is the only implementation the package has -- the real library on a real device, no CPU path. (The planner tests replace
@@ -516,16 +522,16 @@ class UNet2DEngine:
         rp = residual.data_ptr() if residual is not None else None
         op = out.data_ptr() + out_offset * self.esize
         ws = plan.ws if lane == LANE_MAIN else plan.ws_side
-        ext = L.EpilogueExt()
+        ext, text = L.EpilogueExt(0.0, 0, 0, EXT_FLAGS), L.EpilogueExt(0.0, 0, 0, EXT_FLAGS)  # (text: the tuner's launches, never statistics)
         stats = [None]  # device buffer of GroupNorm partial statistics once a consumer asks for them (_fuse_gn_statistics)
-        plan.keep += [p, segs, ext]
+        plan.keep += [p, segs, ext, text]
 
         def launch(stream, p=p, segs=segs, ext=ext, stats=stats):
             L.check(lib.sfast_hip_gemm_ex(xp, segs, bp, None, rp, op, C.byref(p), C.byref(ext), stats[0].data_ptr() if stats[0] is not None else None,
                                           ws[0].data_ptr() if ws[0] is not None else None, ws[1], stream), name)
 
-        def launch_with(stream, ws_ptr, ws_bytes, p=p, segs=segs):
-            return lib.sfast_hip_gemm(xp, segs, bp, None, rp, op, C.byref(p), ws_ptr, ws_bytes, stream)
+        def launch_with(stream, ws_ptr, ws_bytes, p=p, segs=segs, text=text):
+            return lib.sfast_hip_gemm_ex(xp, segs, bp, None, rp, op, C.byref(p), C.byref(text), None, ws_ptr, ws_bytes, stream)
 
         if out_offset == 0 and ldo == N and lane == LANE_MAIN:
             plan.writer[id(out)] = dict(buf=out, name=name, p=p, ext=ext, stats=stats, conv=False, lane=lane)
@@ -592,16 +598,16 @@ class UNet2DEngine:
         zp = z.data_ptr() if z is not None else None
         op = out.data_ptr()
         ws = plan.ws
-        ext = L.EpilogueExt()
+        ext, text = L.EpilogueExt(0.0, 0, 0, EXT_FLAGS), L.EpilogueExt(0.0, 0, 0, EXT_FLAGS)
         stats = [None]
-        plan.keep += [p, ext]
+        plan.keep += [p, ext, text]
 
         def launch(stream, p=p, ext=ext, stats=stats):
             L.check(lib.sfast_hip_conv2d_ex(xp, x2p, wp, bp, rbp, zp, op, C.byref(p), C.byref(ext), stats[0].data_ptr() if stats[0] is not None else None,
                                             ws[0].data_ptr() if ws[0] is not None else None, ws[1], stream), name)
 
-        def launch_with(stream, ws_ptr, ws_bytes, p=p):
-            return lib.sfast_hip_conv2d(xp, x2p, wp, bp, rbp, zp, op, C.byref(p), ws_ptr, ws_bytes, stream)
+        def launch_with(stream, ws_ptr, ws_bytes, p=p, text=text):
+            return lib.sfast_hip_conv2d_ex(xp, x2p, wp, bp, rbp, zp, op, C.byref(p), C.byref(text), None, ws_ptr, ws_bytes, stream)
 
         if os_ is None:
             plan.writer[id(out)] = dict(buf=out, name=name, p=p, ext=ext, stats=stats, conv=True, lane=LANE_MAIN)
@@ -1113,7 +1119,7 @@ class UNet2DEngine:
                 continue  # the library runs these as one single-pass kernel already (norm.hip gn_small)
             lays = []
             for w in srcs:
-                ext = L.EpilogueExt(0.0, unit, p.HW, 0)
+                ext = L.EpilogueExt(0.0, unit, p.HW, w["ext"].flags)
                 lay = L.GnStatsLayout()
                 q = lib.sfast_hip_conv2d_stats_layout if w["conv"] else lib.sfast_hip_gemm_stats_layout
                 if q(C.byref(w["p"]), C.byref(ext), C.byref(lay)) != 0:
@@ -1150,10 +1156,13 @@ class UNet2DEngine:
                     q = lib.sfast_hip_gemm_workspace_bytes if isinstance(p, L.GemmParams) else lib.sfast_hip_conv2d_workspace_bytes
                     self._need_ws(plan, q(C.byref(p)), op.lane)
         self._fuse_gn_statistics(plan)
-        if plan.ws[1]:
-            plan.ws[0] = torch.empty(plan.ws[1], dtype=torch.uint8, device=dev)
-        if plan.ws_side[1]:
-            plan.ws_side[0] = torch.empty(plan.ws_side[1], dtype=torch.uint8, device=dev)
+        # one scratch buffer per lane, shared by all its operators; the split-K ticket counters of the GEMM / conv kernels live in a
+        # block of their own behind the largest need (sfast_hip.h SFAST_EXT_WS_TICKETS), zeroed here once
+        for holder in (plan.ws, plan.ws_side):
+            if holder[1]:
+                holder[1] = (holder[1] + 255) // 256 * 256 + L.WS_TICKET_BYTES
+                holder[0] = torch.empty(holder[1], dtype=torch.uint8, device=dev)
+                L.check(lib.sfast_hip_workspace_init(holder[0].data_ptr(), holder[1], self.host.stream_ptr(dev)), "sfast_hip_workspace_init")
         plan.side_stream = self.host.new_stream(dev)
 
     def _controlnet_cond_embedding(self, plan, h, B, H, W, c0):

@@ -22,7 +22,7 @@ import threading
 import torch
 
 from ..hip import lib as L
-from .unet2d import DeviceHost, UNet2DEngine, UNetPlan, UnsupportedUNet, _Pool, _as2d, _cfg_get, live_norm_eps
+from .unet2d import EXT_FLAGS, DeviceHost, UNet2DEngine, UNetPlan, UnsupportedUNet, _Pool, _as2d, _cfg_get, live_norm_eps
 
 
 class UnsupportedVae(UnsupportedUNet):
@@ -201,7 +201,7 @@ class VaeDecoderEngine(UNet2DEngine):
         xp = x.data_ptr() + x_off * self.esize
         op = out.data_ptr() + out_off * self.esize
         ws = plan.ws
-        ext = L.EpilogueExt(float(out_scale), 0, 0, 0)
+        ext = L.EpilogueExt(float(out_scale), 0, 0, EXT_FLAGS)
         plan.keep += [p, segs, ext]
         plan.writer.pop(id(out), None)
 

@@ -8,6 +8,7 @@ into a hipGraph), errors surface as RuntimeError. PyTorch is only the allocator 
 here -- every byte of arithmetic runs in libsfast_hip.so.
 """
 import ctypes as C
+import os
 import functools
 from typing import Optional, Sequence
 
@@ -68,6 +69,24 @@ def _ws(nbytes, like):
         return None, 0
     buf = torch.empty(nbytes, dtype=torch.uint8, device=like.device)
     return buf, nbytes
+
+
+# SFAST_SPLITK_JOIN=1: split-K problems of linear() / conv2d() finish inside the GEMM kernel (sfast_hip.h SFAST_EXT_WS_TICKETS) instead of
+# a separate reduce kernel. Off by default: measured on the SD1.5 step it does not pay (profiles/r03_splitk_join_*).
+SPLITK_JOIN = os.environ.get("SFAST_SPLITK_JOIN", "0") not in ("0", "false", "off", "")
+
+
+def _ws_tickets(nbytes, like):
+    """Workspace of a GEMM / conv call whose split-K problems finish inside the kernel (sfast_hip.h SFAST_EXT_WS_TICKETS): the
+    ticket block at its end is zeroed here, once per (fresh) workspace. Returns (buffer, bytes, ext flags)."""
+    if nbytes == 0:
+        return None, 0, 0
+    if not SPLITK_JOIN:
+        return _ws(nbytes, like) + (0,)
+    nbytes = (int(nbytes) + 3) // 4 * 4
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=like.device)
+    L.check(L.load().sfast_hip_workspace_init(buf.data_ptr(), nbytes, _stream(like)), "sfast_hip_workspace_init")
+    return buf, nbytes, L.EXT_WS_TICKETS
 
 
 def _i64x4(vals):
@@ -266,8 +285,8 @@ def linear(x, weight, bias=None, *, act=None, residual=None, alpha=1.0, res_befo
     p.in_act, p.variant, p.split_k = _act(in_act), int(variant), int(split_k)
     segs = (C.c_void_p * len(ws_list))(*[w.data_ptr() for w in ws_list])
     nb = lib.sfast_hip_gemm_workspace_bytes(C.byref(p))
-    wsb, nb = _ws(nb, x)
-    ext = L.EpilogueExt(float(out_scale), int(gn_unit), int(rows_per_sample), 0)
+    wsb, nb, flags = _ws_tickets(nb, x)
+    ext = L.EpilogueExt(float(out_scale), int(gn_unit), int(rows_per_sample), flags)
     stats, lay = None, None
     if gn_unit:
         lay = L.GnStatsLayout()
@@ -418,8 +437,8 @@ def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dila
     p.act, p.res_before_act, p.alpha = _act(act), 1 if res_before_act else 0, float(alpha)
     p.ld_rowbias, p.variant, p.split_k = ld_rb, int(variant), int(split_k)
     nb = lib.sfast_hip_conv2d_workspace_bytes(C.byref(p))
-    wsb, nb = _ws(nb, x)
-    ext = L.EpilogueExt(float(out_scale), int(gn_unit), Ho * Wo, 0)
+    wsb, nb, flags = _ws_tickets(nb, x)
+    ext = L.EpilogueExt(float(out_scale), int(gn_unit), Ho * Wo, flags)
     stats, lay = None, None
     if gn_unit:
         lay = L.GnStatsLayout()

@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "_lib", "libsfast_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # enums (include/sfast_hip.h)
 F16, BF16, F32 = 0, 1, 2
@@ -22,6 +22,8 @@ NHWC, NCHW = 0, 1
 MAX_WSEG = 4
 MAX_GROUPS = 32
 MAX_GEMM_GROUPS = 64
+WS_TICKET_BYTES = 65536   # sfast_hip.h SFAST_WS_TICKET_BYTES: split-K ticket counters at the end of a workspace
+EXT_WS_TICKETS = 1        # sfast_epilogue_ext.flags
 
 EXPORTS = [
     "sfast_hip_abi_version", "sfast_hip_init", "sfast_hip_last_error", "sfast_hip_last_kernel",
@@ -31,7 +33,7 @@ EXPORTS = [
     "sfast_hip_group_norm_apply",
     "sfast_hip_attention", "sfast_hip_attention_bias", "sfast_hip_strided_copy", "sfast_hip_timestep_embedding",
     "sfast_hip_gemv_grouped", "sfast_hip_gemm_grouped", "sfast_hip_qlinear_w8", "sfast_hip_cfg_ddim_step", "sfast_hip_linear_step", "sfast_hip_mix_rows", "sfast_hip_igemm_plan", "sfast_hip_set_trace", "sfast_hip_image_postprocess", "sfast_hip_add_strided",
-    "sfast_hip_schedule_advance", "sfast_hip_conv2d_plan",
+    "sfast_hip_schedule_advance", "sfast_hip_conv2d_plan", "sfast_hip_workspace_init",
 ]
 
 
@@ -70,7 +72,7 @@ class GemmParams(C.Structure):
 
 
 class EpilogueExt(C.Structure):
-    _fields_ = [("out_scale", C.c_float), ("gn_unit", C.c_int32), ("gn_rows_per_sample", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("out_scale", C.c_float), ("gn_unit", C.c_int32), ("gn_rows_per_sample", C.c_int32), ("flags", C.c_int32)]
 
 
 class GnStatsLayout(C.Structure):
@@ -190,6 +192,8 @@ def _declare(lib):
     lib.sfast_hip_mix_rows.argtypes = [vp, vp, vp, vp, vp, C.POINTER(MixParams), vp]
     lib.sfast_hip_linear_step.restype = C.c_int
     lib.sfast_hip_linear_step.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int64, C.c_int64, C.c_int32, vp]
+    lib.sfast_hip_workspace_init.restype = C.c_int
+    lib.sfast_hip_workspace_init.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
     lib.sfast_hip_conv2d_plan.restype = C.c_int
     lib.sfast_hip_conv2d_plan.argtypes = [C.POINTER(ConvParams), C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     lib.sfast_hip_schedule_advance.restype = C.c_int

@@ -55,6 +55,10 @@ class EmuLib:
         self.calls = []
         self.err = b""
 
+    def sfast_hip_workspace_init(self, ws, nbytes, stream):
+        self.calls.append(("workspace_init", int(nbytes)))
+        return 0 if ws and nbytes >= L.WS_TICKET_BYTES else L.ERR_WORKSPACE if hasattr(L, "ERR_WORKSPACE") else -3
+
     # ---- forwarded host-only queries ---------------------------------------------------------
     def sfast_hip_group_norm_workspace_bytes(self, ref):
         return self.real.sfast_hip_group_norm_workspace_bytes(ref)

@@ -432,6 +432,68 @@ def test_conv_split_k(split):
         compare(f"conv dma v{v} split{split}", y, R.conv2d_ref(x, w, b, z, 1.0, 1, 1), *tol(x.dtype, 2.0), kernel=last_kernel())
 
 
+@pytest.mark.parametrize("variant,split", [(1, 3), (4, 12), (2, 4), (21, 6), (22, 8), (23, 12), (24, 3), (25, 5), (32, 5), (34, 10)])
+def test_split_k_join_matches_the_reduce_kernel(variant, split, monkeypatch):
+    """Split-K finished inside the GEMM kernel (ticket counters, sfast_hip.h SFAST_EXT_WS_TICKETS) against the two-launch form (fp32
+    row slabs + splitk_reduce_kernel): both sum the splits in order 0 .. S-1, so the outputs agree to the last bit -- whichever
+    workgroup happened to draw the last ticket, launch after launch."""
+    x, w, b = cl(rnd(2, 1280, 16, 16, seed=176)), cl(rnd(1280, 1280, 3, 3, seed=177, scale=11520 ** -0.5)), rnd(1280, seed=178)
+    z = cl(rnd(2, 1280, 16, 16, seed=179))
+    fm = F()
+    monkeypatch.setattr(fm, "SPLITK_JOIN", True)
+    run = lambda: fm.conv2d(x, w, b, z=z, padding=1, act="silu", res_before_act=True, split_k=split, variant=variant)
+    y = run()
+    k = last_kernel()
+    assert f"split={split}," in k and "+join" in k, k
+    for _ in range(4):
+        assert torch.equal(run(), y), k
+    monkeypatch.setattr(fm, "SPLITK_JOIN", False)
+    y2 = run()
+    k2 = last_kernel()
+    assert f"split={split}," in k2 and "+join" not in k2, k2
+    ref = R.conv2d_ref(x, w, b, z, 1.0, 1, 1, act="silu", res_before_act=True)
+    compare(f"conv join v{variant} split{split}", y, ref, *tol(x.dtype, 2.0), kernel=k)
+    compare(f"conv reduce v{variant} split{split}", y2, ref, *tol(x.dtype, 2.0), kernel=k2)
+    assert float((y.float() - y2.float()).abs().max()) <= 2e-3, (k, k2)
+
+
+@pytest.mark.parametrize("variant,split", [(21, 3), (23, 6), (1, 4), (3, 2)])
+def test_split_k_join_linear_geglu_and_ragged(variant, split, monkeypatch):
+    """GEGLU (both halves travel through the slabs) and a problem whose tiles hang over M and N."""
+    monkeypatch.setattr(F(), "SPLITK_JOIN", True)
+    x, w, b = rnd(256, 1280, seed=36), rnd(2 * 640, 1280, seed=37, scale=1280 ** -0.5), rnd(2 * 640, seed=38)
+    y = F().linear(x, w, b, geglu=True, variant=variant, split_k=split)
+    k = last_kernel()
+    if "geglu" in k and f"split={split}," in k:
+        assert "+join" in k, k
+        compare(f"geglu join v{variant} split{split}", y, R.linear_ref(x, w, b, geglu=True), *tol(x.dtype), kernel=k)
+    x, w, b, r = rnd(130, 5128, seed=43), rnd(1284, 5128, seed=44, scale=5128 ** -0.5), rnd(1284, seed=45), rnd(130, 1284, seed=46)
+    y = F().linear(x, w, b, residual=r, variant=variant, split_k=split)
+    k = last_kernel()
+    assert "+join" in k, k
+    compare(f"linear ragged join v{variant} split{split}", y, R.linear_ref(x, w, b, residual=r), *tol(x.dtype), kernel=k)
+
+
+@pytest.mark.parametrize("variant,split", [(21, 4), (23, 6), (3, 3)])
+def test_split_k_join_emits_groupnorm_statistics(variant, split, monkeypatch):
+    """With the join the workgroup that finishes a tile runs the staged epilogue, statistics included (no reduce-rows kernel)."""
+    import numpy as np
+    monkeypatch.setattr(F(), "SPLITK_JOIN", True)
+    cin, cout, hw, unit = 640, 1280, 16, 20
+    x = cl(rnd(2, cin, hw, hw, seed=200, shift=0.5))
+    w = cl(rnd(cout, cin, 3, 3, seed=201, scale=(9 * cin) ** -0.5))
+    b, z = rnd(cout, seed=202, shift=2.0), cl(rnd(2, cout, hw, hw, seed=203))
+    y, stats, lay = F().conv2d(x, w, b, z=z, padding=1, variant=variant, split_k=split, gn_unit=unit)
+    k = last_kernel()
+    assert "+gnstats+join" in k and f"split={split}," in k, k
+    want = _stats_reference(y.permute(0, 2, 3, 1).reshape(-1, cout), lay)
+    got = stats.double().cpu().numpy().reshape(want.shape)
+    used = ~np.isnan(want)
+    assert np.allclose(got[..., 0][used[..., 0]], want[..., 0][used[..., 0]], rtol=1e-4, atol=1e-4), k
+    assert np.allclose(got[..., 1][used[..., 1]], want[..., 1][used[..., 1]], rtol=2e-3, atol=1e-2), k
+    compare(f"conv join+stats v{variant} s{split}", y, R.conv2d_ref(x, w, b, z, 1.0, 1, 1), *tol(x.dtype, 2.0), kernel=k)
+
+
 def test_conv_broadcast_z_folds_to_rowbias():
     x, w, b = cl(rnd(2, 320, 32, 32, seed=80)), cl(rnd(320, 320, 3, 3, seed=81, scale=2880 ** -0.5)), rnd(320, seed=82)
     z = rnd(2, 320, 1, 1, seed=83)  # time-embedding broadcast (cudnn_convolution_impl.cc:1045-1053)

@@ -49,6 +49,16 @@ s6)  # fragment reads pipelined across the tile barrier (igemm_glds_ws + conv_pa
   run bench_pk 600 python bench.py --steps 50 --warmup 10 --no-end-to-end --no-cpu-baseline
   SFAST_TUNE_PACKAGED=0 SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_cache.json run bench_tuned 900 python bench.py --steps 50 --warmup 10 --no-end-to-end --no-cpu-baseline --dump-kernels gpurun_out/kernels.json
   ;;
+s7)  # K-loop experiments of the wave-specialised conv kernel; addmm epilogue parameters
+  run ws_probe 600 python tools/ws_loop_probe.py
+  run t_addmm 600 $PYT tests/test_reference_api_gpu.py -k "addmm or lowp"
+  ;;
+s8)  # split-K finished inside the GEMM kernel: parity of every GEMM / conv test, then the bench with the join on and off (own tune caches)
+  run t_gemm 1200 $PYT tests/test_ops_gpu.py -k "gemm or conv or linear or geglu or split"
+  SFAST_TUNE_PACKAGED=0 SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_cache_join.json run bench_join 900 python bench.py --steps 50 --warmup 10 --no-end-to-end --no-cpu-baseline --dump-kernels gpurun_out/kernels.json
+  SFAST_SPLITK_JOIN=0 SFAST_TUNE_PACKAGED=0 SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_cache_nojoin.json run bench_nojoin 900 python bench.py --steps 50 --warmup 10 --no-end-to-end --no-cpu-baseline
+  run t_unet 900 $PYT tests/test_unet_gpu.py -k "sd15_unet_parity or tiny" 
+  ;;
 full)
   run t_all 1500 $PYT tests
   run smoke 600 python __graft_entry__.py smoke
