@@ -48,7 +48,9 @@ constexpr int CP_SPREAD = 7;   // the next slice's patch is requested during tap
 // producer wave carry both kinds and padded the patch share of every unit with requests into a sink to keep the count constant:
 // 72 requests per slice and wave against the 81 of the implicit-im2col kernel, a ring one stage shallower -- and 0.73-0.82x its speed,
 // profiles/r03_conv_patch_ab_run4.log. A CU retires one 1-KiB LDS-DMA request per ~28 cycles: requests are the currency.)
-template <typename T, int BM, int BN, int WM, int WN, int PWW, int PWP, int NSW, bool STAGED>
+// EXP != 0: timing-only experiment instantiations (tools/ws_loop_probe.py --patch; results are garbage): bit 0 no MFMAs, bit 1 no fragment
+// reads, bit 2 no weight requests inside the loop, bit 3 no patch requests inside the loop.
+template <typename T, int BM, int BN, int WM, int WN, int PWW, int PWP, int NSW, bool STAGED, int EXP = 0>
 __global__ void __launch_bounds__((WM * WN + PWW + PWP) * 64, (WM * WN + PWW + PWP) / 4) conv_patch_kernel(const IgemmArgs a, const PatchGeom g) {
     using vec8 = typename Elem<T>::vec8;
     constexpr int NC = WM * WN * 64, NPW = PWW * 64;
@@ -58,7 +60,7 @@ __global__ void __launch_bounds__((WM * WN + PWW + PWP) * 64, (WM * WN + PWW + P
     constexpr int WNB = FN * 32;
     constexpr int PPT = (CP_MAXPI + CP_SPREAD - 1) / CP_SPREAD;  // patch requests per patch-producer wave and unit
     static_assert((BN * 8) % NPW == 0 && RPP % 16 == 0, "weight staging mismatch");
-    static_assert(NSW >= 3 && NSW <= 5 && WCH * (NSW - 2) <= 63, "ring depth / vmcnt field");
+    static_assert(NSW >= 3 && NSW <= 5 && WCH * (NSW - 1) <= 63, "ring depth / vmcnt field");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *const pbuf0 = smem;
@@ -121,7 +123,7 @@ __global__ void __launch_bounds__((WM * WN + PWW + PWP) * 64, (WM * WN + PWW + P
             const bool more = (cs + 1) * 9 < u_end;
 #pragma unroll
             for (int t = 0; t < CP_SPREAD; ++t) {   // (static indices into ppix: one uniform branch per tap)
-                if (tap == t && more) {
+                if (tap == t && more && (EXP & 8) == 0) {
 #pragma unroll
                     for (int j = 0; j < PPT; ++j)
                         if (t * PPT + j < CP_MAXPI) issue_patch(t * PPT + j, cs + 1);
@@ -161,12 +163,17 @@ __global__ void __launch_bounds__((WM * WN + PWW + PWP) * 64, (WM * WN + PWW + P
             }
             wstage = (wstage + 1 == NSW) ? 0 : wstage + 1;
         };
+        // NSW tiles at the start; barrier u + 1 (the consumers then hold all of unit u in registers) refills unit u's stage with
+        // unit u + NSW (igemm_glds_ws.hip, producer loop)
+        int u_next = u_begin;
 #pragma unroll
-        for (int s = 0; s < NSW - 1; ++s) issue_weights(u_begin + s);
-        for (int u = u_begin; u < u_end; ++u) {
-            cp_wait_vmcnt<WCH *(NSW - 2)>();  // unit u's tile has landed (this wave's share; requests retire in order)
-            __builtin_amdgcn_s_barrier();     // consumers finished unit u - 1: its stage is free
-            issue_weights(u + NSW - 1);
+        for (int s = 0; s < NSW; ++s) issue_weights(u_next++);
+        cp_wait_vmcnt<WCH *(NSW - 1)>();
+        __builtin_amdgcn_s_barrier();
+        for (int u = u_begin + 1; u < u_end; ++u) {
+            cp_wait_vmcnt<((EXP & 4) ? 0 : WCH *(NSW - 2))>();  // unit u's tile has landed (this wave's share; requests retire in order)
+            __builtin_amdgcn_s_barrier();
+            if constexpr ((EXP & 4) == 0) issue_weights(u_next++);
         }
         cp_wait_vmcnt<0>();  // nothing may still be landing when the LDS is released / re-used by the epilogue
         return;
@@ -220,7 +227,17 @@ __global__ void __launch_bounds__((WM * WN + PWW + PWP) * 64, (WM * WN + PWW + P
             pswz[fm] = (pp >> 1) & 7;
         }
     };
+    if constexpr ((EXP & 2) != 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) af[q][fn] = vec8{};
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) bf[q][fm] = vec8{};
+        }
+    }
     auto read_frags = [&](int ks, int set) {
+        if constexpr ((EXP & 2) != 0) return;
         const int chunk = ks * 2 + hi;
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn)
@@ -255,7 +272,13 @@ __global__ void __launch_bounds__((WM * WN + PWW + PWP) * 64, (WM * WN + PWW + P
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
-                for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = mfma32(af[ks & 1][fn], bf[ks & 1][fm], acc[fn][fm]);
+                for (int fm = 0; fm < FM; ++fm) {
+                    if constexpr ((EXP & 1) == 0) {
+                        acc[fn][fm] = mfma32(af[ks & 1][fn], bf[ks & 1][fm], acc[fn][fm]);
+                    } else {
+                        asm volatile("" ::"v"(af[ks & 1][fn]), "v"(bf[ks & 1][fm]));  // the fragment reads stay
+                    }
+                }
         }
     }
 
@@ -297,10 +320,25 @@ bool conv_patch_fits(int H, int W, int M, int BM, int BN) {
     return npi <= 2 * CP_MAXPI && patch_ring_depth(BM, BN, npi * 1024, false) >= 3;
 }
 
+extern int g_igemm_exp;  // igemm_glds.hip (SFAST_IGEMM_EXP, latched by sfast_hip_set_trace)
+
 template <typename T, int BM, int BN, int WM, int WN, int NSW>
 static int patch_launch_one(const IgemmArgs &a, const PatchGeom &g, hipStream_t st) {
     const size_t smem = patch_lds_bytes(BN, NSW, g.patch_bytes);
     const dim3 block((WM * WN + 4) * 64);
+    if constexpr (std::is_same<T, f16>::value && NSW >= 4 && BN >= 128) {
+        if (g_igemm_exp != 0 && !a.stage_out) {  // timing experiments
+#define PATCH_EXP(E)                                                                                                              \
+    if (g_igemm_exp == E) {                                                                                                       \
+        auto kern = conv_patch_kernel<f16, BM, BN, WM, WN, 2, 2, NSW, false, E>;                                                  \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
+        hipLaunchKernelGGL(kern, igemm_grid(a), block, smem, st, a, g);                                                           \
+        return check_launch("conv_patch_exp");                                                                                    \
+    }
+            PATCH_EXP(1) PATCH_EXP(2) PATCH_EXP(3) PATCH_EXP(4) PATCH_EXP(8) PATCH_EXP(12) PATCH_EXP(15)
+#undef PATCH_EXP
+        }
+    }
     static bool attr_done = false;  // per instantiation, idempotent: the kernels may use the whole 160 KiB (the size depends on the image width)
     if (!attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(conv_patch_kernel<T, BM, BN, WM, WN, 2, 2, NSW, true>),

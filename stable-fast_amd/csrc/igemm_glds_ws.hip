@@ -51,7 +51,7 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, ws_min_waves((WM * WN + P
     constexpr int L = XCH + WCH;  // LDS-DMA requests per producer thread per K-tile
     static_assert((BM * 8) % NP == 0 && (BN * 8) % NP == 0, "staging mismatch");
     static_assert(RPP % 16 == 0, "swizzle phase must not depend on the staging pass");
-    static_assert(L * (NS - 2) <= 63, "vmcnt field");
+    static_assert(L * (NS - 1) <= 63, "vmcnt field");
     static_assert(NS >= 3 && NS <= 5, "ring depth");
     static_assert(!GEGLU || (FN % 2 == 0), "GEGLU needs paired fragments");
 
@@ -201,12 +201,17 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, ws_min_waves((WM * WN + P
             istage = (istage + 1 == NS) ? 0 : istage + 1;
         };
 
+        // The consumers meet barrier k + 1 BEFORE the last k-step's MFMAs of tile k, with every fragment of tile k in registers (see
+        // their loop): the stage of tile k is free from that barrier on, one K-tile period earlier than its last MFMA. So the ring
+        // holds NS tiles at the start, and barrier k + 1 refills the stage of tile k with tile k + NS: NS - 1 tiles in flight.
 #pragma unroll
-        for (int s = 0; s < NS - 1; ++s) issue_tile();
-        for (int kt = kt_begin; kt < kt_end; ++kt) {
-            ws_wait_vmcnt<((EXP & 4) ? 0 : L *(NS - 2))>();  // tile kt has landed (this wave's share)
-            __builtin_amdgcn_s_barrier();     // consumers finished tile kt-1: its stage is free
-            if constexpr ((EXP & 4) == 0) issue_tile();  // tile kt+NS-1 -> that stage
+        for (int s = 0; s < NS; ++s) issue_tile();
+        ws_wait_vmcnt<((EXP & 4) ? 0 : L *(NS - 1))>();  // the first tile has landed (this wave's share)
+        __builtin_amdgcn_s_barrier();
+        for (int kt = kt_begin + 1; kt < kt_end; ++kt) {
+            ws_wait_vmcnt<((EXP & 4) ? 0 : L *(NS - 2))>();  // tile kt has landed
+            __builtin_amdgcn_s_barrier();                    // the consumers hold all of tile kt - 1 in registers: its stage is free
+            if constexpr ((EXP & 4) == 0) issue_tile();      // tile kt - 1 + NS -> that stage
         }
         ws_wait_vmcnt<0>();  // the zero-filled tail requests must have landed before the LDS is released
         return;

@@ -59,9 +59,15 @@ s8)  # split-K finished inside the GEMM kernel: parity of every GEMM / conv test
   SFAST_SPLITK_JOIN=0 SFAST_TUNE_PACKAGED=0 SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_cache_nojoin.json run bench_nojoin 900 python bench.py --steps 50 --warmup 10 --no-end-to-end --no-cpu-baseline
   run t_unet 900 $PYT tests/test_unet_gpu.py -k "sd15_unet_parity or tiny" 
   ;;
-full)
-  run t_all 1500 $PYT tests
+s9)  # K-loop experiments of the LDS-patch conv kernel
+  run patch_probe 600 python tools/ws_loop_probe.py --patch
+  ;;
+full)  # everything but the full-size SVD-XT parity case (run on its own: `svdxt`), slowest tests listed
+  run t_all 1700 $PYT tests -k "not svd_xt_full_size" --durations=15
   run smoke 600 python __graft_entry__.py smoke
+  ;;
+svdxt)
+  run t_svdxt 1500 $PYT tests/test_parity_r3_gpu.py -k "svd_xt_full_size" --durations=5
   ;;
 esac
 cut -c1-400 gpurun_out/session.log

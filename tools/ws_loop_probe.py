@@ -14,8 +14,14 @@ CASES = [  # B, Cin, C2, H, W, Cout, variant, split
     (2, 320, 0, 64, 64, 320, 21, 1), (2, 640, 0, 32, 32, 640, 21, 3), (2, 640, 320, 64, 64, 320, 22, 2), (2, 1280, 640, 32, 32, 640, 22, 4),
     (2, 1280, 1280, 16, 16, 1280, 22, 8),
 ]
+if "--patch" in sys.argv:  # the LDS-patch kernel (conv_patch.hip): bit 2 = no weight requests in the loop, bit 3 = no patch requests in the loop
+    CASES = [(2, 320, 0, 64, 64, 320, 32, 1), (2, 640, 0, 32, 32, 640, 32, 3), (2, 640, 320, 64, 64, 320, 31, 2), (2, 1280, 1280, 16, 16, 1280, 31, 8)]
 NAMES = {0: "full", 1: "no MFMA", 2: "no fragment reads", 3: "no MFMA, no fragment reads", 4: "no in-loop DMA", 7: "loop skeleton",
          8: "weight requests only (x requests read the zero block)"}
+if "--patch" in sys.argv:
+    NAMES = {0: "full", 1: "no MFMA", 2: "no fragment reads", 3: "no MFMA, no fragment reads", 4: "no in-loop weight DMA", 8: "no in-loop patch DMA",
+             12: "no in-loop DMA at all", 15: "loop skeleton"}
+SKEL = 15 if "--patch" in sys.argv else 7
 stream = torch.cuda.Stream()
 lib = L.load()
 trace = torch.zeros(16 * 65536, dtype=torch.int64, device="cuda")
@@ -63,4 +69,4 @@ for (B, Cin, C2, H, W, Cout, v, s) in CASES:
     tiles_k = K // 64 // s
     print(f"conv3x3 B={B} {Cin}+{C2}->{Cout} @{H}x{W}  {kname}  K-tiles per workgroup {tiles_k}  pure MFMA time at 2.5 PF {flops / 2.5e15 * 1e6:.1f} us")
     for ex, t in best.items():
-        print(f"   {NAMES[ex]:58s} {t:7.1f} us   ({(t - best[7]) / tiles_k * 1e3:6.0f} ns per K-tile above the skeleton)", flush=True)
+        print(f"   {NAMES[ex]:58s} {t:7.1f} us   ({(t - best[SKEL]) / tiles_k * 1e3:6.0f} ns per K-tile above the skeleton)", flush=True)
