@@ -150,9 +150,16 @@ def _bounded_sdpa(real, limit_bytes=6 << 30):
 def test_svd_xt_full_size_parity():
     """BASELINE.json configs[4] / the reference's examples/optimize_stable_video_diffusion_pipeline.py workload: SVD-XT UNet
     (`SVD_CONFIG` unmodified: 2 layers per block, widths 320..1280, 1,524,623,082 parameters), 25 frames, 72x128 latent, B = 1."""
+    import time
     from sfast.engine import SVDUNetEngine
+    marks = [("start", time.time())]
+
+    def mark(name):
+        torch.cuda.synchronize()
+        marks.append((name, time.time()))
     cfg = S.SVD_CONFIG
     m = S.build(cfg, seed=61, dtype=torch.float16, device=DEV)
+    mark("build")
     assert sum(p.numel() for p in m.parameters()) == 1_524_623_082
     B, Fr, H, W = 1, 25, 72, 128
     g = torch.Generator().manual_seed(62)
@@ -161,13 +168,18 @@ def test_svd_xt_full_size_parity():
     tids = torch.tensor([[6.0, 127.0, 0.02]] * B, device=DEV)
     t = torch.tensor([500.0], device=DEV)
     eng = SVDUNetEngine.from_module(m)
+    mark("engine")
     y = eng.forward(sample, t, ehs, tids)
+    mark("plan+forward")
     assert y.shape == (B, Fr, cfg["out_channels"], H, W) and torch.isfinite(y).all()
     plan = eng.get_plan(B, Fr, H, W)
     launches = len(plan.ops)
     del eng, plan
+    # (the eager legs run without MIOpen: tests/conftest.py eager_references_without_miopen -- first-use solver compilation was
+    #  245 s + 249 s of this test's 534 s)
     with torch.no_grad():
         y16 = m(sample, t, ehs, tids.half()).sample
+    mark("eager16")
     ref = m.float()  # in place: f16 weights are exactly representable
     real = F.scaled_dot_product_attention
     F.scaled_dot_product_attention = _bounded_sdpa(real)
@@ -176,12 +188,15 @@ def test_svd_xt_full_size_parity():
             with torch.no_grad():
                 return ref(sample.float(), t, ehs.float(), tids).sample
         y32 = fwd()
+        mark("fp32 oracle")
         floor = storage_floor(ref, fwd, y32, extra_leaf=(nn.Conv3d,),
                               extra_comp=(S.TemporalResnetBlock, S.SpatioTemporalResBlock, S.TemporalBasicTransformerBlock, S.AlphaBlender,
                                           S.TransformerSpatioTemporalModel))
     finally:
         F.scaled_dot_product_attention = real
+    mark("floor")
     e, e16 = rel_l2(y, y32), rel_l2(y16, y32)
+    log_value("svd-xt FULL size test phases (seconds)", **{b[0]: round(b[1] - a[1], 1) for a, b in zip(marks, marks[1:])})
     log_value("svd-xt FULL size B=1 F=25 72x128 vs fp32 oracle", engine_vs_fp32=e, eager16_vs_fp32=e16, engine_vs_eager16=rel_l2(y, y16),
               f16_storage_floor=floor, launches=launches, max_abs_engine=float((y.float() - y32).abs().max()), ref_absmax=float(y32.abs().max()),
               peak_mem_gb=torch.cuda.max_memory_allocated() / 2 ** 30)

@@ -63,7 +63,7 @@ s9)  # K-loop experiments of the LDS-patch conv kernel
   run patch_probe 600 python tools/ws_loop_probe.py --patch
   ;;
 full)  # everything but the full-size SVD-XT parity case (run on its own: `svdxt`), slowest tests listed
-  run t_all 1700 $PYT tests -k "not svd_xt_full_size" --durations=15
+  run t_all 1700 $PYT tests --durations=15
   run smoke 600 python __graft_entry__.py smoke
   ;;
 svdxt)
