@@ -1,22 +1,26 @@
 #!/bin/bash
 # HBM-side traffic per kernel symbol of the bench step: FETCH_SIZE and WRITE_SIZE in separate --pmc passes
 # (counters only with --kernel-trace, as the pool requires) over the SAME bench command, autotune results cached.
+# usage: tools/gpu_pmc_bench.sh [sd15|sdxl|svd] [steps]   -> gpurun_out/pmcb/traffic_by_symbol[_<config>].json
 cd "$(dirname "$0")/.."
+CFG=${1:-sd15}
+STEPS=${2:-6}
+SUF=""; [ "$CFG" != "sd15" ] && SUF="_$CFG"
 rm -rf gpurun_out/pmcb; mkdir -p gpurun_out/pmcb
 export TMPDIR=/tmp
 R=$PWD
 export SFAST_TUNE_CACHE=$R/gpurun_out/tune_cache.json
-python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > gpurun_out/pmcb/warm.log 2>&1
+python bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-roofline --no-end-to-end > gpurun_out/pmcb/warm.log 2>&1
 pass() { # name, counters...
   local name=$1; shift
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc "$@" -d $R/gpurun_out/pmcb -o $name -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > $R/gpurun_out/pmcb/$name.log 2>&1 )
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc "$@" -d $R/gpurun_out/pmcb -o $name -- python $R/bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-roofline --no-end-to-end > $R/gpurun_out/pmcb/$name.log 2>&1 )
   echo "pmc $name exit=$? $(tail -n 1 $R/gpurun_out/pmcb/$name.log | cut -c1-100)"
   for db in $(find $R/gpurun_out/pmcb -name "*.db"); do python $R/tools/pmc_extract.py $db $R/gpurun_out/pmcb/$name.json --by-symbol --last-frac 0.4; rm -f $db; done
 }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
-python - <<'PY'
-import json
+SUF=$SUF python - <<'PY'
+import json, os
 f = {r["kernel"]: r for r in json.load(open("gpurun_out/pmcb/fetch.json"))["rows"]}
 w = {r["kernel"]: r for r in json.load(open("gpurun_out/pmcb/write.json"))["rows"]}
 out = {}
@@ -26,7 +30,7 @@ for k, r in f.items():
     # gfx950: FETCH_SIZE counts 128-B fabric requests as 64 B (MI355X_MICROARCH.md, HBM section) -> x2; unit KB
     out[k] = dict(bytes_per_launch=(2.0 * fetch_kb + write_kb) * 1024.0, fetch_kb_raw=fetch_kb, write_kb_raw=write_kb,
                   launches=r["dispatches"], avg_us=r.get("avg_us"))
-json.dump(out, open("gpurun_out/pmcb/traffic_by_symbol.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/pmcb/traffic_by_symbol" + os.environ.get("SUF", "") + ".json", "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -(kv[1]["avg_us"] or 0) * kv[1]["launches"])[:12]:
     print(f"{k[:90]:90s} n={v['launches']:5d} {v['avg_us'] or 0:7.1f} us  {v['bytes_per_launch'] / 1e6:8.2f} MB/launch")
 PY

@@ -66,6 +66,24 @@ full)  # everything but the full-size SVD-XT parity case (run on its own: `svdxt
   run t_all 1700 $PYT tests --durations=15
   run smoke 600 python __graft_entry__.py smoke
   ;;
+final)  # the round's SD1.5 evidence: PMC traffic by symbol, the default bench line (roofline + cpu_baseline + end-to-end), rocprofv3 kernel stats
+  run pmc_traffic 900 bash tools/gpu_pmc_bench.sh sd15 6
+  cp gpurun_out/pmcb/traffic_by_symbol.json profiles/r03_pmc_traffic_by_symbol.json
+  run bench_default 900 python bench.py --dump-kernels gpurun_out/kernels.json
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -o bench -- python $OLDPWD/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-end-to-end > $OLDPWD/gpurun_out/rocprof.log 2>&1 )
+  echo "rocprof exit=$?" >> gpurun_out/session.log
+  for db in $(find gpurun_out/prof -name "*.db"); do python tools/rocpd_summary.py $db --csv gpurun_out/kernel_stats.csv --top 60 --step-marker cfg_ddim --steps 12 > gpurun_out/kernel_stats.txt; done
+  rm -rf gpurun_out/prof
+  run bench_torchrun 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 50 --warmup 10 --no-cpu-baseline --no-roofline --no-end-to-end
+  ;;
+final2)  # SDXL and SVD-XT lines with their own PMC traffic files
+  run pmc_sdxl 900 bash tools/gpu_pmc_bench.sh sdxl 4
+  cp gpurun_out/pmcb/traffic_by_symbol_sdxl.json profiles/r03_pmc_traffic_by_symbol_sdxl.json; cp gpurun_out/pmcb/traffic_by_symbol_sdxl.json gpurun_out/
+  run bench_sdxl 900 python bench.py --config sdxl --steps 20 --warmup 3 --no-cpu-baseline --no-end-to-end
+  run pmc_svd 1200 bash tools/gpu_pmc_bench.sh svd 3
+  cp gpurun_out/pmcb/traffic_by_symbol_svd.json profiles/r03_pmc_traffic_by_symbol_svd.json; cp gpurun_out/pmcb/traffic_by_symbol_svd.json gpurun_out/
+  run bench_svd 900 python bench.py --config svd --steps 8 --warmup 2 --no-cpu-baseline --no-end-to-end
+  ;;
 svdxt)
   run t_svdxt 1500 $PYT tests/test_parity_r3_gpu.py -k "svd_xt_full_size" --durations=5
   ;;
