@@ -4,9 +4,14 @@
 // (/root/reference/src/sfast/csrc/operators/cudnn/cudnn_convolution_impl.cc:995-998, 1265-1286) -- for the case the UNet spends its
 // conv time in: 3x3, stride 1, padding 1, dense NHWC, channel counts that are multiples of 64.
 //
-// Why. Every MFMA conv kernel of this library is bound by what a CU can pull from L2 into LDS, not by its matrix pipe: over the whole
-// SD1.5 step the measured launch times follow  bytes_into_LDS / 13.3 TB/s  (52 GB/s per CU) within a few percent -- 64x64 tiles at the
-// 32x32 level: 472 MB -> 35 us predicted, 34.5 measured; the GEGLU GEMM: 419 MB -> 31 us, 28 measured (profiles/r03_kernels_per_op_run1.json).
+// Why it was written. Over the whole SD1.5 step the launch times of the MFMA conv kernels follow  bytes_into_LDS / 13.3 TB/s  (52 GB/s
+// per CU) within a few percent -- 64x64 tiles at the 32x32 level: 472 MB -> 35 us predicted, 34.5 measured; the GEGLU GEMM: 419 MB ->
+// 31 us, 28 measured (profiles/r03_kernels_per_op_run1.json) -- which reads like a bound on what a CU can pull from L2 into LDS.
+// STATUS: measured, and NOT faster than the implicit-im2col pipes on any SD1.5 shape (0.79-1.00x, profiles/r03_conv_ab_run10.log). The
+// K-loop probes (tools/ws_loop_probe.py, profiles/r03_ws_loop_probe_run7.log, r03_conv_patch_loop_probe_run10.log) show why the fit
+// misled: LDS-DMA time and MFMA time ADD in these loops instead of overlapping, and with two weight-producer waves instead of four
+// this kernel's request issue is slower than the one it replaces. The autotuner measures it like any other candidate and does not
+// pick it; it stays as that measured candidate.
 // The implicit-im2col kernels fetch every input pixel NINE times per tile (once per tap) on top of the weights. Here a workgroup
 // owns BM consecutive output pixels = whole image rows, keeps the (rows + 2) x (W + 2) input patch of ONE 64-channel slice in LDS and
 // runs all nine taps against it: the activation traffic into LDS drops ~9x (for the 16x16 / 8x8 levels the launch then moves little
@@ -286,7 +291,6 @@ __global__ void __launch_bounds__((WM * WN + PWW + PWP) * 64, (WM * WN + PWW + P
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
-// variant ids 31.. (igemm.hip kVariants, pipe 3): tile, consumer waves WM x WN, producer waves, weight ring depth
 // variant ids 31.. (igemm.hip kVariants, pipe 3): tile, consumer waves WM x WN; two weight-producer + two patch-producer waves; the
 // weight ring takes what the patch buffers leave of the 160 KiB (3 .. 5 stages)
 #define SFAST_FOR_PATCH_VARIANTS(T, OP) \

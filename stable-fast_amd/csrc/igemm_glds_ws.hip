@@ -9,9 +9,11 @@
 // four waves sharing it) stalls AT ISSUE, in order, and the MFMAs behind the request in its instruction stream
 // wait with it. Interleaving one request per MFMA did not help for the same reason. Here the waves that stall
 // on the memory pipe are not the waves that feed the matrix pipe:
-//   producers   prologue: NS-1 tiles; per K-tile: s_waitcnt vmcnt(L*(NS-2)) (tile kt landed) -> s_barrier ->
-//               L requests of tile kt+NS-1 into the stage the consumers released at that barrier
-//   consumers   per K-tile: s_barrier -> 4 x (fragment reads one step ahead, FN*FM MFMAs); epilogue
+//   producers   prologue: NS tiles; barrier k (k >= 1): s_waitcnt vmcnt(L*(NS-2)) (tile k landed) -> s_barrier ->
+//               L requests of tile k-1+NS into the stage of tile k-1, which the consumers released at that barrier
+//   consumers   per K-tile: 3 x (fragment reads one step ahead, FN*FM MFMAs); then, with ALL fragments of the tile in registers,
+//               s_barrier (next tile landed / this stage released) -> first fragments of the next tile -> the last FN*FM MFMAs;
+//               epilogue (round 3: the barrier sat at the top of a tile before, with an exposed LDS round trip behind it)
 // One barrier per K-tile for everybody, same LDS image / swizzle / zero-block redirect / tap masks as
 // igemm_glds.hip, same epilogue (igemm_device.h). Register budget: 8 waves per CU -> 256 registers per lane.
 #include "igemm_device.h"
