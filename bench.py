@@ -463,73 +463,88 @@ def end_to_end(args, loop, dev, rank, world, use_dist):
     from sfast.engine.unet_spec import SD_VAE_DECODER_CONFIG, random_vae_decoder_params
     from sfast.hip import functional as Fn
     from transformers import CLIPTextConfig, CLIPTextModel
-    images = args.images
-    torch.manual_seed(0)
-    tcfg = CLIPTextConfig(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
-                          max_position_embeddings=77, hidden_act="quick_gelu", projection_dim=768)
-    text = CLIPTextModel(tcfg).to(dev, torch.float16).eval()
-    n_text = sum(p.numel() for p in text.parameters())
-    text.forward = _graphed_with_fallback(text.forward)
-    vcfg = SD_VAE_DECODER_CONFIG
-    vae = VaeDecoderEngine(vcfg, random_vae_decoder_params(vcfg, seed=0, dtype=torch.float16, device=dev))
-    hw = loop.latents.shape[-1]
-    vplan = vae.get_plan(images, hw, hw)
-    g = torch.Generator(device=dev).manual_seed(77 + rank)
-    pq_w = (torch.randn(4, 4, 1, 1, generator=g, device=dev) * 0.5).half()
-    pq_b = torch.zeros(4, device=dev, dtype=torch.float16)
-    lat0 = torch.randn(images, 4, hw, hw, generator=g, device=dev).half()
-    ids = torch.randint(0, 49408, (2 * images, 77), generator=g, device=dev)
-    ids[:, 0], ids[:, -1] = 49406, 49407
-    host = torch.empty((images, 8 * hw, 8 * hw, 3), dtype=torch.uint8).pin_memory()
-    vstream = torch.cuda.Stream(device=dev)
-    vae.load_inputs(vplan, lat0)
-    with torch.cuda.stream(vstream):
-        vplan.run(vstream.cuda_stream)
-    torch.cuda.synchronize()
-    vgraph, _ = capture_plan_graph(vplan, vstream)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-
-    def one_image(mark=False):
-        with torch.no_grad():
-            if mark:
-                ev[0].record()
-            ehs = text(ids)[0]                                   # [2 * images, 77, 768]: rows [uncond..., cond...]
-            if mark:
-                ev[1].record()
-            loop.set_inputs(lat0, ehs)                            # also runs the text-side K/V projections of the UNet, once
-            loop.set_step(0)
-            for i in range(50):
-                loop.step(i)
-            if mark:
-                ev[2].record()
-            z = TF.conv2d(loop.latents * (1.0 / 0.18215), pq_w, pq_b)   # latents / scaling_factor -> post_quant_conv
-            vae.load_inputs(vplan, z)
-            vgraph.replay()
-            if mark:
-                ev[3].record()
-            img = Fn.image_postprocess(vplan.static_out)          # [-1, 1] NCHW f16 -> uint8 NHWC
-            host.copy_(img, non_blocking=True)
-            if mark:
-                ev[4].record()
-            torch.cuda.synchronize()
-
-    one_image()   # warm-up: captures the text-encoder graph
-    one_image()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-        torch.cuda.synchronize()
-    n = max(1, args.e2e_images)
-    t0 = time.perf_counter()
-    for _ in range(n):
-        one_image()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
+    # N > 1: no rank may be left alone in a collective. Everything that can fail runs between two all-reduces that every rank
+    # reaches: the first carries "my set-up / warm-up failed" (and is the start barrier), the second the elapsed time (inf = failed).
+    def agree(value):
+        if not use_dist:
+            return value
+        t = torch.tensor([value], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-        dist.barrier()
+        torch.cuda.synchronize()
+        return float(t.item())
+
+    err = None
+    try:
+        images = args.images
+        torch.manual_seed(0)
+        tcfg = CLIPTextConfig(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+                              max_position_embeddings=77, hidden_act="quick_gelu", projection_dim=768)
+        text = CLIPTextModel(tcfg).to(dev, torch.float16).eval()
+        n_text = sum(p.numel() for p in text.parameters())
+        text.forward = _graphed_with_fallback(text.forward)
+        vcfg = SD_VAE_DECODER_CONFIG
+        vae = VaeDecoderEngine(vcfg, random_vae_decoder_params(vcfg, seed=0, dtype=torch.float16, device=dev))
+        hw = loop.latents.shape[-1]
+        vplan = vae.get_plan(images, hw, hw)
+        g = torch.Generator(device=dev).manual_seed(77 + rank)
+        pq_w = (torch.randn(4, 4, 1, 1, generator=g, device=dev) * 0.5).half()
+        pq_b = torch.zeros(4, device=dev, dtype=torch.float16)
+        lat0 = torch.randn(images, 4, hw, hw, generator=g, device=dev).half()
+        ids = torch.randint(0, 49408, (2 * images, 77), generator=g, device=dev)
+        ids[:, 0], ids[:, -1] = 49406, 49407
+        host = torch.empty((images, 8 * hw, 8 * hw, 3), dtype=torch.uint8).pin_memory()
+        vstream = torch.cuda.Stream(device=dev)
+        vae.load_inputs(vplan, lat0)
+        with torch.cuda.stream(vstream):
+            vplan.run(vstream.cuda_stream)
+        torch.cuda.synchronize()
+        vgraph, _ = capture_plan_graph(vplan, vstream)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+
+        def one_image(mark=False):
+            with torch.no_grad():
+                if mark:
+                    ev[0].record()
+                ehs = text(ids)[0]                                   # [2 * images, 77, 768]: rows [uncond..., cond...]
+                if mark:
+                    ev[1].record()
+                loop.set_inputs(lat0, ehs)                            # also runs the text-side K/V projections of the UNet, once
+                loop.set_step(0)
+                for i in range(50):
+                    loop.step(i)
+                if mark:
+                    ev[2].record()
+                z = TF.conv2d(loop.latents * (1.0 / 0.18215), pq_w, pq_b)   # latents / scaling_factor -> post_quant_conv
+                vae.load_inputs(vplan, z)
+                vgraph.replay()
+                if mark:
+                    ev[3].record()
+                img = Fn.image_postprocess(vplan.static_out)          # [-1, 1] NCHW f16 -> uint8 NHWC
+                host.copy_(img, non_blocking=True)
+                if mark:
+                    ev[4].record()
+                torch.cuda.synchronize()
+
+
+        one_image()   # warm-up: captures the text-encoder graph
+        one_image()
+        torch.cuda.synchronize()
+    except Exception as e:  # reported below, after every rank has been told
+        err = f"{type(e).__name__}: {e}"
+    if agree(1.0 if err else 0.0) > 0:
+        return {"error": err or "set-up failed on another rank", "n_gpus": world}
+    n = max(1, args.e2e_images)
+    try:
+        t0 = time.perf_counter()
+        for _ in range(n):
+            one_image()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    except Exception as e:
+        err, el = f"{type(e).__name__}: {e}", float("inf")
+    el = agree(el)   # max over ranks
+    if el == float("inf"):
+        return {"error": err or "the timed images failed on another rank", "n_gpus": world}
     one_image(mark=True)
     parts = [ev[i].elapsed_time(ev[i + 1]) for i in range(4)]
     ok = bool(host.float().std() > 0) and bool(torch.isfinite(loop.latents).all())
@@ -862,10 +877,8 @@ def main():
     if args.config == "sd15" and not args.no_end_to_end and not args.no_graph:
         try:
             e2e = end_to_end(args, loop, dev, rank, world, use_dist)
-        except Exception as e:  # the it/s line is the contract; this leg must never take it down
-            if use_dist:
-                raise
-            e2e = {"error": f"{type(e).__name__}: {e}"}
+        except Exception as e:  # the it/s line is the contract; this leg must never take it down (end_to_end() itself keeps the ranks
+            e2e = {"error": f"{type(e).__name__}: {e}"}   # of an N > 1 run in step when one of them fails; this catches the rest)
     if rank == 0:
         if e2e is not None:
             out["end_to_end"] = e2e
