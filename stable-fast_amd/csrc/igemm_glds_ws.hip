@@ -35,7 +35,8 @@ constexpr int ws_min_waves(int threads, int lds_bytes) {
 }
 
 // EXP != 0: timing-only experiment instantiations (tools/ws_loop_probe.py; results are garbage): bit 0 no MFMAs, bit 1 no fragment
-// reads, bit 2 no LDS-DMA requests inside the loop (the producers only wait and meet the barrier), bit 3 weight requests only.
+// reads, bit 2 no LDS-DMA requests inside the loop (the producers only wait and meet the barrier), bit 3 weight requests only,
+// bit 4 / bit 5 (results are CORRECT): s_setprio 3 in the producer / consumer waves.
 template <typename T, int BM, int BN, int WM, int WN, int PW, int NS, int MODE, bool GEGLU, bool STAGED = false, int EXP = 0>
 __global__ void __launch_bounds__((WM * WN + PW) * 64, ws_min_waves((WM * WN + PW) * 64, NS *(BM + BN) * 128))
     igemm_glds_ws_kernel(const IgemmArgs a) {
@@ -72,6 +73,7 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, ws_min_waves((WM * WN + P
     const int kt_end = min(a.ktiles, kt_begin + a.ktiles_per_split);
 
     if (wave >= WM * WN) {
+        if constexpr ((EXP & 16) != 0) __builtin_amdgcn_s_setprio(3);  // experiment: the producers' address arithmetic and requests ahead of the MFMAs
         // =============================== producer wave ===============================================
         const int ptid = tid - NC;
         const int pwave = wave - WM * WN;
@@ -220,6 +222,7 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, ws_min_waves((WM * WN + P
     }
 
     // =================================== consumer wave ===============================================
+    if constexpr ((EXP & 32) != 0) __builtin_amdgcn_s_setprio(3);  // experiment: the MFMA waves ahead of the producers
     const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, hi = lane >> 5;
 
@@ -372,6 +375,7 @@ static int ws_dispatch(const IgemmArgs &a, int BM_, int BN_, int NS_, bool geglu
     }
             LAUNCH_EXP(128, 128, 2, 2, 4, 1) LAUNCH_EXP(128, 128, 2, 2, 4, 2) LAUNCH_EXP(128, 128, 2, 2, 4, 3)
             LAUNCH_EXP(128, 128, 2, 2, 4, 4) LAUNCH_EXP(128, 128, 2, 2, 4, 7) LAUNCH_EXP(128, 128, 2, 2, 4, 8)
+            LAUNCH_EXP(128, 128, 2, 2, 4, 16) LAUNCH_EXP(128, 128, 2, 2, 4, 32) LAUNCH_EXP(128, 160, 4, 1, 4, 16) LAUNCH_EXP(128, 160, 4, 1, 4, 32)
             LAUNCH_EXP(128, 160, 4, 1, 4, 1) LAUNCH_EXP(128, 160, 4, 1, 4, 2) LAUNCH_EXP(128, 160, 4, 1, 4, 3)
             LAUNCH_EXP(128, 160, 4, 1, 4, 4) LAUNCH_EXP(128, 160, 4, 1, 4, 7) LAUNCH_EXP(128, 160, 4, 1, 4, 8)
 #undef LAUNCH_EXP
