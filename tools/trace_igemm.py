@@ -22,6 +22,8 @@ EXPERIMENTS = [
     ("down_blocks.0.resnets.0.conv2", 12, 2),
     ("down_blocks.0.attentions.0.transformer_blocks.0.ff.out", 18, 1),
 ]
+if "--ws" in sys.argv:  # the wave-specialised kernel's experiment instantiations (igemm_glds_ws.hip): shader clock under each ablation
+    EXPERIMENTS = [("down_blocks.0.resnets.0.conv2", 21, 1), ("up_blocks.3.resnets.0.conv1", 22, 2)]
 EXP_NAMES = {0: "full", 1: "no MFMA", 2: "no LDS reads", 3: "no MFMA, no LDS reads", 4: "no in-loop DMA", 8: "no barrier",
              7: "loop skeleton (wait + barrier only)"}
 
@@ -55,6 +57,8 @@ def main():
         p, launch_with = op.tune
         p.variant, p.split_k = v, sk
         for ex in (0, 1, 2, 3, 4, 8, 7):
+            if "--ws" in sys.argv and ex == 8 and False:
+                continue
             os.environ["SFAST_IGEMM_EXP"] = str(ex)
             trace.zero_()
             lib.sfast_hip_set_trace(trace.data_ptr())
@@ -68,10 +72,15 @@ def main():
             st = t[:, :7].astype(np.int64)
             kl = st[:, 4] - st[:, 3]
             tot = st[:, 6] - st[:, 0]
-            print(f"EXP {name[-28:]:28s} {kern:40s} {EXP_NAMES[ex]:36s} k-loop med {pct(kl, 50):6.2f} us  WG total {pct(tot, 50):6.2f} us")
+            wall = tot.astype(np.float64)
+            cyc = (t[:, 9] - t[:, 8]).astype(np.float64)
+            ok = wall > 50
+            mhz = float(np.median(cyc[ok] / wall[ok]) * 100.0) if ok.any() else 0.0
+            print(f"EXP {name[-28:]:28s} {kern:40s} {EXP_NAMES[ex]:36s} k-loop med {pct(kl, 50):6.2f} us  WG total {pct(tot, 50):6.2f} us  "
+                  f"shader clock {mhz:5.0f} MHz", flush=True)
         os.environ.pop("SFAST_IGEMM_EXP", None)
         p.variant, p.split_k = 0, 0
-    for name, cfgs in PROBES:
+    for name, cfgs in ([] if "--ws" in sys.argv else PROBES):
         op = ops[name]
         p, launch_with = op.tune
         for v, s in cfgs:
