@@ -20,6 +20,16 @@
 
 namespace sfast {
 
+// experiment (EXP bit 6): the accumulators in AGPRs -- the MFMA reads and writes C / D through the accumulation file's ports instead
+// of the arch VGPR file the LDS returns write into (results are correct; MFMA hazards are not tracked inside inline asm: drained by
+// hand before the epilogue reads the accumulators)
+template <typename T> __device__ __forceinline__ void mfma32_agpr(f32x16 &c, const typename Elem<T>::vec8 &a, const typename Elem<T>::vec8 &b) {
+    if constexpr (std::is_same<T, f16>::value)
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
 template <int N> __device__ __forceinline__ void ws_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
@@ -36,7 +46,7 @@ constexpr int ws_min_waves(int threads, int lds_bytes) {
 
 // EXP != 0: timing-only experiment instantiations (tools/ws_loop_probe.py; results are garbage): bit 0 no MFMAs, bit 1 no fragment
 // reads, bit 2 no LDS-DMA requests inside the loop (the producers only wait and meet the barrier), bit 3 weight requests only,
-// bit 4 / bit 5 (results are CORRECT): s_setprio 3 in the producer / consumer waves.
+// bit 4 / bit 5 (results are CORRECT): s_setprio 3 in the producer / consumer waves; bit 6 (CORRECT): accumulators in AGPRs.
 template <typename T, int BM, int BN, int WM, int WN, int PW, int NS, int MODE, bool GEGLU, bool STAGED = false, int EXP = 0>
 __global__ void __launch_bounds__((WM * WN + PW) * 64, ws_min_waves((WM * WN + PW) * 64, NS *(BM + BN) * 128))
     igemm_glds_ws_kernel(const IgemmArgs a) {
@@ -288,7 +298,9 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, ws_min_waves((WM * WN + P
             for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
                 for (int fm = 0; fm < FM; ++fm) {
-                    if constexpr ((EXP & 1) == 0) {
+                    if constexpr ((EXP & 64) != 0) {
+                        mfma32_agpr<T>(acc[fn][fm], af[ks & 1][fn], bf[ks & 1][fm]);
+                    } else if constexpr ((EXP & 1) == 0) {
                         acc[fn][fm] = mfma32(af[ks & 1][fn], bf[ks & 1][fm], acc[fn][fm]);
                     } else {
                         asm volatile("" ::"v"(af[ks & 1][fn]), "v"(bf[ks & 1][fm]));  // the fragment reads stay
@@ -297,6 +309,7 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, ws_min_waves((WM * WN + P
         }
     }
 
+    if constexpr ((EXP & 64) != 0) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs have written their accumulators
     trace_mark(a, 4);
     run_epilogue<T, BM, BNO, FN, FM, GEGLU, EPI_EARLY, NC, STAGED>(a, acc, epi, smem, m0, n0, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi,
                                                              tid, bt.split);
@@ -376,6 +389,8 @@ static int ws_dispatch(const IgemmArgs &a, int BM_, int BN_, int NS_, bool geglu
             LAUNCH_EXP(128, 128, 2, 2, 4, 1) LAUNCH_EXP(128, 128, 2, 2, 4, 2) LAUNCH_EXP(128, 128, 2, 2, 4, 3)
             LAUNCH_EXP(128, 128, 2, 2, 4, 4) LAUNCH_EXP(128, 128, 2, 2, 4, 7) LAUNCH_EXP(128, 128, 2, 2, 4, 8)
             LAUNCH_EXP(128, 128, 2, 2, 4, 16) LAUNCH_EXP(128, 128, 2, 2, 4, 32) LAUNCH_EXP(128, 160, 4, 1, 4, 16) LAUNCH_EXP(128, 160, 4, 1, 4, 32)
+            LAUNCH_EXP(128, 128, 2, 2, 4, 6) LAUNCH_EXP(128, 160, 4, 1, 4, 6) LAUNCH_EXP(128, 128, 2, 2, 4, 5) LAUNCH_EXP(128, 160, 4, 1, 4, 5)
+            LAUNCH_EXP(128, 128, 2, 2, 4, 64) LAUNCH_EXP(128, 160, 4, 1, 4, 64) LAUNCH_EXP(128, 128, 2, 2, 4, 68) LAUNCH_EXP(128, 160, 4, 1, 4, 68)
             LAUNCH_EXP(128, 160, 4, 1, 4, 1) LAUNCH_EXP(128, 160, 4, 1, 4, 2) LAUNCH_EXP(128, 160, 4, 1, 4, 3)
             LAUNCH_EXP(128, 160, 4, 1, 4, 4) LAUNCH_EXP(128, 160, 4, 1, 4, 7) LAUNCH_EXP(128, 160, 4, 1, 4, 8)
 #undef LAUNCH_EXP

@@ -18,7 +18,9 @@ if "--patch" in sys.argv:  # the LDS-patch kernel (conv_patch.hip): bit 2 = no w
     CASES = [(2, 320, 0, 64, 64, 320, 32, 1), (2, 640, 0, 32, 32, 640, 32, 3), (2, 640, 320, 64, 64, 320, 31, 2), (2, 1280, 1280, 16, 16, 1280, 31, 8)]
 NAMES = {0: "full", 1: "no MFMA", 2: "no fragment reads", 3: "no MFMA, no fragment reads", 4: "no in-loop DMA", 7: "loop skeleton",
          8: "weight requests only (x requests read the zero block)", 16: "full, s_setprio 3 in the producer waves",
-         32: "full, s_setprio 3 in the consumer waves"}
+         32: "full, s_setprio 3 in the consumer waves", 6: "MFMAs + barriers only (no fragment reads, no in-loop DMA)",
+         5: "fragment reads + barriers only (no MFMA, no in-loop DMA)", 64: "full, accumulators in AGPRs",
+         68: "no in-loop DMA, accumulators in AGPRs"}
 if "--patch" in sys.argv:
     NAMES = {0: "full", 1: "no MFMA", 2: "no fragment reads", 3: "no MFMA, no fragment reads", 4: "no in-loop weight DMA", 8: "no in-loop patch DMA",
              12: "no in-loop DMA at all", 15: "loop skeleton"}
