@@ -28,7 +28,7 @@ def check(tag, y, ref, tol=3e-3):
 
 for dt in (torch.float16, torch.bfloat16):
     tol = 3e-3 if dt == torch.float16 else 2e-2
-    for v in (21, 22, 23, 24, 25, 26):
+    for v in (21, 22, 23, 24, 25, 26, 27):  # (27 = the 256x128 tile with 128x64 per consumer wave of run 22: skipped unless it is built in)
         for (M, K, N, s) in ((8192, 320, 320, 1), (2048, 64, 640, 1), (2048, 128, 640, 1), (130, 1280, 1280, 1), (512, 2560, 1280, 3), (512, 2560, 1280, 8),
                              (128, 5120, 1280, 20)):
             if dt == torch.bfloat16 and (M, K) not in ((8192, 320), (512, 2560)):
@@ -74,5 +74,61 @@ for dt in (torch.float16, torch.bfloat16):
         y = F.linear(x, w, b, geglu=True, variant=v)
         full = x.float() @ w.float().t() + b.float()
         check(f"{dt} geglu v{v} M2048 K640 N2560", y, full[:, :2560] * TF.gelu(full[:, 2560:]), tol)
-print("FAILED" if bad else "ALL OK", bad)
+print("FAILED" if bad else "ALL OK", bad, flush=True)
+if "--time" in sys.argv and not bad:
+    stream = torch.cuda.Stream()
+
+    def timed(fn, n=8):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(stream):
+            fn()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=stream):
+                for _ in range(n):
+                    fn()
+        best = 1e9
+        for _ in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(stream):
+                e0.record(stream)
+                g.replay()
+                e1.record(stream)
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / n * 1e3)
+        return best
+
+    dt = torch.float16
+    cl = torch.channels_last
+    for (B, C1, C2, H, Co) in ((2, 320, 0, 64, 320), (2, 640, 320, 64, 320), (2, 640, 0, 32, 640), (2, 640, 0, 64, 640), (2, 1280, 0, 32, 1280)):
+        x = torch.randn(B, C1, H, H, device=dev).to(dt).contiguous(memory_format=cl)
+        x2 = torch.randn(B, C2, H, H, device=dev).to(dt).contiguous(memory_format=cl) if C2 else None
+        w = (torch.randn(Co, C1 + C2, 3, 3, device=dev) * ((C1 + C2) * 9) ** -0.5).to(dt).contiguous(memory_format=cl)
+        b = torch.randn(Co, device=dev).to(dt)
+        line = []
+        for v in (21, 22, 27):
+            for sp in (1, 2, 3, 4, 6):
+                try:
+                    F.conv2d(x, w, b, padding=1, x2=x2, variant=v, split_k=sp)
+                except L.SfastHipError:
+                    continue
+                k = L.last_kernel()
+                if f"split={sp}," not in k:
+                    continue
+                line.append(f"v{v}/s{sp} {timed(lambda: F.conv2d(x, w, b, padding=1, x2=x2, variant=v, split_k=sp)):.1f}")
+        print(f"conv {C1}+{C2}->{Co}@{H}: " + ", ".join(line), flush=True)
+    for (M, K, N) in ((8192, 320, 1280), (8192, 1280, 320), (32768, 640, 640), (32768, 640, 2560)):
+        x = torch.randn(M, K, device=dev).to(dt)
+        w = (torch.randn(N, K, device=dev) * K ** -0.5).to(dt)
+        b = torch.randn(N, device=dev).to(dt)
+        line = []
+        for v in (21, 22, 25, 27):
+            for sp in (1, 2):
+                try:
+                    F.linear(x, w, b, variant=v, split_k=sp)
+                except L.SfastHipError:
+                    continue
+                if f"split={sp}," not in L.last_kernel():
+                    continue
+                line.append(f"v{v}/s{sp} {timed(lambda: F.linear(x, w, b, variant=v, split_k=sp)):.1f}")
+        print(f"linear M{M} K{K} N{N}: " + ", ".join(line), flush=True)
 sys.exit(1 if bad else 0)
