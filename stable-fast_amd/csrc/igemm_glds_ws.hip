@@ -46,7 +46,7 @@ constexpr int ws_min_waves(int threads, int lds_bytes) {
 
 // EXP != 0: timing-only experiment instantiations (tools/ws_loop_probe.py; results are garbage): bit 0 no MFMAs, bit 1 no fragment
 // reads, bit 2 no LDS-DMA requests inside the loop (the producers only wait and meet the barrier), bit 3 weight requests only,
-// bit 4 / bit 5 (results are CORRECT): s_setprio 3 in the producer / consumer waves; bit 6 (CORRECT): accumulators in AGPRs.
+// bit 4 / bit 5 (results are CORRECT): s_setprio 3 in the producer / consumer waves; bit 6 (CORRECT): accumulators in AGPRs; bit 7 (CORRECT): the loop header behind the barrier (see the consumer loop).
 template <typename T, int BM, int BN, int WM, int WN, int PW, int NS, int MODE, bool GEGLU, bool STAGED = false, int EXP = 0>
 __global__ void __launch_bounds__((WM * WN + PW) * 64, ws_min_waves((WM * WN + PW) * 64, NS *(BM + BN) * 128))
     igemm_glds_ws_kernel(const IgemmArgs a) {
@@ -277,38 +277,81 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, ws_min_waves((WM * WN + P
         for (int fm = 0; fm < FM; ++fm)
             bf[set][fm] = *reinterpret_cast<const vec8 *>(xs + lds_off(wm * (FM * 32) + fm * 32 + l31, chunk));
     };
-    __builtin_amdgcn_s_barrier();  // tile kt_begin has landed
-    trace_mark(a, 3);
-    read_frags(smem, 0, 0);
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const char *xs = smem + cstage * STAGE;
-        cstage = (cstage + 1 == NS) ? 0 : cstage + 1;
+    auto mfma_set = [&](int set) {
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks + 1 < 4) {
-                read_frags(xs, ks + 1, (ks + 1) & 1);
-            } else if (kt + 1 < kt_end) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");  // (the reads below stay below)
-                read_frags(smem + cstage * STAGE, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs (the scheduler sinks them otherwise)
+        for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
-            for (int fn = 0; fn < FN; ++fn)
-#pragma unroll
-                for (int fm = 0; fm < FM; ++fm) {
-                    if constexpr ((EXP & 64) != 0) {
-                        mfma32_agpr<T>(acc[fn][fm], af[ks & 1][fn], bf[ks & 1][fm]);
-                    } else if constexpr ((EXP & 1) == 0) {
-                        acc[fn][fm] = mfma32(af[ks & 1][fn], bf[ks & 1][fm], acc[fn][fm]);
-                    } else {
-                        asm volatile("" ::"v"(af[ks & 1][fn]), "v"(bf[ks & 1][fm]));  // the fragment reads stay
-                    }
+            for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = mfma32(af[set][fn], bf[set][fm], acc[fn][fm]);
+    };
+    if constexpr ((EXP & 128) != 0) {
+        // experiment (results are CORRECT): the loop header sits right behind the lgkmcnt(0) + barrier, where no LDS read is
+        // outstanding. In the production loop below the header has the next tile's first fragments in flight, the waitcnt pass of
+        // the compiler loses their order against the reads issued at the top of the body, and it puts a full `s_waitcnt lgkmcnt(0)`
+        // in front of the first MFMA group of EVERY tile -- one exposed LDS round trip per K-tile besides the intended one
+        // (hipcc -S: the `s_waitcnt lgkmcnt(0)` behind the first four ds_read_b128 of the loop body).
+        __builtin_amdgcn_s_barrier();  // tile kt_begin has landed
+        trace_mark(a, 3);
+        {
+            const char *xs = smem;
+            read_frags(xs, 0, 0);
+            read_frags(xs, 1, 1);
+            mfma_set(0);
+            read_frags(xs, 2, 0);
+            mfma_set(1);
+            read_frags(xs, 3, 1);
+            mfma_set(0);
+        }
+        cstage = (NS > 1) ? 1 : 0;
+        for (int kt = kt_begin + 1; kt < kt_end; ++kt) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment of tile kt - 1 is in registers
+            __builtin_amdgcn_s_barrier();                       // tile kt has landed, the stage of tile kt - 1 is released
+            asm volatile("" ::: "memory");
+            const char *xs = smem + cstage * STAGE;
+            cstage = (cstage + 1 == NS) ? 0 : cstage + 1;
+            mfma_set(1);               // the last k-step of tile kt - 1
+            read_frags(xs, 0, 0);
+            read_frags(xs, 1, 1);
+            mfma_set(0);
+            read_frags(xs, 2, 0);
+            mfma_set(1);
+            read_frags(xs, 3, 1);
+            mfma_set(0);
+        }
+        mfma_set(1);
+    } else {
+        __builtin_amdgcn_s_barrier();  // tile kt_begin has landed
+        trace_mark(a, 3);
+        read_frags(smem, 0, 0);
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const char *xs = smem + cstage * STAGE;
+            cstage = (cstage + 1 == NS) ? 0 : cstage + 1;
+    #pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) {
+                    read_frags(xs, ks + 1, (ks + 1) & 1);
+                } else if (kt + 1 < kt_end) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");  // (the reads below stay below)
+                    read_frags(smem + cstage * STAGE, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs (the scheduler sinks them otherwise)
+    #pragma unroll
+                for (int fn = 0; fn < FN; ++fn)
+    #pragma unroll
+                    for (int fm = 0; fm < FM; ++fm) {
+                        if constexpr ((EXP & 64) != 0) {
+                            mfma32_agpr<T>(acc[fn][fm], af[ks & 1][fn], bf[ks & 1][fm]);
+                        } else if constexpr ((EXP & 1) == 0) {
+                            acc[fn][fm] = mfma32(af[ks & 1][fn], bf[ks & 1][fm], acc[fn][fm]);
+                        } else {
+                            asm volatile("" ::"v"(af[ks & 1][fn]), "v"(bf[ks & 1][fm]));  // the fragment reads stay
+                        }
+                    }
+            }
         }
     }
-
     if constexpr ((EXP & 64) != 0) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs have written their accumulators
     trace_mark(a, 4);
     run_epilogue<T, BM, BNO, FN, FM, GEGLU, EPI_EARLY, NC, STAGED>(a, acc, epi, smem, m0, n0, m0 + wm * (FM * 32), n0 + wn * (GEGLU ? WNB / 2 : WNB), l31, hi,
@@ -391,6 +434,7 @@ static int ws_dispatch(const IgemmArgs &a, int BM_, int BN_, int NS_, bool geglu
             LAUNCH_EXP(128, 128, 2, 2, 4, 16) LAUNCH_EXP(128, 128, 2, 2, 4, 32) LAUNCH_EXP(128, 160, 4, 1, 4, 16) LAUNCH_EXP(128, 160, 4, 1, 4, 32)
             LAUNCH_EXP(128, 128, 2, 2, 4, 6) LAUNCH_EXP(128, 160, 4, 1, 4, 6) LAUNCH_EXP(128, 128, 2, 2, 4, 5) LAUNCH_EXP(128, 160, 4, 1, 4, 5)
             LAUNCH_EXP(128, 128, 2, 2, 4, 64) LAUNCH_EXP(128, 160, 4, 1, 4, 64) LAUNCH_EXP(128, 128, 2, 2, 4, 68) LAUNCH_EXP(128, 160, 4, 1, 4, 68)
+            LAUNCH_EXP(128, 128, 2, 2, 4, 128) LAUNCH_EXP(128, 160, 4, 1, 4, 128) LAUNCH_EXP(128, 128, 2, 2, 4, 132) LAUNCH_EXP(128, 160, 4, 1, 4, 132)
             LAUNCH_EXP(128, 160, 4, 1, 4, 1) LAUNCH_EXP(128, 160, 4, 1, 4, 2) LAUNCH_EXP(128, 160, 4, 1, 4, 3)
             LAUNCH_EXP(128, 160, 4, 1, 4, 4) LAUNCH_EXP(128, 160, 4, 1, 4, 7) LAUNCH_EXP(128, 160, 4, 1, 4, 8)
 #undef LAUNCH_EXP

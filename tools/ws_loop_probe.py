@@ -20,7 +20,8 @@ NAMES = {0: "full", 1: "no MFMA", 2: "no fragment reads", 3: "no MFMA, no fragme
          8: "weight requests only (x requests read the zero block)", 16: "full, s_setprio 3 in the producer waves",
          32: "full, s_setprio 3 in the consumer waves", 6: "MFMAs + barriers only (no fragment reads, no in-loop DMA)",
          5: "fragment reads + barriers only (no MFMA, no in-loop DMA)", 64: "full, accumulators in AGPRs",
-         68: "no in-loop DMA, accumulators in AGPRs"}
+         68: "no in-loop DMA, accumulators in AGPRs", 128: "full, loop header behind the barrier (exact LDS waits)",
+         132: "no in-loop DMA, loop header behind the barrier"}
 if "--patch" in sys.argv:
     NAMES = {0: "full", 1: "no MFMA", 2: "no fragment reads", 3: "no MFMA, no fragment reads", 4: "no in-loop weight DMA", 8: "no in-loop patch DMA",
              12: "no in-loop DMA at all", 15: "loop skeleton"}
