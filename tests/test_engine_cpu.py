@@ -398,3 +398,33 @@ def test_norm_eps_is_read_from_the_live_module(built_lib):
         m32.up_blocks[1].attentions[0].transformer_blocks[0].norm2.eps = 1e-5
         default = m32(s.float(), 250, e.float()).sample
     assert rel_l2(y, want) < 3e-3 and rel_l2(default, want) > 1e-2
+
+
+def test_engine_on_the_emulator_matches_round3_goldens(built_lib):
+    """tests/golden/unet_tiny_r3.pt without running the oracle: the plan's time-embedding chain (cond_proj segment, class MLP, text_time
+    stacking) through the C-ABI emulator against the committed fp32 outputs; and the schedule cursor against ops_r3.pt."""
+    import importlib.util
+    import os
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden_r3", os.path.join(gdir, "make_golden_r3.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gold = torch.load(os.path.join(gdir, "unet_tiny_r3.pt"))
+    for name, c in gold.items():
+        cfg = U.tiny_config(**c["over"])
+        m16 = U.build(cfg, seed=c["seed"], dtype=torch.float16)
+        eng = UNet2DEngine.from_module(m16, _host=EmuHost())
+        s, e, kw = gen.inputs(name, cfg, c["seed"] + 1000)
+        added = kw.pop("added_cond_kwargs", None)
+        kw = {k: (v.half() if v.dtype == torch.float32 and k != "class_labels" or (k == "class_labels" and v.ndim == 2) else v) for k, v in kw.items()}
+        y = eng.forward(s.half(), c["timestep"], e.half(), {k: v.half() for k, v in added.items()} if added else None, **kw)
+        assert rel_l2(y, c["y"]) < 3e-3, (name, rel_l2(y, c["y"]))
+    ops = torch.load(os.path.join(gdir, "ops_r3.pt"))["schedule_advance"]
+    emu = EmuLib()
+    cur = torch.tensor([ops["start"]], dtype=torch.int32)
+    ts_out, coef_out = torch.zeros(1), torch.zeros(4)
+    for j in range(len(ops["rows"])):
+        assert emu.sfast_hip_schedule_advance(cur.data_ptr(), ops["ts_table"].data_ptr(), 1, ts_out.data_ptr(), ops["coef_table"].data_ptr(), 4,
+                                              coef_out.data_ptr(), ops["n_steps"], None) == 0
+        assert torch.equal(ts_out, ops["ts_out"][j]) and torch.equal(coef_out, ops["coef_out"][j])
+    assert int(cur[0]) == ops["cursor_after"]

@@ -202,3 +202,34 @@ def test_oracle_reproduces_golden_round2():
     with torch.no_grad():
         y = m(gold["sample"].float(), gold["timesteps"], gold["encoder_hidden_states"].float(), gold["added_time_ids"]).sample
     torch.testing.assert_close(y, gold["y"], rtol=1e-3, atol=1e-4)
+
+
+def test_oracle_reproduces_golden_round3():
+    """Round-3 fixtures (tests/golden/make_golden_r3.py): the tiny UNet with time_cond_proj / class embeddings / the stacked embedding
+    chain (what round 3 added to oracle/unet_ref.py), and the rows the device-side schedule cursor hands out."""
+    import importlib.util
+    from oracle import unet_ref as U
+    spec = importlib.util.spec_from_file_location("make_golden_r3", os.path.join(GOLDEN, "make_golden_r3.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gold = torch.load(os.path.join(GOLDEN, "unet_tiny_r3.pt"))
+    assert set(gold) == set(gen.CASES)
+    for name, c in gold.items():
+        cfg = U.tiny_config(**c["over"])
+        m = U.build(cfg, seed=c["seed"])
+        m.load_state_dict({k: v.half().float() for k, v in m.state_dict().items()})
+        s, e, kw = gen.inputs(name, cfg, c["seed"] + 1000)
+        with torch.no_grad():
+            y = m(s, c["timestep"], e, **kw).sample
+        torch.testing.assert_close(y, c["y"], rtol=1e-3, atol=1e-4, msg=lambda t, name=name: f"{name}: {t}")
+        if "class_labels" in kw:   # the condition really reaches the output
+            kw2 = dict(kw, class_labels=kw["class_labels"].flip(0))
+            with torch.no_grad():
+                assert float((m(s, c["timestep"], e, **kw2).sample - c["y"]).abs().max()) > 1e-3, name
+    ops = torch.load(os.path.join(GOLDEN, "ops_r3.pt"))["schedule_advance"]
+    ts, coef = R.ddim_schedule(ops["n_steps"])
+    for j, row in enumerate(ops["rows"]):
+        assert row == (ops["start"] + j) % ops["n_steps"]
+        assert float(ops["ts_out"][j, 0]) == float(ts[row])
+        torch.testing.assert_close(ops["coef_out"][j], torch.tensor(coef[row], dtype=torch.float32))
+    assert ops["cursor_after"] == (ops["start"] + len(ops["rows"])) % ops["n_steps"]
