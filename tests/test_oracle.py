@@ -233,3 +233,61 @@ def test_oracle_reproduces_golden_round3():
         assert float(ops["ts_out"][j, 0]) == float(ts[row])
         torch.testing.assert_close(ops["coef_out"][j], torch.tensor(coef[row], dtype=torch.float32))
     assert ops["cursor_after"] == (ops["start"] + len(ops["rows"])) % ops["n_steps"]
+
+
+def test_oracle_vs_reference_triton_fixture():
+    """tests/golden/ref_triton_small.pt holds OUTPUTS OF THE REFERENCE'S OWN TRITON KERNELS (group_norm.py, layer_norm.py, copy.py and,
+    if it compiled, conv.py of /root/reference/src/sfast/triton/ops), run on an MI355X through oracle/ref_triton_run.py
+    (tests/golden/make_golden_ref_triton.py). Unlike the other fixtures it is not minted from this oracle, so this pins
+    `oracle.ops_ref` for SURVEY section-8 rows a6-a9 (a15) against the reference itself. Bars as in tests/test_ref_triton_gpu.py:
+    one output ulp, plus -- GroupNorm only -- the reference's f16-rounded statistics (its mean / rstd tensors take the input dtype)."""
+    import torch
+    from oracle import ops_ref as R
+    from oracle import ref_cases as RC
+    path = os.path.join(GOLDEN, "ref_triton_small.pt")
+    fx = torch.load(path)
+    assert fx["status"]["gn"].startswith("ok") and fx["status"]["ln"].startswith("ok") and fx["status"]["copy"].startswith("ok"), fx["status"]
+    u = 2.0 ** -10
+    n = 0
+    for c in RC.GN_CASES:
+        if not c.get("small"):
+            continue
+        x, w, b = RC.gn_inputs(c)
+        want = R.group_norm_ref(x, c["groups"], w, b, c["eps"], c["silu"])
+        got = fx["out"][c["name"]]["y"].float()
+        N, C = x.shape[:2]
+        xs = x.float().reshape(N, c["groups"], -1)
+        mean = xs.mean(2, keepdim=True)
+        rstd = (xs.var(2, unbiased=False, keepdim=True) + c["eps"]).rsqrt()
+        stat = ((u / 2) * ((xs - mean).abs() * rstd + mean.abs() * rstd)).reshape(x.shape) * w.float().abs().reshape(1, C, 1, 1)
+        lim = u * (1.0 + want.abs()) + 1.65 * stat
+        assert int(((got - want).abs() > lim).sum()) == 0, (c["name"], float((got - want).abs().max()))
+        assert torch.allclose(fx["out"][c["name"]]["mean"].float(), mean.reshape(N, -1), atol=u, rtol=u)
+        assert torch.allclose(fx["out"][c["name"]]["rstd"].float(), rstd.reshape(N, -1), atol=u, rtol=2 * u)
+        n += 1
+    for c in RC.LN_CASES:
+        if not c.get("small"):
+            continue
+        x, w, b = RC.ln_inputs(c)
+        want = R.layer_norm_ref(x, (x.shape[-1],), w, b, c["eps"])
+        got = fx["out"][c["name"]]["y"].float()
+        assert torch.allclose(got, want, atol=u, rtol=u), (c["name"], float((got - want).abs().max()))
+        n += 1
+    for c in RC.COPY_CASES:
+        if not c.get("small"):
+            continue
+        x = RC.copy_inputs(c)
+        src, fmt = RC.copy_view(c, x)
+        assert fx["out"][c["name"]]["equal_to_torch_copy"]
+        assert torch.equal(fx["out"][c["name"]]["y"], src.contiguous(memory_format=fmt))
+        n += 1
+    if fx["status"].get("conv", "").startswith("ok"):
+        for c in RC.CONV_CASES:
+            if not c.get("small"):
+                continue
+            x, w, b = RC.conv_inputs(c)
+            want = R.conv2d_ref(x, w, b, stride=c["stride"], padding=c["padding"])
+            got = fx["out"][c["name"]]["y"].float()
+            assert torch.allclose(got, want, atol=2 * u, rtol=2 * u), (c["name"], float((got - want).abs().max()))
+            n += 1
+    assert n >= 7
