@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round-4 GPU sessions (one gpurun call each): tools/gpu_r4.sh <stage>
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+STAGE=${1:-s1}
+export TMPDIR=/tmp
+PYT="python -m pytest -q --no-header --tb=short -p no:cacheprovider --timeout=900 --maxfail=30 -m gpu"
+run() { # name, timeout, command...
+  local name=$1 to=$2; shift 2
+  echo "=== $name ===" | tee -a gpurun_out/session.log
+  local t0=$(date +%s)
+  timeout $to "$@" > gpurun_out/$name.log 2>&1
+  echo "exit=$? $(( $(date +%s) - t0 ))s $(tail -n 1 gpurun_out/$name.log | cut -c1-300)" | tee -a gpurun_out/session.log
+}
+rm -f gpurun_out/parity.jsonl gpurun_out/session.log
+rocminfo 2>/dev/null | grep -E "gfx|Compute Unit" | head -2 >> gpurun_out/session.log
+case $STAGE in
+s1)  # the reference's own Triton kernels on this box (fixture + oracle / HIP comparison + timing); loop-structure probe; baseline bench
+  run ref_fixture 900 python tests/golden/make_golden_ref_triton.py --out gpurun_out/ref_triton_small.pt
+  run t_ref_triton 1500 $PYT tests/test_ref_triton_gpu.py
+  run wdirect 300 tools/micro/wdirect
+  run trread 60 tools/micro/trread
+  run bench 900 python bench.py --steps 50 --warmup 10 --no-end-to-end --dump-kernels gpurun_out/kernels.json
+  ;;
+esac
+cat gpurun_out/session.log
