@@ -52,6 +52,11 @@ def parse():
                     help="skip the end-to-end ms/image leg (text encoder + 50 steps + VAE decode + post-process; sd15 only)")
     ap.add_argument("--e2e-images", type=int, default=3, help="images timed by the end-to-end leg (after one warm-up image)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the extra lines of the same run: text-K/V hoisted out of the step graph, the literal B = 1 (no-CFG) step, "
+                         "and (N = 8 or --bs64-sharded) BASELINE configs[3]: bs = 64 sharded over the ranks")
+    ap.add_argument("--bs64-sharded", action="store_true",
+                    help="run the configs[3] leg (64 images split over the N ranks, 64 / N per GPU) for any N, not only N = 8")
     ap.add_argument("--dump-kernels", default=None, help="write the per-op timing table to this JSON file")
     return ap.parse_args()
 
@@ -446,6 +451,115 @@ def through_compile(args, cfg, params, dev, latents, ehs, engine_ms, added=None)
             "scheduler": type(sched).__name__, "native_scheduler_steps": getattr(sched.step, "native_calls", 0),
             "outputs_finite": bool(torch.isfinite(out).all()),
             "path": "module_from_params -> sfast.compilers.compile(enable_cuda_graph, trace_scheduler) -> pipeline-shaped CFG loop"}
+
+
+def _time_steps(step, steps, warmup, dev):
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / steps
+
+
+def step_variants(args, engine, cfg, hw, dev, latents, ehs, headline_ms):
+    """Two more lines from the same process, same weights (N = 1): (a) the headline step with the 16 text K/V projections hoisted
+    out of the graph (run once per prompt -- a loop-invariant hoist a pipeline may do, `compile()` cannot; the headline keeps them
+    in, so its step is literally one UNet forward + guidance + scheduler update); (b) the LITERAL batch-1 step SURVEY section 8d
+    lists beside the CFG one: UNet forward at B = 1 (no classifier-free guidance) + the DDIM update, one hipGraph."""
+    from sfast.engine import DenoiseLoop
+    from sfast.engine.unet2d import capture_plan_graph
+    from sfast.hip import lib as L
+    out = {}
+    steps, warm = min(args.steps, 100), min(args.warmup, 10)
+    loop = DenoiseLoop(engine, images=args.images, height=hw, width=hw, ctx_len=77, guidance=7.5, num_steps=50,
+                       use_graph=not args.no_graph, hoist_text_kv=True)
+    if args.config == "sdxl":
+        si = loop.plan.static_in
+        si["text_embeds"].normal_()
+        si["time_ids"].copy_(torch.tensor([1024., 1024, 0, 0, 1024, 1024], device=dev).repeat(2 * args.images))
+    loop.set_inputs(latents, ehs)
+    loop.capture(warmups=2)
+    ms = _time_steps(loop.step, steps, warm, dev) * 1e3
+    out["text_kv_hoisted"] = {"value": 1e3 / ms, "unit": "it/s", "ms_per_step": ms, "kernel_launches_per_step": len(loop._step_ops) + 2,
+                              "gain_vs_headline": headline_ms / ms,
+                              "note": "cross-attention K/V projections of the text context run once per prompt (DenoiseLoop(hoist_text_kv=True)), not per step"}
+    del loop
+    if args.images == 1:
+        plan = engine.get_plan(1, hw, hw, 77)
+        kw = {}
+        if args.config == "sdxl":
+            kw["added_cond_kwargs"] = {"text_embeds": torch.randn(1, 1280, device=dev).half(),
+                                       "time_ids": torch.tensor([[1024., 1024, 0, 0, 1024, 1024]], device=dev).half()}
+        engine.load_inputs(plan, latents[:1], 981, ehs[1:2], **kw)
+        coef = torch.tensor([[1.02, -0.05]], dtype=torch.float32, device=dev)   # x_prev = A x + B eps: one DDIM row in linear form
+        lib = L.init_device(dev)
+        lat = latents[:1].clone()
+        n = lat.numel()
+
+        def tail(stream):   # scheduler update written straight into the plan's sample input (eps-prediction, eta = 0)
+            L.check(lib.sfast_hip_linear_step(plan.static_out.data_ptr(), lat.data_ptr(), plan.static_in["sample"].data_ptr(), coef.data_ptr(),
+                                              None, 0, 1, n, engine.dt, stream), "sfast_hip_linear_step")
+        stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(stream):
+            plan.run(stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        graph, _ = capture_plan_graph(plan, stream, tail=tail)
+        with torch.cuda.stream(stream):
+            ms1 = _time_steps(lambda i: graph.replay(), steps, warm, dev) * 1e3
+        out["literal_b1"] = {"value": 1e3 / ms1, "unit": "it/s", "ms_per_step": ms1, "unet_batch": 1, "kernel_launches_per_step": len(plan.ops) + 1,
+                             "note": "UNet forward at batch 1 (no classifier-free guidance) + DDIM update, one hipGraph -- SURVEY 8d config 2, B = 1"}
+    return out
+
+
+def bs64_sharded(args, engine, cfg, hw, dev, rank, world, use_dist):
+    """BASELINE.json configs[3]: SD1.5 512x512 bs = 64 fp16 sharded over the node -- 64 / N images per GPU (UNet batch 128 / N with
+    CFG), independent per-GPU denoise loops, no per-step collective. Reported as image-steps/s over all ranks (max-over-ranks time)
+    and as ms per image-step; N = 8 gives the per-GPU shape the packaged kernel choices cover (8 images, UNet batch 16)."""
+    from sfast.engine import DenoiseLoop
+
+    def agree(value):
+        if not use_dist:
+            return value
+        t = torch.tensor([value], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
+        return float(t.item())
+
+    images = max(1, 64 // world)
+    err, loop = None, None
+    try:
+        loop = DenoiseLoop(engine, images=images, height=hw, width=hw, ctx_len=77, guidance=7.5, num_steps=50, use_graph=not args.no_graph)
+        g = torch.Generator(device=dev).manual_seed(4321 + rank)
+        loop.set_inputs(torch.randn(images, 4, hw, hw, generator=g, device=dev).half(),
+                        torch.randn(2 * images, 77, cfg["cross_attention_dim"], generator=g, device=dev).half())
+        loop.capture(warmups=2)
+        for i in range(3):
+            loop.step(i)
+        torch.cuda.synchronize(dev)
+    except Exception as e:
+        err = f"{type(e).__name__}: {e}"
+    if agree(1.0 if err else 0.0) > 0:      # also the start barrier
+        return {"error": err or "set-up failed on another rank", "n_gpus": world}
+    steps = max(5, min(args.steps, 30))
+    try:
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loop.step(i)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+    except Exception as e:
+        err, el = f"{type(e).__name__}: {e}", float("inf")
+    el = agree(el)
+    if el == float("inf"):
+        return {"error": err or "the timed steps failed on another rank", "n_gpus": world}
+    return {"metric": "SD1.5 512x512 bs=64 fp16 sharded over the node (image-steps/s)", "value": world * images * steps / el, "unit": "image-steps/s",
+            "n_gpus": world, "images_per_gpu": images, "unet_batch_per_gpu": 2 * images, "global_batch": world * images, "steps": steps,
+            "ms_per_step": el / steps * 1e3, "ms_per_image_step": el / steps / images * 1e3, "scaling": "strong" if world * images == 64 else "weak",
+            "outputs_finite": bool(torch.isfinite(loop.latents).all()),
+            "note": "BASELINE.json configs[3]; batch-parallel shards, weights broadcast once (RCCL), no per-step collective"}
 
 
 def end_to_end(args, loop, dev, rank, world, use_dist):
@@ -848,7 +962,7 @@ def main():
                        "images_per_gpu": args.images, "unet_batch": 2 * args.images, "latent": [4, hw, hw], "parallelism": f"replicas x{world}"},
             "gpu_ms_per_step_events": gpu_ms / args.steps, "outputs_finite": finite,
             "reference_published_other_hw": {"H100": 104.6, "A100": 61.8, "RTX4080": 51.6, "source": "BASELINE.md section 1 (stable-fast README)"},
-            "kernel_launches_per_step": len(loop.plan.ops) + 1, "graph_side_lanes": bool(getattr(loop, "graph_forked", False)),
+            "kernel_launches_per_step": len(loop._step_ops) + 2, "text_kv_in_step_graph": not loop.hoist_text_kv,
             "graph_calibration_ms": getattr(loop.plan, "graph_calibration_ms", None),
             "activation_pool_mb": loop.plan.pool.total_bytes() / 1e6,
         }
@@ -870,8 +984,20 @@ def main():
                 si = loop.plan.static_in
                 added = {"text_embeds": si["text_embeds"].reshape(2, -1).clone(), "time_ids": si["time_ids"].reshape(2, -1).clone()}
             out["through_compile"] = through_compile(args, cfg, params, dev, latents, ehs, elapsed / args.steps * 1e3, added)
+        if world == 1 and not args.no_variants:
+            try:
+                out["variants"] = step_variants(args, engine, cfg, hw, dev, latents, ehs, elapsed / args.steps * 1e3)
+            except Exception as e:   # extra lines must never take the contract line down
+                out["variants"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.config, args.images)
+    # BASELINE configs[3] (bs = 64 sharded over the ranks): every rank runs its shard; a leg of the N = 8 run (or --bs64-sharded)
+    c3 = None
+    if args.config == "sd15" and not args.no_variants and args.images == 1 and (world == 8 or args.bs64_sharded):
+        try:
+            c3 = bs64_sharded(args, engine, cfg, hw, dev, rank, world, use_dist)
+        except Exception as e:
+            c3 = {"error": f"{type(e).__name__}: {e}"}
     # end-to-end ms/image (every rank renders its own image; rank 0 reports the max-over-ranks time)
     e2e = None
     if args.config == "sd15" and not args.no_end_to_end and not args.no_graph:
@@ -880,6 +1006,8 @@ def main():
         except Exception as e:  # the it/s line is the contract; this leg must never take it down (end_to_end() itself keeps the ranks
             e2e = {"error": f"{type(e).__name__}: {e}"}   # of an N > 1 run in step when one of them fails; this catches the rest)
     if rank == 0:
+        if c3 is not None:
+            out["configs3_bs64_sharded"] = c3
         if e2e is not None:
             out["end_to_end"] = e2e
             if "ms_per_image_end_to_end" in e2e:

@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define SFAST_HIP_ABI_VERSION 5
+#define SFAST_HIP_ABI_VERSION 6
 
 typedef void *sfast_stream_t; /* hipStream_t */
 
@@ -87,6 +87,13 @@ const char *sfast_hip_last_kernel(void);
  * its phases, HW_ID, shader-clock counter at entry/exit) at buf[(blockIdx.y*gridDim.x+blockIdx.x)*16]; the caller sizes buf for the launch
  * (sfast_hip_igemm_plan gives the grid). NULL (default) = production behaviour. */
 int sfast_hip_set_trace(void *buf);
+/* 1 when the library was built with -DSFAST_PROBES (stable-fast_amd/build.py --probes -> libsfast_hip_probes.so): timing-only
+ * experiment / ablation instantiations whose RESULTS ARE GARBAGE (SFAST_IGEMM_EXP, attention variant >= 1000), the never-selected
+ * LDS-patch conv pipe and the in-kernel split-K join (SFAST_EXT_WS_TICKETS) exist only there. The product library returns 0:
+ * no environment variable or parameter of this ABI can make it run a kernel whose output is not the operator's result
+ * (attention variant >= 1000 -> SFAST_ERR_UNSUPPORTED; SFAST_EXT_WS_TICKETS is accepted and ignored: the reduce launch runs).
+ * ABI 6. Replaces nothing in the reference -- build hygiene of this library. */
+int sfast_hip_has_probes(void);
 
 /* ---- GroupNorm (+SiLU) ------------------------------------------------------------------ */
 enum sfast_layout { SFAST_NHWC = 0, SFAST_NCHW = 1 };

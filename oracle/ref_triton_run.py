@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--time", action="store_true")
     a = ap.parse_args()
     import triton
-    res = {"triton": triton.__version__, "torch": torch.__version__, "device": torch.cuda.get_device_name(0),
+    res = {"triton": str(triton.__version__), "torch": str(torch.__version__), "device": torch.cuda.get_device_name(0),
            "status": {}, "out": {}, "timing": {}}
     for fam in a.families.split(","):
         cases = [c for c in RC.ALL[fam] if c.get("small") or not a.small_only]

@@ -634,6 +634,10 @@ extern "C" int sfast_hip_attention_bias(const void *q, const void *k, const void
     SFAST_REQUIRE(!bias || (bias_strides[0] >= 0 && bias_strides[1] >= 0 && bias_strides[2] >= 0), SFAST_ERR_INVALID,
                   "attention: negative bias strides");
     SFAST_REQUIRE(p->B > 0 && p->H > 0 && p->Sq > 0 && p->Skv > 0 && p->D > 0, SFAST_ERR_INVALID, "attention: bad shape");
+#ifndef SFAST_PROBES
+    SFAST_REQUIRE(p->variant < 1000, SFAST_ERR_UNSUPPORTED,
+                  "attention: variant %d selects a timing-only ablation (garbage results); this library was built without -DSFAST_PROBES", p->variant);
+#endif
     hipStream_t st = (hipStream_t)stream;
     AttnArgs a{};
     a.trace = g_igemm_trace;
@@ -691,7 +695,7 @@ extern "C" int sfast_hip_attention_bias(const void *q, const void *k, const void
         const int64_t tail = units % 1024;
         const bool fills = units <= 1024 ? units >= (p->D == 80 ? 1024 : 512) : (units >= 3072 || tail == 0 || tail >= 512);
         int use = (p->variant == 64 || p->variant == 62) ? 1 : (p->variant != 0 ? 0 : (g_attn_q64 >= 0 ? g_attn_q64 : (fills ? 1 : 0)));
-        if (p->variant >= 1000 && p->variant < 2024) {  // timing-only ablations of the 64-row kernel (tools/attn_ablate.py)
+        if (p->variant >= 1000 && p->variant < 2024) {  // timing-only ablations of the 64-row kernel (tools/attn_ablate.py; probe build only)
             set_kernel_name("attn_q64_ablation[%d]", p->variant - 1000);
             const int rc = attention_q64_launch(a, p->dtype, 4 | (g_attn_xmap << 8) | ((p->variant - 1000) << 16), st);
             if (rc != -1) return rc;

@@ -693,6 +693,7 @@ template <typename T, int D> int q64_launch_d(AttnArgs &a, int nw, int xmap_enab
     return check_launch("attention_q64");
 }
 
+#ifdef SFAST_PROBES
 // timing-only ablations (f16, four waves): variant 1000 + mask, masks listed in kAblations
 #define SFAST_Q64_ABLATIONS(OP) OP(1) OP(3) OP(4) OP(7) OP(8) OP(16) OP(24) OP(32) OP(64) OP(96) OP(128) OP(224) OP(256) OP(512) OP(768) OP(255) OP(1023)
 template <int D> int q64_launch_abl(AttnArgs &a, int abl, int xmap_enabled, hipStream_t st) {
@@ -712,6 +713,7 @@ template <int D> int q64_launch_abl(AttnArgs &a, int abl, int xmap_enabled, hipS
 #undef ABL_OP
     return -1;
 }
+#endif  // SFAST_PROBES
 
 template <typename T> int q64_launch_t(AttnArgs &a, int nw, int xmap_enabled, hipStream_t st) {
     switch (a.D) {
@@ -745,10 +747,12 @@ int attention_q64_launch(const AttnArgs &a_in, int dtype, int nw_and_xmap, hipSt
     AttnArgs a = a_in;
     const int nw = nw_and_xmap & 0xff, xmap = (nw_and_xmap >> 8) & 1, abl = nw_and_xmap >> 16;
     if (abl > 0) {
+#ifdef SFAST_PROBES
         if (dtype != SFAST_F16 || a.bias != nullptr) return -1;
         if (a.D == 40) return q64_launch_abl<40>(a, abl, xmap, st);
         if (a.D == 64) return q64_launch_abl<64>(a, abl, xmap, st);
-        return -1;
+#endif
+        return -1;  // product build: no ablation instantiation exists
     }
     if (a.bias != nullptr || !(a.D == 40 || a.D == 64 || a.D == 80) || !(nw == 2 || nw == 4)) return -1;
     if (dtype == SFAST_F16) return q64_launch_t<f16>(a, nw, xmap, st);

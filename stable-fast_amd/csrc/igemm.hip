@@ -740,7 +740,12 @@ static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, 
 
 // whether a split-K plan finishes its tiles inside the GEMM kernel (splitk_join, igemm_device.h) instead of a second launch
 static bool splitk_joins(const IgemmPlan &p, bool tickets, bool stats, int rows_per_sample) {
+#ifndef SFAST_PROBES
+    (void)p; (void)tickets; (void)stats; (void)rows_per_sample;
+    return false;  // product build: the join is not compiled in (igemm_device.h) -- SFAST_EXT_WS_TICKETS is accepted and ignored
+#else
     return p.splits > 1 && tickets && p.v.pipe != 1 && (int64_t)p.tiles_m * p.tiles_n <= SFAST_WS_TICKET_BYTES / 4 && (!stats || rows_per_sample % p.v.BM == 0);
+#endif
 }
 
 bool igemm_stats_layout(int M, int N, int K, bool geglu, int variant, int split, int glds_ok, int unit, int rows_per_sample,

@@ -603,12 +603,20 @@ __device__ __forceinline__ bool splitk_join(const IgemmArgs &a, f32x16 (&acc)[FN
 
 // JOIN = false compiles the in-kernel split-K join out (the single-stream LDS-DMA kernels of igemm_glds.hip sit at the SGPR limit;
 // igemm_run never hands them tickets)
-template <typename T, int BM, int BNO, int FN, int FM, bool GEGLU, bool EPI_EARLY, int NTC, bool STAGED, bool JOIN = true>
+// Round 4: the join is EVIDENCE code (measured slower than the reduce launch; its ticket protocol rests on
+// sc1 cache behaviour rather than on release / acquire) -- it is compiled only into the probe build (-DSFAST_PROBES, build.py
+// --probes -> libsfast_hip_probes.so); the product library ignores SFAST_EXT_WS_TICKETS and always runs the reduce launch.
+#ifdef SFAST_PROBES
+constexpr bool kJoinDefault = true;
+#else
+constexpr bool kJoinDefault = false;
+#endif
+template <typename T, int BM, int BNO, int FN, int FM, bool GEGLU, bool EPI_EARLY, int NTC, bool STAGED, bool JOIN = kJoinDefault>
 __device__ __forceinline__ void run_epilogue(const IgemmArgs &a, f32x16 (&acc)[FN][FM],
                                              EpiOperands<(EPI_EARLY ? (GEGLU ? FN / 2 : FN) : 1), (EPI_EARLY ? FM : 1)> &epi, char *smem,
                                              int m0, int n0, int mbase, int nbase, int l31, int hi, int ctid, int split_idx) {
     bool whole = false;
-    if (JOIN && a.splits > 1 && a.tickets != nullptr) {
+    if constexpr (JOIN) if (a.splits > 1 && a.tickets != nullptr) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA request of this wave is still on its way into the ring
         const int tile_id = (m0 / BM) * a.tiles_n + n0 / BNO;
         if (!splitk_join<FN, FM, NTC>(a, acc, smem, tile_id, split_idx, ctid)) return;

@@ -62,9 +62,21 @@ int sfast_hip_init(void) {
 
 int sfast_hip_set_trace(void *buf) {
     sfast::g_igemm_trace = (unsigned long long *)buf;
-    const char *e = getenv("SFAST_IGEMM_EXP");  // profiling experiments exist only while tracing
+#ifdef SFAST_PROBES
+    const char *e = getenv("SFAST_IGEMM_EXP");  // timing experiments: probe build only, and only while tracing
     sfast::g_igemm_exp = (buf && e) ? atoi(e) : 0;
+#else
+    sfast::g_igemm_exp = 0;  // the product library holds no experiment instantiation: nothing an environment variable could select
+#endif
     return 0;
+}
+
+int sfast_hip_has_probes(void) {
+#ifdef SFAST_PROBES
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 const char *sfast_hip_last_error(void) { return sfast::g_err; }

@@ -38,16 +38,27 @@ class DenoiseLoop:
 
     One iteration = ONE graph launch and nothing else: the graph's first node (`sfast_hip_schedule_advance`) moves the current
     row of the timestep / coefficient tables into the plan's static inputs and advances a device-side cursor, so the host issues
-    no per-step copies. The cross-attention K/V projections depend on the text context only -- constant over the 50 steps -- and
-    run ONCE, in `set_inputs`, not in every step's graph (`compile()` cannot do that: there the context may change per call)."""
+    no per-step copies.
 
-    def __init__(self, engine, images=1, height=64, width=64, ctx_len=77, guidance=7.5, num_steps=50, use_graph=True):
+    `hoist_text_kv` (default False): the cross-attention K/V projections depend on the text context only -- constant over the 50
+    steps. With the flag they run ONCE, in `set_inputs`, and are left out of the step graph (a pipeline-level loop-invariant
+    hoist that `compile()` cannot do: there the context may change per call). The default keeps them IN the step graph, so a
+    step is literally one `unet.forward` + guidance + scheduler update -- the unit the reference's it/s counts and what
+    `bench.py`'s headline measures; the hoisted form is reported beside it. With the hoist, in-place updates of `to_k` / `to_v`
+    weights (the live-weight / LoRA contract) become visible at the next `set_inputs()` or `refresh_text_kv()`, not at the next
+    step -- every other weight stays live.
+
+    The loop owns a PRIVATE plan (`engine.build_plan`, not the engine's cached plan of the same signature): its static inputs
+    and K/V buffers cannot be overwritten by `engine.forward()` / `compile()` calls that share the engine between two steps."""
+
+    def __init__(self, engine, images=1, height=64, width=64, ctx_len=77, guidance=7.5, num_steps=50, use_graph=True,
+                 hoist_text_kv=False):
         self.engine = engine
         self.images = images
         self.guidance = float(guidance)
         self.lib = self._library(engine)
         dev, dt = engine.device, engine.dtype
-        self.plan = engine.get_plan(2 * images, height, width, ctx_len)
+        self.plan = engine.build_plan(2 * images, height, width, ctx_len)
         ts, rows = ddim_schedule(num_steps)
         self.num_steps = num_steps
         self.ts_table = torch.tensor(ts, dtype=torch.float32, device=dev).reshape(-1, 1).expand(-1, 2 * images).contiguous()
@@ -58,11 +69,15 @@ class DenoiseLoop:
         self.latents = torch.zeros((images, engine.in_ch, height, width), dtype=dt, device=dev)
         self.use_graph = use_graph
         self.graph = None
-        self.graph_forked = False
         from .unet2d import LANE_KV
         self._kv_lane = LANE_KV
-        self._step_ops = [op for op in self.plan.ops if op.lane != LANE_KV]   # what a step launches
-        self._ctx_ops = [op for op in self.plan.ops if op.lane == LANE_KV]    # what a new text context launches, once
+        self.hoist_text_kv = bool(hoist_text_kv)
+        if self.hoist_text_kv:
+            self._step_ops = [op for op in self.plan.ops if op.lane != LANE_KV]   # what a step launches
+            self._ctx_ops = [op for op in self.plan.ops if op.lane == LANE_KV]    # what a new text context launches, once
+        else:
+            self._step_ops = list(self.plan.ops)                                  # the whole forward, every step
+            self._ctx_ops = []
 
     @staticmethod
     def _library(engine):
@@ -79,6 +94,11 @@ class DenoiseLoop:
         si["sample"][: self.images].copy_(latents)
         si["sample"][self.images:].copy_(latents)
         si["encoder_hidden_states"].copy_(ehs_uncond_cond)
+        self.refresh_text_kv()
+
+    def refresh_text_kv(self):
+        """hoist_text_kv only: re-run the text-side launches (every cross-attention block's K/V projection) on the current stream --
+        after a new context (`set_inputs` calls this) or after an in-place update of to_k / to_v weights. A no-op otherwise."""
         sp = self._stream_ptr()
         for op in self._ctx_ops:
             op.launch(sp)

@@ -12,8 +12,13 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "_lib", "libsfast_hip.so")
+# The probe build (build.py --probes: timing-only experiment kernels, the never-selected patch conv pipe, the split-K join) is a
+# separate file that only tools/ and the tests of those candidates ask for, by setting SFAST_HIP_PROBES=1 BEFORE the first load.
+PROBES_LIB_PATH = os.path.join(os.path.dirname(_HERE), "_lib", "libsfast_hip_probes.so")
+if os.environ.get("SFAST_HIP_PROBES", "0") == "1":
+    LIB_PATH = PROBES_LIB_PATH
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # enums (include/sfast_hip.h)
 F16, BF16, F32 = 0, 1, 2
@@ -33,7 +38,7 @@ EXPORTS = [
     "sfast_hip_group_norm_apply",
     "sfast_hip_attention", "sfast_hip_attention_bias", "sfast_hip_strided_copy", "sfast_hip_timestep_embedding",
     "sfast_hip_gemv_grouped", "sfast_hip_gemm_grouped", "sfast_hip_qlinear_w8", "sfast_hip_cfg_ddim_step", "sfast_hip_linear_step", "sfast_hip_mix_rows", "sfast_hip_igemm_plan", "sfast_hip_set_trace", "sfast_hip_image_postprocess", "sfast_hip_add_strided",
-    "sfast_hip_schedule_advance", "sfast_hip_conv2d_plan", "sfast_hip_workspace_init",
+    "sfast_hip_schedule_advance", "sfast_hip_conv2d_plan", "sfast_hip_workspace_init", "sfast_hip_has_probes",
 ]
 
 
@@ -198,6 +203,7 @@ def _declare(lib):
     lib.sfast_hip_conv2d_plan.argtypes = [C.POINTER(ConvParams), C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     lib.sfast_hip_schedule_advance.restype = C.c_int
     lib.sfast_hip_schedule_advance.argtypes = [vp, vp, C.c_int32, vp, vp, C.c_int32, vp, C.c_int32, vp]
+    lib.sfast_hip_has_probes.restype = C.c_int
     lib.sfast_hip_cfg_ddim_step.restype = C.c_int
     lib.sfast_hip_cfg_ddim_step.argtypes = [vp, vp, vp, vp, vp, C.c_float, C.c_int64, C.c_int32, vp]
 
@@ -248,6 +254,11 @@ def init_device(device=None):
                     raise SfastHipError(f"sfast_hip_init failed ({rc}): {last_error()}")
                 _inited.add(idx)
     return lib
+
+
+def has_probes():
+    """True when the loaded library is the probe build (timing-only instantiations, patch conv pipe, split-K join)."""
+    return bool(load().sfast_hip_has_probes())
 
 
 def last_error():

@@ -27,7 +27,7 @@ def main():
     env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
     subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_triton_run.py"), "--out", tmp, "--small-only"],
                    check=True, env=env, cwd=ROOT)
-    res = torch.load(tmp)
+    res = torch.load(tmp, weights_only=False)
     os.remove(tmp)
     keep = {"triton": res["triton"], "torch": res["torch"], "device": res["device"], "status": res["status"], "out": {}}
     for name, rec in res["out"].items():

@@ -32,6 +32,20 @@ def last_kernel():
     return lib.last_kernel()
 
 
+def _probes_loaded():
+    try:
+        from sfast.hip import lib
+        return lib.has_probes()
+    except Exception:
+        return False
+
+
+# Candidates that were measured and never selected (the LDS-patch conv pipe, the in-kernel split-K join) live only in the probe
+# build of the library (stable-fast_amd/build.py --probes -> libsfast_hip_probes.so, loaded when SFAST_HIP_PROBES=1 is set before
+# the first load): `SFAST_HIP_PROBES=1 pytest tests/test_ops_gpu.py -m gpu -k "patch or join"`. In the default run they skip.
+needs_probes = pytest.mark.skipif(not _probes_loaded(), reason="needs the probe build: python stable-fast_amd/build.py --probes; SFAST_HIP_PROBES=1")
+
+
 def tol(dtype, scale=1.0):
     if dtype == torch.bfloat16:
         return 2e-2 * scale, 1.6e-2
@@ -366,6 +380,7 @@ PATCH_CASES = [
 ]
 
 
+@needs_probes
 @pytest.mark.parametrize("case", PATCH_CASES, ids=[c[0] for c in PATCH_CASES])
 @pytest.mark.parametrize("variant,split", [(31, 1), (32, 1), (34, 1), (31, 2), (32, 5), (34, 4), (31, 20)])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -396,6 +411,7 @@ def test_conv_patch_pipe(case, variant, split, dtype):
     compare(f"conv patch {name} v{variant} s{split} {dtype}", y, want, *tol(dtype, 2.0), kernel=k)
 
 
+@needs_probes
 @pytest.mark.parametrize("variant,split", [(31, 1), (32, 1), (34, 1), (31, 5), (32, 2)])
 @pytest.mark.parametrize("cin,cout,hw,unit", [(320, 320, 32, 10), (640, 1280, 16, 20)])
 def test_conv_patch_pipe_emits_groupnorm_statistics(variant, split, cin, cout, hw, unit):
@@ -432,6 +448,7 @@ def test_conv_split_k(split):
         compare(f"conv dma v{v} split{split}", y, R.conv2d_ref(x, w, b, z, 1.0, 1, 1), *tol(x.dtype, 2.0), kernel=last_kernel())
 
 
+@needs_probes
 @pytest.mark.parametrize("variant,split", [(1, 3), (4, 12), (2, 4), (21, 6), (22, 8), (23, 12), (24, 3), (25, 5), (32, 5), (34, 10)])
 def test_split_k_join_matches_the_reduce_kernel(variant, split, monkeypatch):
     """Split-K finished inside the GEMM kernel (ticket counters, sfast_hip.h SFAST_EXT_WS_TICKETS) against the two-launch form (fp32
@@ -457,6 +474,7 @@ def test_split_k_join_matches_the_reduce_kernel(variant, split, monkeypatch):
     assert float((y.float() - y2.float()).abs().max()) <= 2e-3, (k, k2)
 
 
+@needs_probes
 @pytest.mark.parametrize("variant,split", [(21, 3), (23, 6), (1, 4), (3, 2)])
 def test_split_k_join_linear_geglu_and_ragged(variant, split, monkeypatch):
     """GEGLU (both halves travel through the slabs) and a problem whose tiles hang over M and N."""
@@ -474,6 +492,7 @@ def test_split_k_join_linear_geglu_and_ragged(variant, split, monkeypatch):
     compare(f"linear ragged join v{variant} split{split}", y, R.linear_ref(x, w, b, residual=r), *tol(x.dtype), kernel=k)
 
 
+@needs_probes
 @pytest.mark.parametrize("variant,split", [(21, 4), (23, 6), (3, 3)])
 def test_split_k_join_emits_groupnorm_statistics(variant, split, monkeypatch):
     """With the join the workgroup that finishes a tile runs the staged epilogue, statistics included (no reduce-rows kernel)."""

@@ -248,7 +248,7 @@ def test_oracle_vs_reference_triton_fixture():
     if not os.path.exists(path):
         import pytest
         pytest.skip("fixture not generated yet (needs one GPU session: tests/golden/make_golden_ref_triton.py)")
-    fx = torch.load(path)
+    fx = torch.load(path, weights_only=False)
     assert fx["status"]["gn"].startswith("ok") and fx["status"]["ln"].startswith("ok") and fx["status"]["copy"].startswith("ok"), fx["status"]
     u = 2.0 ** -10
     n = 0
@@ -291,6 +291,8 @@ def test_oracle_vs_reference_triton_fixture():
             x, w, b = RC.conv_inputs(c)
             want = R.conv2d_ref(x, w, b, stride=c["stride"], padding=c["padding"])
             got = fx["out"][c["name"]]["y"].float()
-            assert torch.allclose(got, want, atol=2 * u, rtol=2 * u), (c["name"], float((got - want).abs().max()))
+            K = c["w"][1] * c["w"][2] * c["w"][3]
+            f = max(2.0, 0.75 * (K / 32.0) ** 0.5)   # the reference's Triton conv accumulates f16 inputs in f16 (conv.py:844-845)
+            assert torch.allclose(got, want, atol=f * u, rtol=f * u), (c["name"], float((got - want).abs().max()))
             n += 1
     assert n >= 7

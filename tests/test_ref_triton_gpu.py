@@ -49,15 +49,16 @@ def last_kernel():
 def ref():
     if not make_ref.available():
         pytest.skip("oracle/_ref/sfast_ref_triton.zip not staged (run oracle/make_ref.py where /root/reference exists)")
-    out = os.path.join(ROOT, "gpurun_out", "ref_triton_full.pt")
-    os.makedirs(os.path.dirname(out), exist_ok=True)
+    import tempfile
+    out = os.path.join(tempfile.gettempdir(), "sfast_ref_triton_full.pt")  # ~100 MB of outputs: not into gpurun_out/ (64 MiB cap)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_triton_run.py"), "--out", out, "--time"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     with open(os.path.join(ROOT, "gpurun_out", "ref_triton_run.log"), "w") as f:
         f.write(p.stdout + "\n--- stderr ---\n" + p.stderr[-20000:])
     assert p.returncode == 0, p.stderr[-3000:]
-    res = torch.load(out)
+    res = torch.load(out, weights_only=False)
     log_value("ref_triton_status", **{k: str(v) for k, v in res["status"].items()}, triton=res["triton"], device=res["device"])
     return res
 
@@ -110,6 +111,11 @@ def test_group_norm_vs_reference_triton(ref, case):
     else:
         stat_term = stat_term.reshape(x.shape)
     stat_term = stat_term * w.float().abs().reshape(1, C, *([1] * (x.ndim - 2))) * (1.1 if case["silu"] else 1.0)
+    # diagnostics first: the statistics the reference returns against the exact ones (logged whether or not the case passes)
+    ref_mean, ref_rstd = rec["mean"].float().to(DEV), rec["rstd"].float().to(DEV)
+    log_value(f"ref_triton_stats {case['name']}", mean_max_err=float((ref_mean - mean.reshape(N, -1)).abs().max()),
+              rstd_max_rel_err=float(((ref_rstd - rstd.reshape(N, -1)) / rstd.reshape(N, -1)).abs().max()),
+              y_finite=bool(torch.isfinite(y_ref.float()).all()))
     # (a) oracle restatement vs the reference's kernel
     d = (want32 - y_ref.float()).abs()
     lim = u * (1.0 + want32.abs()) + 1.5 * stat_term
@@ -185,9 +191,15 @@ def test_conv_vs_reference_triton(ref, case):
     y_ref = rec["y"].to(DEV)
     want32 = R.conv2d_ref(x, w, b, stride=case["stride"], padding=case["padding"])
     K = case["w"][1] * case["w"][2] * case["w"][3]
-    # the reference's Triton conv accumulates in fp32 (ACC_TYPE) over tl.dot tiles: sqrt(K)-sized rounding of f16 products is exact in fp32,
-    # so reference vs fp32 oracle is the output rounding (1 ulp f16) -- same bar as the other families
+    # The reference's Triton conv accumulates f16 inputs IN F16 (conv.py:844-845 `ACC_TYPE = tl.float16`, `acc += tl.dot(..., out_dtype=ACC_TYPE)`
+    # :449): every one of the K / BLOCK_K partial dot products is rounded into an f16 running sum, a random walk of ~sqrt(K / 32) half-ulps
+    # of the sum's magnitude. The oracle (and the HIP kernels: fp32 MFMA accumulate) do not reproduce that loss, so the bar carries it as
+    # an explicit factor: u * max(2, 0.75 * sqrt(K / 32)) -- 7 ulp at K = 2880, 3.4 at K = 640 (measured on the 320->320 3x3 case:
+    # max 1.0e-2 at |y| = 1.27, rel. L2 1.0e-3, profiles/r04_ref_triton_tests_run1.log). bf16 / fp32 inputs accumulate in fp32 there too.
     u = _ulp(x.dtype)
-    compare(f"oracle_vs_ref_triton {case['name']}", y_ref.float(), want32, 2 * u, 2 * u)
+    f = max(2.0, 0.75 * (K / 32.0) ** 0.5) if x.dtype == torch.float16 else 2.0
+    rec1 = compare(f"oracle_vs_ref_triton {case['name']}", y_ref.float(), want32, f * u, f * u)
     y = F().conv2d(x, w, b, stride=case["stride"], padding=case["padding"])
-    compare(f"hip_vs_ref_triton {case['name']}", y.float(), y_ref.float(), 3 * u, 3 * u, kernel=last_kernel())
+    rec2 = compare(f"hip_vs_ref_triton {case['name']}", y.float(), y_ref.float(), (f + 1) * u, (f + 1) * u, kernel=last_kernel())
+    rec3 = compare(f"hip_vs_oracle {case['name']}", y.float(), want32, 2 * u, 2 * u, kernel=last_kernel())
+    assert rec3["rel_l2"] <= rec1["rel_l2"] + 1e-4, "the HIP conv (fp32 accumulate) should be at least as close to the fp32 oracle as the reference's f16-accumulating kernel"

@@ -6,6 +6,10 @@ import os
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "stable-fast_amd"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _probes  # noqa: E402
+
+_probes.use_probe_build()  # experiment / ablation / patch-pipe instantiations exist only in libsfast_hip_probes.so
 import torch  # noqa: E402
 
 from sfast.hip import functional as F  # noqa: E402

@@ -20,6 +20,7 @@ s1)  # the reference's own Triton kernels on this box (fixture + oracle / HIP co
   run t_ref_triton 1500 $PYT tests/test_ref_triton_gpu.py
   run wdirect 300 tools/micro/wdirect
   run trread 60 tools/micro/trread
+  run t_sanity 900 $PYT tests/test_ops_gpu.py -k "attention or split or conv_bias or group_norm" -x
   run bench 900 python bench.py --steps 50 --warmup 10 --no-end-to-end --dump-kernels gpurun_out/kernels.json
   ;;
 esac

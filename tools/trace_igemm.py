@@ -10,6 +10,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "stable-fast_amd"))
 os.environ.setdefault("SFAST_AUTOTUNE", "0")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _probes  # noqa: E402
+
+_probes.use_probe_build()  # experiment / ablation / patch-pipe instantiations exist only in libsfast_hip_probes.so
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
