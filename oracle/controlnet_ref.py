@@ -82,7 +82,8 @@ class ControlNetModel(nn.Module):
         self.mid_block = MidBlock(boc[-1], temb, g, eps, heads[-1], c.cross_attention_dim, depth[-1], lp)
         self.controlnet_mid_block = nn.Conv2d(boc[-1], boc[-1], 1)
 
-    def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0, return_dict=True, **_):
+    def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0, guess_mode=False,
+                return_dict=True, **_):
         c = self.config
         B = sample.shape[0]
         t = timestep
@@ -95,8 +96,17 @@ class ControlNetModel(nn.Module):
         for blk in self.down_blocks:
             h = blk(h, emb, encoder_hidden_states, skips)
         h = self.mid_block(h, emb, encoder_hidden_states)
-        down = [z(s) * conditioning_scale for s, z in zip(skips, self.controlnet_down_blocks)]
-        mid = self.controlnet_mid_block(h) * conditioning_scale
+        down = [z(s) for s, z in zip(skips, self.controlnet_down_blocks)]
+        mid = self.controlnet_mid_block(h)
+        if guess_mode and not getattr(c, "global_pool_conditions", False):
+            # diffusers ControlNetModel.forward ("6. scaling"): guess mode weights the residuals 0.1 ... 1.0 from the shallowest skip
+            # to the mid block -- torch.logspace(-1, 0, len(down) + 1) * conditioning_scale
+            scales = torch.logspace(-1, 0, len(down) + 1, device=sample.device) * conditioning_scale
+            down = [d * s for d, s in zip(down, scales)]
+            mid = mid * scales[-1]
+        else:
+            down = [d * conditioning_scale for d in down]
+            mid = mid * conditioning_scale
         if not return_dict:
             return down, mid
         return SimpleNamespace(down_block_res_samples=down, mid_block_res_sample=mid)

@@ -272,10 +272,10 @@ class _NativeControlNetForward:
         eng = self.engine
         bad = [k for k, v in dict(class_labels=class_labels, timestep_cond=timestep_cond, attention_mask=attention_mask,
                                   added_cond_kwargs=added_cond_kwargs).items() if v is not None]
-        if cross_attention_kwargs:
-            bad.append("cross_attention_kwargs")
-        if guess_mode:
-            bad.append("guess_mode")
+        if cross_attention_kwargs and set(cross_attention_kwargs) - {"scale"}:   # "scale" acts on LoRA layers only; the engine holds none
+            bad.append("cross_attention_kwargs " + str(sorted(set(cross_attention_kwargs) - {"scale"})))
+        # guess_mode is native (per-residual logspace weights, ControlNetEngine.residual_scales) unless the ControlNet pools its
+        # conditions globally (global_pool_conditions: the engine's config whitelist already refuses such a module)
         if (bad or encoder_hidden_states is None or controlnet_cond is None or not torch.is_tensor(sample)
                 or sample.device.type != "cuda" or sample.dtype != eng.dtype or sample.ndim != 4
                 or not isinstance(conditioning_scale, (int, float))):
@@ -311,7 +311,7 @@ class _NativeControlNetForward:
                 graph.replay()
             else:
                 plan.run(torch.cuda.current_stream(eng.device).cuda_stream)
-            down, mid = eng.outputs(plan, float(conditioning_scale))
+            down, mid = eng.outputs(plan, float(conditioning_scale), bool(guess_mode))
         if not return_dict:
             return down, mid
         return ControlNetOutput(down, mid)

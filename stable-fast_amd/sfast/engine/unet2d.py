@@ -1297,18 +1297,28 @@ class ControlNetEngine(UNet2DEngine):
             raise ValueError("controlnet_cond is required")
         plan.static_in["controlnet_cond"].copy_(controlnet_cond)
 
-    def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0):
+    def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0, guess_mode=False):
         """Eager (no graph) execution on the current stream; returns (down_block_res_samples, mid_block_res_sample)
         as fresh NCHW tensors, ready to be passed to UNet2DConditionModel.forward / UNet2DEngine.forward."""
         B, _, H, W = sample.shape
         plan = self.get_plan(B, H, W, encoder_hidden_states.shape[1])
         self.load_inputs(plan, sample, timestep, encoder_hidden_states, controlnet_cond)
         plan.run(self.host.stream_ptr(self.device))
-        return self.outputs(plan, conditioning_scale)
+        return self.outputs(plan, conditioning_scale, guess_mode)
 
     @staticmethod
-    def outputs(plan, conditioning_scale=1.0):
+    def residual_scales(n_down, conditioning_scale=1.0, guess_mode=False):
+        """Weights of the n_down skip residuals and the mid residual. guess_mode (diffusers ControlNetModel.forward, without
+        global_pool_conditions): torch.logspace(-1, 0, n_down + 1) * conditioning_scale, i.e. 0.1 for the shallowest skip up to 1.0 for the
+        mid block; otherwise conditioning_scale everywhere. Host floats -- the residuals are scaled as they are copied out of the plan."""
+        if guess_mode:
+            return [float(conditioning_scale) * 10.0 ** (-1.0 + i / n_down) for i in range(n_down + 1)]
+        return [float(conditioning_scale)] * (n_down + 1)
+
+    @classmethod
+    def outputs(cls, plan, conditioning_scale=1.0, guess_mode=False):
         so = plan.static_out
-        if conditioning_scale == 1.0:
-            return [t.clone() for t in so["down_block_res_samples"]], so["mid_block_res_sample"].clone()
-        return [t * conditioning_scale for t in so["down_block_res_samples"]], so["mid_block_res_sample"] * conditioning_scale
+        down = so["down_block_res_samples"]
+        sc = cls.residual_scales(len(down), conditioning_scale, guess_mode)
+        return ([t.clone() if s == 1.0 else t * s for t, s in zip(down, sc[:-1])],
+                so["mid_block_res_sample"].clone() if sc[-1] == 1.0 else so["mid_block_res_sample"] * sc[-1])

@@ -227,6 +227,12 @@ def test_controlnet_engine_on_the_emulator(built_lib):
     assert [tuple(t.shape) for t in down] == [tuple(t.shape) for t in wd]
     d2, m2 = ceng.forward(s, 300, e, cond, conditioning_scale=0.5)
     assert rel_l2(d2[0], 0.5 * wd[0]) < 3e-3 and rel_l2(m2, 0.5 * wm) < 3e-3
+    # guess_mode: residual i weighted 10^(-1 + i / n) * conditioning_scale (diffusers ControlNetModel.forward, "6. scaling")
+    d3, m3 = ceng.forward(s, 300, e, cond, conditioning_scale=0.8, guess_mode=True)
+    with torch.no_grad():
+        gd, gm = c32(s.float(), 300, e.float(), cond.float(), conditioning_scale=0.8, guess_mode=True, return_dict=False)
+    assert all(rel_l2(a, b) < 3e-3 for a, b in zip(d3, gd)) and rel_l2(m3, gm) < 3e-3
+    assert abs(float(gd[0].norm() / wd[0].norm()) - 0.08) < 1e-3 and abs(float(gm.norm() / wm.norm()) - 0.8) < 1e-3
     # chain into the UNet plan
     m16, m32 = _pair(U.tiny_config(), 22)
     ueng = UNet2DEngine.from_module(m16, _host=EmuHost())

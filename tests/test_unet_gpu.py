@@ -397,6 +397,13 @@ def test_controlnet_engine_and_compiled_chain():
     assert not cnet.forward._warned and not unet.forward._warned
     d2, m2 = cnet(sample, 444, encoder_hidden_states=ehs, controlnet_cond=cond, conditioning_scale=0.5, return_dict=False)
     assert rel_l2(m2.float(), 0.5 * wm) < 4e-3
+    # guess_mode stays on the native plan (round 4): logspace(-1, 0) residual weights, as diffusers' ControlNetModel.forward applies them
+    with torch.no_grad():
+        gd, gm = cref(sample.float(), 444, ehs.float(), cond.float(), conditioning_scale=0.7, guess_mode=True, return_dict=False)
+    d3, m3 = cnet(sample, 444, encoder_hidden_states=ehs, controlnet_cond=cond, conditioning_scale=0.7, guess_mode=True,
+                  cross_attention_kwargs={"scale": 1.0}, return_dict=False)
+    assert max(rel_l2(a.float(), b) for a, b in zip(d3, gd)) < 4e-3 and rel_l2(m3.float(), gm) < 4e-3
+    assert not cnet.forward._warned
 
 
 # ---- trace_scheduler: the scheduler update as one HIP kernel behind diffusers' step() signature -------------------------
