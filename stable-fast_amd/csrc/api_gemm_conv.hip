@@ -32,7 +32,7 @@ GemmRoute gemm_route(const void *x, const void *const *w_segs, const void *bias,
     if (bias) vec_out = vec_out && aligned8(bias);
     if (rowbias) vec_out = vec_out && aligned8(rowbias) && p->ld_rowbias % 4 == 0 && p->rows_per_batch > 0;
     if (residual) vec_out = vec_out && aligned8(residual) && p->ldr % 4 == 0;
-    if (p->geglu) vec_out = vec_out && p->n_wseg == 1;
+    if (p->geglu) vec_out = vec_out && p->n_wseg <= 2;  // one [2N, K] weight or (hidden, gate) segments
     if (vec_out) r.kind = GemmRoute::IGEMM;
     return r;
 }
@@ -44,7 +44,10 @@ int validate_gemm(const void *x, const void *const *w_segs, const void *out, con
     const int wrows = p->geglu ? 2 * p->N : p->N;
     SFAST_REQUIRE(p->rows_per_seg > 0 && (int64_t)p->rows_per_seg * p->n_wseg >= wrows, SFAST_ERR_INVALID,
                   "gemm: %d segments of %d rows do not cover %d weight rows", p->n_wseg, p->rows_per_seg, wrows);
-    SFAST_REQUIRE(!p->geglu || p->n_wseg == 1, SFAST_ERR_INVALID, "gemm: geglu needs a single weight segment");
+    // GEGLU: one [2N, K] weight (hidden rows, then gate rows) or TWO [N, K] segments (hidden, gate) -- the reference's two-weight
+    // cutlass_linear_geglu(input, weight0, bias0, weight1, bias1) without a concatenated copy
+    SFAST_REQUIRE(!p->geglu || p->n_wseg == 1 || (p->n_wseg == 2 && p->rows_per_seg == p->N), SFAST_ERR_INVALID,
+                  "gemm: geglu takes one [2N, K] weight or two [N, K] segments (got %d segments of %d rows, N = %d)", p->n_wseg, p->rows_per_seg, p->N);
     for (int i = 0; i < p->n_wseg; ++i) SFAST_REQUIRE(w_segs[i], SFAST_ERR_INVALID, "gemm: null weight segment %d", i);
     SFAST_REQUIRE(p->ldx >= p->K && p->ldw >= p->K && p->ldo >= p->N, SFAST_ERR_INVALID, "gemm: bad leading dims");
     return SFAST_OK;
@@ -263,6 +266,8 @@ extern "C" int sfast_hip_gemm_ex(const void *x, const void *const *w_segs, const
         a.x = x;
         a.x2 = nullptr;
         for (int i = 0; i < SFAST_MAX_WSEG; ++i) a.w[i] = i < p->n_wseg ? w_segs[i] : w_segs[0];
+        if (p->geglu && p->n_wseg == 1)  // the MFMA GEGLU kernels read hidden rows from w[0] and gate rows from w[1]
+            a.w[1] = (const char *)w_segs[0] + (int64_t)p->N * p->ldw * (int64_t)dtype_bytes(p->dtype);
         a.bias = bias;
         a.rowbias = rowbias;
         a.res = residual;

@@ -101,7 +101,7 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs &a) {
             const int grp = j / WNB, within = j % WNB;
             const int half = within / (WNB / 2), i2 = within % (WNB / 2);
             const int ncol = n0 + grp * (WNB / 2) + i2;
-            wrow[i] = (ncol < a.N) ? (const T *)a.w[0] + ((int64_t)half * a.N + ncol) * a.ldw : nullptr;
+            wrow[i] = (ncol < a.N) ? (const T *)(half ? a.w[1] : a.w[0]) + (int64_t)ncol * a.ldw : nullptr;  // a.w[1] = first gate row (api_gemm_conv.hip)
         } else {
             const int n = n0 + j;
             if (n < a.N) {

@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, NS *
             const int grp = j / WNB, within = j % WNB;
             const int half = within / (WNB / 2), i2 = within % (WNB / 2);
             const int ncol = n0 + grp * (WNB / 2) + i2;
-            wrow[i] = (ncol < a.N) ? (const T *)a.w[0] + ((int64_t)half * a.N + ncol) * a.ldw + kc * 8 : nullptr;
+            wrow[i] = (ncol < a.N) ? (const T *)(half ? a.w[1] : a.w[0]) + (int64_t)ncol * a.ldw + kc * 8 : nullptr;
         } else {
             const int n = n0 + j;
             if (n < a.N) {

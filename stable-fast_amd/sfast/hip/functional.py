@@ -302,10 +302,11 @@ def linear(x, weight, bias=None, *, act=None, residual=None, alpha=1.0, res_befo
 
 
 @_on_device
-def linear_grouped(x, weight_groups, biases=None, act=None):
+def linear_grouped(x, weight_groups, biases=None, act=None, outs=None):
     """[act(x_g @ cat(W_g)^T + b_g) for g]: every group is a list of <= 2 equally sized [n, K] weights stacked along N; all groups
     have the same shape. `x`: one [M, K] tensor shared by all groups, or a list of per-group [M, K] tensors. Launches of up to
-    64 groups each (sfast_hip_gemm_grouped). Returns a list of [M, N] tensors."""
+    64 groups each (sfast_hip_gemm_grouped). Returns a list of [M, N] tensors. `outs`: optional preallocated dense [M, N] outputs, one
+    per group (e.g. the rows `out[b]` of ONE [B, M, N] tensor: a batched matmul lands in place, no stack)."""
     groups = [list(g) if isinstance(g, (list, tuple)) else [g] for g in weight_groups]
     flat = [w for g in groups for w in g]
     xs = list(x) if isinstance(x, (list, tuple)) else [x] * len(groups)
@@ -321,7 +322,12 @@ def linear_grouped(x, weight_groups, biases=None, act=None):
     nseg, rows = len(groups[0]), groups[0][0].shape[0]
     flat = [w.contiguous() for w in flat]
     N = nseg * rows
-    outs = [torch.empty((M, N), dtype=xs2[0].dtype, device=xs2[0].device) for _ in groups]
+    if outs is None:
+        outs = [torch.empty((M, N), dtype=xs2[0].dtype, device=xs2[0].device) for _ in groups]
+    else:
+        outs = list(outs)
+        if len(outs) != len(groups) or any(tuple(o.shape) != (M, N) or not o.is_contiguous() or o.dtype != xs2[0].dtype for o in outs):
+            raise L.SfastHipError("linear_grouped: `outs` must be one dense [M, N] tensor of the input dtype per group")
     bs = None
     if biases is not None:
         bs = [None if b is None else b.to(xs2[0].dtype).contiguous() for b in biases]
@@ -379,12 +385,14 @@ def _nhwc_strides(t):
 @_on_device
 def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dilation=1, act=None,
            res_before_act=True, x2=None, upsample2x=False, rowbias=None, variant=0, split_k=0,
-           channels_last_out: Optional[bool] = None, pad_extra=0, out_scale=1.0, gn_unit=0):
+           channels_last_out: Optional[bool] = None, pad_extra=0, out_scale=1.0, gn_unit=0, out=None):
     """y = act(conv2d(x, w) + bias + rowbias[b] + alpha*z) on logical NCHW tensors of any strides.
     x2: optional tensor concatenated to x along channels (virtual). upsample2x: nearest 2x first.
     pad_extra: additional zero rows / columns at the bottom / right on top of `padding` (F.pad(x, (0, e, 0, e))).
     out_scale: accumulator scale (sfast_epilogue_ext). gn_unit > 0: also emit GroupNorm partial statistics of y; returns
-    (y, stats float32 tensor, GnStatsLayout) -- feed them to group_norm_apply()."""
+    (y, stats float32 tensor, GnStatsLayout) -- feed them to group_norm_apply().
+    out: optional preallocated [B, Cout, Ho, Wo] tensor of ANY strides (e.g. a channel slice of a larger NHWC tensor: the groups of
+    a grouped convolution write their slices of one output, no concatenation)."""
     _require_cuda(x, weight, bias, z, x2, rowbias)
     lib = L.init_device()
     if x.ndim != 4 or weight.ndim != 4:
@@ -410,7 +418,12 @@ def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dila
             return t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
         channels_last_out = _is_cl(x) or _is_cl(weight)
     fmt = torch.channels_last if channels_last_out else torch.contiguous_format
-    y = torch.empty((B, Cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=fmt)
+    if out is not None:
+        if tuple(out.shape) != (B, Cout, Ho, Wo) or out.dtype != x.dtype or out.device != x.device:
+            raise L.SfastHipError(f"conv2d: `out` must be a {(B, Cout, Ho, Wo)} tensor of the input dtype on its device")
+        y = out
+    else:
+        y = torch.empty((B, Cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=fmt)
     if y.numel() == 0 and not gn_unit:
         return y  # empty batch: nothing to launch
     zz = None

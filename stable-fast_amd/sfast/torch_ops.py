@@ -37,6 +37,8 @@ def cutlass_linear_geglu(input, weight0, bias0, weight1, bias1):
                 weight1.shape == weight0.shape)
     if adjacent:
         w = torch.as_strided(weight0, (2 * n, k), (k, 1))
+    elif (weight1.shape == weight0.shape and weight0.stride(1) == 1 and weight1.stride(1) == 1 and weight0.stride(0) == weight1.stride(0)):
+        w = [weight0, weight1]   # (hidden, gate) weight segments of ONE launch: the live weights are read in place, no concatenated copy
     else:
         w = torch.cat([weight0, weight1], dim=0)
     if (bias0 is None) != (bias1 is None):
@@ -53,30 +55,38 @@ _def("cutlass_linear_geglu(Tensor input, Tensor weight0, Tensor? bias0, Tensor w
 
 
 # ---- conv + bias (+ alpha*z) (+ activation) ----------------------------------------------------------
-def _conv(input, weight, bias, z, alpha, stride, padding, dilation, transposed, output_padding, groups, act):
+def _conv(input, weight, bias, z, alpha, stride, padding, dilation, transposed, output_padding, groups, act, out=None):
     if transposed or any(int(o) != 0 for o in output_padding):
         raise RuntimeError("sfast conv ops on ROCm support non-transposed convolutions only")
-    if groups != 1:
-        # grouped / depthwise: one native launch per group on channel-sliced views (the reference leaves these to ATen,
-        # cudnn_convolution_impl.cc:1265-1286); the groups' outputs are joined by a copy -- data movement only
-        cin_g, cout_g = input.shape[1] // groups, weight.shape[0] // groups
-        if input.shape[1] != cin_g * groups or weight.shape[0] != cout_g * groups or weight.shape[1] != cin_g:
-            raise RuntimeError("sfast conv: channels are not divisible by groups")
-        outs = []
-        for g in range(groups):
-            zg = None if z is None else (z[:, g * cout_g:(g + 1) * cout_g] if z.shape[1] == weight.shape[0] else z)
-            outs.append(_conv(input[:, g * cin_g:(g + 1) * cin_g], weight[g * cout_g:(g + 1) * cout_g],
-                              None if bias is None else bias[g * cout_g:(g + 1) * cout_g], zg, alpha, stride, padding, dilation,
-                              False, output_padding, 1, act))
-        return torch.cat(outs, dim=1)
     if input.ndim == 3:  # 1-D conv as 2-D, like the reference (cudnn_convolution_impl.cc:1242-1252)
         y = _conv(input.unsqueeze(2), weight.unsqueeze(2), bias, None if z is None else z.unsqueeze(2), alpha,
                   [1, stride[0]], [0, padding[0]], [1, dilation[0]], transposed, [0, 0], groups, act)
         return y.squeeze(2)
+    if groups != 1:
+        # grouped / depthwise: one native launch per group on channel-sliced views (the reference leaves these to ATen,
+        # cudnn_convolution_impl.cc:1265-1286); every group writes its channel slice of ONE output tensor through the kernels'
+        # output strides -- no per-group temporaries, no concatenation
+        cin_g, cout_g = input.shape[1] // groups, weight.shape[0] // groups
+        if input.shape[1] != cin_g * groups or weight.shape[0] != cout_g * groups or weight.shape[1] != cin_g:
+            raise RuntimeError("sfast conv: channels are not divisible by groups")
+        y = None
+        for g in range(groups):
+            zg = None if z is None else (z[:, g * cout_g:(g + 1) * cout_g] if z.shape[1] == weight.shape[0] else z)
+            xg, wg = input[:, g * cin_g:(g + 1) * cin_g], weight[g * cout_g:(g + 1) * cout_g]
+            bg = None if bias is None else bias[g * cout_g:(g + 1) * cout_g]
+            if y is None:   # the first group fixes the output geometry and memory format (one allocation for all groups)
+                y0 = _conv(xg, wg, bg, zg, alpha, stride, padding, dilation, False, output_padding, 1, act)
+                cl = y0.is_contiguous(memory_format=torch.channels_last) and not y0.is_contiguous()
+                y = torch.empty((y0.shape[0], weight.shape[0], y0.shape[2], y0.shape[3]), dtype=y0.dtype, device=y0.device,
+                                memory_format=torch.channels_last if cl else torch.contiguous_format)
+                y[:, :cout_g].copy_(y0)
+                continue
+            _conv(xg, wg, bg, zg, alpha, stride, padding, dilation, False, output_padding, 1, act, out=y[:, g * cout_g:(g + 1) * cout_g])
+        return y
     a = 1.0 if alpha is None else float(alpha)
     # y = act(conv + alpha*z + bias)   (cudnn_convolution_impl.cc:995-998)
     return F.conv2d(input, weight, bias, z=z, alpha=a, stride=tuple(stride), padding=tuple(padding),
-                    dilation=tuple(dilation), act=act, res_before_act=True)
+                    dilation=tuple(dilation), act=act, res_before_act=True, out=out)
 
 
 def _mk_conv_bias(act):
@@ -180,6 +190,17 @@ def _addmm(self, mat1, mat2, beta, alpha, act=None, other=None, gamma=1.0):
     beta, alpha, gamma = float(beta), float(alpha), float(gamma)
     w = _as_weight(mat2)
     n = w.shape[0]
+    if alpha == 0.0:
+        # torch.addmm semantics: the product is not computed (NaN / inf in mat1 / mat2 do not propagate) -- and the library reads an
+        # accumulator scale of 0 as "unset" (= 1), so this degenerate case never reaches it. Pure broadcast arithmetic, no GEMM.
+        m = mat1.shape[0]
+        base = torch.zeros((m, n), dtype=mat1.dtype, device=mat1.device) if beta == 0.0 else (self * beta).expand(m, n).to(mat1.dtype)
+        if act is not None:
+            base = torch.relu(base) if act == "relu" else torch.nn.functional.gelu(base)
+        return base + gamma * other if other is not None else base.clone()
+    if beta == 0.0:
+        # torch.addmm ignores `self` when beta == 0 (a NaN there must not reach the result): no residual operand at all
+        return F.linear(mat1, w, None, act=act, residual=other, alpha=gamma, out_scale=alpha)
     if beta == 1.0 and self.ndim == 1 and self.shape[0] == n:
         return F.linear(mat1, w, self, act=act, residual=other, alpha=gamma, out_scale=alpha)
     if other is None:
@@ -209,11 +230,17 @@ def cublas_lowp_bmm(self, batch2):
     N = batch2.shape[2]
     if K % 8 == 0 and N % 4 == 0 and self.dtype in (torch.float16, torch.bfloat16):
         # one grouped launch per 64 batch elements: group b = (self[b], batch2[b]^T), outputs are rows of ONE [B, M, N] tensor
-        w = batch2.transpose(1, 2).contiguous()  # [B, N, K]: the K-contiguous operand layout of the GEMM kernels
-        outs = F.linear_grouped([self[b] for b in range(B)], [[w[b]] for b in range(B)])
-        return torch.stack(outs, dim=0)
-    outs = [F.linear(self[b], _as_weight(batch2[b])) for b in range(B)]
-    return torch.stack(outs, dim=0)
+        # the GEMM kernels read both operands K-contiguous: batch2 [B, K, N] -> [B, N, K] by ONE native strided copy (unless it already
+        # is a transposed view of such a tensor); the outputs are the rows of ONE [B, M, N] tensor -- no stack
+        bt = batch2.transpose(1, 2)
+        w = bt if bt.is_contiguous() else F.strided_copy(bt, torch.empty((B, N, K), dtype=batch2.dtype, device=batch2.device))
+        out = torch.empty((B, M, N), dtype=self.dtype, device=self.device)
+        F.linear_grouped([self[b] for b in range(B)], [[w[b]] for b in range(B)], outs=[out[b] for b in range(B)])
+        return out
+    out = torch.empty((B, M, N), dtype=self.dtype, device=self.device)
+    for b in range(B):
+        F.linear(self[b], _as_weight(batch2[b]), out=out[b])
+    return out
 
 
 def cublas_lowp_baddbmm(self, batch1, batch2, beta, alpha):

@@ -115,7 +115,8 @@ def test_group_norm_generic_and_edges(case):
 
 
 # ---- LayerNorm -------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(1151, 8192), (8192, 320), (2048, 640), (512, 1280), (128, 1280), (2, 77, 768), (5, 77), (3, 2048)])
+@pytest.mark.parametrize("shape", [(1151, 8192), (8192, 320), (2048, 640), (512, 1280), (128, 1280), (2, 77, 768), (5, 77), (3, 2048),
+                                   (7, 4104), (5, 12288), (3, 32768), (2, 32776), (4, 4096)])   # round 4: the wide-row kernel and its edges
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_layer_norm(shape, dtype):
     # (1151, 8192) is the reference self-test (triton/ops/layer_norm.py:522)
@@ -123,6 +124,8 @@ def test_layer_norm(shape, dtype):
     n = shape[-1]
     w, b = rnd(n, dtype=dtype, seed=21, shift=1.0, scale=0.2), rnd(n, dtype=dtype, seed=22)
     y = F().layer_norm(x, (n,), w, b, 1e-5)
+    want_kernel = "ln_wide" if 4096 < n <= 32768 and n % 8 == 0 else ("ln_rows" if n % 8 == 0 and n <= 4096 else "ln_generic")
+    assert last_kernel() == want_kernel, last_kernel()
     compare(f"ln {shape} {dtype}", y, R.layer_norm_ref(x, (n,), w, b), *tol(dtype, 2.0), kernel=last_kernel())
 
 

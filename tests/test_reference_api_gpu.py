@@ -241,6 +241,53 @@ def test_triton_convolution_op(shape, cl):
             torch.ops.sfast_triton._convolution(x, w, b, [1, 1], [1, 1], [1, 1], True, [0, 0], 1, False, False, True, True)
 
 
+def test_lowp_addmm_alpha_zero_and_beta_zero_follow_torch_addmm():
+    """torch.addmm does not compute the product when alpha == 0 and does not read `self` when beta == 0 (NaN / inf there
+    must not reach the result); the library reads an accumulator scale of 0 as 'unset', so both edges are decided in the wrapper."""
+    torch.manual_seed(5)
+    m, k, n = 64, 320, 640
+    x = torch.randn(m, k, device="cuda", dtype=torch.float16)
+    w = torch.randn(k, n, device="cuda", dtype=torch.float16) * k ** -0.5
+    bias = torch.randn(n, device="cuda", dtype=torch.float16)
+    other = torch.randn(m, n, device="cuda", dtype=torch.float16)
+    tol = dict(rtol=4e-3, atol=4e-3)
+    xn = x.clone()
+    xn[3, 5] = float("nan")
+    got = torch.ops.sfast.cublas_lowp_addmm(bias, xn, w, 0.5, 0)
+    torch.testing.assert_close(got.float(), (0.5 * bias.float()).expand(m, n), **tol)
+    assert torch.isfinite(got).all()
+    bn = bias.clone()
+    bn[7] = float("nan")
+    got = torch.ops.sfast.cublas_lowp_addmm(bn, x, w, 0, 1.25)
+    torch.testing.assert_close(got.float(), 1.25 * (x.float() @ w.float()), **tol)
+    got = torch.ops.sfast.cublas_lowp_addmm_add(bn, x, w, other, 0, 1.25, 0.5)
+    torch.testing.assert_close(got.float(), 1.25 * (x.float() @ w.float()) + 0.5 * other.float(), **tol)
+    got = torch.ops.sfast.cublas_lowp_addmm_activation(bias, xn, w, 1, 0, False)
+    torch.testing.assert_close(got.float(), F.relu(bias.float()).expand(m, n), **tol)
+
+
+@pytest.mark.parametrize("m,k,n", [(300, 320, 1280), (4096, 640, 2560), (77, 64, 96)])
+def test_two_weight_geglu_reads_the_weights_in_place(m, k, n):
+    """sfast::cutlass_linear_geglu(input, weight0, bias0, weight1, bias1) (reference cutlass_dual_linear.cc:13-33) with two SEPARATELY
+    allocated weights: both go to ONE launch as (hidden, gate) weight segments -- no torch.cat of the weights."""
+    from sfast.hip import lib
+    torch.manual_seed(11)
+    x = torch.randn(m, k, device="cuda", dtype=torch.float16)
+    w0 = torch.randn(n, k, device="cuda", dtype=torch.float16) * k ** -0.5
+    pad = torch.empty(12345, device="cuda", dtype=torch.float16)  # keeps w1 from landing adjacent to w0
+    w1 = torch.randn(n, k, device="cuda", dtype=torch.float16) * k ** -0.5
+    b0, b1 = torch.randn(n, device="cuda", dtype=torch.float16), torch.randn(n, device="cuda", dtype=torch.float16)
+    import unittest.mock as mock
+    with mock.patch.object(torch, "cat", side_effect=lambda ts, dim=0: (_ for _ in ()).throw(AssertionError("weights concatenated"))
+                           if ts[0].ndim == 2 else torch.concat(ts, dim=dim)):
+        got = torch.ops.sfast.cutlass_linear_geglu(x, w0, b0, w1, b1)
+    k_name = lib.last_kernel()
+    want = (x.float() @ w0.float().t() + b0.float()) * F.gelu(x.float() @ w1.float().t() + b1.float())
+    torch.testing.assert_close(got.float(), want, rtol=2e-2, atol=2e-2)
+    assert "geglu" in k_name, k_name
+    del pad
+
+
 @pytest.mark.parametrize("B", [3, 70])
 def test_bmm_is_one_grouped_launch_per_64_batches(B):
     from sfast.hip import lib
