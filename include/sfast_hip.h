@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define SFAST_HIP_ABI_VERSION 6
+#define SFAST_HIP_ABI_VERSION 7
 
 typedef void *sfast_stream_t; /* hipStream_t */
 
@@ -296,6 +296,31 @@ int sfast_hip_gemm_ex(const void *x, const void *const *w_segs, const void *bias
 int sfast_hip_conv2d_ex(const void *x, const void *x2, const void *w, const void *bias, const void *rowbias, const void *z,
                         void *out, const sfast_conv_params *p, const sfast_epilogue_ext *ext /* or NULL */,
                         void *gn_stats /* or NULL */, void *workspace, size_t workspace_bytes, sfast_stream_t stream);
+
+/* ---- GroupNorm(+SiLU) -> 3x3 conv as ONE weight-streaming launch (ABI 7) ----------------------------------------------------
+ * out = act(conv3x3(gn_act(GroupNorm(cat(x, x2)))) + bias + rowbias[b] + alpha * z): the reference's PAIR
+ * sfast_triton::group_norm[_silu] (triton/torch_ops.py:179-189) -> sfast::cudnn_convolution_bias[_add][_act]
+ * (csrc/operators/cudnn/cudnn_convolution_impl.cc:995-998) in one call, for the UNet's low-resolution levels where the conv is
+ * weight-streaming bound (B*H*W <= 128 pixels: a 1280 -> 1280 conv moves 29.5 MB of weights for 3.8 GFLOP) and a separate
+ * normalisation launch costs as much as a third of that stream. Every workgroup keeps a channel slice of ALL pixels in LDS, computes
+ * the exact two-pass statistics of the slice's groups itself and streams its weight rows global -> registers exactly once
+ * (stable-fast_amd/csrc/gnconv.hip). Same arithmetic contract as sfast_hip_group_norm followed by sfast_hip_conv2d (fp32 statistics
+ * and affine, f16/bf16 rounding of the normalised tensor, fp32 accumulate, the conv epilogue of sfast_conv_params).
+ * Coverage (sfast_hip_gn_conv2d_supported == 1): f16 / bf16; 3x3, stride 1, padding 1, no dilation / upsample / extra padding;
+ * dense NHWC sources, [Cout][3][3][Cin] weights, dense NHWC output; B*H*W <= 128; (Cin / groups) % 8 == 0; Cout % 32 == 0; a channel
+ * slice of >= 80 channels that is a whole number of groups and of 16-channel steps and divides both concat sources. Everything
+ * else: SFAST_ERR_UNSUPPORTED -- callers run the two operators. workspace: sfast_hip_gn_conv2d_workspace_bytes (fp32 slabs). */
+typedef struct {
+    sfast_conv_params conv; /* geometry, strides and epilogue of the convolution (of the NORMALISED input) */
+    int32_t groups;         /* GroupNorm groups over conv.Cin channels */
+    float eps;
+    int32_t gn_act;         /* SFAST_ACT_NONE or SFAST_ACT_SILU, applied after the affine */
+} sfast_gn_conv_params;
+int sfast_hip_gn_conv2d_supported(const sfast_gn_conv_params *p);
+size_t sfast_hip_gn_conv2d_workspace_bytes(const sfast_gn_conv_params *p);
+int sfast_hip_gn_conv2d(const void *x, const void *x2, const void *gamma, const void *beta, const void *w, const void *bias,
+                        const void *rowbias, const void *z, void *out, const sfast_gn_conv_params *p, void *workspace,
+                        size_t workspace_bytes, sfast_stream_t stream);
 
 /* GroupNorm(+SiLU) of an NHWC tensor (optionally a virtual concat x | x2) whose statistics were left behind by the kernels that
  * produced x (stats1 / l1) and x2 (stats2 / l2): one pass, x read once. Records of different row blocks are merged with the

@@ -430,6 +430,77 @@ extern "C" int sfast_hip_conv2d_stats_layout(const sfast_conv_params *p, const s
     return SFAST_OK;
 }
 
+// ---- GroupNorm(+SiLU) -> 3x3 conv as one weight-streaming launch (gnconv.hip) ----------------------------------------------------
+static bool gn_conv_shape_ok(const sfast_gn_conv_params *q, sfast::GnConvPlan &pl) {
+    if (!q) return false;
+    const sfast_conv_params *p = &q->conv;
+    if (!is_half(p->dtype) || p->KH != 3 || p->KW != 3 || p->stride_h != 1 || p->stride_w != 1 || p->pad_h != 1 || p->pad_w != 1 ||
+        p->dil_h != 1 || p->dil_w != 1 || p->upsample2x || p->pad_h_extra || p->pad_w_extra || p->variant >= 100)
+        return false;
+    if (!(q->gn_act == SFAST_ACT_NONE || q->gn_act == SFAST_ACT_SILU)) return false;
+    const ConvGeom g = conv_geom(p, nullptr);
+    if (!(g.x_dense && g.x2_dense && g.w_kcontig && g.out_dense && g.ldo % 4 == 0 && p->Cout % 32 == 0)) return false;
+    return sfast::gnconv_plan(p->B, p->H, p->W, p->C1, p->Cin - p->C1, p->Cout, q->groups, pl);
+}
+
+extern "C" int sfast_hip_gn_conv2d_supported(const sfast_gn_conv_params *q) {
+    sfast::GnConvPlan pl{};
+    return gn_conv_shape_ok(q, pl) ? 1 : 0;
+}
+
+extern "C" size_t sfast_hip_gn_conv2d_workspace_bytes(const sfast_gn_conv_params *q) {
+    sfast::GnConvPlan pl{};
+    return gn_conv_shape_ok(q, pl) ? pl.slab_bytes : 0;
+}
+
+extern "C" int sfast_hip_gn_conv2d(const void *x, const void *x2, const void *gamma, const void *beta, const void *w, const void *bias,
+                                   const void *rowbias, const void *z, void *out, const sfast_gn_conv_params *q, void *workspace,
+                                   size_t workspace_bytes, sfast_stream_t stream) {
+    SFAST_REQUIRE(q, SFAST_ERR_INVALID, "gn_conv2d: null parameters");
+    const sfast_conv_params *p = &q->conv;
+    int rc = validate_conv(x, x2, w, out, p);
+    if (rc) return rc;
+    sfast::GnConvPlan pl{};
+    SFAST_REQUIRE(gn_conv_shape_ok(q, pl), SFAST_ERR_UNSUPPORTED,
+                  "gn_conv2d: outside the fused kernel's coverage (ask sfast_hip_gn_conv2d_supported; run sfast_hip_group_norm + sfast_hip_conv2d instead)");
+    const ConvGeom g = conv_geom(p, z);
+    bool fold = false;
+    const ConvKind kind = conv_route(x, x2, w, bias, rowbias, z, out, p, g, fold);
+    SFAST_REQUIRE(kind == CONV_IGEMM && aligned16(out) && (!gamma || aligned16(gamma)) && (!beta || aligned16(beta)), SFAST_ERR_UNSUPPORTED,
+                  "gn_conv2d: operand alignment / strides outside the fused kernel's coverage");
+    IgemmArgs a{};
+    a.x = x;
+    a.x2 = x2;
+    for (int i = 0; i < SFAST_MAX_WSEG; ++i) a.w[i] = w;
+    a.bias = bias;
+    a.rowbias = fold ? z : rowbias;
+    a.res = fold ? nullptr : z;
+    a.out = out;
+    a.M = p->B * p->H * p->W;
+    a.N = p->Cout;
+    a.K = 9 * p->Cin;
+    a.ldw = a.K;
+    a.ldo = g.ldo;
+    a.ldr = g.ldr;
+    a.ld_rowbias = fold ? p->zs[0] : p->ld_rowbias;
+    a.rows_per_seg = p->Cout;
+    a.rows_per_batch = p->H * p->W;
+    a.act = p->act;
+    a.res_before_act = p->res_before_act;
+    a.alpha = p->alpha;
+    a.H = p->H;
+    a.W = p->W;
+    a.C1 = p->C1;
+    a.C2 = p->Cin - p->C1;
+    a.Ho = p->H;
+    a.Wo = p->W;
+    a.KH = a.KW = 3;
+    a.stride_h = a.stride_w = a.pad_h = a.pad_w = a.dil_h = a.dil_w = 1;
+    a.out_scale = 1.0f;
+    return sfast::gnconv_run(a, p->dtype, p->B, gamma, beta, q->groups, q->eps, q->gn_act == SFAST_ACT_SILU ? 1 : 0, workspace, workspace_bytes,
+                             (hipStream_t)stream);
+}
+
 extern "C" int sfast_hip_conv2d_ex(const void *x, const void *x2, const void *w, const void *bias, const void *rowbias,
                                    const void *z, void *out, const sfast_conv_params *p, const sfast_epilogue_ext *ext, void *gn_stats,
                                    void *workspace, size_t workspace_bytes, sfast_stream_t stream) {

@@ -67,6 +67,16 @@ bool igemm_stats_layout(int M, int N, int K, bool geglu, int variant, int split,
 void igemm_plan_query(int M, int N, int K, bool geglu, int variant, int split, int glds_ok, int out[5]);
 size_t igemm_workspace_bytes(int M, int N, int K, bool geglu, int variant, int split, int glds_ok);
 bool igemm_glds_eligible(const IgemmArgs &a, int mode);
+// split-K reduce + epilogue over fp32 slabs [splits][M][N] another kernel wrote (gnconv.hip)
+int igemm_reduce_only(const IgemmArgs &a, int dtype, hipStream_t st);
+// GroupNorm(+SiLU) -> 3x3 conv as one weight-streaming launch for B*H*W <= 128 (gnconv.hip; api: sfast_hip_gn_conv2d)
+struct GnConvPlan {
+    int MB, NB, CS, S;  // 32-pixel blocks, 32-channel output blocks per wave, channel slice, slices
+    size_t lds_bytes, slab_bytes;
+};
+bool gnconv_plan(int B, int H, int W, int C1, int C2, int Cout, int groups, GnConvPlan &pl);
+int gnconv_run(IgemmArgs &a, int dtype, int B, const void *gamma, const void *beta, int groups, float eps, int silu, void *ws, size_t ws_bytes,
+               hipStream_t st);
 // weight-only int8 linear (sfast::cutlass_qlinear_dynamic): register-staged pipe, no split-K
 int igemm_run_w8(IgemmArgs &a, int dtype, hipStream_t st);
 // grouped launch (register-staged pipe): n_groups problems of identical [M, N, K] sharing x (api: sfast_hip_gemm_grouped)

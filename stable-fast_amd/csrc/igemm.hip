@@ -1017,4 +1017,15 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
     return SFAST_OK;
 }
 
+// split-K reduce + epilogue over slabs another kernel wrote (gnconv.hip): a.partial [splits][M][N] fp32, sums in order 0 .. splits-1
+int igemm_reduce_only(const IgemmArgs &a, int dtype, hipStream_t st) {
+    const int64_t total = (int64_t)a.M * (a.N / 4);
+    const dim3 grid((unsigned)ceil_div64(total, 256));
+    if (dtype == SFAST_F16)
+        hipLaunchKernelGGL((splitk_reduce_kernel<f16, false>), grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((splitk_reduce_kernel<bf16, false>), grid, dim3(256), 0, st, a);
+    return check_launch("splitk_reduce");
+}
+
 }  // namespace sfast

@@ -34,6 +34,7 @@ extern unsigned long long *g_igemm_trace;  // igemm_glds.hip
 extern int g_igemm_exp;                    // igemm_glds.hip
 int igemm_init();      // igemm.hip
 int attention_init();  // attention.hip
+int gnconv_init();     // gnconv.hip
 
 }  // namespace sfast
 
@@ -55,6 +56,7 @@ int sfast_hip_init(void) {
     if (state[dev] == 0) {
         int rc = sfast::igemm_init();
         if (rc == 0) rc = sfast::attention_init();
+        if (rc == 0) rc = sfast::gnconv_init();
         state[dev] = rc == 0 ? 1 : rc;
     }
     return state[dev] == 1 ? 0 : state[dev];

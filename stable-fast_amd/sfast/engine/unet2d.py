@@ -236,6 +236,9 @@ def capture_plan_graph(plan, stream, pool=None, tail=None, calibrate=True):
 # (ticket counters at the end of the plan's workspace) instead of a reduce launch -- off by default, it measured slower on the SD1.5
 # step (one workgroup per tile re-reads all slabs; DESIGN.md round 3, profiles/r03_splitk_join_*.json.log)
 EXT_FLAGS = L.EXT_WS_TICKETS if os.environ.get("SFAST_SPLITK_JOIN", "0") not in ("0", "false", "off", "") else 0
+# GroupNorm+SiLU -> 3x3 conv as one weight-streaming launch where the library covers the shape (B*H*W <= 128: SD1.5's 8x8 level;
+# csrc/gnconv.hip). SFAST_FUSE_GN_CONV=0 keeps the two operators (A/B knob).
+FUSE_GN_CONV = os.environ.get("SFAST_FUSE_GN_CONV", "1") not in ("0", "false", "off", "")
 
 
 class DeviceHost:
@@ -621,6 +624,56 @@ class UNet2DEngine:
                   needs=LANE_TEMB if rowbias is not None else None)
         return Ho, Wo
 
+    def _gnconv_params(self, x2, w, B, H, W, C1, C2, Cout, eps, ld_rowbias, z):
+        q = L.GnConvParams()
+        p = q.conv
+        Cin = C1 + C2
+        p.dtype, p.B, p.H, p.W, p.Cin, p.Cout, p.KH, p.KW = self.dt, B, H, W, Cin, Cout, 3, 3
+        p.stride_h = p.stride_w = p.pad_h = p.pad_w = p.dil_h = p.dil_w = 1
+        p.upsample2x, p.C1 = 0, C1
+        p.xs = (C.c_int64 * 4)(H * W * C1, W * C1, C1, 1)
+        p.x2s = (C.c_int64 * 4)(*((H * W * C2, W * C2, C2, 1) if C2 else (0, 0, 0, 0)))
+        p.ws = (C.c_int64 * 4)(w.stride(0), w.stride(1), w.stride(2), w.stride(3))
+        p.os = (C.c_int64 * 4)(H * W * Cout, W * Cout, Cout, 1)
+        p.zs = (C.c_int64 * 4)(*((H * W * Cout, W * Cout, Cout, 1) if z is not None else (0, 0, 0, 0)))
+        p.act, p.res_before_act, p.alpha = L.ACT_NONE, 1, 1.0
+        p.ld_rowbias, p.variant, p.split_k = ld_rowbias, 0, 0
+        q.groups, q.eps, q.gn_act = self.groups, float(eps), L.ACT_SILU
+        return q
+
+    def _op_gnconv(self, plan, name, x, x2, norm_prefix, w, bias, out, B, H, W, C1, C2, Cout, *, rowbias=None, ld_rowbias=0,
+                   rowbias_offset=0, z=None):
+        """GroupNorm+SiLU -> 3x3 conv as ONE launch (sfast_hip_gn_conv2d, csrc/gnconv.hip) when the library covers the shape -- the
+        low-resolution levels, where the conv streams weights and the separate normalisation launch costs as much as a third of that
+        stream. Returns False (and emits nothing) otherwise: the caller then builds the GroupNorm op and the conv op."""
+        if not FUSE_GN_CONV:
+            return False
+        lib = self.lib
+        eps = self.norm_eps.get(norm_prefix, self.eps)
+        q = self._gnconv_params(x2, w, B, H, W, C1, C2, Cout, eps, ld_rowbias, z)
+        if not lib.sfast_hip_gn_conv2d_supported(C.byref(q)):
+            return False
+        gamma, beta = self.params[norm_prefix + ".weight"], self.params[norm_prefix + ".bias"]
+        self._need_ws(plan, lib.sfast_hip_gn_conv2d_workspace_bytes(C.byref(q)))
+        xp, x2p = x.data_ptr(), (x2.data_ptr() if x2 is not None else None)
+        gp, bep, wp, bp = gamma.data_ptr(), beta.data_ptr(), w.data_ptr(), (bias.data_ptr() if bias is not None else None)
+        rbp = (rowbias.data_ptr() + rowbias_offset * self.esize) if rowbias is not None else None
+        zp = z.data_ptr() if z is not None else None
+        op = out.data_ptr()
+        ws = plan.ws
+        plan.keep.append(q)
+
+        def launch(stream, q=q):
+            L.check(lib.sfast_hip_gn_conv2d(xp, x2p, gp, bep, wp, bp, rbp, zp, op, C.byref(q), ws[0].data_ptr() if ws[0] is not None else None,
+                                            ws[1], stream), name)
+
+        plan.writer.pop(id(out), None)   # this producer emits no GroupNorm statistics: a consumer GroupNorm computes its own
+        Cin, M = C1 + C2, B * H * W
+        flops = 2.0 * M * Cout * Cin * 9
+        nbytes = (2 * M * Cin + 2 * Cin + Cout * Cin * 9 + Cout + M * Cout + (M * Cout if z is not None else 0)) * self.esize
+        self._add(plan, "gnconv3x3", name, flops, nbytes, launch, needs=LANE_TEMB if rowbias is not None else None)
+        return True
+
     def _conv_in(self, plan, sample, h, B, H, W, c0):
         """conv_in on the NCHW latent. With fewer than 8 input channels (4 for SD) the conv read through NCHW strides runs on the
         generic small-channel kernel (37 us at 2 x 64 x 64: 0.7 % of the SD1.5 step); padded to 8 channels it is an MFMA implicit
@@ -707,15 +760,22 @@ class UNet2DEngine:
         pool, P = plan.pool, self.params
         M = B * H * W
         Cin = C1 + C2
-        n1 = pool.get(M * Cin)
-        self._op_gn(plan, pre + ".norm1", x, x2, C1, Cin, B, H * W, n1, self.eps, True, pre + ".norm1")
         h1 = pool.get(M * Cout)
-        self._op_conv(plan, pre + ".conv1", n1, None, P[pre + ".conv1.weight"], P[pre + ".conv1.bias"], h1, B, H, W, Cin, 0,
-                      Cout, 3, 1, 1, rowbias=temb_all, ld_rowbias=temb_ld, rowbias_offset=temb_off)
-        pool.put(n1)
-        n2 = pool.get(M * Cout)
-        self._op_gn(plan, pre + ".norm2", h1, None, Cout, Cout, B, H * W, n2, self.eps, True, pre + ".norm2")
-        pool.put(h1)
+        if not self._op_gnconv(plan, pre + ".norm1+conv1", x, x2, pre + ".norm1", P[pre + ".conv1.weight"], P[pre + ".conv1.bias"], h1,
+                               B, H, W, C1, C2, Cout, rowbias=temb_all, ld_rowbias=temb_ld, rowbias_offset=temb_off):
+            n1 = pool.get(M * Cin)
+            self._op_gn(plan, pre + ".norm1", x, x2, C1, Cin, B, H * W, n1, self.eps, True, pre + ".norm1")
+            self._op_conv(plan, pre + ".conv1", n1, None, P[pre + ".conv1.weight"], P[pre + ".conv1.bias"], h1, B, H, W, Cin, 0,
+                          Cout, 3, 1, 1, rowbias=temb_all, ld_rowbias=temb_ld, rowbias_offset=temb_off)
+            pool.put(n1)
+        # conv2 with norm2 fused: decided before the shortcut is emitted (plan order stays norm2, shortcut, conv2)
+        q2 = self._gnconv_params(None, P[pre + ".conv2.weight"], B, H, W, Cout, 0, Cout, self.norm_eps.get(pre + ".norm2", self.eps), 0, x)
+        fuse2 = FUSE_GN_CONV and bool(self.lib.sfast_hip_gn_conv2d_supported(C.byref(q2)))
+        n2 = None
+        if not fuse2:
+            n2 = pool.get(M * Cout)
+            self._op_gn(plan, pre + ".norm2", h1, None, Cout, Cout, B, H * W, n2, self.eps, True, pre + ".norm2")
+            pool.put(h1)
         if (pre + ".conv_shortcut.weight") in P:
             sc = pool.get(M * Cout)
             wsc, bsc = P[pre + ".conv_shortcut.weight"], P[pre + ".conv_shortcut.bias"]
@@ -730,9 +790,15 @@ class UNet2DEngine:
                 raise UnsupportedUNet(f"{pre}: no conv_shortcut for {Cin}->{Cout}")
             res, own = x, False
         out = pool.get(M * Cout)
-        self._op_conv(plan, pre + ".conv2", n2, None, P[pre + ".conv2.weight"], P[pre + ".conv2.bias"], out, B, H, W, Cout, 0,
-                      Cout, 3, 1, 1, z=res)
-        pool.put(n2)
+        if fuse2:
+            ok = self._op_gnconv(plan, pre + ".norm2+conv2", h1, None, pre + ".norm2", P[pre + ".conv2.weight"], P[pre + ".conv2.bias"], out,
+                                 B, H, W, Cout, 0, Cout, z=res)
+            assert ok
+            pool.put(h1)
+        else:
+            self._op_conv(plan, pre + ".conv2", n2, None, P[pre + ".conv2.weight"], P[pre + ".conv2.bias"], out, B, H, W, Cout, 0,
+                          Cout, 3, 1, 1, z=res)
+            pool.put(n2)
         if own:
             pool.put(res)
         return out

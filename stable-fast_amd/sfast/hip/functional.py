@@ -465,6 +465,66 @@ def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dila
     return y
 
 
+def _gn_conv_params(x, x2, weight, groups, eps, gn_act, z, alpha, act, res_before_act, rowbias, y):
+    B, C1, H, W = x.shape
+    Cin = C1 + (x2.shape[1] if x2 is not None else 0)
+    Cout = weight.shape[0]
+    q = L.GnConvParams()
+    p = q.conv
+    p.dtype, p.B, p.H, p.W, p.Cin, p.Cout, p.KH, p.KW = _dtype(x), B, H, W, Cin, Cout, 3, 3
+    p.stride_h = p.stride_w = p.pad_h = p.pad_w = p.dil_h = p.dil_w = 1
+    p.upsample2x, p.C1 = 0, C1
+    p.xs = _i64x4(_nhwc_strides(x))
+    p.x2s = _i64x4(_nhwc_strides(x2) if x2 is not None else (0, 0, 0, 0))
+    p.ws = _i64x4((weight.stride(0), weight.stride(1), weight.stride(2), weight.stride(3)))
+    p.os = _i64x4(_nhwc_strides(y))
+    p.zs = _i64x4(_nhwc_strides(z) if z is not None else (0, 0, 0, 0))
+    p.act, p.res_before_act, p.alpha = _act(act), 1 if res_before_act else 0, float(alpha)
+    p.ld_rowbias = 0 if rowbias is None else (rowbias.stride(0) if rowbias.shape[0] > 1 else Cout)
+    q.groups, q.eps, q.gn_act = int(groups), float(eps), _act(gn_act)
+    return q
+
+
+@_on_device
+def gn_conv2d_supported(x, weight, groups, x2=None):
+    """Whether sfast_hip_gn_conv2d (GroupNorm(+SiLU) -> 3x3 conv as one weight-streaming launch) covers this problem."""
+    lib = L.init_device()
+    if x.ndim != 4 or weight.ndim != 4 or tuple(weight.shape[2:]) != (3, 3):
+        return False
+    y = torch.empty((x.shape[0], weight.shape[0], x.shape[2], x.shape[3]), dtype=x.dtype, device="meta").contiguous(memory_format=torch.channels_last)
+    q = _gn_conv_params(x, x2, weight, groups, 1e-5, "silu", None, 1.0, None, True, None, y)
+    return bool(lib.sfast_hip_gn_conv2d_supported(C.byref(q)))
+
+
+@_on_device
+def gn_conv2d(x, num_groups, gn_weight, gn_bias, weight, bias=None, *, eps=1e-5, gn_act="silu", x2=None, z=None, alpha=1.0, act=None,
+              res_before_act=True, rowbias=None):
+    """y = act(conv3x3(gn_act(GroupNorm(cat(x, x2)))) + bias + rowbias[b] + alpha * z), stride 1 / padding 1, ONE weight-streaming launch
+    (+ the split-K reduce that carries the epilogue): sfast_hip_gn_conv2d. channels_last tensors; raises when the problem is outside
+    the fused kernel's coverage (`gn_conv2d_supported`) -- callers then run group_norm() and conv2d()."""
+    _require_cuda(x, x2, gn_weight, gn_bias, weight, bias, z, rowbias)
+    lib = L.init_device()
+    B, C1, H, W = x.shape
+    Cout = weight.shape[0]
+    y = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    zz = None if z is None else z.to(x.dtype).expand(B, Cout, H, W)
+    if bias is not None:
+        bias = bias.to(x.dtype).contiguous()
+    if rowbias is not None:
+        rowbias = rowbias.to(x.dtype)
+        if rowbias.stride(-1) != 1:
+            rowbias = rowbias.contiguous()
+    gw = None if gn_weight is None else gn_weight.to(x.dtype).contiguous()
+    gb = None if gn_bias is None else gn_bias.to(x.dtype).contiguous()
+    q = _gn_conv_params(x, x2, weight, num_groups, eps, gn_act, zz, alpha, act, res_before_act, rowbias, y)
+    nb = lib.sfast_hip_gn_conv2d_workspace_bytes(C.byref(q))
+    ws, nb = _ws(nb, x)
+    rc = lib.sfast_hip_gn_conv2d(_ptr(x), _ptr(x2), _ptr(gw), _ptr(gb), _ptr(weight), _ptr(bias), _ptr(rowbias), _ptr(zz), _ptr(y),
+                                 C.byref(q), _ptr(ws), nb, _stream(x))
+    L.check(rc, "sfast_hip_gn_conv2d")
+    return y
+
+
 @_on_device
 def attention(q, k, v, scale: Optional[float] = None, variant=0, attn_bias=None):
     """softmax(q k^T * scale + attn_bias) v with q [B, Sq, H, D], k/v [B, Skv, H, D] (any b/s/h strides).

@@ -18,7 +18,7 @@ PROBES_LIB_PATH = os.path.join(os.path.dirname(_HERE), "_lib", "libsfast_hip_pro
 if os.environ.get("SFAST_HIP_PROBES", "0") == "1":
     LIB_PATH = PROBES_LIB_PATH
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # enums (include/sfast_hip.h)
 F16, BF16, F32 = 0, 1, 2
@@ -39,6 +39,7 @@ EXPORTS = [
     "sfast_hip_attention", "sfast_hip_attention_bias", "sfast_hip_strided_copy", "sfast_hip_timestep_embedding",
     "sfast_hip_gemv_grouped", "sfast_hip_gemm_grouped", "sfast_hip_qlinear_w8", "sfast_hip_cfg_ddim_step", "sfast_hip_linear_step", "sfast_hip_mix_rows", "sfast_hip_igemm_plan", "sfast_hip_set_trace", "sfast_hip_image_postprocess", "sfast_hip_add_strided",
     "sfast_hip_schedule_advance", "sfast_hip_conv2d_plan", "sfast_hip_workspace_init", "sfast_hip_has_probes",
+    "sfast_hip_gn_conv2d_supported", "sfast_hip_gn_conv2d_workspace_bytes", "sfast_hip_gn_conv2d",
 ]
 
 
@@ -110,6 +111,10 @@ class ConvParams(C.Structure):
                 ("act", C.c_int32), ("res_before_act", C.c_int32), ("alpha", C.c_float),
                 ("ld_rowbias", C.c_int64), ("variant", C.c_int32), ("split_k", C.c_int32),
                 ("pad_h_extra", C.c_int32), ("pad_w_extra", C.c_int32)]
+
+
+class GnConvParams(C.Structure):
+    _fields_ = [("conv", ConvParams), ("groups", C.c_int32), ("eps", C.c_float), ("gn_act", C.c_int32)]
 
 
 class AttnParams(C.Structure):
@@ -204,6 +209,12 @@ def _declare(lib):
     lib.sfast_hip_schedule_advance.restype = C.c_int
     lib.sfast_hip_schedule_advance.argtypes = [vp, vp, C.c_int32, vp, vp, C.c_int32, vp, C.c_int32, vp]
     lib.sfast_hip_has_probes.restype = C.c_int
+    lib.sfast_hip_gn_conv2d_supported.restype = C.c_int
+    lib.sfast_hip_gn_conv2d_supported.argtypes = [C.POINTER(GnConvParams)]
+    lib.sfast_hip_gn_conv2d_workspace_bytes.restype = sz
+    lib.sfast_hip_gn_conv2d_workspace_bytes.argtypes = [C.POINTER(GnConvParams)]
+    lib.sfast_hip_gn_conv2d.restype = C.c_int
+    lib.sfast_hip_gn_conv2d.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(GnConvParams), vp, sz, vp]
     lib.sfast_hip_cfg_ddim_step.restype = C.c_int
     lib.sfast_hip_cfg_ddim_step.argtypes = [vp, vp, vp, vp, vp, C.c_float, C.c_int64, C.c_int32, vp]
 

@@ -75,6 +75,12 @@ class EmuLib:
     def sfast_hip_conv2d_stats_layout(self, p, ext, out):
         return self.real.sfast_hip_conv2d_stats_layout(p, ext, out)
 
+    def sfast_hip_gn_conv2d_supported(self, ref):
+        return self.real.sfast_hip_gn_conv2d_supported(ref)
+
+    def sfast_hip_gn_conv2d_workspace_bytes(self, ref):
+        return self.real.sfast_hip_gn_conv2d_workspace_bytes(ref)
+
     def sfast_hip_last_error(self):
         return self.err
 
@@ -275,6 +281,35 @@ class EmuLib:
             o = R.linear_ref(xin, wg, bg, _ACT[p.act], None, 1.0, False, False, None, 0, _ACT[p.in_act])
             _strided(out + off * 2, (p.M, n), (p.ldo, 1), p.dtype).copy_(o)
             off += n
+        return 0
+
+    def sfast_hip_gn_conv2d(self, x, x2, gamma, beta, w, bias, rowbias, z, out, ref, ws, ws_bytes, stream):
+        """GroupNorm(+SiLU) of the (virtually concatenated) NHWC input, rounded to the I/O dtype as the two-operator path stores it,
+        then the 3x3 conv with its epilogue -- the contract of sfast_hip_gn_conv2d."""
+        q = _p(ref)
+        p = q.conv
+        self.calls.append("gn_conv2d")
+        assert self.real.sfast_hip_gn_conv2d_supported(ref) == 1
+        assert ws_bytes >= self.real.sfast_hip_gn_conv2d_workspace_bytes(ref)
+        C1, C2 = p.C1, p.Cin - p.C1
+        HW = p.H * p.W
+        xa = _flat(x, p.B * HW * C1, p.dtype).reshape(p.B, HW, C1)
+        if C2:
+            xa = torch.cat([xa, _flat(x2, p.B * HW * C2, p.dtype).reshape(p.B, HW, C2)], dim=2)
+        g = _flat(gamma, p.Cin, p.dtype).float() if gamma else None
+        b = _flat(beta, p.Cin, p.dtype).float() if beta else None
+        n = R.group_norm_ref(xa.permute(0, 2, 1), q.groups, g, b, q.eps, q.gn_act == L.ACT_SILU)      # [B, Cin, HW] fp32
+        n = n.to(xa.dtype).reshape(p.B, p.Cin, p.H, p.W)
+
+        def nchw(ptr, c, s):
+            return _strided(ptr, (p.B, c, p.H, p.W), (s[0], s[3], s[1], s[2]), p.dtype)
+
+        wt = _strided(w, (p.Cout, p.Cin, 3, 3), tuple(p.ws), p.dtype)
+        bb = _flat(bias, p.Cout, p.dtype) if bias else None
+        rb = _strided(rowbias, (p.B, p.Cout), (p.ld_rowbias, 1), p.dtype) if rowbias else None
+        zz = nchw(z, p.Cout, p.zs).clone() if z else None
+        o = R.conv2d_ref(n, wt, bb, zz, p.alpha, 1, 1, 1, _ACT[p.act], bool(p.res_before_act), None, False, rb)
+        nchw(out, p.Cout, p.os).copy_(o)
         return 0
 
     def sfast_hip_conv2d(self, x, x2, w, bias, rowbias, z, out, ref, ws, ws_bytes, stream):

@@ -115,16 +115,20 @@ def test_sd15_plan_op_inventory(built_lib):
     eng = UNet2DEngine(config, params, _host=EmuHost())
     plan = eng.build_plan(2, 64, 64, 77)
     s = plan.summary()
-    assert s["gn_silu"]["count"] == 45 and s["gn"]["count"] == 16 and s["ln"]["count"] == 48
+    # round 4: at the 8x8 level (B*H*W = 128) the 14 GroupNorm+SiLU -> conv3x3 pairs of the seven resnets are ONE launch each
+    # (sfast_hip_gn_conv2d, kind "gnconv3x3"): 45 GroupNorm+SiLU and 52 3x3 convs in total, as SURVEY 8d counts them
+    fused = s["gnconv3x3"]["count"]
+    assert fused == 14
+    assert s["gn_silu"]["count"] + fused == 45 and s["gn"]["count"] == 16 and s["ln"]["count"] == 48
     assert s["attn_self"]["count"] == 16 and s["attn_cross"]["count"] == 16 and s["geglu"]["count"] == 16
-    assert s["conv3x3"]["count"] + s["conv_in"]["count"] + s["conv_out"]["count"] == 52
+    assert s["conv3x3"]["count"] + fused + s["conv_in"]["count"] + s["conv_out"]["count"] == 52
     assert s["conv1x1"]["count"] == 46
     assert s["temb"]["count"] == 2 + 1  # time MLP + ONE grouped GEMV over the 22 time_emb_proj layers
     # algorithmic work at B=2 is twice the B=1 figures of SURVEY.md section 8d (804 GFLOP total)
     total = sum(v["gflop"] for v in s.values())
     assert abs(total / 2 - 804) / 804 < 0.02, total
     assert abs(s["attn_self"]["gflop"] / 2 - 122.5) < 1.0 and abs(s["geglu"]["gflop"] / 2 - 102.3) < 1.0
-    assert abs((s["conv3x3"]["gflop"] + s["conv_in"]["gflop"] + s["conv_out"]["gflop"]) / 2 - 400.3) < 2.0
+    assert abs((s["conv3x3"]["gflop"] + s["gnconv3x3"]["gflop"] + s["conv_in"]["gflop"] + s["conv_out"]["gflop"]) / 2 - 400.3) < 2.0
     # nothing is materialised for concat / upsample; the only copies of the SD1.5 plan pad conv_in's 4-channel operands to 8
     # channels for the MFMA path (the latent and the live weight: 64 KB + 46 KB per step)
     assert "misc" in s and s["misc"]["count"] == 1 + 2
@@ -434,3 +438,32 @@ def test_engine_on_the_emulator_matches_round3_goldens(built_lib):
                                               coef_out.data_ptr(), ops["n_steps"], None) == 0
         assert torch.equal(ts_out, ops["ts_out"][j]) and torch.equal(coef_out, ops["coef_out"][j])
     assert int(cur[0]) == ops["cursor_after"]
+
+
+def test_gn_conv_fusion_at_the_low_resolution_level(built_lib, monkeypatch):
+    """Round 4: where B*H*W <= 128 and the channel slices are whole GroupNorm groups, a resnet's GroupNorm+SiLU -> conv3x3 pairs are ONE
+    sfast_hip_gn_conv2d launch each (csrc/gnconv.hip). The plan built on the emulator must (a) ask the REAL library which layers it
+    covers, (b) wire raw inputs / concat sources / time-embedding offsets / residuals of the fused op correctly -- parity with the
+    oracle UNet -- and (c) fall back to the two operators when the knob is off, with identical results on the emulator."""
+    import sfast.engine.unet2d as E
+    cfg = U.tiny_config(sample_size=16, block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                        up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), attention_head_dim=8, norm_num_groups=16)
+    m = U.build(cfg, seed=31, dtype=torch.float16)
+    g = torch.Generator().manual_seed(32)
+    sample = torch.randn(2, 4, 16, 16, generator=g).half()
+    ehs = torch.randn(2, 20, cfg["cross_attention_dim"], generator=g).half()
+    emu = EmuLib()
+    eng = UNet2DEngine.from_module(m, _host=EmuHost(emu))
+    y = eng.forward(sample, 500, ehs)
+    n_fused = emu.calls.count("gn_conv2d")
+    kinds = [op.kind for op in eng.get_plan(2, 16, 16, 20).ops]
+    assert n_fused == kinds.count("gnconv3x3") and n_fused >= 6, (n_fused, kinds.count("gnconv3x3"))   # 8x8 level: 640-wide resnets (+ concat 640+640)
+    with torch.no_grad():
+        want = m.float()(sample.float(), 500, ehs.float()).sample
+    assert rel_l2(y, want) < 4e-3
+    monkeypatch.setattr(E, "FUSE_GN_CONV", False)
+    emu2 = EmuLib()
+    eng2 = UNet2DEngine.from_module(U.build(cfg, seed=31, dtype=torch.float16), _host=EmuHost(emu2))
+    y2 = eng2.forward(sample, 500, ehs)
+    assert emu2.calls.count("gn_conv2d") == 0
+    assert rel_l2(y2, y.float()) < 1e-3

@@ -994,3 +994,59 @@ def test_golden_ops_round2():
     c = g["euler_step_eps"]
     coef = torch.tensor([[c["scale"], 0.0]], dtype=torch.float32, device=DEV)
     compare("golden euler scale_model_input", F().linear_step(d(c["sample"]), d(c["sample"]), coef, 0), c["y_scaled"], 2e-3, 2e-3)
+
+
+# ---- round 4: GroupNorm(+SiLU) -> 3x3 conv as one weight-streaming launch (gnconv.hip, sfast_hip_gn_conv2d) --------------------------------
+GNCONV_CASES = [
+    # name, B, C1, C2, H, W, Cout, extras
+    ("sd15 8x8 1280->1280 (resnet conv2 + residual)", 2, 1280, 0, 8, 8, 1280, dict(z=True)),
+    ("sd15 8x8 1280->1280 (conv1 + temb row bias)", 2, 1280, 0, 8, 8, 1280, dict(rowbias=True)),
+    ("sd15 8x8 cat 1280+1280 -> 1280", 2, 1280, 1280, 8, 8, 1280, dict(rowbias=True)),
+    ("literal B=1 8x8 (two 32-pixel blocks)", 1, 1280, 0, 8, 8, 1280, dict(z=True)),
+    ("640 -> 320, cpg 40 via 16 groups", 2, 640, 0, 8, 8, 320, dict(groups=16)),
+    ("cat 640+640 -> 640, 4x4, B=8", 8, 640, 640, 4, 4, 640, dict(groups=16, z=True, rowbias=True)),
+    ("ragged pixels: 2 x 7 x 6 = 84", 2, 320, 0, 7, 6, 64, dict(groups=8)),
+    ("no SiLU, eps 1e-6, no affine bias", 2, 1280, 0, 8, 8, 96, dict(gn_act=None, eps=1e-6)),
+]
+
+
+@pytest.mark.parametrize("case", GNCONV_CASES, ids=[c[0] for c in GNCONV_CASES])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_gn_conv2d_fused(case, dtype):
+    """One launch against (a) the fp32 oracle of the reference's pair group_norm_silu -> conv + bias + residual, with the normalised
+    tensor rounded to the I/O dtype between the two (what the two-operator path stores), and (b) the two HIP operators it replaces."""
+    name, B, C1, C2, H, W, Cout, ex = case
+    G, eps, gn_act = ex.get("groups", 32), ex.get("eps", 1e-5), ex.get("gn_act", "silu")
+    Cin = C1 + C2
+    x = cl(rnd(B, C1, H, W, dtype=dtype, seed=301, scale=2.0, shift=0.7))
+    x2 = cl(rnd(B, C2, H, W, dtype=dtype, seed=302, scale=0.5, shift=-1.0)) if C2 else None
+    gw, gb = rnd(Cin, dtype=dtype, seed=303, scale=0.2, shift=1.0), rnd(Cin, dtype=dtype, seed=304, scale=0.2)
+    w = cl(rnd(Cout, Cin, 3, 3, dtype=dtype, seed=305, scale=(9 * Cin) ** -0.5))
+    b = rnd(Cout, dtype=dtype, seed=306)
+    z = cl(rnd(B, Cout, H, W, dtype=dtype, seed=307)) if ex.get("z") else None
+    rb = rnd(B, Cout, dtype=dtype, seed=308) if ex.get("rowbias") else None
+    assert F().gn_conv2d_supported(x, w, G, x2=x2)
+    y = F().gn_conv2d(x, G, gw, gb, w, b, eps=eps, gn_act=gn_act, x2=x2, z=z, rowbias=rb)
+    k = last_kernel()
+    assert "gnconv" in k, k
+    assert torch.equal(y, F().gn_conv2d(x, G, gw, gb, w, b, eps=eps, gn_act=gn_act, x2=x2, z=z, rowbias=rb)), "not reproducible"
+    xc = x if x2 is None else torch.cat([x, x2], 1)
+    n32 = R.group_norm_ref(xc, G, gw, gb, eps, gn_act == "silu")
+    want = R.conv2d_ref(n32.to(dtype), w, b, z, 1.0, 1, 1, rowbias=rb)
+    compare(f"gn_conv2d {name} {dtype}", y, want, *tol(dtype, 3.0), kernel=k)
+    n = F().group_norm(x, G, gw, gb, eps, gn_act, x2=x2)
+    y2 = F().conv2d(n, w, b, z=z, padding=1, rowbias=rb)
+    compare(f"gn_conv2d vs two operators {name} {dtype}", y, y2.float(), *tol(dtype, 3.0), kernel=k)
+
+
+def test_gn_conv2d_refuses_what_it_does_not_cover():
+    from sfast.hip import lib
+    x = cl(rnd(2, 1280, 16, 16, seed=311))               # 512 pixels
+    w = cl(rnd(1280, 1280, 3, 3, seed=312, scale=0.01))
+    assert not F().gn_conv2d_supported(x, w, 32)
+    with pytest.raises(lib.SfastHipError):
+        F().gn_conv2d(x, 32, None, None, w)
+    x = cl(rnd(2, 1920, 8, 8, seed=313))                 # 60 channels per group: not a multiple of 8
+    assert not F().gn_conv2d_supported(x, cl(rnd(1280, 1920, 3, 3, seed=314, scale=0.01)), 32)
+    x1, x2 = cl(rnd(2, 1280, 8, 8, seed=315)), cl(rnd(2, 640, 8, 8, seed=316))   # concat 1280 + 640: groups of 60 straddle the sources
+    assert not F().gn_conv2d_supported(x1, cl(rnd(1280, 1920, 3, 3, seed=317, scale=0.01)), 32, x2=x2)

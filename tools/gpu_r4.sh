@@ -23,5 +23,15 @@ s1)  # the reference's own Triton kernels on this box (fixture + oracle / HIP co
   run t_sanity 900 $PYT tests/test_ops_gpu.py -k "attention or split or conv_bias or group_norm" -x
   run bench 900 python bench.py --steps 50 --warmup 10 --no-end-to-end --dump-kernels gpurun_out/kernels.json
   ;;
+s2)  # gnconv (fused GroupNorm+SiLU -> conv at the 8x8 level): parity, then the step with and without it; round-4 small items
+  run t_gnconv 900 $PYT tests/test_ops_gpu.py -k "gn_conv2d or layer_norm"
+  run t_api 900 $PYT tests/test_reference_api_gpu.py -k "addmm or geglu or bmm or grouped"
+  run t_unet 1200 $PYT tests/test_unet_gpu.py -k "controlnet or tiny or sd15_unet_parity or compile_drop_in"
+  run t_ref_triton 1500 $PYT tests/test_ref_triton_gpu.py
+  run smoke 600 python __graft_entry__.py smoke
+  run bench_fused 900 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --dump-kernels gpurun_out/kernels_fused.json
+  SFAST_FUSE_GN_CONV=0 run bench_unfused 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --dump-kernels gpurun_out/kernels_unfused.json
+  run bench_fused2 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  ;;
 esac
 cat gpurun_out/session.log
