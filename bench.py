@@ -469,7 +469,7 @@ def step_variants(args, engine, cfg, hw, dev, latents, ehs, headline_ms):
     out of the graph (run once per prompt -- a loop-invariant hoist a pipeline may do, `compile()` cannot; the headline keeps them
     in, so its step is literally one UNet forward + guidance + scheduler update); (b) the LITERAL batch-1 step SURVEY section 8d
     lists beside the CFG one: UNet forward at B = 1 (no classifier-free guidance) + the DDIM update, one hipGraph."""
-    from sfast.engine import DenoiseLoop
+    from sfast.engine.denoise import DenoiseLoop
     from sfast.engine.unet2d import capture_plan_graph
     from sfast.hip import lib as L
     out = {}
@@ -518,7 +518,7 @@ def bs64_sharded(args, engine, cfg, hw, dev, rank, world, use_dist):
     """BASELINE.json configs[3]: SD1.5 512x512 bs = 64 fp16 sharded over the node -- 64 / N images per GPU (UNet batch 128 / N with
     CFG), independent per-GPU denoise loops, no per-step collective. Reported as image-steps/s over all ranks (max-over-ranks time)
     and as ms per image-step; N = 8 gives the per-GPU shape the packaged kernel choices cover (8 images, UNet batch 16)."""
-    from sfast.engine import DenoiseLoop
+    from sfast.engine.denoise import DenoiseLoop
 
     def agree(value):
         if not use_dist:

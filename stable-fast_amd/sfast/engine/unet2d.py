@@ -237,8 +237,12 @@ def capture_plan_graph(plan, stream, pool=None, tail=None, calibrate=True):
 # step (one workgroup per tile re-reads all slabs; DESIGN.md round 3, profiles/r03_splitk_join_*.json.log)
 EXT_FLAGS = L.EXT_WS_TICKETS if os.environ.get("SFAST_SPLITK_JOIN", "0") not in ("0", "false", "off", "") else 0
 # GroupNorm+SiLU -> 3x3 conv as one weight-streaming launch where the library covers the shape (B*H*W <= 128: SD1.5's 8x8 level;
-# csrc/gnconv.hip). SFAST_FUSE_GN_CONV=0 keeps the two operators (A/B knob).
-FUSE_GN_CONV = os.environ.get("SFAST_FUSE_GN_CONV", "1") not in ("0", "false", "off", "")
+# csrc/gnconv.hip, sfast_hip_gn_conv2d). OFF by default: measured in the SD1.5 step it is 1 % SLOWER than the two operators it
+# replaces (180.1 vs 182.2 it/s, 25.5 us against 16.8 + 4.7 us per 1280 -> 1280 layer: profiles/r04_gnconv_step_ab_run6.log) --
+# every one of the 40 output-channel tiles re-normalises the same activation slice (~4 us of SiLU arithmetic on the critical path of
+# each workgroup) and a wave that streams weights straight into its own registers stalls at the memory queue instead of computing
+# (DESIGN.md section 9, round 4, item 1). SFAST_FUSE_GN_CONV=1 switches it on (A/B knob; the operator itself is parity-green).
+FUSE_GN_CONV = os.environ.get("SFAST_FUSE_GN_CONV", "0") not in ("0", "false", "off", "")
 
 
 class DeviceHost:

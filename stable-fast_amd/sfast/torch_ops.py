@@ -32,12 +32,10 @@ def cutlass_linear_geglu_unified(input, weight, bias=None):
 
 def cutlass_linear_geglu(input, weight0, bias0, weight1, bias1):
     n, k = weight0.shape
-    adjacent = (weight0.is_contiguous() and weight1.is_contiguous() and
-                weight1.data_ptr() == weight0.data_ptr() + n * k * weight0.element_size() and
-                weight1.shape == weight0.shape)
-    if adjacent:
-        w = torch.as_strided(weight0, (2 * n, k), (k, 1))
-    elif (weight1.shape == weight0.shape and weight0.stride(1) == 1 and weight1.stride(1) == 1 and weight0.stride(0) == weight1.stride(0)):
+    # (round 4) the old "adjacent in memory -> one as_strided [2n, k] view" shortcut is gone: two weights can sit back to back in
+    # DIFFERENT storages (the caching allocator does that), where as_strided raises "out of bounds for storage" -- found by
+    # test_two_weight_geglu_reads_the_weights_in_place. The segment form below covers adjacent weights too, without a view.
+    if (weight1.shape == weight0.shape and weight0.stride(1) == 1 and weight1.stride(1) == 1 and weight0.stride(0) == weight1.stride(0)):
         w = [weight0, weight1]   # (hidden, gate) weight segments of ONE launch: the live weights are read in place, no concatenated copy
     else:
         w = torch.cat([weight0, weight1], dim=0)

@@ -115,10 +115,12 @@ def test_sd15_plan_op_inventory(built_lib):
     eng = UNet2DEngine(config, params, _host=EmuHost())
     plan = eng.build_plan(2, 64, 64, 77)
     s = plan.summary()
-    # round 4: at the 8x8 level (B*H*W = 128) the 14 GroupNorm+SiLU -> conv3x3 pairs of the seven resnets are ONE launch each
-    # (sfast_hip_gn_conv2d, kind "gnconv3x3"): 45 GroupNorm+SiLU and 52 3x3 convs in total, as SURVEY 8d counts them
-    fused = s["gnconv3x3"]["count"]
-    assert fused == 14
+    # round 4: with SFAST_FUSE_GN_CONV=1 the 14 GroupNorm+SiLU -> conv3x3 pairs of the 8x8 level (B*H*W = 128) are ONE launch each
+    # (sfast_hip_gn_conv2d, kind "gnconv3x3"); off by default (measured slower in the step) -- either way 45 GroupNorm+SiLU and 52 3x3
+    # convs in total, as SURVEY 8d counts them
+    import sfast.engine.unet2d as E
+    fused = s.get("gnconv3x3", {"count": 0, "gflop": 0.0})["count"]
+    assert fused == (14 if E.FUSE_GN_CONV else 0)
     assert s["gn_silu"]["count"] + fused == 45 and s["gn"]["count"] == 16 and s["ln"]["count"] == 48
     assert s["attn_self"]["count"] == 16 and s["attn_cross"]["count"] == 16 and s["geglu"]["count"] == 16
     assert s["conv3x3"]["count"] + fused + s["conv_in"]["count"] + s["conv_out"]["count"] == 52
@@ -128,7 +130,7 @@ def test_sd15_plan_op_inventory(built_lib):
     total = sum(v["gflop"] for v in s.values())
     assert abs(total / 2 - 804) / 804 < 0.02, total
     assert abs(s["attn_self"]["gflop"] / 2 - 122.5) < 1.0 and abs(s["geglu"]["gflop"] / 2 - 102.3) < 1.0
-    assert abs((s["conv3x3"]["gflop"] + s["gnconv3x3"]["gflop"] + s["conv_in"]["gflop"] + s["conv_out"]["gflop"]) / 2 - 400.3) < 2.0
+    assert abs((s["conv3x3"]["gflop"] + s.get("gnconv3x3", {"gflop": 0.0})["gflop"] + s["conv_in"]["gflop"] + s["conv_out"]["gflop"]) / 2 - 400.3) < 2.0
     # nothing is materialised for concat / upsample; the only copies of the SD1.5 plan pad conv_in's 4-channel operands to 8
     # channels for the MFMA path (the latent and the live weight: 64 KB + 46 KB per step)
     assert "misc" in s and s["misc"]["count"] == 1 + 2
@@ -446,6 +448,7 @@ def test_gn_conv_fusion_at_the_low_resolution_level(built_lib, monkeypatch):
     covers, (b) wire raw inputs / concat sources / time-embedding offsets / residuals of the fused op correctly -- parity with the
     oracle UNet -- and (c) fall back to the two operators when the knob is off, with identical results on the emulator."""
     import sfast.engine.unet2d as E
+    monkeypatch.setattr(E, "FUSE_GN_CONV", True)   # opt-in since round 4 measured it slower in the SD1.5 step
     cfg = U.tiny_config(sample_size=16, block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
                         up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), attention_head_dim=8, norm_num_groups=16)
     m = U.build(cfg, seed=31, dtype=torch.float16)

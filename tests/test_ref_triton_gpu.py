@@ -116,6 +116,19 @@ def test_group_norm_vs_reference_triton(ref, case):
     log_value(f"ref_triton_stats {case['name']}", mean_max_err=float((ref_mean - mean.reshape(N, -1)).abs().max()),
               rstd_max_rel_err=float(((ref_rstd - rstd.reshape(N, -1)) / rstd.reshape(N, -1)).abs().max()),
               y_finite=bool(torch.isfinite(y_ref.float()).all()))
+    # A reference-side platform deviation is recorded as such, not papered over: when the statistics the REFERENCE'S kernel returns are
+    # themselves off by more than 8 output ulps, the case cannot pin anything. Seen on exactly one row -- [2, 2560, 8, 8], C/G = 80 ->
+    # ROW_SIZE 128 x BLOCK_SIZE 32, 16 warps: mean off by 2.1e-2, rstd by 9.3 % (profiles/r04_ref_triton_tests_run2.log) -- while the
+    # same kernel run through Triton's CPU interpreter (TRITON_INTERPRET=1, in this container) returns the exact statistics (mean err
+    # 7e-6, rstd 4.8e-4): a Triton-ROCm 3.6 code-generation problem of that tile shape, not the reference's algorithm and not the
+    # oracle. The HIP kernel is still checked against the oracle for the shape, then the case is reported as skipped.
+    ref_stats_bad = (float(((ref_rstd - rstd.reshape(N, -1)) / rstd.reshape(N, -1)).abs().max()) > 8 * u
+                     or float((ref_mean - mean.reshape(N, -1)).abs().max()) > 8 * u * float(1.0 + mean.abs().max()))
+    if ref_stats_bad:
+        y = F().group_norm(x, case["groups"], w, b, case["eps"], "silu" if case["silu"] else None)
+        compare(f"hip_vs_oracle (reference deviates) {case['name']}", y.float(), want32, 2 * u, 2 * u, kernel=last_kernel())
+        pytest.skip("the reference's Triton kernel returns wrong statistics for this tile shape on this Triton-ROCm build "
+                    "(exact under TRITON_INTERPRET=1); HIP kernel checked against the oracle instead")
     # (a) oracle restatement vs the reference's kernel
     d = (want32 - y_ref.float()).abs()
     lim = u * (1.0 + want32.abs()) + 1.5 * stat_term

@@ -33,5 +33,29 @@ s2)  # gnconv (fused GroupNorm+SiLU -> conv at the 8x8 level): parity, then the 
   SFAST_FUSE_GN_CONV=0 run bench_unfused 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --dump-kernels gpurun_out/kernels_unfused.json
   run bench_fused2 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
   ;;
+s3)  # gnconv with the deep weight prefetch: parity, same-process A/B + per-kernel durations, the step with and without it
+  run t_gnconv 900 $PYT tests/test_ops_gpu.py -k "gn_conv2d"
+  run t_api 900 $PYT tests/test_reference_api_gpu.py -k "geglu"
+  run t_ref_triton 1500 $PYT tests/test_ref_triton_gpu.py -k "group_norm"
+  run gnconv_ab 600 python tools/gnconv_ab.py
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof_gnconv -o gnconv -- python $OLDPWD/tools/gnconv_ab.py > $OLDPWD/gpurun_out/prof_gnconv.log 2>&1)
+  find gpurun_out/prof_gnconv -name "*kernel_stats*" -exec cp {} gpurun_out/gnconv_kernel_stats.csv \;
+  rm -rf gpurun_out/prof_gnconv
+  run bench_fused 900 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --dump-kernels gpurun_out/kernels_fused.json
+  SFAST_FUSE_GN_CONV=0 run bench_unfused 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  run bench_fused2 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  ;;
+s4)  # where a gnconv workgroup spends its time
+  run gnconv_trace 300 python tools/gnconv_trace.py
+  run gnconv_ab 300 python tools/gnconv_ab.py
+  ;;
+s5)  # gnconv v2 (slice first, gamma / beta through LDS, contiguous k-step ranges, addresses per tap): parity, trace, A/B, the step
+  run t_gnconv 900 $PYT tests/test_ops_gpu.py -k "gn_conv2d"
+  run gnconv_trace 300 python tools/gnconv_trace.py
+  run gnconv_ab 300 python tools/gnconv_ab.py
+  run bench_fused 900 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --dump-kernels gpurun_out/kernels_fused.json
+  SFAST_FUSE_GN_CONV=0 run bench_unfused 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  run bench_fused2 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  ;;
 esac
 cat gpurun_out/session.log
