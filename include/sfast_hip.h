@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define SFAST_HIP_ABI_VERSION 7
+#define SFAST_HIP_ABI_VERSION 8
 
 typedef void *sfast_stream_t; /* hipStream_t */
 
@@ -267,11 +267,25 @@ int sfast_hip_conv2d(const void *x, const void *x2, const void *w, const void *b
  *             scratch reaches into it. Without the flag nothing changes (row-major slabs + reduce kernel).                    */
 #define SFAST_WS_TICKET_BYTES 65536
 #define SFAST_EXT_WS_TICKETS 1
+/* gn_out (ABI 8)   : the GroupNorm(+SiLU) that CONSUMES the output rides in the split-K reduce launch: besides `out`, the dense
+ *             [M][N] tensor gn_act(GroupNorm(out; gn_groups, gn_eps) * gn_gamma + gn_beta) is written to gn_out -- statistics over
+ *             the STORED (rounded) output per (sample, group), sample = gn_rows_per_sample consecutive rows; the arithmetic contract
+ *             of sfast_hip_group_norm on `out`. Replaces the separate launch of the reference's fused GroupNorm
+ *             (triton/torch_ops.py:179-189) behind a split-K conv / GEMM at the low-resolution levels. Only for problems that run
+ *             split-K (ask sfast_hip_conv2d_plan / sfast_hip_igemm_plan: out[2] > 1) with (N / gn_groups) % 4 == 0 and
+ *             gn_rows_per_sample * N / gn_groups <= 16384; otherwise SFAST_ERR_UNSUPPORTED. Not combinable with gn_unit / gn_stats.  */
 typedef struct {
     float out_scale;
     int32_t gn_unit;
     int32_t gn_rows_per_sample;
     int32_t flags;
+    void *gn_out;           /* NULL: no fused GroupNorm */
+    const void *gn_gamma;   /* [N] or NULL */
+    const void *gn_beta;    /* [N] or NULL */
+    int32_t gn_groups;
+    float gn_eps;
+    int32_t gn_act;         /* SFAST_ACT_NONE or SFAST_ACT_SILU */
+    int32_t reserved;
 } sfast_epilogue_ext;
 
 /* zero the ticket block of a fresh workspace (asynchronous, on `stream`) */

@@ -210,6 +210,25 @@ extern "C" size_t sfast_hip_gemm_workspace_bytes(const sfast_gemm_params *p) {
 }
 
 static float ext_scale(const sfast_epilogue_ext *ext) { return (ext && ext->out_scale != 0.0f) ? ext->out_scale : 1.0f; }
+// sfast_epilogue_ext.gn_out: the consumer GroupNorm rides in the split-K reduce launch (igemm.hip splitk_reduce_gn_kernel)
+static int ext_gn(const sfast_epilogue_ext *ext, const void *gn_stats, IgemmArgs &a) {
+    a.gn_out = nullptr;
+    if (!ext || !ext->gn_out) return SFAST_OK;
+    SFAST_REQUIRE(!gn_stats && ext->gn_unit == 0, SFAST_ERR_INVALID, "epilogue ext: gn_out and statistics emission are exclusive");
+    SFAST_REQUIRE(ext->gn_act == SFAST_ACT_NONE || ext->gn_act == SFAST_ACT_SILU, SFAST_ERR_UNSUPPORTED, "epilogue ext: gn_act %d", ext->gn_act);
+    SFAST_REQUIRE(ext->gn_rows_per_sample > 0 && igemm_reduce_gn_ok(a.M, a.N, ext->gn_rows_per_sample, ext->gn_groups), SFAST_ERR_UNSUPPORTED,
+                  "epilogue ext: fused GroupNorm outside coverage (M=%d N=%d rows/sample=%d groups=%d)", a.M, a.N, ext->gn_rows_per_sample, ext->gn_groups);
+    SFAST_REQUIRE(aligned8(ext->gn_out) && (!ext->gn_gamma || aligned8(ext->gn_gamma)) && (!ext->gn_beta || aligned8(ext->gn_beta)), SFAST_ERR_INVALID,
+                  "epilogue ext: gn_out / gamma / beta must be 8-byte aligned");
+    a.gn_out = ext->gn_out;
+    a.gn_gamma = ext->gn_gamma;
+    a.gn_beta = ext->gn_beta;
+    a.gn_groups = ext->gn_groups;
+    a.gn_eps = ext->gn_eps;
+    a.gn_act = ext->gn_act;
+    a.rows_per_batch = ext->gn_rows_per_sample;
+    return SFAST_OK;
+}
 static bool ext_tickets(const sfast_epilogue_ext *ext) { return ext && (ext->flags & SFAST_EXT_WS_TICKETS) != 0; }
 
 // SFAST_EXT_WS_TICKETS: the last SFAST_WS_TICKET_BYTES of the workspace are the split-K ticket counters; the rest is scratch
@@ -261,6 +280,8 @@ extern "C" int sfast_hip_gemm_ex(const void *x, const void *const *w_segs, const
     const GemmRoute route = gemm_route(x, w_segs, bias, rowbias, residual, out, p);
     SFAST_REQUIRE(!gn_stats || (ext && route.kind == GemmRoute::IGEMM), SFAST_ERR_UNSUPPORTED,
                   "gemm: GroupNorm statistics are emitted by the MFMA path only (and need an sfast_epilogue_ext)");
+    SFAST_REQUIRE(!(ext && ext->gn_out) || route.kind == GemmRoute::IGEMM, SFAST_ERR_UNSUPPORTED,
+                  "gemm: the fused GroupNorm epilogue (sfast_epilogue_ext.gn_out) exists on the split-K MFMA path only");
     if (route.kind == GemmRoute::IGEMM) {
         IgemmArgs a{};
         a.x = x;
@@ -289,6 +310,11 @@ extern "C" int sfast_hip_gemm_ex(const void *x, const void *const *w_segs, const
         a.gn_stats = (float *)gn_stats;
         a.gn_unit = ext ? ext->gn_unit : 0;
         a.gn_rows_per_sample = ext ? ext->gn_rows_per_sample : 0;
+        if (ext && ext->gn_out) {
+            SFAST_REQUIRE(!rowbias || p->rows_per_batch == ext->gn_rows_per_sample, SFAST_ERR_INVALID, "gemm: row-bias batches and GroupNorm samples differ");
+            rc = ext_gn(ext, gn_stats, a);
+            if (rc) return rc;
+        }
         split_workspace(ext, workspace, workspace_bytes, a);
         return igemm_run(a, p->dtype, 0, p->geglu != 0, p->variant < 100 ? p->variant : 0, p->split_k, workspace, workspace_bytes, st);
     }
@@ -515,6 +541,8 @@ extern "C" int sfast_hip_conv2d_ex(const void *x, const void *x2, const void *w,
     const ConvKind kind = conv_route(x, x2, w, bias, rowbias, z, out, p, g, fold);
     SFAST_REQUIRE(!gn_stats || (ext && kind == CONV_IGEMM), SFAST_ERR_UNSUPPORTED,
                   "conv2d: GroupNorm statistics are emitted by the MFMA path only (and need an sfast_epilogue_ext)");
+    SFAST_REQUIRE(!(ext && ext->gn_out) || kind == CONV_IGEMM, SFAST_ERR_UNSUPPORTED,
+                  "conv2d: the fused GroupNorm epilogue (sfast_epilogue_ext.gn_out) exists on the split-K MFMA path only");
     if (kind == CONV_IGEMM) {
         IgemmArgs a{};
         a.x = x;
@@ -556,6 +584,11 @@ extern "C" int sfast_hip_conv2d_ex(const void *x, const void *x2, const void *w,
         a.gn_stats = (float *)gn_stats;
         a.gn_unit = ext ? ext->gn_unit : 0;
         a.gn_rows_per_sample = ext ? ext->gn_rows_per_sample : 0;
+        if (ext && ext->gn_out) {
+            SFAST_REQUIRE(ext->gn_rows_per_sample == g.Ho * g.Wo, SFAST_ERR_INVALID, "conv2d: gn_rows_per_sample must be Ho * Wo");
+            rc = ext_gn(ext, gn_stats, a);
+            if (rc) return rc;
+        }
         split_workspace(ext, workspace, workspace_bytes, a);
         return igemm_run(a, p->dtype, 1, false, p->variant < 100 ? p->variant : 0, p->split_k, workspace, workspace_bytes, st);
     }

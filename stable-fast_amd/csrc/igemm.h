@@ -28,6 +28,11 @@ struct IgemmArgs {
     int gn_slots;      // unit slots per tile_n (host: stats_slots(BNO, unit))
     int gn_rows_per_sample;  // host-side validation only
     int w_int8;              // weights are int8 [N][K] (ldw in bytes), dequantised to T while they are staged (igemm_w8_kernel)
+    // GroupNorm(+SiLU) of the OUTPUT, computed by the split-K reduce launch (splitk_reduce_gn_kernel; sfast_epilogue_ext.gn_out):
+    void *gn_out;            // dense [M][N] normalised tensor, or nullptr
+    const void *gn_gamma, *gn_beta;
+    int gn_groups, gn_act;   // rows_per_batch = pixels per sample
+    float gn_eps;
     // ---- block -> (tile, K-split) map over the 8 XCDs (decode_block, igemm_device.h) ----------------------------
     // xmap = 1: 1-D grid of tiles*splits blocks; XCD b%8 owns a box of x_sp K-splits x x_tm tile rows x x_tn tile columns
     // (2^x_lxn boxes along n, 2^x_lxm along m, the rest of the 8 along the K-splits). xmap = 0: grid (tiles, splits), every XCD a
@@ -67,6 +72,7 @@ bool igemm_stats_layout(int M, int N, int K, bool geglu, int variant, int split,
 void igemm_plan_query(int M, int N, int K, bool geglu, int variant, int split, int glds_ok, int out[5]);
 size_t igemm_workspace_bytes(int M, int N, int K, bool geglu, int variant, int split, int glds_ok);
 bool igemm_glds_eligible(const IgemmArgs &a, int mode);
+bool igemm_reduce_gn_ok(int M, int N, int rows_per_batch, int groups);  // igemm.hip: can the reduce launch normalise its output?
 // split-K reduce + epilogue over fp32 slabs [splits][M][N] another kernel wrote (gnconv.hip)
 int igemm_reduce_only(const IgemmArgs &a, int dtype, hipStream_t st);
 // GroupNorm(+SiLU) -> 3x3 conv as one weight-streaming launch for B*H*W <= 128 (gnconv.hip; api: sfast_hip_gn_conv2d)

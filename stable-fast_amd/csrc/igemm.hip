@@ -394,6 +394,125 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const IgemmArgs a) {
     *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = pack4<T>(o[0], o[1], o[2], o[3]);
 }
 
+// Split-K reduce + epilogue + the GroupNorm(+SiLU) that CONSUMES the output, in one launch (round 4): workgroup (g, b) owns group g of
+// sample b -- every pixel, the group's N / G channels -- sums the K-split slabs in order 0 .. S-1, runs the conv / GEMM epilogue (bias,
+// row bias, residual, activation), stores the f16 / bf16 output as the plain reduce does, and then normalises exactly those stored
+// values: two exact passes over registers (mean, then squared deviations; block reductions in a fixed order -> bitwise reproducible),
+// affine, optional SiLU, second store. At the 16x16 / 8x8 levels this removes the separate single-pass GroupNorm launch that
+// followed every split-K conv (4.5 - 6 us each on <= 2.6 MB, profiles/r03_kernels_per_op_run14.json): same arithmetic contract as
+// sfast_hip_group_norm on the stored tensor (fp32 statistics, biased variance, rstd = rsqrt(var + eps)).
+// Thread t owns the float4 column quads t, t + 512, ... of the (pixels x channels-of-the-group) block: ITEMS <= 8.
+template <typename T, int ITEMS>
+__global__ void __launch_bounds__(512) splitk_reduce_gn_kernel(const IgemmArgs a) {
+    typedef const u32x2 __attribute__((address_space(1))) * g2_ptr;
+    const g2_ptr zero = (g2_ptr)(const void *)g_zero16;
+    __shared__ float red[2][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int HW = a.rows_per_batch, cpg = a.N / a.gn_groups, q4 = cpg / 4;
+    const int nitems = HW * q4;
+    const float rq4 = __builtin_amdgcn_rcpf((float)q4);
+    const int64_t zstride = (int64_t)a.M * a.N;
+    const bool res_now = a.res_before_act || a.act == SFAST_ACT_NONE;
+    float v[ITEMS][4];
+    float s1 = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int i = tid + it * 512;
+        const bool on = i < nitems;
+        const int p = on ? fdiv22(i, q4, rq4) : 0, cq = on ? i - p * q4 : 0;
+        const int m = b * HW + p, n = g * cpg + cq * 4;
+        const u32x2 vb = *(a.bias ? (g2_ptr)(const void *)((const T *)a.bias + n) : zero);
+        const u32x2 vb2 = *(a.rowbias ? (g2_ptr)(const void *)((const T *)a.rowbias + (int64_t)b * a.ld_rowbias + n) : zero);
+        const u32x2 vr = *(a.res ? (g2_ptr)(const void *)((const T *)a.res + (int64_t)m * a.ldr + n) : zero);
+        const float *p0 = a.partial + (int64_t)m * a.N + n;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        int z = 0;
+        for (; z + 3 < a.splits; z += 4) {  // four slab loads in flight, summation order z = 0, 1, 2, ...
+            f32x4 t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = *reinterpret_cast<const f32x4 *>(p0 + (z + k) * zstride);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += t[k][e];
+        }
+        for (; z < a.splits; ++z) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(p0 + z * zstride);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += t[e];
+        }
+        float b0[4], b1[4], r[4], o[4];
+        unpack4<T>(vb, b0);
+        unpack4<T>(vb2, b1);
+        unpack4<T>(vr, r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaf(acc[e], a.out_scale, b0[e]) + b1[e] + (res_now ? r[e] * a.alpha : -0.0f);
+        if (a.act != SFAST_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = apply_act(o[e], a.act) + (res_now ? -0.0f : r[e] * a.alpha);
+        }
+        const u32x2 packed = pack4<T>(o[0], o[1], o[2], o[3]);
+        if (on) *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = packed;
+        unpack4<T>(packed, v[it]);  // the statistics see the STORED (rounded) values, as a separate GroupNorm launch would
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[it][e] = on ? v[it][e] : 0.f;
+            s1 += v[it][e];
+        }
+    }
+    const float inv_n = 1.0f / ((float)HW * (float)cpg);
+    s1 = wave_sum(s1);
+    if (lane == 0) red[0][wave] = s1;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) tot += red[0][w];
+    const float mean = tot * inv_n;
+    float s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const bool on = tid + it * 512 < nitems;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = on ? v[it][e] - mean : 0.f;
+            s2 = fmaf(d, d, s2);
+        }
+    }
+    s2 = wave_sum(s2);
+    if (lane == 0) red[1][wave] = s2;
+    __syncthreads();
+    float tot2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) tot2 += red[1][w];
+    const float rstd = rsqrtf(tot2 * inv_n + a.gn_eps);
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int i = tid + it * 512;
+        if (i < nitems) {
+            const int p = fdiv22(i, q4, rq4), cq = i - p * q4;
+            const int m = b * HW + p, n = g * cpg + cq * 4;
+            float ga[4] = {1.f, 1.f, 1.f, 1.f}, be[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.gn_gamma) unpack4<T>(*reinterpret_cast<const u32x2 *>((const T *)a.gn_gamma + n), ga);
+            if (a.gn_beta) unpack4<T>(*reinterpret_cast<const u32x2 *>((const T *)a.gn_beta + n), be);
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float y = (v[it][e] - mean) * rstd * ga[e] + be[e];
+                o[e] = a.gn_act == SFAST_ACT_SILU ? act_silu(y) : y;
+            }
+            *reinterpret_cast<u32x2 *>((T *)a.gn_out + (int64_t)m * a.N + n) = pack4<T>(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+// can the split-K reduce of an [M, N] problem also run the GroupNorm of its output? (host-side rule shared by igemm_run and the API query)
+bool igemm_reduce_gn_ok(int M, int N, int rows_per_batch, int groups) {
+    if (groups <= 0 || N % groups || rows_per_batch <= 0 || M % rows_per_batch) return false;
+    const int cpg = N / groups;
+    return cpg % 4 == 0 && N % 4 == 0 && (int64_t)rows_per_batch * (cpg / 4) <= 512 * 8 && M / rows_per_batch <= 65535;
+}
+
 // Split-K reduce + epilogue + GroupNorm partial statistics: a workgroup owns R = TY*RT complete output rows, thread (c, ty) the
 // 8-channel chunk column c of rows ty, ty+TY, ... -- the row block is one statistics tile (tile_n = 1, bno = N) in the record layout
 // of flush_staged_tile (igemm_device.h). Shifts: the slot's first element in the block's row 0, shared through LDS.
@@ -970,9 +1089,9 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
     snprintf(pipe, sizeof(pipe), p.v.pipe == 3 ? "patch%d" : p.v.pipe == 2 ? "ws%d" : p.v.pipe ? "dma%d" : "reg", p.v.ns);
     char xmap[24] = "";
     if (a.xmap) snprintf(xmap, sizeof(xmap), "@xcd%dx%dx%d", 8 >> (a.x_lxm + a.x_lxn), 1 << a.x_lxm, 1 << a.x_lxn);  // K-split x row x column boxes
-    set_kernel_name("igemm_%s_%s%s[%dx%d,split=%d,%s]%s%s%s", mode ? "conv" : "lin", dtype == SFAST_F16 ? "f16" : "bf16",
+    set_kernel_name("igemm_%s_%s%s[%dx%d,split=%d,%s]%s%s%s%s", mode ? "conv" : "lin", dtype == SFAST_F16 ? "f16" : "bf16",
                     geglu ? "_geglu" : "", p.v.BM, p.v.BN, p.splits, pipe, a.gn_stats ? "+gnstats" : (a.stage_out ? "+staged" : ""),
-                    joins ? "+join" : "", xmap);  // +join: split-K finished inside this kernel (no reduce launch)
+                    joins ? "+join" : "", a.gn_out ? "+gn" : "", xmap);  // +join: split-K finished inside this kernel (no reduce launch)
     int rc;
     if (p.v.pipe == 3)
         rc = conv_patch_launch(a, dtype, p.v.BM, p.v.BN, st);
@@ -985,6 +1104,20 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
     else
         rc = mode ? dispatch_variant<bf16, 1>(a, p.v, geglu, st) : dispatch_variant<bf16, 0>(a, p.v, geglu, st);
     if (rc || joins) return rc;
+    if (a.gn_out) {  // the GroupNorm that consumes this output rides in the reduce launch
+        SFAST_REQUIRE(p.splits > 1 && !geglu && igemm_reduce_gn_ok(a.M, a.N, a.rows_per_batch, a.gn_groups) && a.ldo % 4 == 0, SFAST_ERR_UNSUPPORTED,
+                      "igemm: the fused GroupNorm epilogue needs a split-K plan (got %d splits) and N / G %% 4 == 0, H*W * N / G <= 16384", p.splits);
+        const int items = ceil_div(a.rows_per_batch * (a.N / a.gn_groups / 4), 512);
+        const dim3 grid((unsigned)a.gn_groups, (unsigned)(a.M / a.rows_per_batch)), block(512);
+#define RG_LAUNCH(T, I) hipLaunchKernelGGL((splitk_reduce_gn_kernel<T, I>), grid, block, 0, st, a)
+        if (dtype == SFAST_F16) {
+            if (items <= 2) RG_LAUNCH(f16, 2); else if (items <= 4) RG_LAUNCH(f16, 4); else RG_LAUNCH(f16, 8);
+        } else {
+            if (items <= 2) RG_LAUNCH(bf16, 2); else if (items <= 4) RG_LAUNCH(bf16, 4); else RG_LAUNCH(bf16, 8);
+        }
+#undef RG_LAUNCH
+        return check_launch("splitk_reduce_gn");
+    }
     if (p.splits > 1 && a.gn_stats) {
         const int R = red_ty * red_rt, CPR = a.N / 8;
         const dim3 grid((unsigned)ceil_div(a.M, R)), block((unsigned)(((CPR * red_ty + 63) / 64) * 64));

@@ -125,6 +125,7 @@ class UNetPlan:
         self.writer = {}
         self.gn_candidates = []
         self.gn_fused = 0      # GroupNorms that run as ONE normalisation pass over statistics their producers emit
+        self.gn_in_reduce = 0  # GroupNorms computed by their producer's split-K reduce launch (no launch of their own)
 
     def writer_of(self, t):
         rec = self.writer.get(id(t)) if t is not None else None
@@ -243,6 +244,8 @@ EXT_FLAGS = L.EXT_WS_TICKETS if os.environ.get("SFAST_SPLITK_JOIN", "0") not in 
 # each workgroup) and a wave that streams weights straight into its own registers stalls at the memory queue instead of computing
 # (DESIGN.md section 9, round 4, item 1). SFAST_FUSE_GN_CONV=1 switches it on (A/B knob; the operator itself is parity-green).
 FUSE_GN_CONV = os.environ.get("SFAST_FUSE_GN_CONV", "0") not in ("0", "false", "off", "")
+# the GroupNorm(+SiLU) behind a split-K conv / GEMM rides in that problem's reduce launch (UNet2DEngine._fuse_gn_into_reduce)
+GN_IN_REDUCE = os.environ.get("SFAST_GN_IN_REDUCE", "1") not in ("0", "false", "off", "")
 
 
 class DeviceHost:
@@ -495,7 +498,7 @@ class UNet2DEngine:
 
         self._add(plan, "gn_silu" if silu else "gn", name, 0.0, (2.0 * N * HW * Ctot + 2 * Ctot) * self.esize, launch)
         plan.gn_candidates.append(dict(name=name, p=p, pre=pre, xw=plan.writer_of(x), x2w=plan.writer_of(x2),
-                                       concat=x2 is not None, HW=HW))
+                                       concat=x2 is not None, HW=HW, gp=gp, bp=bp, yp=yp, eps=float(eps), silu=bool(silu)))
         plan.writer.pop(id(y), None)
 
     def _op_ln(self, plan, name, x, y, M, N, prefix):
@@ -1180,6 +1183,8 @@ class UNet2DEngine:
         if unit < 8 or not hasattr(lib, "sfast_hip_group_norm_apply"):
             return
         for c in plan.gn_candidates:
+            if c.get("in_reduce"):
+                continue  # already computed by its producer's split-K reduce launch
             p = c["p"]
             cpg = p.C // p.G
             srcs = [c["xw"]] + ([c["x2w"]] if c["concat"] else [])
@@ -1214,6 +1219,56 @@ class UNet2DEngine:
             c["pre"][0] = (srcs[0]["stats"][0].data_ptr(), lays[0], s2[0], s2[1])
             plan.gn_fused += 1
 
+    def _fuse_gn_into_reduce(self, plan):
+        """Round 4: a GroupNorm(+SiLU) whose input was written by the split-K reduce launch of the op RIGHT BEFORE it in the plan (the
+        16x16 / 8x8 levels: every resnet's norm2 behind conv1, the next block's norm behind conv2) is computed BY that launch
+        (sfast_epilogue_ext.gn_out, csrc/igemm.hip splitk_reduce_gn_kernel) and leaves the plan: one launch of 4.5 - 6 us less per
+        pair. Decided after tuning (the producer's K-split count is a tuning result); a producer that runs unsplit keeps its
+        separate GroupNorm. SFAST_GN_IN_REDUCE=0 switches the pass off (A/B knob)."""
+        if not GN_IN_REDUCE:
+            return
+        lib = self.lib
+        index = {op.name: i for i, op in enumerate(plan.ops)}
+        drop = set()
+        for c in plan.gn_candidates:
+            w, p = c["xw"], c["p"]
+            if c["concat"] or w is None or c["name"] not in index or w["name"] not in index:
+                continue
+            if index[c["name"]] != index[w["name"]] + 1 or w["stats"][0] is not None or w["ext"].gn_unit or w["ext"].gn_out:
+                continue   # something runs in between, or this producer already serves another consumer
+            cpg = p.C // p.G
+            if p.C1 != p.C or cpg % 4 or p.HW * cpg > 16384 or p.layout != L.NHWC:
+                continue
+            o5 = (C.c_int32 * 5)()
+            wp = w["p"]
+            if w["conv"]:
+                Hin, Win = (2 * wp.H, 2 * wp.W) if wp.upsample2x else (wp.H, wp.W)
+                Ho = (Hin + 2 * wp.pad_h + wp.pad_h_extra - wp.dil_h * (wp.KH - 1) - 1) // wp.stride_h + 1
+                Wo = (Win + 2 * wp.pad_w + wp.pad_w_extra - wp.dil_w * (wp.KW - 1) - 1) // wp.stride_w + 1
+                if Ho * Wo != p.HW or wp.B != p.N:
+                    continue   # the GroupNorm's samples are not the conv's images (e.g. SVD's temporal norms over [B, C, F*H*W])
+                if wp.Cout != p.C or lib.sfast_hip_conv2d_plan(C.byref(wp), wp.variant, wp.split_k, o5) != 0:
+                    continue
+            else:
+                if wp.M != p.N * p.HW:
+                    continue
+                if wp.N != p.C or wp.geglu or wp.ldo != p.C or \
+                        lib.sfast_hip_igemm_plan(wp.M, wp.N, wp.K, 0, wp.variant if wp.variant < 100 else 0, wp.split_k, o5) != 0:
+                    continue
+                if wp.rows_per_batch not in (0, p.HW):
+                    continue
+            if int(o5[2]) <= 1:
+                continue
+            ext = w["ext"]
+            ext.gn_out, ext.gn_gamma, ext.gn_beta = c["yp"], c["gp"], c["bp"]
+            ext.gn_groups, ext.gn_eps, ext.gn_act = p.G, c["eps"], (L.ACT_SILU if c["silu"] else L.ACT_NONE)
+            ext.gn_rows_per_sample = p.HW
+            c["in_reduce"] = True
+            drop.add(c["name"])
+        if drop:
+            plan.ops = [op for op in plan.ops if op.name not in drop]
+            plan.gn_in_reduce = len(drop)
+
     def _finish_plan(self, plan):
         # measured tile / pipe / split-K selection per distinct GEMM / conv problem (cuDNN-benchmark style)
         from . import autotune
@@ -1225,6 +1280,7 @@ class UNet2DEngine:
                     p = op.tune[0]
                     q = lib.sfast_hip_gemm_workspace_bytes if isinstance(p, L.GemmParams) else lib.sfast_hip_conv2d_workspace_bytes
                     self._need_ws(plan, q(C.byref(p)), op.lane)
+        self._fuse_gn_into_reduce(plan)
         self._fuse_gn_statistics(plan)
         # one scratch buffer per lane, shared by all its operators; the split-K ticket counters of the GEMM / conv kernels live in a
         # block of their own behind the largest need (sfast_hip.h SFAST_EXT_WS_TICKETS), zeroed here once

@@ -385,14 +385,16 @@ def _nhwc_strides(t):
 @_on_device
 def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dilation=1, act=None,
            res_before_act=True, x2=None, upsample2x=False, rowbias=None, variant=0, split_k=0,
-           channels_last_out: Optional[bool] = None, pad_extra=0, out_scale=1.0, gn_unit=0, out=None):
+           channels_last_out: Optional[bool] = None, pad_extra=0, out_scale=1.0, gn_unit=0, out=None, gn=None):
     """y = act(conv2d(x, w) + bias + rowbias[b] + alpha*z) on logical NCHW tensors of any strides.
     x2: optional tensor concatenated to x along channels (virtual). upsample2x: nearest 2x first.
     pad_extra: additional zero rows / columns at the bottom / right on top of `padding` (F.pad(x, (0, e, 0, e))).
     out_scale: accumulator scale (sfast_epilogue_ext). gn_unit > 0: also emit GroupNorm partial statistics of y; returns
     (y, stats float32 tensor, GnStatsLayout) -- feed them to group_norm_apply().
     out: optional preallocated [B, Cout, Ho, Wo] tensor of ANY strides (e.g. a channel slice of a larger NHWC tensor: the groups of
-    a grouped convolution write their slices of one output, no concatenation)."""
+    a grouped convolution write their slices of one output, no concatenation).
+    gn = (num_groups, weight, bias, eps, act): ALSO return act(GroupNorm(y)) -- computed by the split-K reduce launch of this conv
+    (sfast_epilogue_ext.gn_out; split-K plans only: pass split_k > 1 or let the planner choose one) -> (y, n), both channels_last."""
     _require_cuda(x, weight, bias, z, x2, rowbias)
     lib = L.init_device()
     if x.ndim != 4 or weight.ndim != 4:
@@ -452,6 +454,14 @@ def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dila
     nb = lib.sfast_hip_conv2d_workspace_bytes(C.byref(p))
     wsb, nb, flags = _ws_tickets(nb, x)
     ext = L.EpilogueExt(float(out_scale), int(gn_unit), Ho * Wo, flags)
+    gn_y = None
+    if gn is not None:
+        groups, g_w, g_b, g_eps, g_act = gn
+        gn_y = torch.empty((B, Cout, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        g_w = None if g_w is None else g_w.to(x.dtype).contiguous()
+        g_b = None if g_b is None else g_b.to(x.dtype).contiguous()
+        ext.gn_out, ext.gn_gamma, ext.gn_beta = gn_y.data_ptr(), _ptr(g_w), _ptr(g_b)
+        ext.gn_groups, ext.gn_eps, ext.gn_act = int(groups), float(g_eps), _act(g_act)
     stats, lay = None, None
     if gn_unit:
         lay = L.GnStatsLayout()
@@ -460,6 +470,8 @@ def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dila
     rc = lib.sfast_hip_conv2d_ex(_ptr(x), _ptr(x2), _ptr(weight), _ptr(bias), _ptr(rowbias), _ptr(zz), _ptr(y),
                                  C.byref(p), C.byref(ext), _ptr(stats), _ptr(wsb), nb, _stream(x))
     L.check(rc, "sfast_hip_conv2d")
+    if gn is not None:
+        return y, gn_y
     if gn_unit:
         return y, stats, lay
     return y

@@ -18,7 +18,7 @@ PROBES_LIB_PATH = os.path.join(os.path.dirname(_HERE), "_lib", "libsfast_hip_pro
 if os.environ.get("SFAST_HIP_PROBES", "0") == "1":
     LIB_PATH = PROBES_LIB_PATH
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # enums (include/sfast_hip.h)
 F16, BF16, F32 = 0, 1, 2
@@ -78,7 +78,10 @@ class GemmParams(C.Structure):
 
 
 class EpilogueExt(C.Structure):
-    _fields_ = [("out_scale", C.c_float), ("gn_unit", C.c_int32), ("gn_rows_per_sample", C.c_int32), ("flags", C.c_int32)]
+    _fields_ = [("out_scale", C.c_float), ("gn_unit", C.c_int32), ("gn_rows_per_sample", C.c_int32), ("flags", C.c_int32),
+                # ABI 8: the GroupNorm(+SiLU) that consumes the output, computed by the split-K reduce launch
+                ("gn_out", C.c_void_p), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("gn_groups", C.c_int32), ("gn_eps", C.c_float),
+                ("gn_act", C.c_int32), ("reserved", C.c_int32)]
 
 
 class GnStatsLayout(C.Structure):

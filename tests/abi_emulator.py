@@ -75,6 +75,12 @@ class EmuLib:
     def sfast_hip_conv2d_stats_layout(self, p, ext, out):
         return self.real.sfast_hip_conv2d_stats_layout(p, ext, out)
 
+    def sfast_hip_conv2d_plan(self, ref, variant, split_k, out):
+        return self.real.sfast_hip_conv2d_plan(ref, variant, split_k, out)
+
+    def sfast_hip_igemm_plan(self, M, N, K, geglu, variant, split_k, out):
+        return self.real.sfast_hip_igemm_plan(M, N, K, geglu, variant, split_k, out)
+
     def sfast_hip_gn_conv2d_supported(self, ref):
         return self.real.sfast_hip_gn_conv2d_supported(ref)
 
@@ -176,6 +182,27 @@ class EmuLib:
                         rec[rb, tn, j, 0] = m
                         rec[rb, tn, j, 1] = ((v - m) ** 2).sum()
 
+    @staticmethod
+    def _splits(query, M, N, K, geglu, variant, split_k):
+        o5 = (C.c_int32 * 5)()
+        assert query(M, N, K, int(geglu), variant if variant < 100 else 0, split_k, o5) == 0
+        return int(o5[2])
+
+    def _emit_fused_gn(self, out2d, ext, M, N, dtype, splits):
+        """sfast_epilogue_ext.gn_out: GroupNorm(+SiLU) of the STORED output, written dense [M][N]; only split-K plans have the reduce
+        launch it rides in (the real library refuses the others -- so does the emulator)."""
+        assert splits > 1, "fused GroupNorm epilogue on a plan without a split-K reduce launch"
+        assert ext.gn_unit == 0 and ext.gn_rows_per_sample > 0 and M % ext.gn_rows_per_sample == 0
+        HW = ext.gn_rows_per_sample
+        Bn = M // HW
+        assert (N // ext.gn_groups) % 4 == 0 and HW * (N // ext.gn_groups) <= 16384
+        g = _flat(ext.gn_gamma, N, dtype).float() if ext.gn_gamma else None
+        b = _flat(ext.gn_beta, N, dtype).float() if ext.gn_beta else None
+        xin = out2d.reshape(Bn, HW, N).permute(0, 2, 1)   # [B, C, HW] of the rounded output
+        y = R.group_norm_ref(xin, ext.gn_groups, g, b, ext.gn_eps, ext.gn_act == L.ACT_SILU)
+        _flat(ext.gn_out, M * N, dtype).reshape(Bn, HW, N).copy_(y.permute(0, 2, 1))
+        self.calls.append("fused_gn")
+
     def sfast_hip_gemm_ex(self, x, segs, bias, rowbias, res, out, ref, ext_ref, stats, ws, ws_bytes, stream):
         ext = _p(ext_ref) if ext_ref is not None else None
         p0 = _p(ref)
@@ -189,6 +216,9 @@ class EmuLib:
             self.calls.append("gemm")
             return 0
         rc = self.sfast_hip_gemm(x, segs, bias, rowbias, res, out, ref, ws, ws_bytes, stream)
+        if ext is not None and ext.gn_out:
+            self._emit_fused_gn(_strided(out, (p0.M, p0.N), (p0.ldo, 1), p0.dtype), ext, p0.M, p0.N, p0.dtype,
+                                self._splits(self.real.sfast_hip_igemm_plan, p0.M, p0.N, p0.K, p0.geglu, p0.variant, p0.split_k))
         if stats:
             p = _p(ref)
             lay = L.GnStatsLayout()
@@ -201,6 +231,12 @@ class EmuLib:
         ext = _p(ext_ref) if ext_ref is not None else None
         assert ext is None or ext.out_scale in (0.0, 1.0)
         rc = self.sfast_hip_conv2d(x, x2, w, bias, rowbias, z, out, ref, ws, ws_bytes, stream)
+        if ext is not None and ext.gn_out:
+            p = _p(ref)
+            M = p.B * ext.gn_rows_per_sample
+            o5 = (C.c_int32 * 5)()
+            assert self.real.sfast_hip_conv2d_plan(ref, p.variant, p.split_k, o5) == 0
+            self._emit_fused_gn(_strided(out, (M, p.Cout), (p.os[2], 1), p.dtype), ext, M, p.Cout, p.dtype, int(o5[2]))
         if stats:
             p = _p(ref)
             lay = L.GnStatsLayout()

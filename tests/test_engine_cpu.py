@@ -121,7 +121,10 @@ def test_sd15_plan_op_inventory(built_lib):
     import sfast.engine.unet2d as E
     fused = s.get("gnconv3x3", {"count": 0, "gflop": 0.0})["count"]
     assert fused == (14 if E.FUSE_GN_CONV else 0)
-    assert s["gn_silu"]["count"] + fused == 45 and s["gn"]["count"] == 16 and s["ln"]["count"] == 48
+    # GroupNorms behind a split-K conv ride in that conv's reduce launch and leave the plan (plan.gn_in_reduce; which ones depends on the
+    # planner's K-split choices): 45 + 16 GroupNorms in total, however they run
+    assert s["gn_silu"]["count"] + s["gn"]["count"] + fused + plan.gn_in_reduce == 45 + 16 and s["ln"]["count"] == 48
+    assert plan.gn_in_reduce >= 10, plan.gn_in_reduce   # the 16x16 / 8x8 levels
     assert s["attn_self"]["count"] == 16 and s["attn_cross"]["count"] == 16 and s["geglu"]["count"] == 16
     assert s["conv3x3"]["count"] + fused + s["conv_in"]["count"] + s["conv_out"]["count"] == 52
     assert s["conv1x1"]["count"] == 46

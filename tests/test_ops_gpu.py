@@ -1050,3 +1050,50 @@ def test_gn_conv2d_refuses_what_it_does_not_cover():
     assert not F().gn_conv2d_supported(x, cl(rnd(1280, 1920, 3, 3, seed=314, scale=0.01)), 32)
     x1, x2 = cl(rnd(2, 1280, 8, 8, seed=315)), cl(rnd(2, 640, 8, 8, seed=316))   # concat 1280 + 640: groups of 60 straddle the sources
     assert not F().gn_conv2d_supported(x1, cl(rnd(1280, 1920, 3, 3, seed=317, scale=0.01)), 32, x2=x2)
+
+
+# ---- round 4: the consumer GroupNorm(+SiLU) computed by the split-K reduce launch (sfast_epilogue_ext.gn_out) -------------------------------
+@pytest.mark.parametrize("case", [
+    # name, B, Cin, H, W, Cout, split, groups, act, extras
+    ("8x8 1280->1280 split 12 + temb", 2, 1280, 8, 8, 1280, 12, 32, "silu", dict(rowbias=True)),
+    ("8x8 1280->1280 split 12 + residual, plain GN eps 1e-6", 2, 1280, 8, 8, 1280, 12, 32, None, dict(z=True, eps=1e-6)),
+    ("16x16 1280->1280 split 6", 2, 1280, 16, 16, 1280, 6, 32, "silu", dict(z=True)),
+    ("16x16 640->1280 split 3", 2, 640, 16, 16, 1280, 3, 32, "silu", dict(rowbias=True)),
+    ("stride-2 downsampler 16->8, split 8", 2, 1280, 16, 16, 1280, 8, 32, "silu", dict(stride=2)),
+    ("B=1 8x8 split 5, 16 groups", 1, 640, 8, 8, 640, 5, 16, "silu", {}),
+    ("ragged 7x6, Cout 96 (3 channels... 24 per group)", 3, 320, 7, 6, 96, 4, 4, "silu", dict(z=True)),
+], ids=lambda c: c[0])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_conv_split_k_reduce_carries_the_consumer_groupnorm(case, dtype):
+    """(y, n) from ONE conv call: y bit-identical to the same conv without the fused GroupNorm, n == GroupNorm(+SiLU) of the STORED y
+    within one output rounding (both against the fp32 oracle on y and against the separate HIP GroupNorm launch)."""
+    name, B, Cin, H, W, Cout, split, G, act, ex = case
+    stride, eps = ex.get("stride", 1), ex.get("eps", 1e-5)
+    x = cl(rnd(B, Cin, H, W, dtype=dtype, seed=401))
+    w = cl(rnd(Cout, Cin, 3, 3, dtype=dtype, seed=402, scale=(9 * Cin) ** -0.5))
+    b = rnd(Cout, dtype=dtype, seed=403)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    z = cl(rnd(B, Cout, Ho, Wo, dtype=dtype, seed=404)) if ex.get("z") else None
+    rb = rnd(B, Cout, dtype=dtype, seed=405) if ex.get("rowbias") else None
+    gw, gb = rnd(Cout, dtype=dtype, seed=406, scale=0.2, shift=1.0), rnd(Cout, dtype=dtype, seed=407, scale=0.2)
+    y, n = F().conv2d(x, w, b, z=z, stride=stride, padding=1, rowbias=rb, split_k=split, gn=(G, gw, gb, eps, act))
+    k = last_kernel()
+    assert "+gn" in k and f"split={split}," in k, k
+    y0 = F().conv2d(x, w, b, z=z, stride=stride, padding=1, rowbias=rb, split_k=split)
+    assert torch.equal(y, y0), "the fused reduce changed the conv output"
+    y_again, n_again = F().conv2d(x, w, b, z=z, stride=stride, padding=1, rowbias=rb, split_k=split, gn=(G, gw, gb, eps, act))
+    assert torch.equal(n, n_again) and torch.equal(y, y_again), "not reproducible"
+    compare(f"conv+gn y {name} {dtype}", y, R.conv2d_ref(x, w, b, z, 1.0, stride, 1, rowbias=rb), *tol(dtype, 2.0), kernel=k)
+    compare(f"conv+gn n {name} {dtype}", n, R.group_norm_ref(y, G, gw, gb, eps, act == "silu"), *tol(dtype, 2.0), kernel=k)
+    n2 = F().group_norm(y, G, gw, gb, eps, act)
+    compare(f"conv+gn n vs separate launch {name} {dtype}", n, n2.float(), *tol(dtype, 1.0), kernel=k)
+
+
+def test_fused_groupnorm_epilogue_refuses_unsplit_plans():
+    from sfast.hip import lib
+    x, w = cl(rnd(2, 320, 32, 32, seed=411)), cl(rnd(320, 320, 3, 3, seed=412, scale=0.02))
+    with pytest.raises(lib.SfastHipError):   # 32x32: 1024 pixels x 10 channels per group: fine, but split 1 has no reduce launch to ride in
+        F().conv2d(x, w, None, padding=1, split_k=1, variant=4, gn=(32, None, None, 1e-5, "silu"))
+    x, w = cl(rnd(2, 640, 64, 64, seed=413)), cl(rnd(640, 640, 3, 3, seed=414, scale=0.02))
+    with pytest.raises(lib.SfastHipError):   # 4096 pixels x 20 channels per group > 16384 values per workgroup
+        F().conv2d(x, w, None, padding=1, split_k=2, gn=(32, None, None, 1e-5, "silu"))
