@@ -414,7 +414,45 @@ __global__ void __launch_bounds__(512) splitk_reduce_gn_kernel(const IgemmArgs a
     const float rq4 = __builtin_amdgcn_rcpf((float)q4);
     const int64_t zstride = (int64_t)a.M * a.N;
     const bool res_now = a.res_before_act || a.act == SFAST_ACT_NONE;
+    // phase 1: the slab loads. K-split index OUTERMOST, four splits x all items per round (up to 32 independent 16-byte loads in flight
+    // per thread), every element still summed in the order z = 0, 1, 2, ... History (profiles/r04_reduce_gn_ab_run{7,8}.log): item by
+    // item with the store in between, then item by item without it, both measured ~21 us for a 16x16 conv's reduce -- the compiler
+    // does not interleave the runtime-length split loops of different items, so each item paid its own round trips.
     float v[ITEMS][4];
+    const float *p0[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int i = tid + it * 512;
+        const bool on = i < nitems;
+        const int p = on ? fdiv22(i, q4, rq4) : 0, cq = on ? i - p * q4 : 0;
+        p0[it] = a.partial + (int64_t)(b * HW + p) * a.N + g * cpg + cq * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[it][e] = 0.f;
+    }
+    int z = 0;
+    for (; z + 3 < a.splits; z += 4) {
+        f32x4 t[ITEMS][4];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[it][k] = *reinterpret_cast<const f32x4 *>(p0[it] + (z + k) * zstride);
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[it][e] += t[it][k][e];
+    }
+    for (; z < a.splits; ++z) {
+        f32x4 t[ITEMS];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) t[it] = *reinterpret_cast<const f32x4 *>(p0[it] + z * zstride);
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[it][e] += t[it][e];
+    }
+    // phase 2: epilogue, store, and the rounded values the statistics are taken over
     float s1 = 0.f;
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
@@ -425,29 +463,12 @@ __global__ void __launch_bounds__(512) splitk_reduce_gn_kernel(const IgemmArgs a
         const u32x2 vb = *(a.bias ? (g2_ptr)(const void *)((const T *)a.bias + n) : zero);
         const u32x2 vb2 = *(a.rowbias ? (g2_ptr)(const void *)((const T *)a.rowbias + (int64_t)b * a.ld_rowbias + n) : zero);
         const u32x2 vr = *(a.res ? (g2_ptr)(const void *)((const T *)a.res + (int64_t)m * a.ldr + n) : zero);
-        const float *p0 = a.partial + (int64_t)m * a.N + n;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        int z = 0;
-        for (; z + 3 < a.splits; z += 4) {  // four slab loads in flight, summation order z = 0, 1, 2, ...
-            f32x4 t[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) t[k] = *reinterpret_cast<const f32x4 *>(p0 + (z + k) * zstride);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] += t[k][e];
-        }
-        for (; z < a.splits; ++z) {
-            const f32x4 t = *reinterpret_cast<const f32x4 *>(p0 + z * zstride);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] += t[e];
-        }
         float b0[4], b1[4], r[4], o[4];
         unpack4<T>(vb, b0);
         unpack4<T>(vb2, b1);
         unpack4<T>(vr, r);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = fmaf(acc[e], a.out_scale, b0[e]) + b1[e] + (res_now ? r[e] * a.alpha : -0.0f);
+        for (int e = 0; e < 4; ++e) o[e] = fmaf(v[it][e], a.out_scale, b0[e]) + b1[e] + (res_now ? r[e] * a.alpha : -0.0f);
         if (a.act != SFAST_ACT_NONE) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = apply_act(o[e], a.act) + (res_now ? -0.0f : r[e] * a.alpha);

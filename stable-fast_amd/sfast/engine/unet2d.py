@@ -244,8 +244,12 @@ EXT_FLAGS = L.EXT_WS_TICKETS if os.environ.get("SFAST_SPLITK_JOIN", "0") not in 
 # each workgroup) and a wave that streams weights straight into its own registers stalls at the memory queue instead of computing
 # (DESIGN.md section 9, round 4, item 1). SFAST_FUSE_GN_CONV=1 switches it on (A/B knob; the operator itself is parity-green).
 FUSE_GN_CONV = os.environ.get("SFAST_FUSE_GN_CONV", "0") not in ("0", "false", "off", "")
-# the GroupNorm(+SiLU) behind a split-K conv / GEMM rides in that problem's reduce launch (UNet2DEngine._fuse_gn_into_reduce)
-GN_IN_REDUCE = os.environ.get("SFAST_GN_IN_REDUCE", "1") not in ("0", "false", "off", "")
+# the GroupNorm(+SiLU) behind a split-K conv / GEMM rides in that problem's reduce launch (UNet2DEngine._fuse_gn_into_reduce,
+# sfast_epilogue_ext.gn_out). OFF by default: 22 launches fewer per SD1.5 step and still 0.6 - 1.1 % SLOWER (180.2 vs 181.2 it/s,
+# profiles/r04_reduce_gn_ab_run{7,8,9}.log) -- the statistics need a whole (sample, group) in ONE workgroup, i.e. 64 workgroups, and 64
+# CUs pull a 16x16 level's 15.7 MB of fp32 slabs at ~16 GB/s each: 43 us for conv + fused reduce against 31 + 7 us for the
+# chip-wide reduce and the separate 64-workgroup GroupNorm of a 1.3 MB tensor; at the 8x8 level it is a wash (21.5 vs 21.4 us).
+GN_IN_REDUCE = os.environ.get("SFAST_GN_IN_REDUCE", "0") not in ("0", "false", "off", "")
 
 
 class DeviceHost:

@@ -57,5 +57,23 @@ s5)  # gnconv v2 (slice first, gamma / beta through LDS, contiguous k-step range
   SFAST_FUSE_GN_CONV=0 run bench_unfused 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
   run bench_fused2 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
   ;;
+s6)  # the consumer GroupNorm inside the split-K reduce launch: parity, whole-UNet parity, the step with and without the pass
+  run t_reduce_gn 900 $PYT tests/test_ops_gpu.py -k "consumer_groupnorm or fused_groupnorm_epilogue"
+  run t_unet 1500 $PYT tests/test_unet_gpu.py -k "tiny or sd15_unet_parity or compile_drop_in or controlnet or live_weight" tests/test_vae_gpu.py
+  run smoke 600 python __graft_entry__.py smoke
+  run bench_on 900 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --dump-kernels gpurun_out/kernels_on.json
+  SFAST_GN_IN_REDUCE=0 run bench_off 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  run bench_on2 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  SFAST_GN_IN_REDUCE=0 run bench_off2 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  ;;
+s7)  # crash hunt (ControlNet chain) with the reduce pass off / on; reduce+GN two-phase loads: parity + step A/B
+  SFAST_GN_IN_REDUCE=0 run t_cn_off 600 $PYT tests/test_unet_gpu.py -k "controlnet"
+  run t_cn_on 600 $PYT tests/test_unet_gpu.py -k "controlnet"
+  run t_reduce_gn 900 $PYT tests/test_ops_gpu.py -k "consumer_groupnorm or fused_groupnorm_epilogue"
+  run bench_on 900 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --dump-kernels gpurun_out/kernels_on.json
+  SFAST_GN_IN_REDUCE=0 run bench_off 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  run bench_on2 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  SFAST_GN_IN_REDUCE=0 run bench_off2 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  ;;
 esac
 cat gpurun_out/session.log
