@@ -75,5 +75,29 @@ s7)  # crash hunt (ControlNet chain) with the reduce pass off / on; reduce+GN tw
   run bench_on2 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
   SFAST_GN_IN_REDUCE=0 run bench_off2 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
   ;;
+s8)  # GroupNorm apply: input rows requested before the statistics prologue -- parity + step A/B
+  run t_gn 900 $PYT tests/test_ops_gpu.py -k "group_norm or gn_apply or statistics"
+  run t_unet 900 $PYT tests/test_unet_gpu.py -k "tiny or sd15_unet_parity"
+  run bench_on 900 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --dump-kernels gpurun_out/kernels_on.json
+  SFAST_GN_PREFETCH=0 run bench_off 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --dump-kernels gpurun_out/kernels_off.json
+  run bench_on2 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  SFAST_GN_PREFETCH=0 run bench_off2 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  ;;
+full)  # the whole GPU suite as the driver runs it, then the probe-build subset, then smoke
+  run t_all 1700 $PYT tests --durations=12
+  SFAST_HIP_PROBES=1 run t_probes 900 $PYT tests/test_ops_gpu.py -k "patch or join"
+  run smoke 600 python __graft_entry__.py smoke
+  ;;
+final)  # the round's SD1.5 evidence: PMC traffic by symbol, the default bench line (roofline + cpu_baseline + end-to-end + variants), rocprofv3 kernel stats
+  run pmc_traffic 900 bash tools/gpu_pmc_bench.sh sd15 6
+  cp gpurun_out/pmcb/traffic_by_symbol.json profiles/r04_pmc_traffic_by_symbol.json
+  run bench_default 900 python bench.py --dump-kernels gpurun_out/kernels.json
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -o bench -- python $OLDPWD/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants > $OLDPWD/gpurun_out/rocprof.log 2>&1 )
+  echo "rocprof exit=$?" >> gpurun_out/session.log
+  for db in $(find gpurun_out/prof -name "*.db"); do python tools/rocpd_summary.py $db --csv gpurun_out/kernel_stats.csv --top 60 --step-marker cfg_ddim --steps 12 > gpurun_out/kernel_stats.txt; done
+  rm -rf gpurun_out/prof
+  run pmc_attn 700 bash tools/gpu_pmc_attn.sh
+  run bench_torchrun 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 50 --warmup 10 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants
+  ;;
 esac
 cat gpurun_out/session.log
