@@ -290,7 +290,8 @@ _def("linear_gelu(Tensor input, Tensor weight, Tensor? bias=None) -> Tensor", li
 # for the CUDA / QuantizedCUDA dispatch keys (cutlass_qlinear.cc:73-81), so that `torch.quantization.quantize_dynamic(unet)` modules
 # reach its kernel, and exposes the same function as `sfast::cutlass_qlinear_dynamic` (:83-88). Same binding here; the kernel behind
 # it is libsfast_hip's int8-weight MFMA GEMM (weights stay int8 in HBM, widened while staged into LDS; activations stay 16-bit --
-# the reference also quantises the activations per call, which only lowers accuracy: its own test tolerance is 3e-2).
+# exactly the reference's arithmetic: its kernel is CUTLASS' mixed-input GEMM, `OpMultiplyAddMixedInputUpcast`, int8 weights upcast
+# to the 16-bit activation type, cutlass_qlinear_dynamic_kernel.cu:68,82 -- weight-only despite the "dynamic" in the op name).
 def cutlass_qlinear_dynamic_unpacked(input, weight, bias=None):
     """`weight`: a per-tensor-affine quantized qint8 tensor [N, K] (torch.quantize_per_tensor); like the reference the zero point
     is ignored (weight.int_repr() * weight.q_scale(), cutlass_qlinear_dynamic_kernel.cu:272-279). f16 / bf16 inputs run the

@@ -685,6 +685,30 @@ def test_strided_copy_reference_case():
     assert torch.equal(out, a.reshape(4, -1))
 
 
+@pytest.mark.parametrize("shape,perm,tile", [
+    ((512, 256), (1, 0), True), ((4096, 4096), (1, 0), True), ((16, 256, 4096), (0, 2, 1), True), ((16, 32, 128, 256), (0, 1, 3, 2), True),
+    ((2, 320, 64, 64), "to_cl", True), ((2, 64, 64, 320), "to_nchw", True), ((3, 70, 33), (0, 2, 1), True), ((5, 17, 130, 66), (0, 3, 2, 1), True),
+    ((2, 3, 100, 20), (1, 3, 0, 2), None),   # source-contiguous dim of extent 20 lands last: a plain (non-transposing) copy
+    ((7, 16, 16), (2, 0, 1), None), ((9, 8, 40), (0, 2, 1), False)])   # last: extent 8 < 16 along the source-contiguous dim -> generic kernel
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_strided_copy_transposes_bit_exact(shape, perm, tile, dtype):
+    """Round 4: transposing copies run through an LDS tile (transpose_tile_kernel); every layout the reference's Triton copy is written
+    for (triton/ops/copy.py:303-311 sizes + NCHW <-> NHWC), ragged extents and permutations the tile path must NOT take -- bit exact."""
+    x = rnd(*shape, dtype=dtype, seed=121)
+    if perm == "to_cl":
+        src, dst = x, torch.empty_like(x, memory_format=torch.channels_last)
+    elif perm == "to_nchw":
+        src = x.permute(0, 3, 1, 2)                                    # logical NCHW view of an NHWC tensor
+        dst = torch.empty(src.shape, dtype=dtype, device=DEV)
+    else:
+        src = x.permute(*perm)
+        dst = torch.empty(src.shape, dtype=dtype, device=DEV)
+    F().strided_copy(src, dst)
+    assert torch.equal(dst, src), last_kernel()
+    if tile is not None:
+        assert ("transpose_tile" in last_kernel()) == tile, last_kernel()
+
+
 def test_timestep_embedding():
     from oracle.unet_ref import timestep_embedding as ref
     t = torch.tensor([981.0, 1.0, 500.0], device=DEV)
