@@ -66,6 +66,9 @@ class ControlNetModel(nn.Module):
         g, eps, lp, L = c.norm_num_groups, c.norm_eps, c.use_linear_projection, c.layers_per_block
         self.conv_in = nn.Conv2d(c.in_channels, boc[0], 3, padding=1)
         self.time_embedding = TimestepEmbedding(boc[0], temb)
+        if getattr(c, "addition_embed_type", None) == "text_time":
+            # SDXL ControlNets (diffusers ControlNetModel.__init__): the same pooled-text + micro-conditioning embedding as the SDXL UNet
+            self.add_embedding = TimestepEmbedding(c.projection_class_embeddings_input_dim, temb)
         self.controlnet_cond_embedding = ControlNetConditioningEmbedding(boc[0], c.conditioning_channels,
                                                                          c.conditioning_embedding_out_channels)
         self.down_blocks = nn.ModuleList()
@@ -83,7 +86,7 @@ class ControlNetModel(nn.Module):
         self.controlnet_mid_block = nn.Conv2d(boc[-1], boc[-1], 1)
 
     def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0, guess_mode=False,
-                return_dict=True, **_):
+                added_cond_kwargs=None, return_dict=True, **_):
         c = self.config
         B = sample.shape[0]
         t = timestep
@@ -91,6 +94,12 @@ class ControlNetModel(nn.Module):
             t = torch.tensor([t], dtype=torch.float32, device=sample.device)
         t = t.to(sample.device).reshape(-1).expand(B)
         emb = self.time_embedding(timestep_embedding(t, c.block_out_channels[0], c.flip_sin_to_cos, c.freq_shift).to(sample.dtype))
+        if getattr(c, "addition_embed_type", None) == "text_time":
+            if not added_cond_kwargs or "text_embeds" not in added_cond_kwargs or "time_ids" not in added_cond_kwargs:
+                raise ValueError("addition_embed_type 'text_time' requires text_embeds and time_ids in added_cond_kwargs")
+            te, tid = added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"]
+            tide = timestep_embedding(tid.flatten(), c.addition_time_embed_dim, c.flip_sin_to_cos, c.freq_shift)
+            emb = emb + self.add_embedding(torch.cat([te, tide.reshape(B, -1).to(te.dtype)], dim=-1).to(emb.dtype))
         h = self.conv_in(sample) + self.controlnet_cond_embedding(controlnet_cond)
         skips = [h]
         for blk in self.down_blocks:

@@ -109,6 +109,20 @@ class ResnetBlock2D(nn.Module):
         return x + h
 
 
+class IPAdapterAttnProcessor(nn.Module):
+    """diffusers `IPAdapterAttnProcessor2_0` (models/attention_processor.py), the decoupled image cross-attention of IP-Adapter: per
+    adapter i a key / value projection of the image tokens, `to_k_ip[i]` / `to_v_ip[i]` (Linear(cross_attention_dim -> hidden, bias =
+    False); state-dict keys `...attn2.processor.to_k_ip.{i}.weight`), and a python float `scale[i]`. The processor computes
+    `attn(q, k_text, v_text) + sum_i scale[i] * attn(q, to_k_ip[i](ip_i), to_v_ip[i](ip_i))` -- two SEPARATE softmaxes -- before `to_out`."""
+
+    def __init__(self, hidden_size, cross_attention_dim, num_tokens=(4,), scale=1.0):
+        super().__init__()
+        self.num_tokens = tuple(num_tokens)
+        self.scale = [float(scale)] * len(self.num_tokens)
+        self.to_k_ip = nn.ModuleList([nn.Linear(cross_attention_dim, hidden_size, bias=False) for _ in self.num_tokens])
+        self.to_v_ip = nn.ModuleList([nn.Linear(cross_attention_dim, hidden_size, bias=False) for _ in self.num_tokens])
+
+
 class Attention(nn.Module):
     def __init__(self, dim, heads, ctx_dim=None):
         super().__init__()
@@ -118,8 +132,9 @@ class Attention(nn.Module):
         self.to_k = nn.Linear(ctx_dim, dim, bias=False)
         self.to_v = nn.Linear(ctx_dim, dim, bias=False)
         self.to_out = nn.ModuleList([nn.Linear(dim, dim), nn.Identity()])
+        self.processor = None  # an IPAdapterAttnProcessor on attn2 after load_ip_adapter()
 
-    def forward(self, x, ctx=None, bias=None):
+    def forward(self, x, ctx=None, bias=None, ip=None):
         ctx = x if ctx is None else ctx
         B, S, C = x.shape
         H = self.heads
@@ -127,7 +142,29 @@ class Attention(nn.Module):
         k = self.to_k(ctx).view(B, -1, H, C // H).transpose(1, 2)
         v = self.to_v(ctx).view(B, -1, H, C // H).transpose(1, 2)
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=None if bias is None else bias[:, None].to(q.dtype))  # scale = head_dim ** -0.5
+        if ip is not None and self.processor is not None:
+            for i, ip_i in enumerate(ip):
+                ik = self.processor.to_k_ip[i](ip_i).view(B, -1, H, C // H).transpose(1, 2)
+                iv = self.processor.to_v_ip[i](ip_i).view(B, -1, H, C // H).transpose(1, 2)
+                o = o + self.processor.scale[i] * F.scaled_dot_product_attention(q, ik, iv)
         return self.to_out[0](o.transpose(1, 2).reshape(B, S, C))
+
+
+class ImageProjection(nn.Module):
+    """diffusers `ImageProjection` (models/embeddings.py): image embedding [B, D_img] -> num_image_text_embeds tokens of width
+    cross_attention_dim: Linear, reshape, LayerNorm. `load_ip_adapter` installs it as `unet.encoder_hid_proj`
+    (`encoder_hid_dim_type = "ip_image_proj"`)."""
+
+    def __init__(self, image_embed_dim, cross_attention_dim, num_image_text_embeds=4):
+        super().__init__()
+        self.num_image_text_embeds = num_image_text_embeds
+        self.image_embeds = nn.Linear(image_embed_dim, num_image_text_embeds * cross_attention_dim)
+        self.norm = nn.LayerNorm(cross_attention_dim)
+
+    def forward(self, image_embeds):
+        B = image_embeds.shape[0]
+        x = self.image_embeds(image_embeds.to(self.image_embeds.weight.dtype))
+        return self.norm(x.reshape(B, self.num_image_text_embeds, -1))
 
 
 class GEGLU(nn.Module):
@@ -160,11 +197,11 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, x, ctx):
-        cross_bias = None
-        if isinstance(ctx, tuple):  # (encoder_hidden_states, additive cross-attention bias [B, 1, S_ctx])
-            ctx, cross_bias = ctx
+        cross_bias, ip = None, None
+        if isinstance(ctx, tuple):  # (encoder_hidden_states, additive cross-attention bias [B, 1, S_ctx] or None[, IP-Adapter image tokens])
+            ctx, cross_bias, ip = (tuple(ctx) + (None,))[:3]
         x = self.attn1(self.norm1(x)) + x
-        x = self.attn2(self.norm2(x), ctx, cross_bias) + x
+        x = self.attn2(self.norm2(x), ctx, cross_bias, ip) + x
         return self.ff(self.norm3(x)) + x
 
 
@@ -335,6 +372,33 @@ class UNet2DConditionModel(nn.Module):
         self.conv_norm_out = nn.GroupNorm(g, boc[0], eps=eps)
         self.conv_out = nn.Conv2d(boc[0], c.out_channels, 3, padding=1)
 
+    def load_ip_adapter(self, image_embed_dim=32, num_tokens=4, scale=1.0, seed=0):
+        """What diffusers' `pipe.load_ip_adapter(...)` does to the UNet (loaders/unet.py `_load_ip_adapter_weights`), with seeded random
+        weights: `encoder_hid_proj` = ImageProjection, config.encoder_hid_dim_type = "ip_image_proj", and an IPAdapterAttnProcessor
+        (to_k_ip / to_v_ip) on every cross-attention (`attn2`)."""
+        g = torch.Generator().manual_seed(seed)
+        ctx_dim = self.config.cross_attention_dim
+        self.encoder_hid_proj = ImageProjection(image_embed_dim, ctx_dim, num_tokens).to(self.device, self.dtype)
+        self.config.encoder_hid_dim_type = "ip_image_proj"
+        for name, m in self.named_modules():
+            if name.endswith(".attn2"):
+                p = IPAdapterAttnProcessor(m.to_q.weight.shape[0], ctx_dim, (num_tokens,), scale)
+                with torch.no_grad():
+                    for q in p.parameters():
+                        q.copy_(torch.randn(q.shape, generator=g) * q.shape[1] ** -0.5)
+                m.processor = p.to(self.device, self.dtype)
+        with torch.no_grad():
+            for q in self.encoder_hid_proj.parameters():
+                q.copy_((torch.randn(q.shape, generator=g) * (q.shape[-1] ** -0.5 if q.ndim > 1 else 0.1) + (1.0 if q.ndim == 1 and q is self.encoder_hid_proj.norm.weight else 0.0)).to(q.dtype))
+        for q in self.parameters():
+            q.requires_grad_(False)
+        return self
+
+    def set_ip_adapter_scale(self, scale):
+        for m in self.modules():
+            if isinstance(m, IPAdapterAttnProcessor):
+                m.scale = [float(scale)] * len(m.scale)
+
     @property
     def dtype(self):
         return self.conv_in.weight.dtype
@@ -358,6 +422,20 @@ class UNet2DConditionModel(nn.Module):
             if m_.ndim == 2:
                 m_ = ((1 - m_.to(sample.dtype)) * -10000.0).unsqueeze(1)
             encoder_hidden_states = (encoder_hidden_states, m_)
+        if getattr(c, "encoder_hid_dim_type", None) == "ip_image_proj":
+            # diffusers UNet2DConditionModel.process_encoder_hidden_states: the image embeddings of `added_cond_kwargs` pass through
+            # encoder_hid_proj and travel beside the text context: encoder_hidden_states = (text, [image tokens per adapter])
+            if not added_cond_kwargs or "image_embeds" not in added_cond_kwargs:
+                raise ValueError("encoder_hid_dim_type 'ip_image_proj' requires `image_embeds` in added_cond_kwargs")
+            ie = added_cond_kwargs["image_embeds"]
+            ie = list(ie) if isinstance(ie, (list, tuple)) else [ie]
+            ip = []
+            for t_ in ie:  # MultiIPAdapterImageProjection.forward: [B, images, D] -> project every image -> [B, images * T, ctx]
+                t_ = t_[:, None] if t_.ndim == 2 else t_
+                b_, n_ = t_.shape[:2]
+                ip.append(self.encoder_hid_proj(t_.reshape(b_ * n_, -1)).reshape(b_, -1, c.cross_attention_dim).to(sample.dtype))
+            base = encoder_hidden_states if isinstance(encoder_hidden_states, tuple) else (encoder_hidden_states, None)
+            encoder_hidden_states = (base[0], base[1], ip)
         t = timestep
         if not torch.is_tensor(t):
             t = torch.tensor([t], dtype=torch.float32, device=sample.device)

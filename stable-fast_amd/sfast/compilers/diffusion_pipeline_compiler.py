@@ -107,12 +107,12 @@ class _NativeUNetForward:
 
     def _prepare(self, key, sample, timestep, ehs, added, down_res, mid_res, emask=None, tcond=None, clabels=None):
         eng = self.engine
-        B, H, W, S, ctrl, has_mask, has_tcond = key
+        B, H, W, S, ctrl, has_mask, has_tcond, ip = key
         # everything below (kernel-attribute setup, autotune launches and their event timing, warm-up, capture) must run with
         # the MODEL's device current, whatever device the caller has selected (reference: graphs.py wraps capture and replay
         # in torch.cuda.device(execution_env.device))
         with torch.cuda.device(eng.device):
-            plan = eng.get_plan(B, H, W, S, ctrl, has_mask, has_tcond)
+            plan = eng.get_plan(B, H, W, S, ctrl, has_mask, has_tcond, ip)
         env = get_per_device_graph_execution_env(eng.device)
         graph = None
         # warm-up: runs the whole plan eagerly (also validates every launch before capture)
@@ -170,6 +170,16 @@ class _NativeUNetForward:
                           for r in list(down_block_additional_residuals) + [mid_block_additional_residual]))
             if not ok:
                 bad.append("controlnet residuals (need both kinds, engine dtype, on the GPU)")
+        # IP-Adapter (load_ip_adapter: encoder_hid_dim_type "ip_image_proj"): the image embeddings of added_cond_kwargs are plan inputs;
+        # the number of images per adapter and the live processor scales are part of the plan signature
+        ip = None
+        if getattr(eng, "ip_proj", None) and not bad:
+            try:
+                ip = eng.ip_signature(added_cond_kwargs)
+                if not all(t.device.type == "cuda" for t in eng._ip_embeds(added_cond_kwargs, sample.shape[0])):
+                    bad.append("image_embeds (need tensors on the GPU)")
+            except (NotImplementedError, ValueError, AttributeError) as e:
+                bad.append(f"image_embeds ({e})")  # the original forward raises diffusers' own error for a missing input
         if (bad or encoder_hidden_states is None or not torch.is_tensor(sample) or sample.device.type != "cuda"
                 or sample.dtype != eng.dtype or sample.ndim != 4):
             # hand the original forward exactly what the caller passed (only the arguments that were given, so older
@@ -184,7 +194,7 @@ class _NativeUNetForward:
                                   encoder_hidden_states=encoder_hidden_states, return_dict=return_dict,
                                   **{k: v for k, v in given.items() if v is not None})
         B, _, H, W = sample.shape
-        key = (B, H, W, encoder_hidden_states.shape[1], ctrl, emask is not None, tcond is not None)
+        key = (B, H, W, encoder_hidden_states.shape[1], ctrl, emask is not None, tcond is not None, ip)
         entry = self._cached.get(key)
         if entry is None:
             with self._lock:
@@ -246,7 +256,7 @@ class _NativeControlNetForward:
         self.__self__ = module
         self.__name__ = "forward"
 
-    def _prepare(self, key, sample, timestep, ehs, cond):
+    def _prepare(self, key, sample, timestep, ehs, cond, added=None):
         eng = self.engine
         B, H, W, S = key
         with torch.cuda.device(eng.device):
@@ -254,7 +264,7 @@ class _NativeControlNetForward:
         graph = None
         torch.cuda.synchronize(eng.device)
         with torch.cuda.device(eng.device), torch.cuda.stream(torch.cuda.Stream(device=eng.device)):
-            eng.load_inputs(plan, sample, timestep, ehs, cond)
+            eng.load_inputs(plan, sample, timestep, ehs, cond, added)
             plan.run(torch.cuda.current_stream(eng.device).cuda_stream)
         torch.cuda.synchronize(eng.device)
         env = get_per_device_graph_execution_env(eng.device)
@@ -270,8 +280,15 @@ class _NativeControlNetForward:
                  class_labels=None, timestep_cond=None, attention_mask=None, added_cond_kwargs=None, cross_attention_kwargs=None,
                  guess_mode=False, return_dict=True):
         eng = self.engine
-        bad = [k for k, v in dict(class_labels=class_labels, timestep_cond=timestep_cond, attention_mask=attention_mask,
-                                  added_cond_kwargs=added_cond_kwargs).items() if v is not None]
+        bad = [k for k, v in dict(class_labels=class_labels, timestep_cond=timestep_cond, attention_mask=attention_mask).items() if v is not None]
+        # added_cond_kwargs: SDXL ControlNets (addition_embed_type "text_time") take text_embeds + time_ids natively; any other key, or
+        # extra conditioning handed to a ControlNet without the addition embedding (diffusers ignores it there), keeps diffusers' forward
+        if added_cond_kwargs is not None:
+            if eng.add_type != "text_time" or set(added_cond_kwargs) - {"text_embeds", "time_ids"} or not all(
+                    torch.is_tensor(v) and v.device.type == "cuda" for v in added_cond_kwargs.values()):
+                bad.append("added_cond_kwargs")
+        elif eng.add_type == "text_time":
+            bad.append("added_cond_kwargs missing")  # the original forward raises diffusers' own error
         if cross_attention_kwargs and set(cross_attention_kwargs) - {"scale"}:   # "scale" acts on LoRA layers only; the engine holds none
             bad.append("cross_attention_kwargs " + str(sorted(set(cross_attention_kwargs) - {"scale"})))
         # guess_mode is native (per-residual logspace weights, ControlNetEngine.residual_scales) unless the ControlNet pools its
@@ -295,7 +312,7 @@ class _NativeControlNetForward:
                 entry = self._cached.get(key)
                 if entry is None:
                     try:
-                        entry = self._prepare(key, sample, timestep, encoder_hidden_states, controlnet_cond)
+                        entry = self._prepare(key, sample, timestep, encoder_hidden_states, controlnet_cond, added_cond_kwargs)
                     except (NotImplementedError, KeyError) as e:
                         logger.warning("sfast: no native plan for ControlNet call %s (%s: %s); this signature runs the original forward",
                                        key, type(e).__name__, e)
@@ -303,10 +320,11 @@ class _NativeControlNetForward:
                     self._cached[key] = entry
         if entry is _FALLBACK:
             return self.orig_forward(sample, timestep, encoder_hidden_states=encoder_hidden_states, controlnet_cond=controlnet_cond,
-                                     conditioning_scale=conditioning_scale, return_dict=return_dict)
+                                     conditioning_scale=conditioning_scale, guess_mode=guess_mode, return_dict=return_dict,
+                                     **({"added_cond_kwargs": added_cond_kwargs} if added_cond_kwargs is not None else {}))
         plan, graph, env = entry
         with env.lock, torch.cuda.device(eng.device):
-            eng.load_inputs(plan, sample, timestep, encoder_hidden_states, controlnet_cond.to(eng.dtype))
+            eng.load_inputs(plan, sample, timestep, encoder_hidden_states, controlnet_cond.to(eng.dtype), added_cond_kwargs)
             if graph is not None:
                 graph.replay()
             else:

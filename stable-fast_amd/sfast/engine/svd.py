@@ -87,17 +87,6 @@ class SVDUNetEngine(UNet2DEngine):
         self.n_time_ids = P["add_embedding.linear_1.weight"].shape[1] // self.add_time_dim
 
     # ------------------------------------------------------------------------------------------
-    def _op_mix(self, plan, name, x, y, vec, out, M, Cc, *, mix=None, switch=False, vec_rows=1, vec_mod=1, ld_vec=0, wx=1.0, wy=0.0,
-                lane=LANE_MAIN, needs=None):
-        lib = self.lib
-        p = L.MixParams(self.dt, int(M), int(Cc), int(vec_rows), int(vec_mod), int(ld_vec), float(wx), float(wy), int(switch))
-        plan.keep.append(p)
-        xp, yp, vp = x.data_ptr(), (y.data_ptr() if y is not None else None), (vec.data_ptr() if vec is not None else None)
-        mp, op = (mix.data_ptr() if mix is not None else None), out.data_ptr()
-        plan.writer.pop(id(out), None)
-        self._add(plan, "misc", name, 0.0, (2 + (y is not None)) * float(M) * Cc * self.esize,
-                  lambda s, p=p: L.check(lib.sfast_hip_mix_rows(xp, yp, vp, mp, op, C.byref(p), s), name), lane=lane, needs=needs)
-
     def _single_key_cross_attention(self, plan, pre, ctx, B, Cc):
         """Cross-attention against ONE context token: softmax over a single key is exactly 1, so the layer's output is
         to_out(to_v(context)) for every query -- a [B, C] table computed on the context side lane. Returns that table."""

@@ -120,6 +120,7 @@ class UNetPlan:
         self.pool = None
         self.keep = []  # ctypes objects / tensors that must outlive the launches
         self.kv_requests = []  # (name, Wk, Wv, kv buffer, C) of every cross-attention block, grouped at the end of build_plan
+        self.ip = None  # IP-Adapter: dict(tokens=[(buffer [B, S_ip, ctx], S_ip)], requests=[[kv request] per adapter], scales={block: [float]})
         # id(buffer) -> producer record of the op that last wrote the whole buffer (GroupNorm statistics hand-over). A record holds its
         # buffer (`buf`), so the id cannot be recycled by another tensor while the record exists, and writer_of() checks identity.
         self.writer = {}
@@ -282,6 +283,9 @@ class DeviceHost:
 class UNet2DEngine:
     """Executor for SD1.5 / SD2.x / SDXL-family `UNet2DConditionModel` parameter sets."""
 
+    ip_proj = None  # [(prefix, tokens per image, image embedding width)] when an IP-Adapter is loaded (_parse_ip_adapter)
+    _ip_processors = {}
+
     def __init__(self, config, params, device=None, dtype=None, _host=None):
         self.host = _host if _host is not None else DeviceHost()
         self.lib = self.host.library()
@@ -324,6 +328,10 @@ class UNet2DEngine:
                 params[name] = d
         eng = cls(cfg, params, _host=_host)
         eng.norm_eps = live_norm_eps(m)
+        if getattr(eng, "ip_proj", None):
+            # IP-Adapter: `scale` is a python attribute of each attn2 processor (pipe.set_ip_adapter_scale); read live by ip_scales()
+            eng._ip_processors = {name: mod.processor for name, mod in m.named_modules()
+                                  if name.endswith(".attn2") and hasattr(getattr(mod, "processor", None), "to_k_ip")}
         return eng
 
     def refresh_parameters(self, m):
@@ -370,10 +378,15 @@ class UNet2DEngine:
         if self.add_type not in (None, "text_time"):
             raise UnsupportedUNet(f"addition_embed_type {self.add_type}")
         self.add_time_dim = g("addition_time_embed_dim")
-        for k in ("encoder_hid_dim_type", "time_embedding_type"):
-            v = g(k)
-            if v not in (None, "positional"):
-                raise UnsupportedUNet(f"{k}={v}")
+        if g("time_embedding_type") not in (None, "positional"):
+            raise UnsupportedUNet(f"time_embedding_type={g('time_embedding_type')}")
+        # encoder_hid_dim_type "ip_image_proj" = an IP-Adapter is loaded (diffusers loaders/unet.py _load_ip_adapter_weights): the image
+        # embeddings of added_cond_kwargs pass through `encoder_hid_proj` and feed a second, decoupled cross-attention per block
+        hid = g("encoder_hid_dim_type")
+        if hid not in (None, "ip_image_proj"):
+            raise UnsupportedUNet(f"encoder_hid_dim_type={hid}")
+        self.ip_proj = self._parse_ip_adapter() if hid == "ip_image_proj" else None
+        self._ip_processors = {}
         # class conditioning: "timestep" (sinusoid -> MLP) and "projection" (float vector -> MLP) are plan inputs; an nn.Embedding
         # table (class_embed_type None + num_class_embeds), "identity" and "simple_projection" are not built
         self.class_type = g("class_embed_type")
@@ -436,6 +449,64 @@ class UNet2DEngine:
             elif v not in (None, False):
                 raise UnsupportedUNet(f"unknown config option {k}={v!r}: refusing to guess its meaning")
 
+    def _parse_ip_adapter(self):
+        """[(parameter prefix, image tokens per image T, image embedding width)] of the ImageProjection layers under `encoder_hid_proj`
+        (one per loaded adapter; `MultiIPAdapterImageProjection.image_projection_layers.{i}` or, in older diffusers, the bare layer)."""
+        P, ctx = self.params, _cfg_get(self.cfg, "cross_attention_dim")
+        pres = []
+        if "encoder_hid_proj.image_embeds.weight" in P:
+            pres = ["encoder_hid_proj"]
+        else:
+            while f"encoder_hid_proj.image_projection_layers.{len(pres)}.image_embeds.weight" in P:
+                pres.append(f"encoder_hid_proj.image_projection_layers.{len(pres)}")
+        if not pres or not isinstance(ctx, int):
+            raise UnsupportedUNet("encoder_hid_proj is not an ImageProjection (IP-Adapter Plus / FaceID resamplers are not built)")
+        out = []
+        for pre in pres:
+            w = P[pre + ".image_embeds.weight"]
+            if w.ndim != 2 or w.shape[0] % ctx or w.shape[1] % 8 or (pre + ".norm.weight") not in P:
+                raise UnsupportedUNet(f"{pre} is not an ImageProjection the plan knows")
+            out.append((pre, w.shape[0] // ctx, w.shape[1]))
+        return out
+
+    def ip_scales(self):
+        """Snapshot of the live IP-Adapter scales: ((block path, (scale per adapter, ...)), ...). Part of the plan signature -- a scale
+        is a launch constant of the plan (and of its captured graph); set_ip_adapter_scale() selects / builds another plan."""
+        if not self.ip_proj:
+            return None
+        n = len(self.ip_proj)
+        out = []
+        for name in sorted(self._ip_processors):
+            s = getattr(self._ip_processors[name], "scale", 1.0)
+            s = list(s) if isinstance(s, (list, tuple)) else [s] * n
+            if len(s) != n or not all(isinstance(v, (int, float)) for v in s):
+                raise UnsupportedUNet("IP-Adapter scale that is not one number per adapter (masked / per-image scales)")
+            out.append((name, tuple(float(v) for v in s)))
+        return tuple(out)
+
+    def ip_signature(self, added_cond_kwargs):
+        """The `ip` argument of get_plan / build_plan for one call: (images per adapter, live scales), or None without an adapter."""
+        if not self.ip_proj:
+            return None
+        return (tuple(int(t.shape[1]) for t in self._ip_embeds(added_cond_kwargs, None)), self.ip_scales())
+
+    def _ip_embeds(self, added_cond_kwargs, B):
+        """added_cond_kwargs["image_embeds"] as diffusers' MultiIPAdapterImageProjection takes it: one [B, images, D] tensor per adapter
+        (a bare tensor = one adapter; [B, D] = one image)."""
+        if not added_cond_kwargs or added_cond_kwargs.get("image_embeds") is None:
+            raise ValueError("encoder_hid_dim_type 'ip_image_proj' requires `image_embeds` in added_cond_kwargs")  # diffusers' own error
+        ie = added_cond_kwargs["image_embeds"]
+        ie = list(ie) if isinstance(ie, (list, tuple)) else [ie]
+        if len(ie) != len(self.ip_proj):
+            raise ValueError(f"image_embeds holds {len(ie)} tensors, the UNet has {len(self.ip_proj)} IP-Adapters")
+        out = []
+        for t, (_, _, dimg) in zip(ie, self.ip_proj):
+            t = t[:, None] if t.ndim == 2 else t
+            if t.ndim != 3 or t.shape[2] != dimg or (B is not None and t.shape[0] != B):
+                raise UnsupportedUNet(f"image_embeds of shape {tuple(t.shape)} (want [B, images, {dimg}])")
+            out.append(t)
+        return out
+
     def _validate_params(self):
         """Parameter inventory check: every tensor the plan will read exists with the expected shape, and the module holds no
         parameter the plan would ignore (attention biases, gated-attention fusers, LoRA wrappers, class embeddings, ...)."""
@@ -459,6 +530,19 @@ class UNet2DEngine:
         if missing:
             raise UnsupportedUNet(f"parameters missing for the native plan: {missing[:3]}{' ...' if len(missing) > 3 else ''} "
                                   "(wrapped / renamed modules such as peft LoRA layers keep the eager forward)")
+        if self.ip_proj:
+            # IP-Adapter parameters: ImageProjection (Linear + LayerNorm) per adapter, to_k_ip / to_v_ip per cross-attention and adapter
+            ctx = self.ctx_dim
+            for pre, T_, dimg in self.ip_proj:
+                want.update({pre + ".image_embeds.weight": (T_ * ctx, dimg), pre + ".image_embeds.bias": (T_ * ctx,),
+                             pre + ".norm.weight": (ctx,), pre + ".norm.bias": (ctx,)})
+            for k in [k for k in want if k.endswith(".attn2.to_k.weight")]:
+                for i in range(len(self.ip_proj)):
+                    for kv in ("to_k_ip", "to_v_ip"):
+                        want[k[:-len("to_k.weight")] + f"processor.{kv}.{i}.weight"] = (want[k][0], ctx)
+            missing = [k for k in want if k not in have]
+            if missing:
+                raise UnsupportedUNet(f"IP-Adapter parameters missing for the native plan: {missing[:3]}")
         extra = [k for k in have if k not in want and not k.startswith("controlnet_")]
         if extra:
             raise UnsupportedUNet(f"module has parameters the native plan would ignore: {extra[:3]}{' ...' if len(extra) > 3 else ''}")
@@ -505,7 +589,7 @@ class UNet2DEngine:
                                        concat=x2 is not None, HW=HW, gp=gp, bp=bp, yp=yp, eps=float(eps), silu=bool(silu)))
         plan.writer.pop(id(y), None)
 
-    def _op_ln(self, plan, name, x, y, M, N, prefix):
+    def _op_ln(self, plan, name, x, y, M, N, prefix, lane=LANE_MAIN):
         lib = self.lib
         gamma, beta = self.params[prefix + ".weight"], self.params[prefix + ".bias"]
         p = L.LnParams(self.dt, M, N, float(self.norm_eps.get(prefix, 1e-5)))
@@ -516,7 +600,19 @@ class UNet2DEngine:
         def launch(stream, p=p):
             L.check(lib.sfast_hip_layer_norm(xp, gp, bp, yp, C.byref(p), stream), name)
 
-        self._add(plan, "ln", name, 0.0, (2.0 * M * N + 2 * N) * self.esize, launch)
+        self._add(plan, "ln", name, 0.0, (2.0 * M * N + 2 * N) * self.esize, launch, lane=lane)
+
+    def _op_mix(self, plan, name, x, y, vec, out, M, Cc, *, mix=None, switch=False, vec_rows=1, vec_mod=1, ld_vec=0, wx=1.0, wy=0.0,
+                lane=LANE_MAIN, needs=None):
+        """out[r] = wx * x[r] + wy * y[r] + vec[(r / vec_rows) % vec_mod]  (sfast_hip_mix_rows; `mix`: a live AlphaBlender factor)."""
+        lib = self.lib
+        p = L.MixParams(self.dt, int(M), int(Cc), int(vec_rows), int(vec_mod), int(ld_vec), float(wx), float(wy), int(switch))
+        plan.keep.append(p)
+        xp, yp, vp = x.data_ptr(), (y.data_ptr() if y is not None else None), (vec.data_ptr() if vec is not None else None)
+        mp, op = (mix.data_ptr() if mix is not None else None), out.data_ptr()
+        plan.writer.pop(id(out), None)
+        self._add(plan, "misc", name, 0.0, (2 + (y is not None)) * float(M) * Cc * self.esize,
+                  lambda s, p=p: L.check(lib.sfast_hip_mix_rows(xp, yp, vp, mp, op, C.byref(p), s), name), lane=lane, needs=needs)
 
     def _op_gemm(self, plan, name, x, weights, bias, out, M, N, K, ldx, ldo, *, residual=None, ldr=0, act=L.ACT_NONE,
                  geglu=False, res_before_act=False, out_offset=0, kind=None, lane=LANE_MAIN):
@@ -855,6 +951,23 @@ class UNet2DEngine:
             ebias = plan.static_in.get("encoder_attention_bias")
             self._op_attn(plan, bp + ".attn2", q, kv, kv, a, B, heads, S, S_ctx, D, (S * Cc, Cc, D), skv, skv, (S * Cc, Cc, D),
                           k_off=0, v_off=Cc, bias=ebias, bias_strides=(ebias.stride(0), 0, 0) if ebias is not None else None)
+            if plan.ip is not None:
+                # IP-Adapter (diffusers IPAdapterAttnProcessor2_0): the same queries attend to the projected image tokens with the
+                # adapter's own to_k_ip / to_v_ip -- a second softmax, not more keys -- and a += scale * that, before to_out
+                for i, (_, S_ip) in enumerate(plan.ip["tokens"]):
+                    sc = plan.ip["scales"].get(bp + ".attn2", (1.0,) * len(plan.ip["tokens"]))[i]
+                    if sc == 0.0:
+                        continue  # diffusers skips the adapter as well
+                    kvi = torch.empty(B * S_ip * 2 * Cc, dtype=self.dtype, device=self.device)
+                    plan.keep.append(kvi)
+                    plan.ip["requests"][i].append((f"{bp}.attn2.processor.to_kv_ip.{i}", P[f"{bp}.attn2.processor.to_k_ip.{i}.weight"],
+                                                   P[f"{bp}.attn2.processor.to_v_ip.{i}.weight"], kvi, Cc))
+                    a2 = pool.get(M * Cc)
+                    si_ = (S_ip * 2 * Cc, 2 * Cc, D)
+                    self._op_attn(plan, f"{bp}.attn2.ip_adapter.{i}", q, kvi, kvi, a2, B, heads, S, S_ip, D, (S * Cc, Cc, D), si_, si_,
+                                  (S * Cc, Cc, D), k_off=0, v_off=Cc, kind="attn_cross")
+                    self._op_mix(plan, f"{bp}.attn2.ip_adapter.{i}.add", a, a2, None, a, M, Cc, wx=1.0, wy=sc)
+                    pool.put(a2)
             pool.put(q)
             self._op_gemm(plan, bp + ".attn2.to_out", a, [P[bp + ".attn2.to_out.0.weight"]], P[bp + ".attn2.to_out.0.bias"], t,
                           M, Cc, Cc, Cc, Cc, residual=t, ldr=Cc)
@@ -885,10 +998,17 @@ class UNet2DEngine:
         return names
 
     # ------------------------------------------------------------------------------------------
-    def build_plan(self, B, H, W, S_ctx, ctrl=False, enc_mask=False, tcond=False):
+    def build_plan(self, B, H, W, S_ctx, ctrl=False, enc_mask=False, tcond=False, ip=None):
         """`ctrl`: the plan also takes ControlNet residuals (one NCHW tensor per skip connection + one for the mid block,
         diffusers `down_block_additional_residuals` / `mid_block_additional_residual`) as static inputs.
-        `tcond`: the plan takes `timestep_cond` [B, time_cond_proj_dim] (LCM-distilled UNets)."""
+        `tcond`: the plan takes `timestep_cond` [B, time_cond_proj_dim] (LCM-distilled UNets).
+        `ip`: (images per adapter, scales) as ip_signature() returns it -- required when an IP-Adapter is loaded: the plan then takes
+        `image_embeds` (one [B, images, D] tensor per adapter) and runs ImageProjection + the decoupled image cross-attention."""
+        if (ip is not None) != bool(self.ip_proj):
+            if ip is None:
+                ip = ((1,) * len(self.ip_proj), self.ip_scales())  # one image per adapter, live scales
+            else:
+                raise UnsupportedUNet("image_embeds given, but no IP-Adapter is loaded (encoder_hid_dim_type is not 'ip_image_proj')")
         if tcond and self.tcond_dim is None:
             raise UnsupportedUNet("timestep_cond given, but the UNet has no time_embedding.cond_proj (time_cond_proj_dim is None)")
         self.host.init_device(self.device)
@@ -913,6 +1033,14 @@ class UNet2DEngine:
             plan.static_in["encoder_attention_bias"] = torch.zeros((B, ld), dtype=dt, device=dev)[:, :S_ctx]
         plan.static_out = out
         lib = self.lib
+        if ip is not None:
+            n_img, scales = ip
+            if len(n_img) != len(self.ip_proj):
+                raise UnsupportedUNet(f"{len(n_img)} image_embeds tensors for {len(self.ip_proj)} IP-Adapters")
+            plan.static_in["image_embeds"] = [torch.zeros((B, int(n), dimg), dtype=dt, device=dev) for n, (_, _, dimg) in zip(n_img, self.ip_proj)]
+            plan.ip = dict(tokens=[(torch.zeros((B, int(n) * T_, self.ctx_dim), dtype=dt, device=dev), int(n) * T_)
+                                   for n, (_, T_, _) in zip(n_img, self.ip_proj)],
+                           requests=[[] for _ in self.ip_proj], scales=dict(scales or ()))
 
         # ---- time embedding --------------------------------------------------------------------
         c0 = self.boc[0]
@@ -1131,15 +1259,33 @@ class UNet2DEngine:
         """Cross-attention K/V projections: they depend on the text context only, so every block's `to_k` / `to_v` pair runs at the
         top of the plan on the side lane -- blocks of equal width (same [M, 2C, ctx_dim] problem) share one grouped GEMM launch."""
         reqs, plan.kv_requests = plan.kv_requests, []
+        new_ops = []
+        saved, plan.ops = plan.ops, new_ops
+        self._emit_kv_projections(plan, reqs, ctx, B * S_ctx, "attn2.to_kv")
+        if plan.ip is not None:
+            P = self.params
+            for i, ((pre, T_, dimg), emb, (tok, S_ip), rq) in enumerate(zip(self.ip_proj, plan.static_in["image_embeds"], plan.ip["tokens"],
+                                                                            plan.ip["requests"])):
+                if not rq:
+                    continue  # every scale of this adapter is 0
+                # ImageProjection: Linear(D_img -> T * ctx) per image, the row re-read as T tokens, LayerNorm over ctx
+                rows = B * (S_ip // T_)
+                lin = torch.empty(rows * T_ * self.ctx_dim, dtype=self.dtype, device=self.device)
+                plan.keep.append(lin)
+                self._op_gemm(plan, pre + ".image_embeds", emb, [P[pre + ".image_embeds.weight"]], P[pre + ".image_embeds.bias"], lin,
+                              rows, T_ * self.ctx_dim, dimg, dimg, T_ * self.ctx_dim, lane=LANE_KV)
+                self._op_ln(plan, pre + ".norm", lin, tok, B * S_ip, self.ctx_dim, pre + ".norm", lane=LANE_KV)
+                self._emit_kv_projections(plan, rq, tok, B * S_ip, f"attn2.to_kv_ip.{i}")
+        plan.ops = new_ops + saved
+
+    def _emit_kv_projections(self, plan, reqs, ctx, M, label):
         if not reqs:
             return
         lib = self.lib
-        M, K = B * S_ctx, self.ctx_dim
+        K = self.ctx_dim
         by_c = defaultdict(list)
         for r in reqs:
             by_c[r[4]].append(r)
-        new_ops = []
-        saved, plan.ops = plan.ops, new_ops
         for Cc, rs in by_c.items():
             groupable = K % 8 == 0 and all(w.stride() == (K, 1) for r in rs for w in (r[1], r[2]))
             if not groupable:
@@ -1159,14 +1305,13 @@ class UNet2DEngine:
                 op = (C.c_void_p * n)(*[r[3].data_ptr() for r in grp])
                 xp = (C.c_void_p * n)(*([ctx.data_ptr()] * n))
                 plan.keep += [p, wp, op, xp]
-                name = f"attn2.to_kv[C={Cc},x{n}]"
+                name = f"{label}[C={Cc},x{n}]"
 
                 def launch(stream, p=p, wp=wp, op=op, xp=xp, n=n, name=name):
                     L.check(lib.sfast_hip_gemm_grouped(xp, wp, None, op, C.byref(p), n, stream), name)
 
                 self._add(plan, "linear", name, 2.0 * M * 2 * Cc * K * n, (M * K + n * (2 * Cc * K + M * 2 * Cc)) * self.esize, launch,
                           lane=LANE_KV)
-        plan.ops = new_ops + saved
 
     def _fuse_gn_statistics(self, plan):
         """GroupNorm as ONE pass: every large GroupNorm whose input tensor(s) were written by MFMA GEMM / conv launches gets its
@@ -1333,8 +1478,10 @@ class UNet2DEngine:
         return out
 
     # ------------------------------------------------------------------------------------------
-    def get_plan(self, B, H, W, S_ctx, ctrl=False, enc_mask=False, tcond=False):
-        key = (B, H, W, S_ctx, bool(ctrl), bool(enc_mask), bool(tcond))
+    def get_plan(self, B, H, W, S_ctx, ctrl=False, enc_mask=False, tcond=False, ip=None):
+        if ip is None and self.ip_proj:
+            ip = ((1,) * len(self.ip_proj), self.ip_scales())
+        key = (B, H, W, S_ctx, bool(ctrl), bool(enc_mask), bool(tcond), ip)
         plan = self._plans.get(key)
         if plan is None:
             with self._lock:
@@ -1347,6 +1494,8 @@ class UNet2DEngine:
                         kw["enc_mask"] = True
                     if tcond:
                         kw["tcond"] = True
+                    if ip is not None:
+                        kw["ip"] = ip
                     plan = self.build_plan(B, H, W, S_ctx, **kw)
                     self._plans[key] = plan
         return plan
@@ -1378,6 +1527,11 @@ class UNet2DEngine:
             if encoder_attention_mask is None:
                 raise ValueError("this plan takes an encoder_attention_mask")
             si["encoder_attention_bias"].copy_(self.encoder_attention_bias(encoder_attention_mask, self.dtype))
+        if "image_embeds" in si:
+            for dst, src in zip(si["image_embeds"], self._ip_embeds(added_cond_kwargs, plan.B)):
+                if src.shape[1] != dst.shape[1]:
+                    raise ValueError(f"this plan takes {dst.shape[1]} image(s) per adapter, got {src.shape[1]}")
+                dst.copy_(src)
         si["sample"].copy_(sample)
         if torch.is_tensor(timestep):
             si["timestep"].copy_(timestep.reshape(-1).to(torch.float32).expand(plan.B), non_blocking=True)
@@ -1403,7 +1557,8 @@ class UNet2DEngine:
         """Eager (no graph) execution on the current stream; returns a fresh NCHW tensor."""
         B, _, H, W = sample.shape
         ctrl = down_block_additional_residuals is not None
-        plan = self.get_plan(B, H, W, encoder_hidden_states.shape[1], ctrl, encoder_attention_mask is not None, timestep_cond is not None)
+        plan = self.get_plan(B, H, W, encoder_hidden_states.shape[1], ctrl, encoder_attention_mask is not None, timestep_cond is not None,
+                             self.ip_signature(added_cond_kwargs))
         self.load_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs, down_block_additional_residuals,
                          mid_block_additional_residual, encoder_attention_mask, timestep_cond, class_labels)
         plan.run(self.host.stream_ptr(self.device))
@@ -1418,21 +1573,23 @@ class ControlNetEngine(UNet2DEngine):
         super().__init__(config, params, device=device, dtype=dtype, _host=_host)
         if not self.is_controlnet:
             raise UnsupportedUNet("parameters do not look like a ControlNetModel (no controlnet_mid_block)")
-        if self.add_type is not None:
-            raise UnsupportedUNet("ControlNet with addition_embed_type (SDXL ControlNet) is not covered yet")
+        if self.ip_proj:
+            raise UnsupportedUNet("ControlNet with an IP-Adapter image projection")
 
-    def load_inputs(self, plan, sample, timestep, encoder_hidden_states, controlnet_cond=None, **_):
-        super().load_inputs(plan, sample, timestep, encoder_hidden_states)
+    def load_inputs(self, plan, sample, timestep, encoder_hidden_states, controlnet_cond=None, added_cond_kwargs=None, **_):
+        # SDXL ControlNets (addition_embed_type "text_time") take text_embeds / time_ids exactly as the SDXL UNet does
+        super().load_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs)
         if controlnet_cond is None:
             raise ValueError("controlnet_cond is required")
         plan.static_in["controlnet_cond"].copy_(controlnet_cond)
 
-    def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0, guess_mode=False):
+    def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0, guess_mode=False,
+                added_cond_kwargs=None):
         """Eager (no graph) execution on the current stream; returns (down_block_res_samples, mid_block_res_sample)
         as fresh NCHW tensors, ready to be passed to UNet2DConditionModel.forward / UNet2DEngine.forward."""
         B, _, H, W = sample.shape
         plan = self.get_plan(B, H, W, encoder_hidden_states.shape[1])
-        self.load_inputs(plan, sample, timestep, encoder_hidden_states, controlnet_cond)
+        self.load_inputs(plan, sample, timestep, encoder_hidden_states, controlnet_cond, added_cond_kwargs)
         plan.run(self.host.stream_ptr(self.device))
         return self.outputs(plan, conditioning_scale, guess_mode)
 

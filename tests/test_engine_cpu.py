@@ -495,3 +495,121 @@ def test_groupnorm_inside_the_split_k_reduce_launch(built_lib, monkeypatch):
     with torch.no_grad():
         want = m.float()(sample.float(), 500, ehs.float()).sample
     assert rel_l2(y, want) < 4e-3
+
+
+# ---- IP-Adapter: ImageProjection + decoupled image cross-attention as plan ops -------------------------------
+def _ip_pair(seed, scale, **kw):
+    m16, m32 = _pair(U.tiny_config(**kw), seed)
+    m16.load_ip_adapter(image_embed_dim=32, num_tokens=4, scale=scale, seed=seed + 1)
+    m32.load_ip_adapter(image_embed_dim=32, num_tokens=4, scale=scale, seed=seed + 1)
+    m32.load_state_dict({k: v.float() for k, v in m16.state_dict().items()})
+    return m16, m32
+
+
+def test_plan_runs_a_loaded_ip_adapter(built_lib):
+    """diffusers `pipe.load_ip_adapter()` leaves the UNet with encoder_hid_dim_type "ip_image_proj", an ImageProjection as
+    encoder_hid_proj and to_k_ip / to_v_ip on every attn2 processor; the reference traces straight through them
+    (/root/reference/src/sfast/compilers/diffusion_pipeline_compiler.py:89-107 compiles whatever unet.forward runs). The native plan takes the image
+    embeddings as a static input, projects them on the context side lane and runs the second softmax per cross-attention block."""
+    m16, m32 = _ip_pair(4, 0.6)
+    eng = UNet2DEngine.from_module(m16, _host=EmuHost())
+    assert eng.ip_proj == [("encoder_hid_proj", 4, 32)]
+    g = torch.Generator().manual_seed(5)
+    s = torch.randn(2, 4, 16, 16, generator=g).half()
+    e = torch.randn(2, 20, 64, generator=g).half()
+    ie = torch.randn(2, 1, 32, generator=g).half()
+    y = eng.forward(s, 700, e, added_cond_kwargs={"image_embeds": [ie]})
+    with torch.no_grad():
+        want = m32(s.float(), 700, e.float(), added_cond_kwargs={"image_embeds": [ie.float()]}).sample
+        m32.set_ip_adapter_scale(0.0)
+        without = m32(s.float(), 700, e.float(), added_cond_kwargs={"image_embeds": [ie.float()]}).sample
+    assert rel_l2(y, want) < 3e-3 and rel_l2(without, want) > 1e-2
+    plan = next(iter(eng._plans.values()))
+    names = [op.name for op in plan.ops]
+    n_cross = sum(1 for n in names if n.endswith(".attn2"))
+    assert sum(1 for n in names if n.endswith(".attn2.ip_adapter.0")) == n_cross == sum(1 for n in names if n.endswith(".ip_adapter.0.add"))
+    # ImageProjection and the image K/V projections sit with the text K/V at the top of the plan, off the main lane
+    head = names[:names.index("conv_in") if "conv_in" in names else 12]
+    assert "encoder_hid_proj.image_embeds" in head and "encoder_hid_proj.norm" in head and any(n.startswith("attn2.to_kv_ip.0[") for n in head)
+    # a bare [B, D] tensor is one image of one adapter (diffusers' deprecated form); same plan, same result
+    y1 = eng.forward(s, 700, e, added_cond_kwargs={"image_embeds": ie[:, 0]})
+    assert torch.equal(y1, y) and len(eng._plans) == 1
+    # set_ip_adapter_scale: the scale is a launch constant -> another plan; scale 0 drops the adapter's launches as diffusers does
+    m16.set_ip_adapter_scale(0.0)
+    y0 = eng.forward(s, 700, e, added_cond_kwargs={"image_embeds": [ie]})
+    assert rel_l2(y0, without) < 3e-3 and len(eng._plans) == 2
+    names0 = [op.name for op in list(eng._plans.values())[1].ops]
+    assert not any("ip_adapter" in n or "encoder_hid_proj" in n for n in names0)
+    # two images for the adapter: 8 image tokens, its own plan
+    m16.set_ip_adapter_scale(0.6)
+    m32.set_ip_adapter_scale(0.6)
+    ie2 = torch.randn(2, 2, 32, generator=g).half()
+    y2 = eng.forward(s, 700, e, added_cond_kwargs={"image_embeds": [ie2]})
+    with torch.no_grad():
+        want2 = m32(s.float(), 700, e.float(), added_cond_kwargs={"image_embeds": [ie2.float()]}).sample
+    assert rel_l2(y2, want2) < 3e-3 and len(eng._plans) == 3
+    # missing input: diffusers' own error, not a silent text-only result
+    with pytest.raises(ValueError, match="image_embeds"):
+        eng.forward(s, 700, e)
+
+
+def test_ip_adapter_with_text_padding_mask_and_refusals(built_lib):
+    m16, m32 = _ip_pair(8, 1.0)
+    eng = UNet2DEngine.from_module(m16, _host=EmuHost())
+    g = torch.Generator().manual_seed(9)
+    s = torch.randn(2, 4, 16, 16, generator=g).half()
+    e = torch.randn(2, 20, 64, generator=g).half()
+    ie = torch.randn(2, 1, 32, generator=g).half()
+    mask = torch.ones(2, 20)
+    mask[1, 7:] = 0
+    y = eng.forward(s, 300, e, added_cond_kwargs={"image_embeds": [ie]}, encoder_attention_mask=mask)
+    with torch.no_grad():
+        want = m32(s.float(), 300, e.float(), added_cond_kwargs={"image_embeds": [ie.float()]}, encoder_attention_mask=mask).sample
+    assert rel_l2(y, want) < 3e-3      # the mask biases the text keys only; the image tokens are never masked
+    # an adapter whose projection is not Linear + LayerNorm (IP-Adapter Plus resampler, FaceID) keeps the module's forward
+    sd = {k: v for k, v in m16.named_parameters()}
+    bad = {k: v.data for k, v in sd.items() if not k.startswith("encoder_hid_proj.norm")}
+    with pytest.raises(UnsupportedUNet):
+        UNet2DEngine(m16.config, bad, _host=EmuHost())
+    # per-image / masked scales are not numbers: refused when the plan is requested
+    next(iter(eng._ip_processors.values())).scale = [[0.5, 0.2]]
+    with pytest.raises(UnsupportedUNet):
+        eng.forward(s, 300, e, added_cond_kwargs={"image_embeds": [ie]})
+    # image_embeds for a UNet without an adapter
+    eng2 = UNet2DEngine.from_module(U.build(U.tiny_config(), seed=1, dtype=torch.float16), _host=EmuHost())
+    with pytest.raises(UnsupportedUNet):
+        eng2.build_plan(2, 16, 16, 20, ip=((1,), None))
+
+
+def _sdxl_controlnet_cfg():
+    from oracle import controlnet_ref as CN
+    return CN.tiny_config(down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                          transformer_layers_per_block=(1, 2, 2), attention_head_dim=(1, 2, 2), use_linear_projection=True,
+                          addition_embed_type="text_time", addition_time_embed_dim=32, projection_class_embeddings_input_dim=64 + 6 * 32)
+
+
+def test_sdxl_style_controlnet_takes_text_time_conditioning(built_lib):
+    """SDXL ControlNets carry the UNet's `add_embedding` (addition_embed_type "text_time"): text_embeds / time_ids are inputs of the
+    ControlNet plan too (the reference keeps `pipe.controlnet` compiled, diffusion_pipeline_compiler.py:89-90)."""
+    from oracle import controlnet_ref as CN
+    from sfast.engine import ControlNetEngine
+    ccfg = _sdxl_controlnet_cfg()
+    c16 = CN.build(ccfg, seed=31, dtype=torch.float16)
+    c32 = CN.build(ccfg, seed=31)
+    c32.load_state_dict({k: v.float() for k, v in c16.state_dict().items()})
+    assert "add_embedding.linear_1.weight" in dict(c16.named_parameters())
+    ceng = ControlNetEngine.from_module(c16, _host=EmuHost())
+    g = torch.Generator().manual_seed(3)
+    s = torch.randn(2, 4, 16, 16, generator=g).half()
+    e = torch.randn(2, 20, 64, generator=g).half()
+    cond = torch.rand(2, 3, 64, 64, generator=g).half()
+    added = dict(text_embeds=torch.randn(2, 64, generator=g).half(), time_ids=torch.tensor([[1024., 1024, 0, 0, 1024, 1024]] * 2).half())
+    added2 = dict(added, text_embeds=-added["text_embeds"])
+    down, mid = ceng.forward(s, 300, e, cond, added_cond_kwargs=added)
+    with torch.no_grad():
+        wd, wm = c32(s.float(), 300, e.float(), cond.float(), added_cond_kwargs={k: v.float() for k, v in added.items()}, return_dict=False)
+        od, om = c32(s.float(), 300, e.float(), cond.float(), added_cond_kwargs={k: v.float() for k, v in added2.items()}, return_dict=False)
+    assert all(rel_l2(a, b) < 3e-3 for a, b in zip(down, wd)) and rel_l2(mid, wm) < 3e-3
+    assert rel_l2(om, wm) > 1e-2                                   # the conditioning reaches the output
+    with pytest.raises(ValueError, match="text_embeds"):
+        ceng.forward(s, 300, e, cond)                              # required, as in diffusers

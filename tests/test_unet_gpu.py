@@ -566,3 +566,109 @@ def test_native_scheduler_step_matches_euler(pred, dtype):
     assert p.shape == x.shape and n2.step.native_calls == 1
     n2.step(e, n2.timesteps[1], x, s_churn=0.5)
     assert n2.step.native_calls == 1 and n2.step_index == 2
+
+
+def _ip_models(cfg, seed, scale, image_embed_dim, dev=DEV):
+    m = U.build(cfg, seed=seed, dtype=torch.float16, device=dev)
+    m.load_ip_adapter(image_embed_dim=image_embed_dim, num_tokens=4, scale=scale, seed=seed + 1)
+    ref = U.build(cfg, seed=seed, dtype=torch.float32, device=dev)
+    ref.load_ip_adapter(image_embed_dim=image_embed_dim, num_tokens=4, scale=scale, seed=seed + 1)
+    ref.load_state_dict({k: v.float() for k, v in m.state_dict().items()})
+    return m, ref
+
+
+def test_ip_adapter_native_and_through_compile():
+    """A UNet after `load_ip_adapter()` (encoder_hid_dim_type "ip_image_proj"; ImageProjection + to_k_ip / to_v_ip on every attn2) stays
+    on the native plan: image embeddings are a static input, the decoupled image cross-attention is a second attention launch."""
+    from sfast.compilers.diffusion_pipeline_compiler import CompilationConfig, compile_unet
+    cfg = U.tiny_config()
+    m, ref = _ip_models(cfg, 21, 0.7, 32)
+    sample, ehs = _inputs(cfg, 2, seed=6, S=77)
+    g = torch.Generator().manual_seed(7)
+    ie = torch.randn(2, 1, 32, generator=g).to(DEV, torch.float16)
+    ie3 = torch.randn(2, 3, 32, generator=g).to(DEV, torch.float16)
+    with torch.no_grad():
+        want = ref(sample.float(), 400, ehs.float(), added_cond_kwargs={"image_embeds": [ie.float()]}).sample
+        want3 = ref(sample.float(), 400, ehs.float(), added_cond_kwargs={"image_embeds": [ie3.float()]}).sample
+        ref.set_ip_adapter_scale(0.0)
+        text_only = ref(sample.float(), 400, ehs.float(), added_cond_kwargs={"image_embeds": [ie.float()]}).sample
+    eng = _engine(m)
+    y = eng.forward(sample, 400, ehs, added_cond_kwargs={"image_embeds": [ie]})
+    y3 = eng.forward(sample, 400, ehs, added_cond_kwargs={"image_embeds": [ie3]})   # 12 image tokens
+    log_value("tiny unet + ip-adapter vs fp32 oracle", rel_l2=rel_l2(y, want), rel_l2_3_images=rel_l2(y3, want3),
+              adapter_effect=rel_l2(text_only, want))
+    assert rel_l2(y, want) < 4e-3 and rel_l2(y3, want3) < 4e-3 and rel_l2(text_only, want) > 1e-2
+    config = CompilationConfig.Default()
+    config.enable_cuda_graph = True
+    cm = compile_unet(m, config)
+    kw = dict(encoder_hidden_states=ehs, added_cond_kwargs={"image_embeds": [ie]}, return_dict=False)
+    out = cm(sample, 400, **kw)[0]
+    assert not cm.forward._warned and torch.equal(out, y)
+    assert torch.equal(cm(sample, 400, **kw)[0], y) and len(cm.forward._cached) == 1            # graph replay
+    m.set_ip_adapter_scale(0.0)                                                                   # pipe.set_ip_adapter_scale(0)
+    out0 = cm(sample, 400, **kw)[0]
+    assert len(cm.forward._cached) == 2 and rel_l2(out0, text_only) < 4e-3 and not cm.forward._warned
+    m.set_ip_adapter_scale(0.7)
+    assert torch.equal(cm(sample, 400, **kw)[0], y) and len(cm.forward._cached) == 2             # back on the first graph
+    # without image_embeds the original forward raises diffusers' error
+    with pytest.raises(ValueError, match="image_embeds"):
+        cm(sample, 400, encoder_hidden_states=ehs, return_dict=False)
+
+
+def test_sd15_ip_adapter_parity(sd15):
+    """Full-size SD1.5 + IP-Adapter geometry (CLIP image embedding 1024 -> 4 tokens of 768; 16 cross-attention blocks)."""
+    import copy
+    m = copy.deepcopy(sd15)
+    m.load_ip_adapter(image_embed_dim=1024, num_tokens=4, scale=1.0, seed=5)
+    sample, ehs = _inputs(U.SD15_CONFIG, 2, seed=3)
+    ie = torch.randn(2, 1, 1024, generator=torch.Generator().manual_seed(1)).to(DEV, torch.float16)
+    eng = _engine(m)
+    y = eng.forward(sample, 981, ehs, added_cond_kwargs={"image_embeds": [ie]})
+    with torch.no_grad():
+        y16 = m(sample, 981, ehs, added_cond_kwargs={"image_embeds": [ie]}).sample
+        ref = U.build("sd15", seed=0, dtype=torch.float32, device=DEV)
+        ref.load_ip_adapter(image_embed_dim=1024, num_tokens=4, scale=1.0, seed=5)
+        ref.load_state_dict({k: v.float() for k, v in m.state_dict().items()})
+        y32 = ref(sample.float(), 981, ehs.float(), added_cond_kwargs={"image_embeds": [ie.float()]}).sample
+        ref.set_ip_adapter_scale(0.0)
+        y32_text = ref(sample.float(), 981, ehs.float(), added_cond_kwargs={"image_embeds": [ie.float()]}).sample
+        del ref
+    e_engine, e_eager = rel_l2(y, y32), rel_l2(y16, y32)
+    plan = next(iter(eng._plans.values()))
+    log_value("sd15 B=2 + ip-adapter parity", engine_vs_fp32=e_engine, eager16_vs_fp32=e_eager, adapter_effect=rel_l2(y32_text, y32),
+              launches=len(plan.ops))
+    assert torch.isfinite(y).all() and e_engine < 2.5e-3 and e_engine < e_eager, (e_engine, e_eager)
+    assert sum(1 for op in plan.ops if op.name.endswith(".ip_adapter.0")) == 16
+
+
+def test_sdxl_style_controlnet_native_and_through_compile():
+    """ControlNetModel with addition_embed_type "text_time" (SDXL ControlNets): native plan, eager and behind compile_controlnet-style
+    wrapping, guess_mode included."""
+    from oracle import controlnet_ref as CN
+    from sfast.engine import ControlNetEngine
+    from sfast.compilers.diffusion_pipeline_compiler import CompilationConfig, compile_unet
+    ccfg = CN.tiny_config(down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                          transformer_layers_per_block=(1, 2, 2), attention_head_dim=(1, 2, 2), use_linear_projection=True,
+                          addition_embed_type="text_time", addition_time_embed_dim=32, projection_class_embeddings_input_dim=64 + 6 * 32)
+    c16 = CN.build(ccfg, seed=33, dtype=torch.float16, device=DEV)
+    c32 = CN.build(ccfg, seed=33, device=DEV)
+    c32.load_state_dict({k: v.float() for k, v in c16.state_dict().items()})
+    sample, ehs = _inputs(ccfg, 2, seed=2, S=77)
+    cond = torch.rand(2, 3, 64, 64, device=DEV, dtype=torch.float16)
+    added = dict(text_embeds=torch.randn(2, 64, device=DEV, dtype=torch.float16),
+                 time_ids=torch.tensor([[1024., 1024, 0, 0, 1024, 1024]] * 2, device=DEV, dtype=torch.float16))
+    with torch.no_grad():
+        wd, wm = c32(sample.float(), 300, ehs.float(), cond.float(), guess_mode=True, conditioning_scale=0.9,
+                     added_cond_kwargs={k: v.float() for k, v in added.items()}, return_dict=False)
+    eng = ControlNetEngine.from_module(c16)
+    down, mid = eng.forward(sample, 300, ehs, cond, conditioning_scale=0.9, guess_mode=True, added_cond_kwargs=added)
+    errs = [rel_l2(a, b) for a, b in zip(down + [mid], list(wd) + [wm])]
+    log_value("tiny sdxl-style controlnet vs fp32 oracle", worst_rel_l2=max(errs))
+    assert max(errs) < 4e-3, errs
+    config = CompilationConfig.Default()
+    config.enable_cuda_graph = True
+    cm = compile_unet(c16, config)
+    for _ in range(2):
+        d2, m2 = cm(sample, 300, encoder_hidden_states=ehs, controlnet_cond=cond, conditioning_scale=0.9, guess_mode=True,
+                    added_cond_kwargs=added, return_dict=False)
+        assert not cm.forward._warned and torch.equal(m2, mid) and all(torch.equal(a, b) for a, b in zip(d2, down))

@@ -99,5 +99,15 @@ final)  # the round's SD1.5 evidence: PMC traffic by symbol, the default bench l
   run pmc_attn 700 bash tools/gpu_pmc_attn.sh
   run bench_torchrun 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 50 --warmup 10 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants
   ;;
+s9)  # transposing copies; probe-build subset; crash hunt with the reduce pass on over the whole UNet / VAE files
+  run t_copy 600 $PYT tests/test_ops_gpu.py -k "strided_copy or transposes" tests/test_ref_triton_gpu.py -k "copy or strided"
+  SFAST_HIP_PROBES=1 run t_probes 900 $PYT tests/test_ops_gpu.py -k "patch or join"
+  SFAST_GN_IN_REDUCE=1 run t_unet_gnred 1500 $PYT tests/test_unet_gpu.py tests/test_vae_gpu.py
+  ;;
+s10)  # IP-Adapter + SDXL-style ControlNet (native plans, through compile); the SDXL and SVD-XT bench lines of the round
+  run t_ip 1200 $PYT tests/test_unet_gpu.py -k "ip_adapter or sdxl_style_controlnet or controlnet"
+  run bench_sdxl 1200 python bench.py --config sdxl --no-cpu-baseline
+  run bench_svd 1200 python bench.py --config svd --no-cpu-baseline
+  ;;
 esac
 cat gpurun_out/session.log
