@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define SFAST_HIP_ABI_VERSION 8
+#define SFAST_HIP_ABI_VERSION 9
 
 typedef void *sfast_stream_t; /* hipStream_t */
 
@@ -274,6 +274,12 @@ int sfast_hip_conv2d(const void *x, const void *x2, const void *w, const void *b
  *             (triton/torch_ops.py:179-189) behind a split-K conv / GEMM at the low-resolution levels. Only for problems that run
  *             split-K (ask sfast_hip_conv2d_plan / sfast_hip_igemm_plan: out[2] > 1) with (N / gn_groups) % 4 == 0 and
  *             gn_rows_per_sample * N / gn_groups <= 16384; otherwise SFAST_ERR_UNSUPPORTED. Not combinable with gn_unit / gn_stats.  */
+/* w_packed (ABI 9): packed copies of the weight segments, made by sfast_hip_pack_weight from the live parameters. With them the
+ *             planner may pick a pipe-4 kernel (variant ids 41 ..: weight fragments global -> VGPR in MFMA order, activations through
+ *             the LDS ring; csrc/igemm_pk.h) -- the reference's vendor GEMMs / convs re-lay out filters inside the call as well.
+ *             The caller keeps a packed copy as fresh as it needs (re-pack after the parameter changed); `w` is still passed and
+ *             still read by every other pipe. Every segment needs a copy, and segments of a multi-segment weight must hold a
+ *             multiple of 32 rows; otherwise the pipe is not eligible and the launch uses another one.                              */
 typedef struct {
     float out_scale;
     int32_t gn_unit;
@@ -286,6 +292,7 @@ typedef struct {
     float gn_eps;
     int32_t gn_act;         /* SFAST_ACT_NONE or SFAST_ACT_SILU */
     int32_t reserved;
+    const void *const *w_packed; /* ABI 9: n_wseg (conv: 1) packed copies of the weight segments (sfast_hip_pack_weight), or NULL */
 } sfast_epilogue_ext;
 
 /* zero the ticket block of a fresh workspace (asynchronous, on `stream`) */
@@ -454,6 +461,45 @@ typedef struct {
 
 int sfast_hip_mix_rows(const void *x, const void *y, const void *vec, const void *mix_factor, void *out,
                        const sfast_mix_params *p, sfast_stream_t stream);
+
+/* ---- packed weights for the pipe-4 GEMM / conv kernels (ABI 9) ------------------------------------------------------------
+ * packed[(nb * KS + s) * 64 + lane] (16 bytes each) = the 8 elements w[nb * 32 + lane % 32][s * 16 + (lane / 32) * 8 .. + 8], zero
+ * outside [N) x [K); KS = ceil(K / 64) * 4 -- i.e. one contiguous 1 KB block per (32-row block, 16-wide k-step) in the A-operand
+ * layout of v_mfma_f32_32x32x16. w: [N][K] with rows ldw elements apart (a conv weight [Cout][KH][KW][Cin]: N = Cout,
+ * K = KH * KW * Cin). sfast_hip_packed_weight_bytes gives the size of `packed` (16-byte aligned). Measured motive:
+ * profiles/r04_wdirect_probe_run15.log (row-major fragment loads 44-47 % of the MFMA peak, packed 78 %). */
+size_t sfast_hip_packed_weight_bytes(int32_t N, int32_t K);
+int sfast_hip_pack_weight(const void *w, void *packed, int32_t N, int32_t K, int64_t ldw, int32_t dtype, sfast_stream_t stream);
+
+/* ---- un-fused LoRA: effective weights rebuilt from the live parameters, one launch for all LoRA'd linears (ABI 9) ------------
+ * out_i[n][k] = w_i[n][k] + scales[scale_index_i] * sum_j up_i[n][j] * down_i[j][k]      (fp32 math, one rounding to the dtype)
+ * for every entry i of a DEVICE-resident table. Stands for what the reference does with a UNet whose LoRA layers are loaded but not
+ * fused: it traces linear(x, W) + scale * up(down(x)) as it is (diffusers LoRACompatibleLinear / peft lora.Linear forward, through
+ * sfast::cublas_lowp_linear, src/sfast/csrc/operators/cublas/cublas_gemm.cpp:798-948) and lets the user switch adapters by copying
+ * into the same tensors in place (README.md:228-265 "Dynamically Switch LoRA", tests/compilers/
+ * test_stable_diffusion_pipeline_compiler.py:327-328,438-465). The plan's GEMMs read `out`; base / down / up are read at EVERY
+ * launch, so the in-place switch needs no re-capture. `scales` is a device float array (diffusers' cross_attention_kwargs["scale"]
+ * times network_alpha / rank, or peft's scaling[adapter]; the caller rewrites it when a value changes), NULL = 1.0 everywhere.
+ * Geometry: w rows ldw apart, down [r][K] rows ldd apart, up [N][r] rows ldu apart, out dense [N][K]; K % 8 == 0, ldw % 8 == 0,
+ * ldd % 8 == 0, r <= SFAST_LORA_MAX_RANK, w / down / out 16-byte aligned; f16 / bf16.
+ * sfast_hip_lora_merge_plan (host, no device work) validates a HOST copy of the table and fills tile_begin / *total_tiles; the
+ * caller uploads the filled table and passes both to sfast_hip_lora_merge. */
+#define SFAST_LORA_TILE_N 32
+#define SFAST_LORA_TILE_K 256
+#define SFAST_LORA_MAX_RANK 128
+typedef struct {
+    const void *w, *down, *up;
+    void *out;
+    int32_t N, K, r;
+    int32_t tile_begin;  /* filled by sfast_hip_lora_merge_plan */
+    int64_t ldw, ldd, ldu;
+    int32_t scale_index;
+    int32_t reserved;
+} sfast_lora_entry;
+
+int sfast_hip_lora_merge_plan(sfast_lora_entry *entries_host, int32_t n, int32_t *total_tiles);
+int sfast_hip_lora_merge(const sfast_lora_entry *entries_device, int32_t n, int32_t total_tiles, const float *scales_device,
+                         int32_t dtype, sfast_stream_t stream);
 
 /* ---- image post-process: NCHW f16/bf16/f32 image -> NHWC uint8 or float32 ----------------------
  * replaces the reference's patched VaeImageProcessor.postprocess / pt_to_pil / pt_to_numpy

@@ -178,7 +178,8 @@ static int conv_caps(const sfast_conv_params *p) {
     const bool glds_ok = !p->upsample2x && p->C1 % 64 == 0 && C2 % 64 == 0 && p->KH * p->KW <= 32;
     const bool patch = glds_ok && p->KH == 3 && p->KW == 3 && p->stride_h == 1 && p->stride_w == 1 && p->pad_h == 1 && p->pad_w == 1 &&
                        p->pad_h_extra == 0 && p->pad_w_extra == 0 && p->dil_h == 1 && p->dil_w == 1;
-    return igemm_caps(glds_ok, patch ? p->H : 0, patch ? p->W : 0);
+    // forced pipe-4 variants (41..): the query assumes the packed copy the launch will be handed (sfast_epilogue_ext.w_packed)
+    return igemm_caps(glds_ok, patch ? p->H : 0, patch ? p->W : 0, p->variant >= 40 && p->variant < 100);
 }
 
 }  // namespace
@@ -199,14 +200,15 @@ extern "C" int sfast_hip_igemm_plan(int32_t M, int32_t N, int32_t K, int32_t geg
                                     int32_t out[5]) {
     if (!out || M <= 0 || N <= 0 || K <= 0) return SFAST_ERR_INVALID;
     int o[5];
-    igemm_plan_query(M, N, K, geglu != 0, variant < 100 ? variant : 0, split_k, true, o);
+    igemm_plan_query(M, N, K, geglu != 0, variant < 100 ? variant : 0, split_k, igemm_caps(true, 0, 0, variant >= 40 && variant < 100), o);
     for (int i = 0; i < 5; ++i) out[i] = o[i];
     return SFAST_OK;
 }
 
 extern "C" size_t sfast_hip_gemm_workspace_bytes(const sfast_gemm_params *p) {
     if (!p || !is_half(p->dtype) || (p->M <= 16 && p->variant == 0) || p->variant >= 100 || p->K % 8 != 0) return 0;
-    return igemm_workspace_bytes(p->M, p->N, p->K, p->geglu != 0, p->variant < 100 ? p->variant : 0, p->split_k, true);
+    return igemm_workspace_bytes(p->M, p->N, p->K, p->geglu != 0, p->variant < 100 ? p->variant : 0, p->split_k,
+                                 igemm_caps(true, 0, 0, p->variant >= 40 && p->variant < 100));
 }
 
 static float ext_scale(const sfast_epilogue_ext *ext) { return (ext && ext->out_scale != 0.0f) ? ext->out_scale : 1.0f; }
@@ -228,6 +230,10 @@ static int ext_gn(const sfast_epilogue_ext *ext, const void *gn_stats, IgemmArgs
     a.gn_act = ext->gn_act;
     a.rows_per_batch = ext->gn_rows_per_sample;
     return SFAST_OK;
+}
+// sfast_epilogue_ext.w_packed: packed copies of the weight segments (sfast_hip_pack_weight) -> pipe 4 may be chosen
+static void ext_packed(const sfast_epilogue_ext *ext, int nseg, IgemmArgs &a) {
+    for (int i = 0; i < SFAST_MAX_WSEG; ++i) a.wpk[i] = (ext && ext->w_packed && i < nseg) ? ext->w_packed[i] : nullptr;
 }
 static bool ext_tickets(const sfast_epilogue_ext *ext) { return ext && (ext->flags & SFAST_EXT_WS_TICKETS) != 0; }
 
@@ -258,7 +264,7 @@ extern "C" int sfast_hip_gemm_stats_layout(const sfast_gemm_params *p, const sfa
     SFAST_REQUIRE(p && ext && out, SFAST_ERR_INVALID, "gemm_stats_layout: null argument");
     StatsLayout l{};
     const bool igemm = is_half(p->dtype) && p->K % 8 == 0 && !(p->M <= 16 && p->variant == 0) && p->variant < 100 && p->N % 8 == 0 && p->ldo % 8 == 0;
-    if (!igemm || !igemm_stats_layout(p->M, p->N, p->K, p->geglu != 0, p->variant, p->split_k, true, ext->gn_unit, ext->gn_rows_per_sample, ext_tickets(ext), l)) {
+    if (!igemm || !igemm_stats_layout(p->M, p->N, p->K, p->geglu != 0, p->variant, p->split_k, igemm_caps(true, 0, 0, p->variant >= 40 && p->variant < 100), ext->gn_unit, ext->gn_rows_per_sample, ext_tickets(ext), l)) {
         set_error("gemm_stats_layout: this problem / kernel choice cannot emit GroupNorm statistics");
         return SFAST_ERR_UNSUPPORTED;
     }
@@ -315,6 +321,7 @@ extern "C" int sfast_hip_gemm_ex(const void *x, const void *const *w_segs, const
             rc = ext_gn(ext, gn_stats, a);
             if (rc) return rc;
         }
+        ext_packed(ext, p->n_wseg, a);
         split_workspace(ext, workspace, workspace_bytes, a);
         return igemm_run(a, p->dtype, 0, p->geglu != 0, p->variant < 100 ? p->variant : 0, p->split_k, workspace, workspace_bytes, st);
     }
@@ -589,6 +596,7 @@ extern "C" int sfast_hip_conv2d_ex(const void *x, const void *x2, const void *w,
             rc = ext_gn(ext, gn_stats, a);
             if (rc) return rc;
         }
+        ext_packed(ext, 1, a);
         split_workspace(ext, workspace, workspace_bytes, a);
         return igemm_run(a, p->dtype, 1, false, p->variant < 100 ? p->variant : 0, p->split_k, workspace, workspace_bytes, st);
     }

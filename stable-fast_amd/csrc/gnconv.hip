@@ -30,6 +30,7 @@ struct GnConvArgs {
     const void *x, *x2, *gamma, *beta, *w;
     float *partial;
     int B, H, W, C1, C2, Cout;
+    int gamma_on;    // 1: normalise (GN instantiation); 0: plain weight-streaming conv
     int P, HW;       // pixels in total (= M), per sample
     int cpg;         // channels per GroupNorm group
     int CS, S, KS;   // channel slice, number of slices, 16-wide k-steps per tap (CS / 16)
@@ -60,7 +61,8 @@ template <int NB> struct GcDepth {
 };
 constexpr int GC_PRE = 4;  // steps requested right behind the slice, and again during the statistics
 
-template <typename T, int MB, int NB>
+// GN = false: the same launch without the normalisation (the input is already the conv's operand): slice -> LDS, weight stream, K loop.
+template <typename T, int MB, int NB, bool GN>
 __global__ void __launch_bounds__(256, 2) gnconv_kernel(const GnConvArgs a) {
     constexpr int GC_D = GcDepth<NB>::D;
     constexpr int SL_MAX = 10;  // 16-byte chunks of the slice per thread: the planner keeps P * CS / 8 <= 2560 (128 pixels x 160 channels)
@@ -97,7 +99,7 @@ __global__ void __launch_bounds__(256, 2) gnconv_kernel(const GnConvArgs a) {
         }
     }
     u32x4 gbv = u32x4{0u, 0u, 0u, 0u};
-    const bool gb_thread = tid < 2 * CCH;  // threads 0 .. CCH-1: a gamma chunk, CCH .. 2 CCH - 1: a beta chunk
+    const bool gb_thread = GN && tid < 2 * CCH;  // threads 0 .. CCH-1: a gamma chunk, CCH .. 2 CCH - 1: a beta chunk
     if (gb_thread) {
         const T *gp = tid < CCH ? (const T *)a.gamma : (const T *)a.beta;
         if (gp) gbv = *reinterpret_cast<const u32x4 *>(gp + c0 + (tid < CCH ? tid : tid - CCH) * 8);
@@ -133,7 +135,7 @@ __global__ void __launch_bounds__(256, 2) gnconv_kernel(const GnConvArgs a) {
     };
     u32x4 wq[GC_D][NB];
 #pragma unroll
-    for (int d = 0; d < GC_PRE; ++d) {
+    for (int d = 0; d < (GN ? GC_PRE : GC_D); ++d) {  // without a prologue to hide behind, the whole pre-loop queue goes out at once
         load_step(wq[d]);
         __builtin_amdgcn_sched_barrier(0);  // issue order = consumption order
     }
@@ -159,6 +161,8 @@ __global__ void __launch_bounds__(256, 2) gnconv_kernel(const GnConvArgs a) {
     for (int q = tid; q < CCH; q += 256) *reinterpret_cast<u32x4 *>(lds + ZR * ROWB + q * 16) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
     gc_mark(a, 2);
+    const float rhw = __builtin_amdgcn_rcpf((float)a.HW);
+    if constexpr (GN) {
     const int GS = a.CS / a.cpg, CPG8 = a.cpg / 8;
     const int npairs = a.B * GS;
     const float inv_n = 1.0f / ((float)a.HW * (float)a.cpg);
@@ -210,7 +214,7 @@ __global__ void __launch_bounds__(256, 2) gnconv_kernel(const GnConvArgs a) {
     }
     __syncthreads();
     gc_mark(a, 3);
-    const float rhw = __builtin_amdgcn_rcpf((float)a.HW), rcpg8 = __builtin_amdgcn_rcpf((float)CPG8);
+    const float rcpg8 = __builtin_amdgcn_rcpf((float)CPG8);
 #pragma unroll
     for (int j = 0; j < SL_MAX; ++j) {
         const int q = tid + j * 256;
@@ -238,6 +242,7 @@ __global__ void __launch_bounds__(256, 2) gnconv_kernel(const GnConvArgs a) {
         }
     }
     __syncthreads();
+    }  // GN
     gc_mark(a, 4);
 
     // ---- 4. main loop: no barrier, no LDS write; per k-step MB fragment reads + NB fragments already in registers -> MB * NB MFMAs.
@@ -391,8 +396,8 @@ static int gcd_i(int x, int y) {
 // number of 16-wide k-steps, at least 80 channels, and does not straddle the two concat sources.
 bool gnconv_plan(int B, int H, int W, int C1, int C2, int Cout, int groups, GnConvPlan &pl) {
     const int Cin = C1 + C2, P = B * H * W;
-    if (groups <= 0 || Cin % groups || P <= 0 || P > 128 || Cout % 32 || H * W < 1) return false;
-    const int cpg = Cin / groups;
+    if (groups < 0 || (groups > 0 && Cin % groups) || P <= 0 || P > 128 || Cout % 32 || H * W < 1 || Cin % 16) return false;
+    const int cpg = groups > 0 ? Cin / groups : 16;  // groups == 0: no normalisation, any 16-channel multiple may be a slice
     if (cpg % 8) return false;
     const int unit = cpg / gcd_i(cpg, 16) * 16;  // lcm(cpg, 16)
     pl.MB = P <= 64 ? 2 : 4;
@@ -429,7 +434,10 @@ template <typename T> static int gnconv_launch(const GnConvArgs &g, const GnConv
     const dim3 grid((unsigned)((g.Cout / (32 * pl.NB)) * pl.S)), block(256);
 #define GC_OP(MB_, NB_)                                                            \
     if (pl.MB == MB_ && pl.NB == NB_) {                                            \
-        hipLaunchKernelGGL((gnconv_kernel<T, MB_, NB_>), grid, block, pl.lds_bytes, st, g); \
+        if (g.cpg > 0 && g.gamma_on)                                                                       \
+            hipLaunchKernelGGL((gnconv_kernel<T, MB_, NB_, true>), grid, block, pl.lds_bytes, st, g);     \
+        else                                                                                               \
+            hipLaunchKernelGGL((gnconv_kernel<T, MB_, NB_, false>), grid, block, pl.lds_bytes, st, g);    \
         return check_launch("gnconv");                                             \
     }
     GC_OP(4, 1) GC_OP(4, 2) GC_OP(2, 1) GC_OP(2, 2)
@@ -463,7 +471,8 @@ int gnconv_run(IgemmArgs &a, int dtype, int B, const void *gamma, const void *be
     g.Cout = a.N;
     g.P = a.M;
     g.HW = a.H * a.W;
-    g.cpg = (a.C1 + a.C2) / groups;
+    g.cpg = groups > 0 ? (a.C1 + a.C2) / groups : 16;
+    g.gamma_on = groups > 0 ? 1 : 0;
     g.CS = pl.CS;
     g.S = pl.S;
     g.KS = pl.CS / 16;
@@ -473,7 +482,7 @@ int gnconv_run(IgemmArgs &a, int dtype, int B, const void *gamma, const void *be
     g.eps = eps;
     g.silu = silu;
     g.trace = a.trace;
-    set_kernel_name("gnconv_%s[P=%d,%dx%d,slices=%d]", dtype == SFAST_F16 ? "f16" : "bf16", a.M, 32 * pl.NB, pl.CS, pl.S);
+    set_kernel_name("%s_%s[P=%d,%dx%d,slices=%d]", groups > 0 ? "gnconv" : "wsconv", dtype == SFAST_F16 ? "f16" : "bf16", a.M, 32 * pl.NB, pl.CS, pl.S);
     const int rc = dtype == SFAST_F16 ? gnconv_launch<f16>(g, pl, st) : gnconv_launch<bf16>(g, pl, st);
     if (rc) return rc;
     a.splits = pl.S;
@@ -487,7 +496,9 @@ int gnconv_init() {
     hipError_t e = hipSuccess;
 #define GC_ATTR(T, MB_, NB_)                                                                                                         \
     if (e == hipSuccess)                                                                                                             \
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(gnconv_kernel<T, MB_, NB_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(gnconv_kernel<T, MB_, NB_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+    if (e == hipSuccess)                                                                                                             \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(gnconv_kernel<T, MB_, NB_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     GC_ATTR(f16, 4, 1) GC_ATTR(f16, 4, 2) GC_ATTR(f16, 2, 1) GC_ATTR(f16, 2, 2)
     GC_ATTR(bf16, 4, 1) GC_ATTR(bf16, 4, 2) GC_ATTR(bf16, 2, 1) GC_ATTR(bf16, 2, 2)
 #undef GC_ATTR

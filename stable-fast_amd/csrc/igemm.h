@@ -7,6 +7,8 @@ namespace sfast {
 struct IgemmArgs {
     const void *x, *x2;
     const void *w[SFAST_MAX_WSEG];
+    const void *wpk[SFAST_MAX_WSEG];  // pipe 4: the segments' packed copies (sfast_hip_pack_weight), or nullptr
+    int pk_ksteps;                    //         16-wide k-steps per 32-row block of a packed segment: ceil(K / 64) * 4
     const void *bias, *rowbias, *res;
     void *out;
     float *partial;
@@ -49,10 +51,11 @@ static inline dim3 igemm_grid(const IgemmArgs &a) {
 static inline int stats_slots(int bno, int unit) { return (bno - 1) / unit + 2; }
 
 // `caps` of a problem (the `glds_ok` argument of the planning functions below, an int): bit 0 = the LDS-DMA pipes may be chosen;
+// bit 1 = packed copies of the weights are at hand (pipe 4, igemm_pk.hip);
 // for convs the patch pipe (conv_patch.hip) may be chosen can: 3x3, stride 1, padding 1, dense NHWC, C1 / C2 multiples of 64 -- then
 // bits 8..19 = image width W, bits 20..31 = image height H (the tile has to cover whole image rows).
-static inline int igemm_caps(bool glds_ok, int patch_h, int patch_w) {
-    return (glds_ok ? 1 : 0) | ((patch_h > 0 && patch_w > 0 && patch_h < 4096 && patch_w < 4096) ? ((patch_w << 8) | (patch_h << 20)) : 0);
+static inline int igemm_caps(bool glds_ok, int patch_h, int patch_w, bool packed = false) {
+    return (glds_ok ? 1 : 0) | (packed ? 2 : 0) | ((patch_h > 0 && patch_w > 0 && patch_h < 4096 && patch_w < 4096) ? ((patch_w << 8) | (patch_h << 20)) : 0);
 }
 bool conv_patch_fits(int H, int W, int M, int BM, int BN);                                 // conv_patch.hip
 int conv_patch_launch(const IgemmArgs &a, int dtype, int BM, int BN, hipStream_t st);       // conv_patch.hip

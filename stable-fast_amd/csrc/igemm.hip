@@ -675,6 +675,10 @@ static const Variant kVariants[] = {
     {26, 64, 64, 2, 2, 2, 3, 0.60f},   // 48 KB ring: three workgroups per CU
     // pipe 3: LDS-resident input patch for 3x3 / stride 1 / pad 1 convs (conv_patch.hip); autotuner candidates
     {31, 128, 160, 4, 1, 3, 5, 1.00f}, {32, 128, 128, 2, 2, 3, 5, 1.00f}, {34, 128, 64, 2, 2, 3, 5, 0.80f},  // (ring: 3 .. 5, by LDS left)
+    // pipe 4: packed weights global -> VGPR, activations through a 4-deep LDS ring (igemm_pk.hip); BM pixels x BN weight rows, 1 x WN waves;
+    // autotuner candidates, only when the caller hands over packed copies (caps bit 1)
+    {41, 128, 256, 1, 4, 4, 4, 1.10f}, {42, 64, 256, 1, 4, 4, 4, 0.90f},  {43, 64, 320, 1, 5, 4, 4, 0.90f},
+    {44, 128, 160, 1, 5, 4, 4, 0.90f}, {45, 64, 160, 1, 5, 4, 4, 0.70f},  {46, 128, 128, 1, 4, 4, 4, 0.90f},
 };
 static const Variant kGegluVariants[] = {
     {1, 128, 128, 2, 2, 0, 2, 1.00f},  {3, 64, 128, 2, 2, 0, 2, 0.75f},  {11, 128, 128, 2, 2, 1, 4, 1.00f},
@@ -685,6 +689,8 @@ static const Variant kGegluVariants[] = {
 extern unsigned long long *g_igemm_trace;  // igemm_glds.hip
 int igemm_glds_ws_init();  // igemm_glds_ws.hip
 int igemm_glds_ws_launch(const IgemmArgs &a, int dtype, int mode, bool geglu, int BM, int BN, int NS, hipStream_t st);
+int igemm_pk_init();                                                                                 // igemm_pk.hip
+int igemm_pk_launch(const IgemmArgs &a, int dtype, int mode, int BM, int BN, hipStream_t st);       // igemm_pk.hip
 int igemm_glds_init();                                                                               // igemm_glds.hip
 int igemm_glds_launch(const IgemmArgs &a, int dtype, int mode, bool geglu, int BM, int BN, int NS, hipStream_t st);  // igemm_glds.hip
 
@@ -740,6 +746,7 @@ int igemm_init() {
     if (!rc) rc = igemm_grouped_init();
     if (!rc) rc = igemm_glds_init();
     if (!rc) rc = igemm_glds_ws_init();
+    if (!rc) rc = igemm_pk_init();
     const char *so = getenv("SFAST_STAGE_OUT");
     g_stage_pref = (so && so[0] == '1') ? 1 : 0;
     const char *xm = getenv("SFAST_XCD_MAP");
@@ -816,11 +823,12 @@ static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, 
             if (v.pipe == 0 && glds_ok && g_pipe_pref == 1) continue;
         }
         if (v.pipe >= 1 && !glds_ok) continue;
+        if (v.pipe == 4 && !(caps & 2)) continue;
         if (v.pipe == 3 && !(patch_w > 0 && K % 576 == 0 && conv_patch_fits(patch_h, patch_w, M, v.BM, v.BN))) continue;
         const int bno = geglu ? v.BN / 2 : v.BN;
         const int tm = ceil_div(M, v.BM), tn = ceil_div(N, bno);
         const int tiles = tm * tn;
-        const int lds = v.ns * (v.BM + v.BN) * 128;
+        const int lds = v.pipe == 4 ? v.ns * v.BM * 128 : v.ns * (v.BM + v.BN) * 128;
         const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;
         const double wrows = geglu ? 2.0 * N : (double)N;
         // unique operand bytes stream from HBM (~4 TB/s); panel re-reads by other tiles are served
@@ -1067,7 +1075,12 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
     const bool glds_elig = igemm_glds_eligible(a, mode);
     const bool patch_elig = mode == 1 && glds_elig && a.KH == 3 && a.KW == 3 && a.stride_h == 1 && a.stride_w == 1 && a.pad_h == 1 && a.pad_w == 1 &&
                             a.dil_h == 1 && a.dil_w == 1 && !a.ups && a.Ho == a.H && a.Wo == a.W;
-    const int glds_ok = igemm_caps(glds_elig, patch_elig ? a.H : 0, patch_elig ? a.W : 0);
+    // pipe 4 needs a packed copy of every weight segment the problem touches and row blocks that do not straddle segments
+    const int nseg = a.rows_per_seg > 0 ? ceil_div(a.N, a.rows_per_seg) : 1;
+    bool packed = glds_elig && !geglu && !a.w_int8 && nseg <= SFAST_MAX_WSEG && (nseg == 1 || a.rows_per_seg % 32 == 0);
+    for (int i = 0; i < nseg && packed; ++i) packed = a.wpk[i] != nullptr;
+    const int glds_ok = igemm_caps(glds_elig, patch_elig ? a.H : 0, patch_elig ? a.W : 0, packed);
+    a.pk_ksteps = ceil_div(a.K, 64) * 4;
     IgemmPlan p = igemm_plan(a.M, a.N, a.K, geglu, variant, split, glds_ok);
     const bool want_staged = !geglu && (a.gn_stats != nullptr || g_stage_pref > 0);
     if (want_staged && p.v.pipe == 1 && p.splits == 1) p = igemm_plan(a.M, a.N, a.K, geglu, staged_variant(p.v.id), p.splits, glds_ok);
@@ -1107,14 +1120,16 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
         a.partial = (float *)ws;
     }
     char pipe[8];
-    snprintf(pipe, sizeof(pipe), p.v.pipe == 3 ? "patch%d" : p.v.pipe == 2 ? "ws%d" : p.v.pipe ? "dma%d" : "reg", p.v.ns);
+    snprintf(pipe, sizeof(pipe), p.v.pipe == 4 ? "pk%d" : p.v.pipe == 3 ? "patch%d" : p.v.pipe == 2 ? "ws%d" : p.v.pipe ? "dma%d" : "reg", p.v.ns);
     char xmap[24] = "";
     if (a.xmap) snprintf(xmap, sizeof(xmap), "@xcd%dx%dx%d", 8 >> (a.x_lxm + a.x_lxn), 1 << a.x_lxm, 1 << a.x_lxn);  // K-split x row x column boxes
     set_kernel_name("igemm_%s_%s%s[%dx%d,split=%d,%s]%s%s%s%s", mode ? "conv" : "lin", dtype == SFAST_F16 ? "f16" : "bf16",
                     geglu ? "_geglu" : "", p.v.BM, p.v.BN, p.splits, pipe, a.gn_stats ? "+gnstats" : (a.stage_out ? "+staged" : ""),
                     joins ? "+join" : "", a.gn_out ? "+gn" : "", xmap);  // +join: split-K finished inside this kernel (no reduce launch)
     int rc;
-    if (p.v.pipe == 3)
+    if (p.v.pipe == 4)
+        rc = igemm_pk_launch(a, dtype, mode, p.v.BM, p.v.BN, st);
+    else if (p.v.pipe == 3)
         rc = conv_patch_launch(a, dtype, p.v.BM, p.v.BN, st);
     else if (p.v.pipe == 2)
         rc = igemm_glds_ws_launch(a, dtype, mode, geglu, p.v.BM, p.v.BN, p.v.ns, st);

@@ -219,6 +219,7 @@ class _NativeUNetForward:
                                      **{k: v for k, v in given.items() if v is not None})
         plan, graph, env = entry
         with env.lock, torch.cuda.device(eng.device):
+            eng.sync_packed()  # packed weight copies follow the live parameters (version counters); a no-op when nothing changed
             eng.load_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs,
                             down_block_additional_residuals, mid_block_additional_residual, emask, tcond, clabels)
             if graph is not None:
@@ -324,6 +325,7 @@ class _NativeControlNetForward:
                                      **({"added_cond_kwargs": added_cond_kwargs} if added_cond_kwargs is not None else {}))
         plan, graph, env = entry
         with env.lock, torch.cuda.device(eng.device):
+            eng.sync_packed()  # packed weight copies follow the live parameters (version counters); a no-op when nothing changed
             eng.load_inputs(plan, sample, timestep, encoder_hidden_states, controlnet_cond.to(eng.dtype), added_cond_kwargs)
             if graph is not None:
                 graph.replay()
@@ -394,6 +396,7 @@ class _NativeSVDForward:
             return self.orig_forward(sample, timestep, encoder_hidden_states, added_time_ids, return_dict=return_dict)
         plan, graph, env = entry
         with env.lock, torch.cuda.device(eng.device):
+            eng.sync_packed()  # packed weight copies follow the live parameters (version counters); a no-op when nothing changed
             eng.load_inputs(plan, sample, timestep, encoder_hidden_states, added_time_ids)
             if graph is not None:
                 graph.replay()
@@ -539,6 +542,7 @@ class _NativeVaeDecoderForward:
         graph = None
         torch.cuda.synchronize(eng.device)
         with torch.cuda.device(eng.device), torch.cuda.stream(torch.cuda.Stream(device=eng.device)):
+            eng.sync_packed()  # packed weight copies follow the live parameters (version counters); a no-op when nothing changed
             eng.load_inputs(plan, z)
             plan.run(torch.cuda.current_stream(eng.device).cuda_stream)  # validates every launch before capture
         torch.cuda.synchronize(eng.device)
@@ -581,6 +585,7 @@ class _NativeVaeDecoderForward:
         # static buffers and the workspace are shared by every call of this shape: serialised per device, like the UNet
         # wrapper and the reference's graphed callables (cuda/graphs.py:148)
         with env.lock, torch.cuda.device(eng.device):
+            eng.sync_packed()  # packed weight copies follow the live parameters (version counters); a no-op when nothing changed
             eng.load_inputs(plan, sample)
             if graph is not None:
                 graph.replay()

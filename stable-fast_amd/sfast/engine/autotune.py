@@ -25,6 +25,7 @@ _loaded_files = set()
 SPLITS = (1, 2, 3, 4, 5, 6, 8, 10, 12, 15, 16, 20, 24)
 VARIANTS = (1, 2, 3, 5, 11, 12, 13, 15, 16, 17, 18, 21, 22, 23, 24, 25, 26)
 GEGLU_VARIANTS = (1, 3, 11, 13, 16, 18, 21, 23)
+PK_VARIANTS = (41, 42, 43, 44, 45, 46)  # igemm_pk.h: packed weights global -> VGPR; only for ops that were handed packed copies
 CONV_PATCH_VARIANTS = (31, 32, 34)   # conv_patch.hip: 3x3 / stride 1 / pad 1 convs only (sfast_hip_conv2d_plan says whether a problem fits)
 MAX_SLAB_BYTES = 192 << 20
 
@@ -129,7 +130,7 @@ def tune_plan(plan, device, dtype_tag="f16", verbose=False):
         M, N, K, geglu = _mnk(p)
         if M <= 16 or (not isinstance(p, L.GemmParams) and (p.Cout < 16 or p.Cin % 8)):
             continue
-        key = problem_key(p, dtype_tag, devname)
+        key = problem_key(p, dtype_tag, devname) + ("|pk" if getattr(op, "packed", None) else "")
         hit = _cache.get(key)
         if hit is not None:
             p.variant, p.split_k = int(hit[0]), int(hit[1])
@@ -153,8 +154,17 @@ def tune_plan(plan, device, dtype_tag="f16", verbose=False):
         best = None
         is_conv = not isinstance(p, L.GemmParams)
         cands = GEGLU_VARIANTS if geglu else (VARIANTS + CONV_PATCH_VARIANTS if is_conv else VARIANTS)
+        only = None
+        if key.endswith("|pk"):
+            base = _cache.get(key[:-3])
+            if base is not None and int(base[0]) > 0:
+                cands, only = (int(base[0]),) + PK_VARIANTS, (int(base[0]), int(base[1]))  # the known best ring kernel against the packed pipe
+            else:
+                cands = cands + PK_VARIANTS
         for v in cands:
             for s in SPLITS:
+                if only is not None and v == only[0] and s != only[1] and only[1] > 0:
+                    continue
                 if s > 1 and ktiles // s < 2:
                     continue
                 if s > 1 and s * M * wrows * 4 > MAX_SLAB_BYTES:
@@ -176,7 +186,7 @@ def tune_plan(plan, device, dtype_tag="f16", verbose=False):
                 if launch_with(sp, ws.data_ptr(), ws.numel()) != 0:
                     continue
                 k = L.last_kernel()
-                if ("patch" if v >= 30 else "ws" if v >= 20 else "dma" if v >= 10 else "reg") not in k.split(",")[-1]:
+                if ("pk" if v >= 40 else "patch" if v >= 30 else "ws" if v >= 20 else "dma" if v >= 10 else "reg") not in k.split(",")[-1]:
                     continue  # pipe not applicable to this problem: the library substituted another
                 t = _time(lambda: launch_with(sp, ws.data_ptr(), ws.numel()), stream)
                 if best is None or t < best[0]:

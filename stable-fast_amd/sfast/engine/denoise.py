@@ -91,6 +91,7 @@ class DenoiseLoop:
         (every cross-attention block's K/V projection) for this context."""
         self.latents.copy_(latents)
         si = self.plan.static_in
+        self.engine.sync_packed()
         si["sample"][: self.images].copy_(latents)
         si["sample"][self.images:].copy_(latents)
         si["encoder_hidden_states"].copy_(ehs_uncond_cond)

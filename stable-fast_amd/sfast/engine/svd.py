@@ -43,6 +43,7 @@ class SVDUNetEngine(UNet2DEngine):
                 params[name] = d
         eng = cls(cfg, params, _host=_host)
         eng.norm_eps = live_norm_eps(m)
+        eng._param_objs = dict(m.named_parameters())
         return eng
 
     def _parse_config(self):

@@ -95,13 +95,14 @@ LANE_MAIN, LANE_TEMB, LANE_KV = 0, 1, 2
 
 
 class OpRecord:
-    __slots__ = ("kind", "name", "flops", "bytes", "kernel", "launch", "tune", "lane", "needs")
+    __slots__ = ("kind", "name", "flops", "bytes", "kernel", "launch", "tune", "lane", "needs", "packed")
 
     def __init__(self, kind, name, flops, nbytes, kernel, launch, tune=None, lane=LANE_MAIN, needs=None):
         self.kind, self.name, self.flops, self.bytes, self.kernel, self.launch = kind, name, flops, nbytes, kernel, launch
         self.tune = tune  # (params struct, launch_with(stream, ws_ptr, ws_bytes)) for tools/tune_igemm.py
         self.lane = lane  # ops that depend only on (timestep | text context) form side lanes of the graph
         self.needs = needs  # LANE_TEMB / LANE_KV: first consumer of a side lane's results joins it
+        self.packed = None  # (ext structs, packed-weight records) when the op was handed packed copies of its weights (pipe 4)
 
 
 class UNetPlan:
@@ -127,6 +128,7 @@ class UNetPlan:
         self.gn_candidates = []
         self.gn_fused = 0      # GroupNorms that run as ONE normalisation pass over statistics their producers emit
         self.gn_in_reduce = 0  # GroupNorms computed by their producer's split-K reduce launch (no launch of their own)
+        self.packed_ops = 0    # GEMM / conv launches that read packed weight copies (pipe 4)
 
     def writer_of(self, t):
         rec = self.writer.get(id(t)) if t is not None else None
@@ -251,6 +253,13 @@ FUSE_GN_CONV = os.environ.get("SFAST_FUSE_GN_CONV", "0") not in ("0", "false", "
 # CUs pull a 16x16 level's 15.7 MB of fp32 slabs at ~16 GB/s each: 43 us for conv + fused reduce against 31 + 7 us for the
 # chip-wide reduce and the separate 64-workgroup GroupNorm of a 1.3 MB tensor; at the 8x8 level it is a wash (21.5 vs 21.4 us).
 GN_IN_REDUCE = os.environ.get("SFAST_GN_IN_REDUCE", "0") not in ("0", "false", "off", "")
+# Packed weights (pipe 4, csrc/igemm_pk.h): every GEMM / conv whose weight is a parameter of the engine is offered a packed copy (1 KB
+# MFMA fragments, sfast_hip_pack_weight); the autotuner then times the pipe-4 kernels beside the ring kernels and keeps a copy only
+# where one of them won. The copies are re-packed when the parameter's version counter moved (UNet2DEngine.sync_packed, called by
+# every compiled forward before it replays): in-place updates through the parameter or its state_dict() tensor -- the reference's
+# "Dynamically Switch LoRA" recipe, README.md:228-265 -- are seen at the next call; writes that bypass autograd's version counter
+# (`p.data.copy_`, raw pointers) need `engine.sync_packed(force=True)`. SFAST_PACKED_WEIGHTS=0: no copies, weights read live only.
+PACKED_WEIGHTS = os.environ.get("SFAST_PACKED_WEIGHTS", "1") not in ("0", "false", "off", "")
 
 
 class DeviceHost:
@@ -285,6 +294,12 @@ class UNet2DEngine:
 
     ip_proj = None  # [(prefix, tokens per image, image embedding width)] when an IP-Adapter is loaded (_parse_ip_adapter)
     _ip_processors = {}
+    _param_objs = {}  # parameter name -> nn.Parameter (set per instance by from_module): the version counters sync_packed() watches
+
+    @property
+    def _pk(self):
+        """(data_ptr, N, K, ldw) -> packed-weight record (dict: w, buf, N, K, ldw, users, name, version); see _packed_for."""
+        return self.__dict__.setdefault("_pk_records", {})
 
     def __init__(self, config, params, device=None, dtype=None, _host=None):
         self.host = _host if _host is not None else DeviceHost()
@@ -328,6 +343,7 @@ class UNet2DEngine:
                 params[name] = d
         eng = cls(cfg, params, _host=_host)
         eng.norm_eps = live_norm_eps(m)
+        eng._param_objs = dict(m.named_parameters())
         if getattr(eng, "ip_proj", None):
             # IP-Adapter: `scale` is a python attribute of each attn2 processor (pipe.set_ip_adapter_scale); read live by ip_scales()
             eng._ip_processors = {name: mod.processor for name, mod in m.named_modules()
@@ -557,6 +573,88 @@ class UNet2DEngine:
     # ------------------------------------------------------------------------------------------
     # plan construction helpers
     # ------------------------------------------------------------------------------------------
+    # ------------------------------------------------------------------------------------------
+    # packed weights (pipe 4)
+    # ------------------------------------------------------------------------------------------
+    def _packed_for(self, w):
+        """Packed copy of a weight that is one of this engine's parameters (else None): a [N, K] view or a [Cout][KH][KW][Cin] conv
+        weight. One record per distinct (storage offset, geometry); packed now, on the current stream."""
+        if not PACKED_WEIGHTS or not hasattr(self.lib, "sfast_hip_pack_weight"):
+            return None
+        if w.ndim == 4:
+            Cout, Cin, KH, KW = w.shape
+            if not (w.stride(1) == 1 and (KW == 1 or w.stride(3) == Cin) and (KH == 1 or w.stride(2) == KW * Cin)):
+                return None
+            N, K, ldw = Cout, KH * KW * Cin, (w.stride(0) if Cout > 1 else KH * KW * Cin)
+        elif w.ndim == 2 and w.stride(1) == 1:
+            N, K = w.shape
+            ldw = w.stride(0) if N > 1 else K
+        else:
+            return None
+        if K % 8 or ldw % 8 or w.data_ptr() % 16:
+            return None
+        key = (w.data_ptr(), N, K, ldw)
+        rec = self._pk.get(key)
+        if rec is None:
+            names = getattr(self, "_ptr_names", None)
+            if names is None:
+                names = self._ptr_names = {t.data_ptr(): n for n, t in self.params.items() if torch.is_tensor(t)}
+            name = names.get(w.data_ptr())
+            if name is None:
+                return None  # a plan-owned buffer (padded conv_in image, merged LoRA weight, ...): rewritten per step, never packed here
+            buf = torch.empty(self.lib.sfast_hip_packed_weight_bytes(N, K), dtype=torch.uint8, device=self.device)
+            rec = self._pk[key] = dict(w=w, buf=buf, N=N, K=K, ldw=ldw, users=0, name=name, version=None)
+            self._pack(rec)
+        return rec
+
+    def _pack(self, rec):
+        L.check(self.lib.sfast_hip_pack_weight(rec["w"].data_ptr(), rec["buf"].data_ptr(), rec["N"], rec["K"], rec["ldw"], self.dt,
+                                               self.host.stream_ptr(self.device)), "sfast_hip_pack_weight")
+        p = self._param_objs.get(rec["name"])
+        rec["version"] = p._version if p is not None else None
+
+    def sync_packed(self, force=False):
+        """Re-pack every packed weight whose parameter changed since it was packed (version counter), or all of them (`force`).
+        Launches on the current stream, outside any graph; a no-op costing a few microseconds when nothing changed."""
+        n = 0
+        for rec in self._pk.values():
+            if rec["users"] <= 0:
+                continue
+            p = self._param_objs.get(rec["name"])
+            if force or (p is not None and p._version != rec["version"]):
+                self._pack(rec)
+                n += 1
+        return n
+
+    def _offer_packed(self, plan, weights, exts):
+        """Give the op's launches packed copies of `weights` (all or nothing). Returns the records, or None."""
+        recs = [self._packed_for(w) for w in weights]
+        if any(r is None for r in recs):
+            return None
+        arr = (C.c_void_p * len(recs))(*[r["buf"].data_ptr() for r in recs])
+        plan.keep.append(arr)
+        for x in exts:
+            x.w_packed = C.cast(arr, C.c_void_p)
+        for r in recs:
+            r["users"] += 1
+        return recs
+
+    def _settle_packed(self, plan):
+        """After tuning: an op that did not choose a pipe-4 kernel gives its packed copies back; copies nobody uses are freed."""
+        for op in plan.ops:
+            if op.packed is None:
+                continue
+            exts, recs = op.packed
+            if int(op.tune[0].variant) < 40 or int(op.tune[0].variant) >= 100:
+                for x in exts:
+                    x.w_packed = None
+                for r in recs:
+                    r["users"] -= 1
+                op.packed = None
+        for key in [k for k, r in self._pk.items() if r["users"] <= 0]:
+            del self._pk[key]
+        plan.packed_ops = sum(1 for op in plan.ops if op.packed is not None)
+
     def _add(self, plan, kind, name, flops, nbytes, launch, tune=None, lane=LANE_MAIN, needs=None):
         plan.ops.append(OpRecord(kind, name, flops, nbytes, None, launch, tune, lane, needs))
 
@@ -653,6 +751,10 @@ class UNet2DEngine:
         nbytes = (M * K + wrows * K + wrows + M * N + (M * N if residual is not None else 0)) * self.esize
         self._add(plan, kind or ("geglu" if geglu else ("gemv" if M <= 16 else "linear")), name, flops, nbytes, launch,
                   tune=(p, launch_with), lane=lane)
+        if not geglu and M > 16:
+            recs = self._offer_packed(plan, weights, (ext, text))
+            if recs is not None:
+                plan.ops[-1].packed = ((ext, text), recs)
 
     def _op_gemv_grouped(self, plan, name, x, weights, biases, out, M, K, ldx, ldo, *, out_offset=0, act=L.ACT_NONE, lane=LANE_MAIN):
         """out[m][out_offset + off_g + n] = act(x[m] . W_g[n] + b_g[n]) for every weight matrix of `weights`, one launch."""
@@ -729,6 +831,10 @@ class UNet2DEngine:
         nbytes = (B * H * W * Cin + Cout * Cin * k * kw + Cout + M * Cout + (M * Cout if z is not None else 0)) * self.esize
         self._add(plan, kind or ("conv3x3" if k == 3 else "conv1x1"), name, flops, nbytes, launch, tune=(p, launch_with),
                   needs=LANE_TEMB if rowbias is not None else None)
+        if not ups and C1 % 64 == 0 and C2 % 64 == 0:
+            recs = self._offer_packed(plan, [w], (ext, text))
+            if recs is not None:
+                plan.ops[-1].packed = ((ext, text), recs)
         return Ho, Wo
 
     def _gnconv_params(self, x2, w, B, H, W, C1, C2, Cout, eps, ld_rowbias, z):
@@ -1429,6 +1535,7 @@ class UNet2DEngine:
                     p = op.tune[0]
                     q = lib.sfast_hip_gemm_workspace_bytes if isinstance(p, L.GemmParams) else lib.sfast_hip_conv2d_workspace_bytes
                     self._need_ws(plan, q(C.byref(p)), op.lane)
+        self._settle_packed(plan)
         self._fuse_gn_into_reduce(plan)
         self._fuse_gn_statistics(plan)
         # one scratch buffer per lane, shared by all its operators; the split-K ticket counters of the GEMM / conv kernels live in a
@@ -1559,6 +1666,7 @@ class UNet2DEngine:
         ctrl = down_block_additional_residuals is not None
         plan = self.get_plan(B, H, W, encoder_hidden_states.shape[1], ctrl, encoder_attention_mask is not None, timestep_cond is not None,
                              self.ip_signature(added_cond_kwargs))
+        self.sync_packed()
         self.load_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs, down_block_additional_residuals,
                          mid_block_additional_residual, encoder_attention_mask, timestep_cond, class_labels)
         plan.run(self.host.stream_ptr(self.device))

@@ -66,6 +66,7 @@ class VaeDecoderEngine(UNet2DEngine):
                 params[name] = p.data
         eng = cls(cfg, params, _host=_host)
         eng.norm_eps = live_norm_eps(m)
+        eng._param_objs = dict(m.named_parameters())
         return eng
 
     def _parse_config(self):

@@ -217,11 +217,34 @@ def softmax_rows(x, scale=1.0, out=None):
 
 
 @_on_device
+def pack_weight(weight):
+    """Packed copy of a [N, K] linear weight or a [Cout, Cin, KH, KW] channels_last conv weight for the pipe-4 kernels
+    (sfast_hip_pack_weight: contiguous 1 KB MFMA A-fragments). Pass it as `w_packed=` to linear() / conv2d(); re-pack after the
+    weight changed."""
+    _require_cuda(weight)
+    lib = L.init_device()
+    if weight.ndim == 4:
+        Cout, Cin, KH, KW = weight.shape
+        if not (weight.stride(1) == 1 and (KW == 1 or weight.stride(3) == Cin) and (KH == 1 or weight.stride(2) == KW * Cin)):
+            raise L.SfastHipError("pack_weight: conv weight must be [Cout][KH][KW][Cin]-contiguous (channels_last)")
+        N, K, ldw = Cout, KH * KW * Cin, weight.stride(0) if Cout > 1 else KH * KW * Cin
+    elif weight.ndim == 2 and weight.stride(1) == 1:
+        N, K = weight.shape
+        ldw = weight.stride(0) if N > 1 else K
+    else:
+        raise L.SfastHipError("pack_weight: a K-contiguous [N, K] or channels_last [Cout, Cin, KH, KW] weight is required")
+    out = torch.empty(lib.sfast_hip_packed_weight_bytes(N, K), dtype=torch.uint8, device=weight.device)
+    L.check(lib.sfast_hip_pack_weight(_ptr(weight), _ptr(out), N, K, ldw, _dtype(weight), _stream(weight)), "sfast_hip_pack_weight")
+    return out
+
+
+@_on_device
 def linear(x, weight, bias=None, *, act=None, residual=None, alpha=1.0, res_before_act=False,
            geglu=False, rowbias=None, rows_per_batch=0, in_act=None, variant=0, split_k=0, out=None, out_scale=1.0, gn_unit=0,
-           rows_per_sample=0):
+           rows_per_sample=0, w_packed=None):
     """out[..., N] = epilogue(x[..., K] @ W[N, K]^T). `weight` may be a list of <= 4 equally sized
-    [n_i, K] tensors stacked along N (e.g. live to_q / to_k / to_v weights)."""
+    [n_i, K] tensors stacked along N (e.g. live to_q / to_k / to_v weights). `w_packed`: pack_weight() of every segment (a tensor
+    or a list) -- makes the pipe-4 kernels (variant 41 ..) eligible."""
     ws_list = list(weight) if isinstance(weight, (list, tuple)) else [weight]
     _require_cuda(x, bias, residual, rowbias, *ws_list)
     lib = L.init_device()
@@ -287,6 +310,12 @@ def linear(x, weight, bias=None, *, act=None, residual=None, alpha=1.0, res_befo
     nb = lib.sfast_hip_gemm_workspace_bytes(C.byref(p))
     wsb, nb, flags = _ws_tickets(nb, x)
     ext = L.EpilogueExt(float(out_scale), int(gn_unit), int(rows_per_sample), flags)
+    if w_packed is not None:
+        pk_list = list(w_packed) if isinstance(w_packed, (list, tuple)) else [w_packed]
+        if len(pk_list) != len(ws_list):
+            raise L.SfastHipError("linear: one packed copy per weight segment is required")
+        pk_arr = (C.c_void_p * len(pk_list))(*[t.data_ptr() for t in pk_list])
+        ext.w_packed = C.cast(pk_arr, C.c_void_p)
     stats, lay = None, None
     if gn_unit:
         lay = L.GnStatsLayout()
@@ -385,7 +414,7 @@ def _nhwc_strides(t):
 @_on_device
 def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dilation=1, act=None,
            res_before_act=True, x2=None, upsample2x=False, rowbias=None, variant=0, split_k=0,
-           channels_last_out: Optional[bool] = None, pad_extra=0, out_scale=1.0, gn_unit=0, out=None, gn=None):
+           channels_last_out: Optional[bool] = None, pad_extra=0, out_scale=1.0, gn_unit=0, out=None, gn=None, w_packed=None):
     """y = act(conv2d(x, w) + bias + rowbias[b] + alpha*z) on logical NCHW tensors of any strides.
     x2: optional tensor concatenated to x along channels (virtual). upsample2x: nearest 2x first.
     pad_extra: additional zero rows / columns at the bottom / right on top of `padding` (F.pad(x, (0, e, 0, e))).
@@ -454,6 +483,9 @@ def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dila
     nb = lib.sfast_hip_conv2d_workspace_bytes(C.byref(p))
     wsb, nb, flags = _ws_tickets(nb, x)
     ext = L.EpilogueExt(float(out_scale), int(gn_unit), Ho * Wo, flags)
+    if w_packed is not None:  # pack_weight(weight): the pipe-4 kernels (variant 41 ..) become eligible
+        pk_arr = (C.c_void_p * 1)(w_packed.data_ptr())
+        ext.w_packed = C.cast(pk_arr, C.c_void_p)
     gn_y = None
     if gn is not None:
         groups, g_w, g_b, g_eps, g_act = gn

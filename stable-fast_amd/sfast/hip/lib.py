@@ -18,7 +18,7 @@ PROBES_LIB_PATH = os.path.join(os.path.dirname(_HERE), "_lib", "libsfast_hip_pro
 if os.environ.get("SFAST_HIP_PROBES", "0") == "1":
     LIB_PATH = PROBES_LIB_PATH
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # enums (include/sfast_hip.h)
 F16, BF16, F32 = 0, 1, 2
@@ -40,7 +40,9 @@ EXPORTS = [
     "sfast_hip_gemv_grouped", "sfast_hip_gemm_grouped", "sfast_hip_qlinear_w8", "sfast_hip_cfg_ddim_step", "sfast_hip_linear_step", "sfast_hip_mix_rows", "sfast_hip_igemm_plan", "sfast_hip_set_trace", "sfast_hip_image_postprocess", "sfast_hip_add_strided",
     "sfast_hip_schedule_advance", "sfast_hip_conv2d_plan", "sfast_hip_workspace_init", "sfast_hip_has_probes",
     "sfast_hip_gn_conv2d_supported", "sfast_hip_gn_conv2d_workspace_bytes", "sfast_hip_gn_conv2d",
+    "sfast_hip_lora_merge_plan", "sfast_hip_lora_merge", "sfast_hip_packed_weight_bytes", "sfast_hip_pack_weight",
 ]
+LORA_MAX_RANK = 128
 
 
 class GnParams(C.Structure):
@@ -81,7 +83,9 @@ class EpilogueExt(C.Structure):
     _fields_ = [("out_scale", C.c_float), ("gn_unit", C.c_int32), ("gn_rows_per_sample", C.c_int32), ("flags", C.c_int32),
                 # ABI 8: the GroupNorm(+SiLU) that consumes the output, computed by the split-K reduce launch
                 ("gn_out", C.c_void_p), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("gn_groups", C.c_int32), ("gn_eps", C.c_float),
-                ("gn_act", C.c_int32), ("reserved", C.c_int32)]
+                ("gn_act", C.c_int32), ("reserved", C.c_int32),
+                # ABI 9: packed copies of the weight segments (sfast_hip_pack_weight): array of n_wseg pointers, or NULL
+                ("w_packed", C.c_void_p)]
 
 
 class GnStatsLayout(C.Structure):
@@ -95,6 +99,12 @@ class GnStatsLayout(C.Structure):
 class MixParams(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("M", C.c_int64), ("C", C.c_int32), ("vec_rows", C.c_int32), ("vec_mod", C.c_int32),
                 ("ld_vec", C.c_int64), ("wx", C.c_float), ("wy", C.c_float), ("switch_spatial_to_temporal", C.c_int32)]
+
+
+class LoraEntry(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("down", C.c_void_p), ("up", C.c_void_p), ("out", C.c_void_p),
+                ("N", C.c_int32), ("K", C.c_int32), ("r", C.c_int32), ("tile_begin", C.c_int32),
+                ("ldw", C.c_int64), ("ldd", C.c_int64), ("ldu", C.c_int64), ("scale_index", C.c_int32), ("reserved", C.c_int32)]
 
 
 class GemvGroupedParams(C.Structure):
@@ -201,6 +211,14 @@ def _declare(lib):
     lib.sfast_hip_set_trace.argtypes = [C.c_void_p]
     lib.sfast_hip_igemm_plan.restype = C.c_int
     lib.sfast_hip_igemm_plan.argtypes = [C.c_int32] * 6 + [C.POINTER(C.c_int32 * 5)]
+    lib.sfast_hip_packed_weight_bytes.restype = sz
+    lib.sfast_hip_packed_weight_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.sfast_hip_pack_weight.restype = C.c_int
+    lib.sfast_hip_pack_weight.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int32, vp]
+    lib.sfast_hip_lora_merge_plan.restype = C.c_int
+    lib.sfast_hip_lora_merge_plan.argtypes = [C.POINTER(LoraEntry), C.c_int32, C.POINTER(C.c_int32)]
+    lib.sfast_hip_lora_merge.restype = C.c_int
+    lib.sfast_hip_lora_merge.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_int32, vp]
     lib.sfast_hip_mix_rows.restype = C.c_int
     lib.sfast_hip_mix_rows.argtypes = [vp, vp, vp, vp, vp, C.POINTER(MixParams), vp]
     lib.sfast_hip_linear_step.restype = C.c_int

@@ -62,6 +62,17 @@ def main():
         err = float((y1.float() - y2.float()).abs().max())
         t1, t2 = timed(fused), timed(two)
         wbytes = Cout * Cin * 9 * 2
+        # the same weight-streaming launch WITHOUT the normalisation (groups = 0: "wsconv") against the autotuned conv alone
+        xn = F.group_norm(x, 32, gw, gb, 1e-5, "silu", x2=x2)
+        plain = lambda: F.gn_conv2d(xn, 0, None, None, w, b, z=z, rowbias=rb)
+        conv = lambda: F.conv2d(xn, w, b, z=z, padding=1, rowbias=rb)
+        y3 = plain()
+        k3 = L.last_kernel()
+        y4 = conv()
+        k4 = L.last_kernel()
+        t3, t4 = timed(plain), timed(conv)
+        print(f"{name:32s} wsconv {t3:6.1f} us  conv alone {t4:6.1f} us  ratio {t4 / t3:4.2f}x  max|diff| {float((y3.float() - y4.float()).abs().max()):.3g}  "
+              f"[{k3}] vs [{k4}]", flush=True)
         print(f"{name:32s} fused {t1:6.1f} us ({wbytes / t1 / 1e6:5.2f} TB/s of weights)  two operators {t2:6.1f} us ({wbytes / t2 / 1e6:5.2f} TB/s)  "
               f"ratio {t2 / t1:4.2f}x  max|diff| {err:.3g}  [{k1}] vs [gn + {k2}]", flush=True)
 

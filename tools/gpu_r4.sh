@@ -109,5 +109,20 @@ s10)  # IP-Adapter + SDXL-style ControlNet (native plans, through compile); the 
   run bench_sdxl 1200 python bench.py --config sdxl --no-cpu-baseline
   run bench_svd 1200 python bench.py --config svd --no-cpu-baseline
   ;;
+s11)  # fragment-load probe, second pass (own rows per wave, L2-resident, strided vs pre-swizzled); the weight-streaming conv without GN
+  run wdirect 300 tools/micro/wdirect
+  run t_gnconv 900 $PYT tests/test_ops_gpu.py -k "gn_conv2d"
+  run gnconv_ab 300 python tools/gnconv_ab.py
+  ;;
+s12)  # pipe 4 (packed weights): parity
+  run t_pk 1500 $PYT tests/test_packed_weights_gpu.py
+  ;;
+s13)  # pipe 4 in the step: 1x1 conv parity, whole-UNet parity + live weight update, bench with / without packed weights
+  run t_pk 900 $PYT tests/test_packed_weights_gpu.py -k "conv_packed or repack"
+  run t_unet 1200 $PYT tests/test_unet_gpu.py -k "sd15_unet_parity or tiny or live_weight or compile_drop_in"
+  SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_pk.json run bench_pk 900 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --dump-kernels gpurun_out/kernels_pk.json
+  SFAST_PACKED_WEIGHTS=0 run bench_nopk 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_pk.json run bench_pk2 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  ;;
 esac
 cat gpurun_out/session.log

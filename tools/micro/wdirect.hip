@@ -36,7 +36,12 @@ __global__ __launch_bounds__(256, 1) void probe(const f16 *W, float *out, int it
     const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void *)(((uintptr_t)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
     int voff[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) voff[nb] = ((nb * 32 + r) * ldw + g * 32) * 2;
+    for (int nb = 0; nb < NB; ++nb) voff[nb] = (MODE & 16) ? lane * 16 + nb * 4096 : ((nb * 32 + r) * ldw + g * 32) * 2;
+    // MODE bit 16: PRE-SWIZZLED weights -- every (row block, k-step) fragment is one contiguous 1 KB block [lane][8 elements], so a
+    // buffer_load_dwordx4 touches 8 full 128-byte lines instead of 32 lines at 32 bytes each (the tag rate of the vector L1 is one line
+    // per clock: 32 clocks per strided fragment load, which is what the "shared rows" lines above measure)
+    constexpr int JS = (MODE & 16) ? 1024 : 16;          // byte step between the four k-steps of a chunk
+    constexpr int CS_ = (MODE & 16) ? NB * 4096 : 128;   // byte step between chunks
     const int lbase = (wave * (MB * 32) % 512 + r) * ROW_BYTES + g * 64;
 
     f32x16 acc[MB][NB];
@@ -54,7 +59,7 @@ __global__ __launch_bounds__(256, 1) void probe(const f16 *W, float *out, int it
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (MODE & 1)
-                    wreg[d][nb][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, voff[nb] + j * 16, d * 128, AUX));
+                    wreg[d][nb][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, voff[nb] + j * JS, d * CS_, AUX));
                 else
                     wreg[d][nb][j] = u32x4{0x2c002c00u + lane, 0x2c002c00u, 0x2c012c00u, 0x2c002c01u};
                 __builtin_amdgcn_sched_barrier(0);  // issue order = consumption order (else the loop-header wait collapses to vmcnt(0..3))
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(256, 1) void probe(const f16 *W, float *out, int it
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        wreg[d][nb][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, voff[nb] + j * 16, (c + D) * 128, AUX));
+                        wreg[d][nb][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, voff[nb] + j * JS, (c + D) * CS_, AUX));
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -189,5 +194,17 @@ int main() {
     run<4, 4, 2, 7, 0>("MB4 NB4 D2   all, W from HBM, shared rows", W, out, wbytes, IT, true);
     run<4, 4, 2, 6, 0>("MB4 NB4      MFMA + LDS", W, out, wbytes, IT, false);
     run<4, 4, 2, 4, 0>("MB4 NB4      MFMA only", W, out, wbytes, IT, false);
+    // round 4, second pass: every wave owns its weight rows (4 x 1 waves over the weight rows of a 256 x 128 tile: no two waves of a
+    // workgroup load the same bytes) with the rows L2-resident (all workgroups share them, as the M-tiles of one N-tile do), strided
+    // against pre-swizzled fragments
+    run<4, 2, 4, 15, 0>("MB4 NB2 D4   all, W in L2, own rows/wave", W, out, wbytes, IT, false);
+    run<4, 2, 4, 31, 0>("MB4 NB2 D4   all, W in L2, own rows, SWIZZLED", W, out, wbytes, IT, false);
+    run<4, 2, 6, 31, 0>("MB4 NB2 D6   all, W in L2, own rows, SWIZZLED", W, out, wbytes, IT, false);
+    run<4, 2, 4, 29, 0>("MB4 NB2 D4   MFMA + W(L2 own, SWIZZLED), no LDS", W, out, wbytes, IT, false);
+    run<4, 2, 4, 23, 0>("MB4 NB2 D4   all, W in L2, shared rows, SWIZZLED", W, out, wbytes, IT, false);
+    run<4, 2, 4, 31, 0>("MB4 NB2 D4   all, W from HBM, own rows, SWIZZLED", W, out, wbytes, ITS, true);
+    run<4, 4, 2, 31, 0>("MB4 NB4 D2   all, W in L2, own rows, SWIZZLED", W, out, wbytes, IT, false);
+    run<2, 4, 3, 31, 0>("MB2 NB4 D3   all, W in L2, own rows, SWIZZLED", W, out, wbytes, IT, false);
+    run<2, 2, 4, 31, 0>("MB2 NB2 D4   all, W in L2, own rows, SWIZZLED", W, out, wbytes, IT, false);
     return 0;
 }
