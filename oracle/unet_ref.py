@@ -109,6 +109,62 @@ class ResnetBlock2D(nn.Module):
         return x + h
 
 
+class LoRALinearLayer(nn.Module):
+    """diffusers models/lora.py `LoRALinearLayer`: up(down(x)), times network_alpha / rank when network_alpha is set."""
+
+    def __init__(self, in_features, out_features, rank=4, network_alpha=None):
+        super().__init__()
+        self.down = nn.Linear(in_features, rank, bias=False)
+        self.up = nn.Linear(rank, out_features, bias=False)
+        self.network_alpha, self.rank = network_alpha, rank
+
+    def forward(self, x):
+        y = self.up(self.down(x))
+        return y * (self.network_alpha / self.rank) if self.network_alpha is not None else y
+
+
+class LoRACompatibleLinear(nn.Linear):
+    """diffusers models/lora.py `LoRACompatibleLinear` (0.21 - 0.24: what `unet.load_attn_procs(lora)` leaves on to_q / to_k / to_v /
+    to_out.0): linear(x) + scale * lora_layer(x); `scale` is the call's cross_attention_kwargs["scale"] (read from a box shared by
+    the UNet's LoRA layers). State-dict keys: `<linear>.lora_layer.down.weight`, `<linear>.lora_layer.up.weight`."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.lora_layer = None
+        self._scale_box = [1.0]
+
+    def forward(self, x):
+        y = super().forward(x)
+        if self.lora_layer is not None:
+            y = y + self._scale_box[0] * self.lora_layer(x)
+        return y
+
+
+class PeftLoraLinear(nn.Module):
+    """The attribute layout of `peft.tuners.lora.Linear` (diffusers >= 0.25 with the peft backend): base_layer, lora_A / lora_B
+    ModuleDicts keyed by adapter name, scaling[adapter] = lora_alpha / r, active_adapters, merged, disable_adapters. State-dict keys:
+    `<linear>.base_layer.weight`, `<linear>.lora_A.<adapter>.weight` [r, in], `<linear>.lora_B.<adapter>.weight` [out, r]. diffusers
+    multiplies `scaling` by the call's cross_attention_kwargs["scale"] for the duration of the forward (scale_lora_layers)."""
+
+    def __init__(self, base, rank, lora_alpha, adapter="default"):
+        super().__init__()
+        self.base_layer = base
+        self.lora_A = nn.ModuleDict({adapter: nn.Linear(base.in_features, rank, bias=False)})
+        self.lora_B = nn.ModuleDict({adapter: nn.Linear(rank, base.out_features, bias=False)})
+        self.scaling = {adapter: lora_alpha / rank}
+        self.r = {adapter: rank}
+        self.active_adapters = [adapter]
+        self.merged, self.disable_adapters = False, False
+        self._scale_box = [1.0]
+
+    def forward(self, x):
+        y = self.base_layer(x)
+        if not self.disable_adapters and not self.merged:
+            for a in self.active_adapters:
+                y = y + self.lora_B[a](self.lora_A[a](x)) * (self.scaling[a] * self._scale_box[0])
+        return y
+
+
 class IPAdapterAttnProcessor(nn.Module):
     """diffusers `IPAdapterAttnProcessor2_0` (models/attention_processor.py), the decoupled image cross-attention of IP-Adapter: per
     adapter i a key / value projection of the image tokens, `to_k_ip[i]` / `to_v_ip[i]` (Linear(cross_attention_dim -> hidden, bias =
@@ -394,6 +450,37 @@ class UNet2DConditionModel(nn.Module):
             q.requires_grad_(False)
         return self
 
+    def load_lora(self, rank=4, network_alpha=None, seed=0, targets=("to_q", "to_k", "to_v", "to_out.0"), style="diffusers", up_scale=0.3):
+        """What `unet.load_attn_procs(lora)` / `pipe.load_lora_weights(lora)` leave behind, UN-fused, with seeded random factors: every
+        attention projection named in `targets` becomes a LoRACompatibleLinear with a lora_layer (style "diffusers") or a peft-style
+        wrapper (style "peft"); the base weight / bias Parameters are the same objects as before."""
+        g = torch.Generator().manual_seed(seed)
+        box = self.__dict__.setdefault("_lora_scale_box", [1.0])
+        for name, attn in [(n, m) for n, m in self.named_modules() if isinstance(m, Attention)]:
+            for t in targets:
+                holder, key = (attn.to_out, 0) if t == "to_out.0" else (attn, t)
+                lin = holder[key] if isinstance(key, int) else getattr(holder, key)
+                if style == "peft":
+                    new = PeftLoraLinear(lin, rank, float(network_alpha if network_alpha is not None else rank))
+                    fac = [new.lora_A["default"].weight, new.lora_B["default"].weight]
+                else:
+                    new = LoRACompatibleLinear(lin.in_features, lin.out_features, bias=lin.bias is not None)
+                    new.weight, new.bias = lin.weight, lin.bias
+                    new.lora_layer = LoRALinearLayer(lin.in_features, lin.out_features, rank, network_alpha)
+                    fac = [new.lora_layer.down.weight, new.lora_layer.up.weight]
+                new._scale_box = box
+                new.to(lin.weight.device, lin.weight.dtype)
+                with torch.no_grad():
+                    fac[0].copy_(torch.randn(fac[0].shape, generator=g) * fac[0].shape[1] ** -0.5)
+                    fac[1].copy_(torch.randn(fac[1].shape, generator=g) * up_scale)
+                if isinstance(key, int):
+                    holder[key] = new
+                else:
+                    setattr(holder, key, new)
+        for q in self.parameters():
+            q.requires_grad_(False)
+        return self
+
     def set_ip_adapter_scale(self, scale):
         for m in self.modules():
             if isinstance(m, IPAdapterAttnProcessor):
@@ -410,9 +497,11 @@ class UNet2DConditionModel(nn.Module):
     def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, return_dict=True,
                 down_block_additional_residuals=None, mid_block_additional_residual=None, encoder_attention_mask=None,
                 timestep_cond=None, class_labels=None, cross_attention_kwargs=None, **_):
-        # cross_attention_kwargs: only {"scale": s} is meaningful without LoRA / IP-Adapter processors, and then it is a no-op
-        # (diffusers scales the LoRA layers by it; this restatement has none)
+        # cross_attention_kwargs: only {"scale": s} is meaningful here: diffusers scales the LoRA layers by it for this call
+        # (load_lora(); a no-op without them)
         assert not cross_attention_kwargs or set(cross_attention_kwargs) <= {"scale"}
+        if "_lora_scale_box" in self.__dict__:
+            self.__dict__["_lora_scale_box"][0] = float((cross_attention_kwargs or {}).get("scale", 1.0))
         c = self.config
         B = sample.shape[0]
         if encoder_attention_mask is not None:

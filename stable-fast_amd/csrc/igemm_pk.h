@@ -36,21 +36,23 @@ constexpr int pk_smem_bytes(int BM, int BN, int NS, bool staged) {
     return (staged && stage > ring) ? stage : ring;
 }
 
-// BM pixels x BN weight rows per workgroup; WN waves, each owns FN = BN / (32 WN) blocks of 32 weight rows over ALL FM = BM / 32 pixel
-// blocks (no two waves load the same weight bytes). NS = activation ring depth (K-tiles of 64), PD = weight tiles in registers.
+// BM pixels x BN weight rows per workgroup; WN consumer waves, each owns FN = BN / (32 WN) blocks of 32 weight rows over ALL FM = BM / 32
+// pixel blocks (no two waves load the same weight bytes), plus ONE producer wave that streams the activation K-tiles into the LDS
+// ring (the producer half of igemm_glds_ws.hip). NS = ring depth (K-tiles of 64), PD = weight tiles a consumer holds in registers.
+// The first version let the consumer waves issue the LDS-DMA requests themselves: the compiler orders a wave's ds_reads behind its own
+// pending LDS-DMA writes with s_waitcnt vmcnt(0), which also waits for the weight tile requested a moment earlier -- a full L2 round
+// trip per K-tile, 19 - 33 % MFMA utilisation in the loop (profiles/r04_pk_ab_trace_run17.log). A wave that never issues LDS-DMA keeps
+// exact vmcnt counts for its weight loads.
 template <typename T, int BM, int BN, int WN, int NS, int PD, int MODE, bool STAGED>
-__global__ void __launch_bounds__(WN * 64, (BM >= 128 && BN / (WN * 32) >= 2) ? 1 : 2) igemm_pk_kernel(const IgemmArgs a) {
+__global__ void __launch_bounds__((WN + 1) * 64, 2) igemm_pk_kernel(const IgemmArgs a) {
     using vec8 = typename Elem<T>::vec8;
     constexpr int NC = WN * 64;
-    constexpr int NSTG = 256;               // threads that stage activations (waves 0..3)
     constexpr int FM = BM / 32, FN = BN / (WN * 32);
-    constexpr int XCH = BM * 8 / NSTG;      // LDS-DMA requests per staging thread per K-tile
-    constexpr int RPP = NSTG / 8;
+    constexpr int XCH = BM / 8;             // LDS-DMA requests of the producer wave per K-tile (8 rows of 128 bytes each)
     constexpr int STAGE = BM * 128;
     constexpr int WNB = FN * 32;
-    constexpr int AL = FN * 4;              // weight loads per thread per K-tile
-    static_assert(WN >= 4 && (BM * 8) % NSTG == 0 && PD == 3 && NS >= 3, "tile / pipeline shape");
-    static_assert((PD - 1) * (XCH + AL) <= 63, "vmcnt field");
+    static_assert(XCH * (NS - 1) <= 63, "vmcnt field");
+    static_assert(NS >= 3 && PD >= 2 && PD <= 3, "pipeline shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     touch_args(a);
@@ -58,7 +60,6 @@ __global__ void __launch_bounds__(WN * 64, (BM >= 128 && BN / (WN * 32) >= 2) ? 
     trace_mark(a, 0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool stager = wave < 4;
     const int l31 = lane & 31, hi = lane >> 5;
 
     const BlockTile bt = decode_block(a);
@@ -66,23 +67,25 @@ __global__ void __launch_bounds__(WN * 64, (BM >= 128 && BN / (WN * 32) >= 2) ? 
     const int kt_begin = bt.split * a.ktiles_per_split;
     const int kt_end = min(a.ktiles, kt_begin + a.ktiles_per_split);
 
-    // ---- activation staging (the producer half of igemm_glds_ws.hip, run by waves 0..3 of this workgroup) --------------------------
-    const int rbase = (tid & 255) >> 3;
-    const int kc = (tid & 7) ^ ((rbase >> 1) & 7);  // source-side swizzle (LDS-DMA writes lane-linearly)
-    const pk_src_t zero_src = (pk_src_t)(const void *)g_zero16;
-    const T *xrow[XCH];
-    int xoffB[XCH], xdAB[XCH];
-    unsigned xmask[XCH];
-    if (stager) {
+    if (wave == WN) {
+        // =============================== producer wave: activations -> LDS ring ========================================
+        const int rbase = lane >> 3;
+        const pk_src_t zero_src = (pk_src_t)(const void *)g_zero16;
+        const T *xrow[XCH];
+        int xoffB[XCH], xdAB[XCH];
+        unsigned xmask[XCH];
         const PixelDecoder decode(a);
         unsigned rep_all = 0;
         if (MODE == 1)
             for (int r = 0; r < a.KH; ++r) rep_all |= 1u << (r * a.KW);
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
-            const int m = m0 + rbase + i * RPP;
+            const int row = rbase + i * 8;
+            const int kc = (lane & 7) ^ ((row >> 1) & 7);  // source-side swizzle (LDS-DMA writes lane-linearly)
+            const int m = m0 + row;
             if (MODE == 0) {
                 xrow[i] = (m < a.M) ? (const T *)a.x + (int64_t)m * a.ldx + kc * 8 : nullptr;
+                xoffB[i] = kc * 8;
             } else {
                 unsigned mask = 0;
                 int pix = 0;
@@ -111,28 +114,26 @@ __global__ void __launch_bounds__(WN * 64, (BM >= 128 && BN / (WN * 32) >= 2) ? 
                 xmask[i] = mask;
             }
         }
-    }
-    const int cin = a.C1 + a.C2;
-    int t_tap = 0, t_r = 0, t_s = 0, t_c = 0;
-    if (MODE == 1) {
-        const int k0 = kt_begin * 64;
-        t_tap = k0 / cin;
-        t_c = k0 - t_tap * cin;
-        t_r = t_tap / a.KW;
-        t_s = t_tap - t_r * a.KW;
-    }
-    int issued = kt_begin, istage = 0;
-    auto issue_x = [&]() __attribute__((always_inline)) {  // the XCH requests of the next K-tile; tiles past kt_end are all-zero requests
-        if (stager) {
-            char *sx = smem + istage * STAGE + wave * 1024;
+        const int cin = a.C1 + a.C2;
+        int t_tap = 0, t_r = 0, t_s = 0, t_c = 0;
+        if (MODE == 1) {
+            const int k0 = kt_begin * 64;
+            t_tap = k0 / cin;
+            t_c = k0 - t_tap * cin;
+            t_r = t_tap / a.KW;
+            t_s = t_tap - t_r * a.KW;
+        }
+        int issued = kt_begin, istage = 0;
+        auto issue_x = [&]() __attribute__((always_inline)) {  // the XCH requests of the next K-tile; tiles past kt_end are all-zero requests
+            char *sx = smem + istage * STAGE;
             const bool tile_ok = issued < kt_end;
             const int k = issued * 64;
             if (MODE == 0) {
 #pragma unroll
                 for (int i = 0; i < XCH; ++i) {
-                    const bool ok = tile_ok & (xrow[i] != nullptr) & (k + kc * 8 < a.K);
+                    const bool ok = tile_ok & (xrow[i] != nullptr) & (k + xoffB[i] < a.K);
                     const pk_src_t src = ok ? (pk_src_t)(const void *)(xrow[i] + k) : zero_src;
-                    __builtin_amdgcn_global_load_lds(src, (pk_dst_t)(sx + i * (RPP * 128)), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(src, (pk_dst_t)(sx + i * 1024), 16, 0, 0);
                 }
             } else {
                 const bool first = t_c < a.C1;
@@ -144,26 +145,38 @@ __global__ void __launch_bounds__(WN * 64, (BM >= 128 && BN / (WN * 32) >= 2) ? 
                     const int off = xoffB[i] + (xdAB[i] & fmask);
                     const bool ok = tile_ok & (((xmask[i] >> (t_tap & 31)) & 1u) != 0);
                     const pk_src_t src = ok ? (pk_src_t)(const void *)(sbase + off) : zero_src;
-                    __builtin_amdgcn_global_load_lds(src, (pk_dst_t)(sx + i * (RPP * 128)), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(src, (pk_dst_t)(sx + i * 1024), 16, 0, 0);
+                }
+                t_c += 64;
+                if (t_c >= cin) {
+                    t_c -= cin;
+                    ++t_tap;
+                    if (++t_s == a.KW) {
+                        t_s = 0;
+                        ++t_r;
+                    }
                 }
             }
+            ++issued;
+            istage = (istage + 1 == NS) ? 0 : istage + 1;
+        };
+        // ring protocol of igemm_glds_ws.hip: NS tiles at the start; the consumers meet barrier k + 1 with every fragment of tile k in
+        // registers, so that barrier releases the stage of tile k and it is refilled with tile k + NS
+#pragma unroll
+        for (int s = 0; s < NS; ++s) issue_x();
+        pk_wait_vmcnt<XCH *(NS - 1)>();  // the first tile has landed
+        __builtin_amdgcn_s_barrier();
+        for (int kt = kt_begin + 1; kt < kt_end; ++kt) {
+            pk_wait_vmcnt<XCH *(NS - 2)>();  // tile kt has landed
+            __builtin_amdgcn_s_barrier();
+            issue_x();
         }
-        if (MODE == 1) {
-            t_c += 64;
-            if (t_c >= cin) {
-                t_c -= cin;
-                ++t_tap;
-                if (++t_s == a.KW) {
-                    t_s = 0;
-                    ++t_r;
-                }
-            }
-        }
-        ++issued;
-        istage = (istage + 1 == NS) ? 0 : istage + 1;
-    };
+        pk_wait_vmcnt<0>();  // the zero-filled tail requests have landed before the LDS is handed to the epilogue
+        return;
+    }
 
-    // ---- weight fragments: this wave's FN row blocks, 4 KB per (block, K-tile), contiguous along K --------------------------------
+    // =================================== consumer waves ====================================================================
+    // weight fragments: this wave's FN row blocks, 4 KB per (block, K-tile), contiguous along K
     const char *ap[FN];
     const int rs = a.rows_per_seg;
 #pragma unroll
@@ -178,28 +191,23 @@ __global__ void __launch_bounds__(WN * 64, (BM >= 128 && BN / (WN * 32) >= 2) ? 
     int a_left = kt_end - kt_begin;  // K-tiles of this split whose weights are not requested yet
     u32x4 wq[PD][FN][4];
     auto load_a = [&](u32x4 (&dst)[FN][4]) __attribute__((always_inline)) {
-        // past the split's range the last tile is requested again (valid bytes; its MFMAs multiply all-zero activations)
+        // past the split's range the last tile is requested again (valid bytes; never multiplied)
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dst[fn][j] = *reinterpret_cast<const u32x4 *>(ap[fn] + j * 1024);
+            for (int j = 0; j < 4; ++j) {
+                dst[fn][j] = *reinterpret_cast<const u32x4 *>(ap[fn] + j * 1024);
+                __builtin_amdgcn_sched_barrier(0);  // issue order = consumption order (exact vmcnt waits)
+            }
         if (a_left > 1) {
             --a_left;
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn) ap[fn] += 4096;
         }
-        __builtin_amdgcn_sched_barrier(0);
     };
-
-    // ---- prologue: requests in the steady-state order, so that one vmcnt constant serves every wait --------------------------------
-    //      steady state, iteration kt:  top: A(kt + PD - 1)   |   before the last k-step: wait, barrier, X(kt + NS)
-    //      the wait needs A(kt + 1) and X(kt + 1): behind A(kt + 1) in issue order sit X(kt - 1 + NS) and A(kt + 2)  -> vmcnt(XCH + AL)
 #pragma unroll
-    for (int j = 0; j < NS - 1; ++j) {
-        issue_x();
-        __builtin_amdgcn_sched_barrier(0);
-        if (j >= NS - PD) load_a(wq[j - (NS - PD)]);
-    }
+    for (int p = 0; p < PD - 1; ++p) load_a(wq[p]);
+
     constexpr bool EPI_EARLY = FN * FM <= 4;
     EpiOperands<(EPI_EARLY ? FN : 1), (EPI_EARLY ? FM : 1)> epi;
     if constexpr (EPI_EARLY) epilogue_prefetch<T, FN, FM, false>(a, epi, m0, n0 + wave * WNB, l31, hi);
@@ -211,10 +219,8 @@ __global__ void __launch_bounds__(WN * 64, (BM >= 128 && BN / (WN * 32) >= 2) ? 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[fn][fm][r] = 0.f;
     trace_mark(a, 1);
-    if (stager) pk_wait_vmcnt<XCH + AL>(); else pk_wait_vmcnt<AL>();  // X(kt_begin), A(kt_begin) have landed (this wave's share)
-    __builtin_amdgcn_s_barrier();
-    issue_x();  // X(kt_begin + NS - 1)
     trace_mark(a, 2);
+    __builtin_amdgcn_s_barrier();  // tile kt_begin has landed
     trace_mark(a, 3);
 
     int cstage = 0;
@@ -229,17 +235,15 @@ __global__ void __launch_bounds__(WN * 64, (BM >= 128 && BN / (WN * 32) >= 2) ? 
         constexpr int SLOT = decltype(slot_tag)::value;
         const char *xs = smem + cstage * STAGE;
         cstage = (cstage + 1 == NS) ? 0 : cstage + 1;
-        load_a(wq[(SLOT + PD - 1) % PD]);  // A(kt + PD - 1) into the registers of tile kt - 1
+        load_a(wq[(SLOT + PD - 1) % PD]);  // weights of tile kt + PD - 1 into the registers tile kt - 1 has finished with
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             if (ks + 1 < 4) {
                 read_b(xs, ks + 1, (ks + 1) & 1);
             } else if (kt + 1 < kt_end) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every activation fragment of tile kt is in registers
-                if (stager) pk_wait_vmcnt<XCH + AL>(); else pk_wait_vmcnt<AL>();
-                __builtin_amdgcn_s_barrier();  // X(kt + 1) has landed everywhere, the stage of tile kt is free
+                __builtin_amdgcn_s_barrier();                       // tile kt + 1 has landed, the stage of tile kt is released
                 asm volatile("" ::: "memory");
-                issue_x();                     // X(kt + NS) into it
                 read_b(smem + cstage * STAGE, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -255,12 +259,14 @@ __global__ void __launch_bounds__(WN * 64, (BM >= 128 && BN / (WN * 32) >= 2) ? 
     for (int kt = kt_begin;;) {
         tile(std::integral_constant<int, 0>{}, kt);
         if (++kt >= kt_end) break;
-        tile(std::integral_constant<int, 1>{}, kt);
+        tile(std::integral_constant<int, 1 % PD>{}, kt);
         if (++kt >= kt_end) break;
-        tile(std::integral_constant<int, 2>{}, kt);
-        if (++kt >= kt_end) break;
+        if constexpr (PD == 3) {
+            tile(std::integral_constant<int, 2>{}, kt);
+            if (++kt >= kt_end) break;
+        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus requests (zero tiles, repeated weight tiles) have landed: LDS and registers are free
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus weight requests have landed before their registers die
     trace_mark(a, 4);
     run_epilogue<T, BM, BN, FN, FM, false, EPI_EARLY, NC, STAGED>(a, acc, epi, smem, m0, n0, m0, n0 + wave * WNB, l31, hi, tid, bt.split);
     trace_finish(a);
@@ -276,10 +282,11 @@ __global__ void __launch_bounds__(WN * 64, (BM >= 128 && BN / (WN * 32) >= 2) ? 
     OP(T, 64, 160, 5, MODE)                \
     OP(T, 128, 128, 4, MODE)
 
-constexpr int PK_NS = 4, PK_PD = 3;
+constexpr int PK_NS = 4;
+constexpr int pk_pd(int BM, int BN, int WN) { return (BM / 32) * (BN / (WN * 32)) >= 8 ? 2 : 3; }
 
 template <typename T, int BM, int BN, int WN, int MODE, bool STAGED> static int pk_set_attr() {
-    auto kern = igemm_pk_kernel<T, BM, BN, WN, PK_NS, PK_PD, MODE, STAGED>;
+    auto kern = igemm_pk_kernel<T, BM, BN, WN, PK_NS, pk_pd(BM, BN, WN), MODE, STAGED>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pk_smem_bytes(BM, BN, PK_NS, STAGED));
     if (e != hipSuccess) {
         set_error("hipFuncSetAttribute(igemm_pk %dx%d): %s", BM, BN, hipGetErrorString(e));
@@ -304,11 +311,11 @@ template <typename T, int MODE> static int pk_dispatch(const IgemmArgs &a, int B
 #define LAUNCH_OP(TT, BM, BN, WN, MODE_)                                                                                            \
     if (BM_ == BM && BN_ == BN) {                                                                                                   \
         if (a.stage_out) {                                                                                                          \
-            hipLaunchKernelGGL((igemm_pk_kernel<TT, BM, BN, WN, PK_NS, PK_PD, MODE_, true>), igemm_grid(a), dim3(WN * 64),          \
+            hipLaunchKernelGGL((igemm_pk_kernel<TT, BM, BN, WN, PK_NS, pk_pd(BM, BN, WN), MODE_, true>), igemm_grid(a), dim3((WN + 1) * 64),          \
                                pk_smem_bytes(BM, BN, PK_NS, true), st, a);                                                          \
             return check_launch("igemm_pk_staged");                                                                                 \
         }                                                                                                                           \
-        hipLaunchKernelGGL((igemm_pk_kernel<TT, BM, BN, WN, PK_NS, PK_PD, MODE_, false>), igemm_grid(a), dim3(WN * 64),             \
+        hipLaunchKernelGGL((igemm_pk_kernel<TT, BM, BN, WN, PK_NS, pk_pd(BM, BN, WN), MODE_, false>), igemm_grid(a), dim3((WN + 1) * 64),             \
                            pk_smem_bytes(BM, BN, PK_NS, false), st, a);                                                             \
         return check_launch("igemm_pk");                                                                                            \
     }

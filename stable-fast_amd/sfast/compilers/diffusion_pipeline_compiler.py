@@ -105,7 +105,7 @@ class _NativeUNetForward:
             self._warned = True
         return self.orig_forward(*args, **kwargs)
 
-    def _prepare(self, key, sample, timestep, ehs, added, down_res, mid_res, emask=None, tcond=None, clabels=None):
+    def _prepare(self, key, sample, timestep, ehs, added, down_res, mid_res, emask=None, tcond=None, clabels=None, lora_scale=1.0):
         eng = self.engine
         B, H, W, S, ctrl, has_mask, has_tcond, ip = key
         # everything below (kernel-attribute setup, autotune launches and their event timing, warm-up, capture) must run with
@@ -118,7 +118,7 @@ class _NativeUNetForward:
         # warm-up: runs the whole plan eagerly (also validates every launch before capture)
         torch.cuda.synchronize(eng.device)
         with torch.cuda.device(eng.device), torch.cuda.stream(torch.cuda.Stream(device=eng.device)):
-            eng.load_inputs(plan, sample, timestep, ehs, added, down_res, mid_res, emask, tcond, clabels)
+            eng.load_inputs(plan, sample, timestep, ehs, added, down_res, mid_res, emask, tcond, clabels, lora_scale)
             for _ in range(self.warmups if self.enable_graph else 1):
                 plan.run(torch.cuda.current_stream(eng.device).cuda_stream)
         torch.cuda.synchronize(eng.device)
@@ -143,8 +143,8 @@ class _NativeUNetForward:
         if emask is not None and not (torch.is_tensor(emask) and emask.device.type == "cuda" and emask.shape[0] == sample.shape[0]
                                       and ((emask.ndim == 2) or (emask.ndim == 3 and emask.shape[1] == 1))):
             bad.append("encoder_attention_mask (need [B, S] or [B, 1, S] on the GPU)")
-        # cross_attention_kwargs: diffusers pops "scale" and applies it to LoRA layers only. The engine refuses modules with LoRA /
-        # adapter parameters at construction (parameter inventory), so here the scale has nothing to act on and is accepted; any
+        # cross_attention_kwargs: diffusers pops "scale" and applies it to LoRA layers only: un-fused LoRA factors the engine took over
+        # (UNet2DEngine.lora) are scaled by it through the merge launch's scale table, without them it has nothing to act on; any
         # other key (ip_adapter_masks, gligen, ...) selects an attention processor the plan does not implement
         if cross_attention_kwargs and set(cross_attention_kwargs) - {"scale"}:
             bad.append("cross_attention_kwargs " + str(sorted(set(cross_attention_kwargs) - {"scale"})))
@@ -194,6 +194,7 @@ class _NativeUNetForward:
                                   encoder_hidden_states=encoder_hidden_states, return_dict=return_dict,
                                   **{k: v for k, v in given.items() if v is not None})
         B, _, H, W = sample.shape
+        lora_scale = float((cross_attention_kwargs or {}).get("scale", 1.0))
         key = (B, H, W, encoder_hidden_states.shape[1], ctrl, emask is not None, tcond is not None, ip)
         entry = self._cached.get(key)
         if entry is None:
@@ -203,7 +204,7 @@ class _NativeUNetForward:
                     logger.info("sfast: building native UNet plan for %s (graph=%s)", key, self.enable_graph)
                     try:
                         entry = self._prepare(key, sample, timestep, encoder_hidden_states, added_cond_kwargs,
-                                              down_block_additional_residuals, mid_block_additional_residual, emask, tcond, clabels)
+                                              down_block_additional_residuals, mid_block_additional_residual, emask, tcond, clabels, lora_scale)
                     except (NotImplementedError, KeyError) as e:
                         # this signature is outside the plan's coverage (e.g. a latent size the levels do not divide, a
                         # parameter the planner expected but a wrapper renamed): keep the module's own forward for it
@@ -221,7 +222,7 @@ class _NativeUNetForward:
         with env.lock, torch.cuda.device(eng.device):
             eng.sync_packed()  # packed weight copies follow the live parameters (version counters); a no-op when nothing changed
             eng.load_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs,
-                            down_block_additional_residuals, mid_block_additional_residual, emask, tcond, clabels)
+                            down_block_additional_residuals, mid_block_additional_residual, emask, tcond, clabels, lora_scale)
             if graph is not None:
                 graph.replay()
             else:

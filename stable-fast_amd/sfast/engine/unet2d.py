@@ -18,6 +18,7 @@ Weights are read from the live parameter storage at every launch (the reference'
 `preserve_parameters=True` / LoRA in-place update contract, README.md:228-265): nothing is baked.
 """
 import ctypes as C
+import logging
 import os
 import threading
 from collections import defaultdict
@@ -62,6 +63,29 @@ def live_norm_eps(m):
     return out
 
 
+def lora_multiplier_sources(m):
+    """base weight name -> callable giving the LIVE factor that multiplies up @ down besides the call's `scale`: diffusers
+    LoRALinearLayer: network_alpha / rank (or 1); peft lora.Linear: scaling[adapter], 0 while the layer is merged or disabled."""
+    out = {}
+    for name, mod in m.named_modules():
+        ll = getattr(mod, "lora_layer", None)
+        if ll is not None and hasattr(ll, "down") and hasattr(ll, "up"):
+            out[name + ".weight"] = (lambda ll=ll: (float(ll.network_alpha) / float(ll.rank)) if getattr(ll, "network_alpha", None) is not None else 1.0)
+        elif hasattr(mod, "base_layer") and hasattr(mod, "lora_A") and hasattr(mod, "lora_B"):
+            def peft_factor(mod=mod):
+                if getattr(mod, "merged", False) or getattr(mod, "disable_adapters", False):
+                    return 0.0
+                act = [a for a in getattr(mod, "active_adapters", []) if a in mod.lora_A]
+                return float(mod.scaling[act[0]]) if act else 0.0
+            out[name + ".weight"] = peft_factor
+        for t in ("to_q", "to_k", "to_v", "to_out"):  # diffusers <= 0.20 LoRAAttnProcessor: <attn>.processor.to_q_lora.{down, up}
+            ll = getattr(getattr(mod, "processor", None), t + "_lora", None)
+            if ll is not None and hasattr(ll, "down"):
+                out[f"{name}.{'to_out.0' if t == 'to_out' else t}.weight"] = (
+                    lambda ll=ll: (float(ll.network_alpha) / float(ll.rank)) if getattr(ll, "network_alpha", None) is not None else 1.0)
+    return out
+
+
 class _Pool:
     """Size-keyed free list of device buffers; a plan is executed in order on one stream, so a
     buffer released by the planner can be handed to any later op."""
@@ -91,6 +115,7 @@ class _Pool:
         return sum(t.numel() * t.element_size() for t in self.all)
 
 
+logger = logging.getLogger(__name__)
 LANE_MAIN, LANE_TEMB, LANE_KV = 0, 1, 2
 
 
@@ -121,6 +146,8 @@ class UNetPlan:
         self.pool = None
         self.keep = []  # ctypes objects / tensors that must outlive the launches
         self.kv_requests = []  # (name, Wk, Wv, kv buffer, C) of every cross-attention block, grouped at the end of build_plan
+        self.P = None     # parameter name -> tensor the plan's launches read: the engine's parameters, LoRA'd weights replaced by merged copies
+        self.lora = None  # un-fused LoRA: dict(table, n, total, eff, eff_ids, last) (UNet2DEngine._emit_lora)
         self.ip = None  # IP-Adapter: dict(tokens=[(buffer [B, S_ip, ctx], S_ip)], requests=[[kv request] per adapter], scales={block: [float]})
         # id(buffer) -> producer record of the op that last wrote the whole buffer (GroupNorm statistics hand-over). A record holds its
         # buffer (`buf`), so the id cannot be recycled by another tensor while the record exists, and writer_of() checks identity.
@@ -292,6 +319,8 @@ class DeviceHost:
 class UNet2DEngine:
     """Executor for SD1.5 / SD2.x / SDXL-family `UNet2DConditionModel` parameter sets."""
 
+    lora = ()         # [(base weight name, down name, up name)] of the un-fused LoRA factors found among the parameters (_parse_lora)
+    _lora_mult = {}   # base weight name -> callable: the live network_alpha / rank or peft scaling (from_module)
     ip_proj = None  # [(prefix, tokens per image, image embedding width)] when an IP-Adapter is loaded (_parse_ip_adapter)
     _ip_processors = {}
     _param_objs = {}  # parameter name -> nn.Parameter (set per instance by from_module): the version counters sync_packed() watches
@@ -340,10 +369,13 @@ class UNet2DEngine:
                         pass
                     else:
                         p.data = d = d.contiguous(memory_format=torch.channels_last)
-                params[name] = d
+                # peft lora.Linear keeps the wrapped layer's tensors under `<linear>.base_layer.*`: the plan knows them by the plain name
+                params[name.replace(".base_layer.", ".")] = d
         eng = cls(cfg, params, _host=_host)
         eng.norm_eps = live_norm_eps(m)
-        eng._param_objs = dict(m.named_parameters())
+        eng._param_objs = {n.replace(".base_layer.", "."): p for n, p in m.named_parameters()}
+        if eng.lora:
+            eng._lora_mult = lora_multiplier_sources(m)
         if getattr(eng, "ip_proj", None):
             # IP-Adapter: `scale` is a python attribute of each attn2 processor (pipe.set_ip_adapter_scale); read live by ip_scales()
             eng._ip_processors = {name: mod.processor for name, mod in m.named_modules()
@@ -465,6 +497,79 @@ class UNet2DEngine:
             elif v not in (None, False):
                 raise UnsupportedUNet(f"unknown config option {k}={v!r}: refusing to guess its meaning")
 
+    _LORA_PATTERNS = (  # (regex on the parameter name, base weight name template): the three layouts diffusers has used
+        (r"^(.*)\.lora_layer\.down\.weight$", "{0}.weight", "{0}.lora_layer.up.weight"),                       # LoRACompatibleLinear (0.21 - 0.24)
+        (r"^(.*)\.lora_A\.([^.]+)\.weight$", "{0}.weight", "{0}.lora_B.{1}.weight"),                             # peft lora.Linear (>= 0.25)
+        (r"^(.*)\.processor\.(to_q|to_k|to_v)_lora\.down\.weight$", "{0}.{1}.weight", "{0}.processor.{1}_lora.up.weight"),  # LoRAAttnProcessor
+        (r"^(.*)\.processor\.to_out_lora\.down\.weight$", "{0}.to_out.0.weight", "{0}.processor.to_out_lora.up.weight"),
+    )
+
+    def _parse_lora(self, want):
+        """Un-fused LoRA factors among the parameters -> [(base, down, up)]. Native for the linears of the transformer blocks (attention
+        projections, feed-forward, linear proj_in / proj_out): their effective weight W + s * up @ down is rebuilt by ONE launch per
+        step (sfast_hip_lora_merge) from the live tensors, so the reference's in-place adapter switch (README.md:228-265) needs no
+        re-capture. Anything else (conv LoRA, two adapters on one layer, DoRA, rank > 128) keeps the module's own forward."""
+        import re
+        found, have = {}, self.params
+        for k in have:
+            if "lora" not in k:
+                continue
+            for pat, base_t, up_t in self._LORA_PATTERNS:
+                mt = re.match(pat, k)
+                if mt:
+                    base, up = base_t.format(*mt.groups()), up_t.format(*mt.groups())
+                    if base in found:
+                        raise UnsupportedUNet(f"more than one LoRA adapter on {base}")
+                    found[base] = (k, up)
+                    break
+        out = []
+        for base, (dn, un) in sorted(found.items()):
+            w = have.get(base)
+            ok = (base in want and un in have and w is not None and w.ndim == 2 and have[dn].ndim == 2 and have[un].ndim == 2
+                  and (".attn1." in base or ".attn2." in base or ".ff.net." in base or base.endswith((".proj_in.weight", ".proj_out.weight")))
+                  and have[dn].shape[1] == w.shape[1] and have[un].shape[0] == w.shape[0] and have[un].shape[1] == have[dn].shape[0]
+                  and have[dn].shape[0] <= L.LORA_MAX_RANK and w.shape[1] % 8 == 0 and hasattr(self.lib, "sfast_hip_lora_merge"))
+            if not ok:
+                raise UnsupportedUNet(f"LoRA factors on {base} are outside the native plan (linear layers of the transformer blocks, rank <= {L.LORA_MAX_RANK})")
+            out.append((base, dn, un))
+        return tuple(out)
+
+    def lora_multipliers(self, scale=1.0):
+        """scales[i] of sfast_hip_lora_merge for this call: cross_attention_kwargs["scale"] times the layer's own live factor."""
+        return [float(scale) * float(self._lora_mult.get(base, lambda: 1.0)()) for base, _, _ in self.lora]
+
+    def _emit_lora(self, plan):
+        lib, n = self.lib, len(self.lora)
+        ents = (L.LoraEntry * n)()
+        eff = {}
+        for i, (base, dn, un) in enumerate(self.lora):
+            w, d, u = self.params[base], self.params[dn], self.params[un]
+            if d.stride(1) != 1 or u.stride(1) != 1 or w.stride(1) != 1:
+                raise UnsupportedUNet(f"LoRA factors of {base} are not row-major")
+            out = torch.empty((w.shape[0], w.shape[1]), dtype=self.dtype, device=self.device)
+            e = ents[i]
+            e.w, e.down, e.up, e.out = w.data_ptr(), d.data_ptr(), u.data_ptr(), out.data_ptr()
+            e.N, e.K, e.r = w.shape[0], w.shape[1], d.shape[0]
+            e.ldw, e.ldd, e.ldu, e.scale_index = w.stride(0), d.stride(0), u.stride(0), i
+            eff[base] = out
+        total = C.c_int32()
+        rc = lib.sfast_hip_lora_merge_plan(ents, n, C.byref(total))
+        if rc != 0:
+            raise UnsupportedUNet(f"LoRA merge table refused ({rc}): {L.last_error() if hasattr(lib, 'sfast_hip_last_error') else ''}")
+        table = torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8).to(self.device)
+        scales = torch.ones(n, dtype=torch.float32, device=self.device)
+        plan.static_in["lora_scale"] = scales
+        plan.lora = dict(table=table, n=n, total=int(total.value), eff=eff, eff_ids={id(t) for t in eff.values()}, last=None)
+        plan.P = dict(self.params)
+        plan.P.update(eff)
+
+    def _op_lora_merge(self, plan):
+        lib, lo = self.lib, plan.lora
+        tp, sp, n, total = lo["table"].data_ptr(), plan.static_in["lora_scale"].data_ptr(), lo["n"], lo["total"]
+        nbytes = sum(2.0 * t.numel() * self.esize for t in lo["eff"].values())
+        self._add(plan, "misc", f"lora.merge[{n} linears]", 0.0, nbytes,
+                  lambda s: L.check(lib.sfast_hip_lora_merge(tp, n, total, sp, self.dt, s), "sfast_hip_lora_merge"), lane=LANE_TEMB)
+
     def _parse_ip_adapter(self):
         """[(parameter prefix, image tokens per image T, image embedding width)] of the ImageProjection layers under `encoder_hid_proj`
         (one per loaded adapter; `MultiIPAdapterImageProjection.image_projection_layers.{i}` or, in older diffusers, the bare layer)."""
@@ -559,6 +664,9 @@ class UNet2DEngine:
             missing = [k for k in want if k not in have]
             if missing:
                 raise UnsupportedUNet(f"IP-Adapter parameters missing for the native plan: {missing[:3]}")
+        self.lora = self._parse_lora(want)
+        for _, dn, un in self.lora:
+            want[dn], want[un] = tuple(have[dn].shape), tuple(have[un].shape)
         extra = [k for k in have if k not in want and not k.startswith("controlnet_")]
         if extra:
             raise UnsupportedUNet(f"module has parameters the native plan would ignore: {extra[:3]}{' ...' if len(extra) > 3 else ''}")
@@ -621,6 +729,11 @@ class UNet2DEngine:
             if rec["users"] <= 0:
                 continue
             p = self._param_objs.get(rec["name"])
+            if p is not None and p.data_ptr() != rec["w"].data_ptr() and not rec.get("warned"):
+                # `p.data = other` / load_state_dict(assign=True): the plan still reads the OLD storage (packed or not)
+                rec["warned"] = True
+                logger.warning("sfast: parameter %s was re-assigned after the engine was built; call refresh_parameters() "
+                               "(the plan reads the storage it was built on)", rec["name"])
             if force or (p is not None and p._version != rec["version"]):
                 self._pack(rec)
                 n += 1
@@ -749,8 +862,10 @@ class UNet2DEngine:
         wrows = (2 * N if geglu else N)
         flops = 2.0 * M * wrows * K
         nbytes = (M * K + wrows * K + wrows + M * N + (M * N if residual is not None else 0)) * self.esize
+        # merged LoRA weights are written by the lora.merge launch at the head of the time-embedding lane: their first reader joins it
+        needs = LANE_TEMB if (lane == LANE_MAIN and plan.lora is not None and any(id(w) in plan.lora["eff_ids"] for w in weights)) else None
         self._add(plan, kind or ("geglu" if geglu else ("gemv" if M <= 16 else "linear")), name, flops, nbytes, launch,
-                  tune=(p, launch_with), lane=lane)
+                  tune=(p, launch_with), lane=lane, needs=needs)
         if not geglu and M > 16:
             recs = self._offer_packed(plan, weights, (ext, text))
             if recs is not None:
@@ -1017,7 +1132,7 @@ class UNet2DEngine:
         return out
 
     def _transformer(self, plan, pre, x, Cc, B, H, W, heads, depth, ctx, S_ctx):
-        pool, P = plan.pool, self.params
+        pool, P = plan.pool, (plan.P if plan.P is not None else self.params)
         M = B * H * W
         S = H * W
         D = Cc // heads
@@ -1126,12 +1241,15 @@ class UNet2DEngine:
         plan = UNetPlan(self, B, H, W, S_ctx)
         pool = plan.pool = _Pool(dev, dt)
         pool.writer = plan.writer
+        plan.P = self.params
+        if self.lora:
+            self._emit_lora(plan)
         # static inputs / output
         sample = torch.zeros((B, self.in_ch, H, W), dtype=dt, device=dev)
         tbuf = torch.zeros((B,), dtype=torch.float32, device=dev)
         ctx = torch.zeros((B, S_ctx, self.ctx_dim), dtype=dt, device=dev)
         out = torch.zeros((B, self.out_ch, H, W), dtype=dt, device=dev)
-        plan.static_in = {"sample": sample, "timestep": tbuf, "encoder_hidden_states": ctx}
+        plan.static_in.update({"sample": sample, "timestep": tbuf, "encoder_hidden_states": ctx})
         if enc_mask:
             # additive key bias of the cross-attention layers: (1 - encoder_attention_mask) * -10000 as diffusers'
             # UNet2DConditionModel.forward builds it, [B, S_ctx] broadcast over heads and queries (row padded to 8 halves)
@@ -1367,6 +1485,8 @@ class UNet2DEngine:
         reqs, plan.kv_requests = plan.kv_requests, []
         new_ops = []
         saved, plan.ops = plan.ops, new_ops
+        if plan.lora is not None:
+            self._op_lora_merge(plan)  # first launch of the step: every LoRA'd linear's effective weight from the live tensors
         self._emit_kv_projections(plan, reqs, ctx, B * S_ctx, "attn2.to_kv")
         if plan.ip is not None:
             P = self.params
@@ -1619,8 +1739,13 @@ class UNet2DEngine:
 
     def load_inputs(self, plan, sample, timestep, encoder_hidden_states, added_cond_kwargs=None,
                     down_block_additional_residuals=None, mid_block_additional_residual=None, encoder_attention_mask=None,
-                    timestep_cond=None, class_labels=None):
+                    timestep_cond=None, class_labels=None, lora_scale=1.0):
         si = plan.static_in
+        if "lora_scale" in si:
+            vals = self.lora_multipliers(lora_scale)
+            if vals != plan.lora["last"]:  # cross_attention_kwargs["scale"] / set_adapters() moved: one small copy, no re-capture
+                si["lora_scale"].copy_(torch.tensor(vals, dtype=torch.float32))
+                plan.lora["last"] = vals
         if "timestep_cond" in si:
             if timestep_cond is None:
                 raise ValueError("this plan takes a timestep_cond")
@@ -1660,7 +1785,7 @@ class UNet2DEngine:
             si["mid_block_additional_residual"].copy_(mid_block_additional_residual)
 
     def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, down_block_additional_residuals=None,
-                mid_block_additional_residual=None, encoder_attention_mask=None, timestep_cond=None, class_labels=None):
+                mid_block_additional_residual=None, encoder_attention_mask=None, timestep_cond=None, class_labels=None, lora_scale=1.0):
         """Eager (no graph) execution on the current stream; returns a fresh NCHW tensor."""
         B, _, H, W = sample.shape
         ctrl = down_block_additional_residuals is not None
@@ -1668,7 +1793,7 @@ class UNet2DEngine:
                              self.ip_signature(added_cond_kwargs))
         self.sync_packed()
         self.load_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs, down_block_additional_residuals,
-                         mid_block_additional_residual, encoder_attention_mask, timestep_cond, class_labels)
+                         mid_block_additional_residual, encoder_attention_mask, timestep_cond, class_labels, lora_scale)
         plan.run(self.host.stream_ptr(self.device))
         return plan.static_out.clone()
 

@@ -391,6 +391,21 @@ class EmuLib:
         _strided(out, (p.B, p.Sq, p.H, p.D), tuple(p.os) + (1,), p.dtype).copy_(o)
         return 0
 
+    def sfast_hip_lora_merge_plan(self, entries, n, total):
+        return self.real.sfast_hip_lora_merge_plan(entries, n, total)  # host-only: validates the table, fills tile_begin
+
+    def sfast_hip_lora_merge(self, table, n, total_tiles, scales, dtype, stream):
+        self.calls.append("lora_merge")
+        ents = (L.LoraEntry * int(n)).from_address(int(table))
+        sc = _flat(scales, n, L.F32) if scales else None
+        for e in ents:
+            w = _strided(e.w, (e.N, e.K), (e.ldw, 1), dtype).float()
+            d = _strided(e.down, (e.r, e.K), (e.ldd, 1), dtype).float()
+            u = _strided(e.up, (e.N, e.r), (e.ldu, 1), dtype).float()
+            s = float(sc[e.scale_index]) if sc is not None else 1.0
+            _flat(e.out, e.N * e.K, dtype).reshape(e.N, e.K).copy_(w + s * (u @ d))
+        return 0
+
     def sfast_hip_mix_rows(self, x, y, vec, mix, out, ref, stream):
         p = _p(ref)
         self.calls.append("mix_rows")

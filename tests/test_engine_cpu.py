@@ -613,3 +613,61 @@ def test_sdxl_style_controlnet_takes_text_time_conditioning(built_lib):
     assert rel_l2(om, wm) > 1e-2                                   # the conditioning reaches the output
     with pytest.raises(ValueError, match="text_embeds"):
         ceng.forward(s, 300, e, cond)                              # required, as in diffusers
+
+
+# ---- un-fused LoRA (/root/reference/README.md:228-265 "Dynamically Switch LoRA") ----------------------------------
+@pytest.mark.parametrize("style", ["diffusers", "peft"])
+def test_plan_takes_over_unfused_lora(built_lib, style):
+    """`unet.load_attn_procs(lora)` before compile (the reference's own LoRA test, tests/compilers/test_stable_diffusion_pipeline_compiler.py
+    :327-328): the factors stay separate parameters. The plan rebuilds W + s * up @ down per step from the live tensors (one launch)
+    and reads the merged copies -- same numbers as the un-fused forward, for both state-dict layouts, for any cross_attention_kwargs
+    scale, and after an in-place adapter switch without rebuilding anything."""
+    m16, m32 = _pair(U.tiny_config(), 12)
+    for m in (m16, m32):
+        m.load_lora(rank=4, network_alpha=8.0, seed=5, style=style, up_scale=0.05)
+    m32.load_state_dict({k: v.float() for k, v in m16.state_dict().items()})
+    emu = EmuLib()
+    eng = UNet2DEngine.from_module(m16, _host=EmuHost(emu))
+    n_lin = sum(1 for n, mod in m16.named_modules() if n.endswith((".attn1", ".attn2"))) * 4
+    assert len(eng.lora) == n_lin and all(b.endswith(".weight") and ".base_layer" not in b for b, _, _ in eng.lora)
+    g = torch.Generator().manual_seed(6)
+    s = torch.randn(2, 4, 16, 16, generator=g).half()
+    e = torch.randn(2, 20, 64, generator=g).half()
+    y = eng.forward(s, 600, e)
+    with torch.no_grad():
+        want = m32(s.float(), 600, e.float()).sample
+        base = m32(s.float(), 600, e.float(), cross_attention_kwargs={"scale": 0.0}).sample
+        half = m32(s.float(), 600, e.float(), cross_attention_kwargs={"scale": 0.5}).sample
+    assert rel_l2(y, want) < 3e-3 and rel_l2(base, want) > 1e-2                      # the adapter matters and is applied
+    plan = next(iter(eng._plans.values()))
+    assert plan.ops[0].name.startswith("lora.merge[") and emu.calls.count("lora_merge") == 1
+    # cross_attention_kwargs["scale"]: a value of the merge launch's scale table, not a new plan
+    yh = eng.forward(s, 600, e, lora_scale=0.5)
+    y0 = eng.forward(s, 600, e, lora_scale=0.0)
+    assert rel_l2(yh, half) < 3e-3 and rel_l2(y0, base) < 3e-3 and len(eng._plans) == 1
+    # the reference's adapter switch: copy another adapter's tensors into the SAME storage, in place
+    sd16, sd32 = m16.state_dict(), m32.state_dict()
+    with torch.no_grad():
+        for k in [k for k in sd16 if "lora" in k]:
+            new = torch.randn(sd16[k].shape, generator=g) * (0.05 if ("up" in k or "lora_B" in k) else sd16[k].shape[1] ** -0.5)
+            sd16[k].copy_(new)
+            sd32[k].copy_(sd16[k].float())
+        want2 = m32(s.float(), 600, e.float()).sample
+    y2 = eng.forward(s, 600, e)
+    assert rel_l2(y2, want2) < 3e-3 and rel_l2(want2, want) > 1e-2 and len(eng._plans) == 1
+
+
+def test_lora_outside_the_native_coverage_is_refused(built_lib):
+    m16 = U.build(U.tiny_config(), seed=2, dtype=torch.float16)
+    m16.load_lora(rank=4, seed=1)
+    params = {k: v.data for k, v in m16.named_parameters()}
+    bad = dict(params)
+    k = next(k for k in params if k.endswith("attn1.to_q.lora_layer.up.weight"))
+    del bad[k]                                                                       # a down factor without its up factor
+    with pytest.raises(UnsupportedUNet):
+        UNet2DEngine(m16.config, bad, _host=EmuHost())
+    conv_lora = dict(params)
+    conv_lora["conv_in.lora_layer.down.weight"] = torch.zeros(4, 4, 3, 3).half()     # conv LoRA: not built
+    conv_lora["conv_in.lora_layer.up.weight"] = torch.zeros(64, 4, 1, 1).half()
+    with pytest.raises(UnsupportedUNet):
+        UNet2DEngine(m16.config, conv_lora, _host=EmuHost())

@@ -250,12 +250,18 @@ def test_packaged_tune_cache_is_well_formed():
     with open(autotune.PACKAGED_CACHE) as f:
         d = json.load(f)
     assert len(d) > 100
+    n_pk = 0
     for k, (v, s) in d.items():
-        arch, dt, kind, mnk, epi = k.split("|")
+        arch, dt, kind, mnk, epi = k.split("|")[:5]
+        packed = k.endswith("|pk")   # the same problem with a packed copy of the weight at hand: pipe-4 variants are candidates too
+        assert len(k.split("|")) == (6 if packed else 5), k
         assert arch == "gfx950" and dt in ("f16", "bf16") and kind in ("gemm", "conv"), k
         assert len(mnk.split("x")) == 3
         geglu = kind == "gemm" and epi.startswith("(1,")
-        assert v in (autotune.GEGLU_VARIANTS if geglu else autotune.VARIANTS) and s in autotune.SPLITS, (k, v, s)
+        allowed = autotune.GEGLU_VARIANTS if geglu else (autotune.VARIANTS + (autotune.PK_VARIANTS if packed else ()))
+        assert v in allowed and s in autotune.SPLITS, (k, v, s)
+        n_pk += packed
+    assert n_pk > 50   # round 4: the SD1.5 / SDXL problems were re-timed with the packed-weight pipe among the candidates
     n0 = len(autotune.export_cache())
     assert autotune.import_cache(d) >= 0 and len(autotune.export_cache()) >= max(n0, len(d))
 

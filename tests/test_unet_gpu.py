@@ -672,3 +672,78 @@ def test_sdxl_style_controlnet_native_and_through_compile():
         d2, m2 = cm(sample, 300, encoder_hidden_states=ehs, controlnet_cond=cond, conditioning_scale=0.9, guess_mode=True,
                     added_cond_kwargs=added, return_dict=False)
         assert not cm.forward._warned and torch.equal(m2, mid) and all(torch.equal(a, b) for a, b in zip(d2, down))
+
+
+@pytest.mark.parametrize("style", ["diffusers", "peft"])
+def test_unfused_lora_native_and_switched_in_place(style):
+    """A UNet with LoRA factors loaded and NOT fused (the reference's own LoRA test loads the adapter before compile(),
+    /root/reference/tests/compilers/test_stable_diffusion_pipeline_compiler.py:327-328) runs on the native plan: one merge launch per
+    step rebuilds the effective weights from the live tensors. cross_attention_kwargs["scale"] and the README's in-place adapter
+    switch (README.md:228-265) act on the captured graph without re-capture."""
+    from sfast.compilers.diffusion_pipeline_compiler import CompilationConfig, compile_unet
+    cfg = U.tiny_config()
+    m = U.build(cfg, seed=31, dtype=torch.float16, device=DEV)
+    ref = U.build(cfg, seed=31, dtype=torch.float32, device=DEV)
+    for mm in (m, ref):
+        mm.load_lora(rank=8, network_alpha=4.0, seed=9, style=style, up_scale=0.05)
+    ref.load_state_dict({k: v.float() for k, v in m.state_dict().items()})
+    sample, ehs = _inputs(cfg, 2, seed=8, S=77)
+    with torch.no_grad():
+        want = ref(sample.float(), 300, ehs.float()).sample
+        want_half = ref(sample.float(), 300, ehs.float(), cross_attention_kwargs={"scale": 0.5}).sample
+        want_off = ref(sample.float(), 300, ehs.float(), cross_attention_kwargs={"scale": 0.0}).sample
+    eng = _engine(m)
+    y = eng.forward(sample, 300, ehs)
+    log_value(f"tiny unet + un-fused lora ({style}) vs fp32 oracle", rel_l2=rel_l2(y, want), adapter_effect=rel_l2(want_off, want), linears=len(eng.lora))
+    assert rel_l2(y, want) < 4e-3 and rel_l2(want_off, want) > 1e-2
+    config = CompilationConfig.Default()
+    config.enable_cuda_graph = True
+    cm = compile_unet(m, config)
+    out = cm(sample, 300, encoder_hidden_states=ehs, return_dict=False)[0]
+    assert not cm.forward._warned and torch.equal(out, y)
+    half = cm(sample, 300, encoder_hidden_states=ehs, cross_attention_kwargs={"scale": 0.5}, return_dict=False)[0]
+    off = cm(sample, 300, encoder_hidden_states=ehs, cross_attention_kwargs={"scale": 0.0}, return_dict=False)[0]
+    assert rel_l2(half, want_half) < 4e-3 and rel_l2(off, want_off) < 4e-3 and len(cm.forward._cached) == 1     # one graph, three scales
+    # switch the adapter: other factors into the same tensors
+    g = torch.Generator().manual_seed(77)
+    sd, sdr = m.state_dict(), ref.state_dict()
+    with torch.no_grad():
+        for k in [k for k in sd if "lora" in k]:
+            sd[k].copy_((torch.randn(sd[k].shape, generator=g) * (0.05 if ("up" in k or "lora_B" in k) else sd[k].shape[1] ** -0.5)).to(DEV))
+            sdr[k].copy_(sd[k].float())
+        want2 = ref(sample.float(), 300, ehs.float()).sample
+    out2 = cm(sample, 300, encoder_hidden_states=ehs, return_dict=False)[0]
+    assert rel_l2(out2, want2) < 4e-3 and rel_l2(want2, want) > 1e-2 and len(cm.forward._cached) == 1
+
+
+def test_sd15_lora_step_cost(sd15):
+    """Full-size SD1.5 with rank-16 LoRA on all 128 attention projections: parity, and what the per-step merge launch costs."""
+    import copy
+    m = copy.deepcopy(sd15)
+    m.load_lora(rank=16, network_alpha=16.0, seed=2, up_scale=0.02)
+    sample, ehs = _inputs(U.SD15_CONFIG, 2, seed=3)
+    eng = _engine(m)
+    assert len(eng.lora) == 128
+    y = eng.forward(sample, 981, ehs)
+    with torch.no_grad():
+        y16 = m(sample, 981, ehs).sample
+        ref = U.build("sd15", seed=0, dtype=torch.float32, device=DEV)
+        ref.load_lora(rank=16, network_alpha=16.0, seed=2, up_scale=0.02)
+        ref.load_state_dict({k: v.float() for k, v in m.state_dict().items()})
+        y32 = ref(sample.float(), 981, ehs.float()).sample
+        y32_off = ref(sample.float(), 981, ehs.float(), cross_attention_kwargs={"scale": 0.0}).sample
+        del ref
+    plan = next(iter(eng._plans.values()))
+    merge = plan.ops[0]
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s = torch.cuda.current_stream().cuda_stream
+    merge.launch(s)
+    a.record()
+    for _ in range(20):
+        merge.launch(s)
+    b.record()
+    b.synchronize()
+    e_engine, e_eager = rel_l2(y, y32), rel_l2(y16, y32)
+    log_value("sd15 B=2 + un-fused lora r16 parity", engine_vs_fp32=e_engine, eager16_vs_fp32=e_eager, adapter_effect=rel_l2(y32_off, y32),
+              merge_launch_us=a.elapsed_time(b) * 1e3 / 20, merged_mbytes=merge.bytes / 2e6)
+    assert merge.name.startswith("lora.merge[128") and torch.isfinite(y).all() and e_engine < 2.5e-3, (e_engine, e_eager)

@@ -124,5 +124,24 @@ s13)  # pipe 4 in the step: 1x1 conv parity, whole-UNet parity + live weight upd
   SFAST_PACKED_WEIGHTS=0 run bench_nopk 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
   SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_pk.json run bench_pk2 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
   ;;
+s14)  # where pipe 4 stands against the ring kernels per shape, and where its workgroups spend their time
+  run t_pk 1500 $PYT tests/test_packed_weights_gpu.py -x
+  run pk_ab 900 python tools/pk_ab.py
+  run pk_trace 300 python tools/pk_trace.py
+  ;;
+s15)  # the step with pipe 4 among the tuner's candidates, against the same build without packed copies
+  SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_pk.json run bench_pk 900 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --dump-kernels gpurun_out/kernels_pk.json
+  SFAST_PACKED_WEIGHTS=0 run bench_nopk 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_pk.json run bench_pk2 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  SFAST_PACKED_WEIGHTS=0 run bench_nopk2 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_pk_sdxl.json run bench_sdxl_pk 900 python bench.py --config sdxl --no-cpu-baseline --no-roofline
+  SFAST_PACKED_WEIGHTS=0 run bench_sdxl_nopk 900 python bench.py --config sdxl --no-cpu-baseline --no-roofline
+  run t_unet 1200 $PYT tests/test_unet_gpu.py -k "sd15_unet_parity or tiny or live_weight or compile_drop_in"
+  ;;
+s16)  # un-fused LoRA on the native plan (both layouts, scale, in-place switch, SD1.5-size merge cost); op-level tests of the round
+  run t_lora 1500 $PYT tests/test_unet_gpu.py -k "lora"
+  run t_pk 1500 $PYT tests/test_packed_weights_gpu.py
+  run t_gnconv 600 $PYT tests/test_ops_gpu.py -k "gn_conv2d"
+  ;;
 esac
 cat gpurun_out/session.log
