@@ -333,7 +333,8 @@ int sfast_hip_conv2d_ex(const void *x, const void *x2, const void *w, const void
  * else: SFAST_ERR_UNSUPPORTED -- callers run the two operators. workspace: sfast_hip_gn_conv2d_workspace_bytes (fp32 slabs). */
 typedef struct {
     sfast_conv_params conv; /* geometry, strides and epilogue of the convolution (of the NORMALISED input) */
-    int32_t groups;         /* GroupNorm groups over conv.Cin channels */
+    int32_t groups;         /* GroupNorm groups over conv.Cin channels; 0: no normalisation (the weight-streaming conv alone, a measured
+                             * candidate that no plan selects: gamma / beta / eps / gn_act are ignored, Cin % 16 == 0) */
     float eps;
     int32_t gn_act;         /* SFAST_ACT_NONE or SFAST_ACT_SILU, applied after the affine */
 } sfast_gn_conv_params;

@@ -283,7 +283,9 @@ __global__ void __launch_bounds__((WN + 1) * 64, 2) igemm_pk_kernel(const IgemmA
     OP(T, 128, 128, 4, MODE)
 
 constexpr int PK_NS = 4;
-constexpr int pk_pd(int BM, int BN, int WN) { return (BM / 32) * (BN / (WN * 32)) >= 8 ? 2 : 3; }
+// weight tiles held in registers: 3 where one tile is 4 loads per lane (FN = 1), 2 where it is 8 (FN = 2: the third set does not fit
+// under 256 registers beside a 64 x 64 .. 128 x 64 accumulator without spilling)
+constexpr int pk_pd(int BM, int BN, int WN) { return BN / (WN * 32) >= 2 ? 2 : 3; }
 
 template <typename T, int BM, int BN, int WN, int MODE, bool STAGED> static int pk_set_attr() {
     auto kern = igemm_pk_kernel<T, BM, BN, WN, PK_NS, pk_pd(BM, BN, WN), MODE, STAGED>;

@@ -1063,6 +1063,19 @@ def test_gn_conv2d_fused(case, dtype):
     compare(f"gn_conv2d vs two operators {name} {dtype}", y, y2.float(), *tol(dtype, 3.0), kernel=k)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_gn_conv2d_without_groupnorm_is_the_plain_conv(dtype):
+    """groups = 0: the same weight-streaming launch without the normalisation ("wsconv") -- measured against the tuned ring kernels and not
+    selected anywhere (profiles/r04_wdirect_wsconv_run15.log: 20.6 vs 16.5 us at the 8x8 level); kept as the probe it is."""
+    x = cl(rnd(2, 1280, 8, 8, dtype=dtype, seed=311))
+    x2 = cl(rnd(2, 1280, 8, 8, dtype=dtype, seed=312))
+    w = cl(rnd(640, 2560, 3, 3, dtype=dtype, seed=313, scale=(9 * 2560) ** -0.5))
+    b, rb = rnd(640, dtype=dtype, seed=314), rnd(2, 640, dtype=dtype, seed=315)
+    y = F().gn_conv2d(x, 0, None, None, w, b, x2=x2, rowbias=rb)
+    assert "wsconv" in last_kernel(), last_kernel()
+    compare(f"wsconv {dtype}", y, R.conv2d_ref(x, w, b, None, 1.0, 1, 1, x2=x2, rowbias=rb), *tol(dtype, 2.0), kernel=last_kernel())
+
+
 def test_gn_conv2d_refuses_what_it_does_not_cover():
     from sfast.hip import lib
     x = cl(rnd(2, 1280, 16, 16, seed=311))               # 512 pixels

@@ -143,5 +143,17 @@ s16)  # un-fused LoRA on the native plan (both layouts, scale, in-place switch, 
   run t_pk 1500 $PYT tests/test_packed_weights_gpu.py
   run t_gnconv 600 $PYT tests/test_ops_gpu.py -k "gn_conv2d"
   ;;
+final2)  # end of round 4: the whole GPU suite on HEAD, smoke, the default bench line, kernel stats, 1-rank torchrun, 8 images per GPU, SVD-XT
+  run pytest_full 2400 $PYT tests
+  run smoke 600 python __graft_entry__.py smoke
+  run bench_default 1200 python bench.py --dump-kernels gpurun_out/kernels.json
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -o bench -- python $OLDPWD/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants > $OLDPWD/gpurun_out/rocprof.log 2>&1 )
+  echo "rocprof exit=$?" >> gpurun_out/session.log
+  for db in $(find gpurun_out/prof -name "*.db"); do python tools/rocpd_summary.py $db --csv gpurun_out/kernel_stats.csv --top 60 --step-marker cfg_ddim --steps 12 > gpurun_out/kernel_stats.txt; done
+  rm -rf gpurun_out/prof
+  run bench_torchrun 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 50 --warmup 10 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants
+  SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_images8.json run bench_images8 1200 python bench.py --images 8 --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants
+  SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_svd.json run bench_svd 1500 python bench.py --config svd --no-cpu-baseline
+  ;;
 esac
 cat gpurun_out/session.log
