@@ -963,6 +963,7 @@ def main():
             "gpu_ms_per_step_events": gpu_ms / args.steps, "outputs_finite": finite,
             "reference_published_other_hw": {"H100": 104.6, "A100": 61.8, "RTX4080": 51.6, "source": "BASELINE.md section 1 (stable-fast README)"},
             "kernel_launches_per_step": len(loop._step_ops) + 2, "text_kv_in_step_graph": not loop.hoist_text_kv,
+            "packed_weight_launches": int(getattr(loop.plan, "packed_ops", 0)),  # GEMM / conv launches on the pipe-4 kernels (SFAST_PACKED_WEIGHTS=0: none)
             "graph_calibration_ms": getattr(loop.plan, "graph_calibration_ms", None),
             "activation_pool_mb": loop.plan.pool.total_bytes() / 1e6,
         }
