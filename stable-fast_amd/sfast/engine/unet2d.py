@@ -725,7 +725,7 @@ class UNet2DEngine:
         """Re-pack every packed weight whose parameter changed since it was packed (version counter), or all of them (`force`).
         Launches on the current stream, outside any graph; a no-op costing a few microseconds when nothing changed."""
         n = 0
-        for rec in self._pk.values():
+        for rec in list(self._pk.values()):  # a snapshot: another thread may be building a plan (new records) while this one replays
             if rec["users"] <= 0:
                 continue
             p = self._param_objs.get(rec["name"])
