@@ -242,6 +242,43 @@ class FeedForward(nn.Module):
         return self.net[2](self.net[0](x))
 
 
+class ImageResampler(nn.Module):
+    """Stand-in for diffusers `IPAdapterPlusImageProjection` (the perceiver resampler of IP-Adapter Plus): learned latents
+    cross-attend to the patch embeddings of the image encoder, then a projection and a LayerNorm -- [N, patches, D] -> [N, T, ctx].
+    One attention layer instead of four: what matters here is that it is NOT Linear + LayerNorm, so the engine cannot run it."""
+
+    def __init__(self, embed_dim, cross_attention_dim, num_queries=6, heads=2):
+        super().__init__()
+        self.latents = nn.Parameter(torch.randn(1, num_queries, embed_dim) / embed_dim ** 0.5)
+        self.norm_in = nn.LayerNorm(embed_dim)
+        self.attn = nn.MultiheadAttention(embed_dim, heads, batch_first=True)
+        self.proj_out = nn.Linear(embed_dim, cross_attention_dim)
+        self.norm_out = nn.LayerNorm(cross_attention_dim)
+
+    def forward(self, x):
+        lat = self.latents.expand(x.shape[0], -1, -1).to(x.dtype)
+        xn = self.norm_in(x)
+        lat = lat + self.attn(lat, xn, xn, need_weights=False)[0]
+        return self.norm_out(self.proj_out(lat))
+
+
+class MultiIPAdapterImageProjection(nn.Module):
+    """diffusers `MultiIPAdapterImageProjection` (models/embeddings.py): one projection layer per adapter; forward takes the LIST of
+    image embeddings ([B, images, ...] each), projects every image and returns one [B, images * T, ctx] tensor per adapter."""
+
+    def __init__(self, layers):
+        super().__init__()
+        self.image_projection_layers = nn.ModuleList(layers)
+
+    def forward(self, image_embeds):
+        out = []
+        for emb, layer in zip(image_embeds, self.image_projection_layers):
+            b, n = emb.shape[:2]
+            y = layer(emb.reshape((b * n,) + emb.shape[2:]))
+            out.append(y.reshape((b, n * y.shape[1]) + y.shape[2:]))
+        return out
+
+
 class BasicTransformerBlock(nn.Module):
     def __init__(self, dim, heads, ctx_dim):
         super().__init__()
@@ -428,6 +465,16 @@ class UNet2DConditionModel(nn.Module):
         self.conv_norm_out = nn.GroupNorm(g, boc[0], eps=eps)
         self.conv_out = nn.Conv2d(boc[0], c.out_channels, 3, padding=1)
 
+    def load_ip_adapter_plus(self, image_embed_dim=32, num_tokens=6, scale=1.0, seed=0):
+        """IP-Adapter Plus: as load_ip_adapter(), with a resampler over PATCH embeddings ([B, images, patches, D]) as the projection."""
+        self.load_ip_adapter(image_embed_dim, num_tokens, scale, seed)
+        torch.manual_seed(seed + 100)
+        res = ImageResampler(image_embed_dim, self.config.cross_attention_dim, num_tokens).to(self.device, self.dtype)
+        self.encoder_hid_proj = MultiIPAdapterImageProjection([res])
+        for q in self.parameters():
+            q.requires_grad_(False)
+        return self
+
     def load_ip_adapter(self, image_embed_dim=32, num_tokens=4, scale=1.0, seed=0):
         """What diffusers' `pipe.load_ip_adapter(...)` does to the UNet (loaders/unet.py `_load_ip_adapter_weights`), with seeded random
         weights: `encoder_hid_proj` = ImageProjection, config.encoder_hid_dim_type = "ip_image_proj", and an IPAdapterAttnProcessor
@@ -519,6 +566,9 @@ class UNet2DConditionModel(nn.Module):
             ie = added_cond_kwargs["image_embeds"]
             ie = list(ie) if isinstance(ie, (list, tuple)) else [ie]
             ip = []
+            if isinstance(self.encoder_hid_proj, MultiIPAdapterImageProjection):
+                ip = [t_.to(sample.dtype) for t_ in self.encoder_hid_proj([t_.to(self.dtype) for t_ in ie])]
+                ie = []
             for t_ in ie:  # MultiIPAdapterImageProjection.forward: [B, images, D] -> project every image -> [B, images * T, ctx]
                 t_ = t_[:, None] if t_.ndim == 2 else t_
                 b_, n_ = t_.shape[:2]

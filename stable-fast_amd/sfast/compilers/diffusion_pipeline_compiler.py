@@ -99,6 +99,20 @@ class _NativeUNetForward:
         self.__self__ = module
         self.__name__ = "forward"
 
+    def _projected_image_tokens(self, image_embeds):
+        """IP-Adapters whose image projection is not a plain ImageProjection (IP-Adapter Plus' resampler, ...): the module's own
+        `encoder_hid_proj` runs eagerly, ONCE per distinct image_embeds -- pipelines pass the same tensors at every denoise step -- and
+        the plan takes the projected tokens. The cache key is (storage, version counter, shape) of every tensor."""
+        ie = list(image_embeds) if isinstance(image_embeds, (list, tuple)) else [image_embeds]
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype) for t in ie)
+        hit = getattr(self, "_ip_tokens", None)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                out = self.module.encoder_hid_proj(image_embeds if isinstance(image_embeds, (list, tuple)) else ie[0])
+            out = list(out) if isinstance(out, (list, tuple)) else [out]
+            hit = self._ip_tokens = (key, [t.to(self.engine.dtype).contiguous() for t in out])
+        return hit[1]
+
     def _fallback(self, why, *args, **kwargs):
         if not self._warned:
             logger.warning("sfast: UNet call not handled by the native engine (%s); running the original forward", why)
@@ -175,6 +189,8 @@ class _NativeUNetForward:
         ip = None
         if getattr(eng, "ip_proj", None) and not bad:
             try:
+                if eng.ip_external and added_cond_kwargs and added_cond_kwargs.get("image_embeds") is not None:
+                    added_cond_kwargs = dict(added_cond_kwargs, ip_hidden_states=self._projected_image_tokens(added_cond_kwargs["image_embeds"]))
                 ip = eng.ip_signature(added_cond_kwargs)
                 if not all(t.device.type == "cuda" for t in eng._ip_embeds(added_cond_kwargs, sample.shape[0])):
                     bad.append("image_embeds (need tensors on the GPU)")

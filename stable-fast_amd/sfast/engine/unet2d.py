@@ -580,8 +580,19 @@ class UNet2DEngine:
         else:
             while f"encoder_hid_proj.image_projection_layers.{len(pres)}.image_embeds.weight" in P:
                 pres.append(f"encoder_hid_proj.image_projection_layers.{len(pres)}")
-        if not pres or not isinstance(ctx, int):
-            raise UnsupportedUNet("encoder_hid_proj is not an ImageProjection (IP-Adapter Plus / FaceID resamplers are not built)")
+        if not isinstance(ctx, int):
+            raise UnsupportedUNet("IP-Adapter with a per-block cross_attention_dim")
+        if not pres:
+            # another projection (IP-Adapter Plus' resampler, a user module): the plan does not run it -- it takes the PROJECTED image
+            # tokens (`ip_hidden_states`, one [B, tokens, cross_attention_dim] tensor per adapter) as its input; the compiled forward
+            # computes them with the module's own encoder_hid_proj, once per distinct image_embeds (they do not change along a denoise
+            # loop). One entry (None, None, None) per adapter = per `to_k_ip.{i}` of the attention processors.
+            n = 0
+            while any(k.endswith(f".attn2.processor.to_k_ip.{n}.weight") for k in P):
+                n += 1
+            if n == 0:
+                raise UnsupportedUNet("encoder_hid_dim_type 'ip_image_proj' without to_k_ip / to_v_ip parameters")
+            return [(None, None, None)] * n
         out = []
         for pre in pres:
             w = P[pre + ".image_embeds.weight"]
@@ -589,6 +600,11 @@ class UNet2DEngine:
                 raise UnsupportedUNet(f"{pre} is not an ImageProjection the plan knows")
             out.append((pre, w.shape[0] // ctx, w.shape[1]))
         return out
+
+    @property
+    def ip_external(self):
+        """True when the image projection runs outside the plan (anything but a plain ImageProjection)."""
+        return bool(self.ip_proj) and self.ip_proj[0][0] is None
 
     def ip_scales(self):
         """Snapshot of the live IP-Adapter scales: ((block path, (scale per adapter, ...)), ...). Part of the plan signature -- a scale
@@ -616,6 +632,15 @@ class UNet2DEngine:
         (a bare tensor = one adapter; [B, D] = one image)."""
         if not added_cond_kwargs or added_cond_kwargs.get("image_embeds") is None:
             raise ValueError("encoder_hid_dim_type 'ip_image_proj' requires `image_embeds` in added_cond_kwargs")  # diffusers' own error
+        if self.ip_external:
+            ie = added_cond_kwargs.get("ip_hidden_states")
+            if ie is None:
+                raise UnsupportedUNet("this IP-Adapter's image projection is not part of the plan: pass the projected tokens as "
+                                      "added_cond_kwargs['ip_hidden_states'] (the compiled forward does, with module.encoder_hid_proj)")
+            ie = list(ie) if isinstance(ie, (list, tuple)) else [ie]
+            if len(ie) != len(self.ip_proj) or any(t.ndim != 3 or t.shape[2] != self.ctx_dim or (B is not None and t.shape[0] != B) for t in ie):
+                raise UnsupportedUNet(f"ip_hidden_states: want {len(self.ip_proj)} tensors [B, tokens, {self.ctx_dim}]")
+            return ie
         ie = added_cond_kwargs["image_embeds"]
         ie = list(ie) if isinstance(ie, (list, tuple)) else [ie]
         if len(ie) != len(self.ip_proj):
@@ -655,6 +680,9 @@ class UNet2DEngine:
             # IP-Adapter parameters: ImageProjection (Linear + LayerNorm) per adapter, to_k_ip / to_v_ip per cross-attention and adapter
             ctx = self.ctx_dim
             for pre, T_, dimg in self.ip_proj:
+                if pre is None:  # external projection: its parameters belong to the module's encoder_hid_proj, which the plan never reads
+                    want.update({k: tuple(v.shape) for k, v in have.items() if k.startswith("encoder_hid_proj.")})
+                    continue
                 want.update({pre + ".image_embeds.weight": (T_ * ctx, dimg), pre + ".image_embeds.bias": (T_ * ctx,),
                              pre + ".norm.weight": (ctx,), pre + ".norm.bias": (ctx,)})
             for k in [k for k in want if k.endswith(".attn2.to_k.weight")]:
@@ -1227,6 +1255,8 @@ class UNet2DEngine:
         `image_embeds` (one [B, images, D] tensor per adapter) and runs ImageProjection + the decoupled image cross-attention."""
         if (ip is not None) != bool(self.ip_proj):
             if ip is None:
+                if self.ip_external:
+                    raise UnsupportedUNet("an IP-Adapter with an external image projection needs the `ip` signature (tokens per adapter)")
                 ip = ((1,) * len(self.ip_proj), self.ip_scales())  # one image per adapter, live scales
             else:
                 raise UnsupportedUNet("image_embeds given, but no IP-Adapter is loaded (encoder_hid_dim_type is not 'ip_image_proj')")
@@ -1261,10 +1291,13 @@ class UNet2DEngine:
             n_img, scales = ip
             if len(n_img) != len(self.ip_proj):
                 raise UnsupportedUNet(f"{len(n_img)} image_embeds tensors for {len(self.ip_proj)} IP-Adapters")
-            plan.static_in["image_embeds"] = [torch.zeros((B, int(n), dimg), dtype=dt, device=dev) for n, (_, _, dimg) in zip(n_img, self.ip_proj)]
-            plan.ip = dict(tokens=[(torch.zeros((B, int(n) * T_, self.ctx_dim), dtype=dt, device=dev), int(n) * T_)
-                                   for n, (_, T_, _) in zip(n_img, self.ip_proj)],
-                           requests=[[] for _ in self.ip_proj], scales=dict(scales or ()))
+            if self.ip_external:  # n_img = projected tokens per adapter; the token buffers themselves are the static inputs
+                toks = [(torch.zeros((B, int(n), self.ctx_dim), dtype=dt, device=dev), int(n)) for n in n_img]
+                plan.static_in["ip_hidden_states"] = [t for t, _ in toks]
+            else:
+                plan.static_in["image_embeds"] = [torch.zeros((B, int(n), dimg), dtype=dt, device=dev) for n, (_, _, dimg) in zip(n_img, self.ip_proj)]
+                toks = [(torch.zeros((B, int(n) * T_, self.ctx_dim), dtype=dt, device=dev), int(n) * T_) for n, (_, T_, _) in zip(n_img, self.ip_proj)]
+            plan.ip = dict(tokens=toks, requests=[[] for _ in self.ip_proj], scales=dict(scales or ()))
 
         # ---- time embedding --------------------------------------------------------------------
         c0 = self.boc[0]
@@ -1490,10 +1523,13 @@ class UNet2DEngine:
         self._emit_kv_projections(plan, reqs, ctx, B * S_ctx, "attn2.to_kv")
         if plan.ip is not None:
             P = self.params
-            for i, ((pre, T_, dimg), emb, (tok, S_ip), rq) in enumerate(zip(self.ip_proj, plan.static_in["image_embeds"], plan.ip["tokens"],
-                                                                            plan.ip["requests"])):
+            embs = plan.static_in.get("image_embeds") or [None] * len(self.ip_proj)
+            for i, ((pre, T_, dimg), emb, (tok, S_ip), rq) in enumerate(zip(self.ip_proj, embs, plan.ip["tokens"], plan.ip["requests"])):
                 if not rq:
                     continue  # every scale of this adapter is 0
+                if pre is None:  # projected tokens are a plan input
+                    self._emit_kv_projections(plan, rq, tok, B * S_ip, f"attn2.to_kv_ip.{i}")
+                    continue
                 # ImageProjection: Linear(D_img -> T * ctx) per image, the row re-read as T tokens, LayerNorm over ctx
                 rows = B * (S_ip // T_)
                 lin = torch.empty(rows * T_ * self.ctx_dim, dtype=self.dtype, device=self.device)
@@ -1706,7 +1742,7 @@ class UNet2DEngine:
 
     # ------------------------------------------------------------------------------------------
     def get_plan(self, B, H, W, S_ctx, ctrl=False, enc_mask=False, tcond=False, ip=None):
-        if ip is None and self.ip_proj:
+        if ip is None and self.ip_proj and not self.ip_external:
             ip = ((1,) * len(self.ip_proj), self.ip_scales())
         key = (B, H, W, S_ctx, bool(ctrl), bool(enc_mask), bool(tcond), ip)
         plan = self._plans.get(key)
@@ -1759,11 +1795,12 @@ class UNet2DEngine:
             if encoder_attention_mask is None:
                 raise ValueError("this plan takes an encoder_attention_mask")
             si["encoder_attention_bias"].copy_(self.encoder_attention_bias(encoder_attention_mask, self.dtype))
-        if "image_embeds" in si:
-            for dst, src in zip(si["image_embeds"], self._ip_embeds(added_cond_kwargs, plan.B)):
-                if src.shape[1] != dst.shape[1]:
-                    raise ValueError(f"this plan takes {dst.shape[1]} image(s) per adapter, got {src.shape[1]}")
-                dst.copy_(src)
+        for key in ("image_embeds", "ip_hidden_states"):
+            if key in si:
+                for dst, src in zip(si[key], self._ip_embeds(added_cond_kwargs, plan.B)):
+                    if src.shape[1] != dst.shape[1]:
+                        raise ValueError(f"this plan takes {dst.shape[1]} image(s) / token(s) per adapter, got {src.shape[1]}")
+                    dst.copy_(src)
         si["sample"].copy_(sample)
         if torch.is_tensor(timestep):
             si["timestep"].copy_(timestep.reshape(-1).to(torch.float32).expand(plan.B), non_blocking=True)

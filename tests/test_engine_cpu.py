@@ -671,3 +671,29 @@ def test_lora_outside_the_native_coverage_is_refused(built_lib):
     conv_lora["conv_in.lora_layer.up.weight"] = torch.zeros(64, 4, 1, 1).half()
     with pytest.raises(UnsupportedUNet):
         UNet2DEngine(m16.config, conv_lora, _host=EmuHost())
+
+
+def test_ip_adapter_plus_takes_projected_tokens(built_lib):
+    """An image projection the plan cannot run (IP-Adapter Plus' resampler): the engine takes the PROJECTED tokens as its input
+    (`ip_hidden_states`); everything downstream -- to_k_ip / to_v_ip, second softmax, scaled add -- is the same plan."""
+    m16, m32 = _pair(U.tiny_config(), 14)
+    for m in (m16, m32):
+        m.load_ip_adapter_plus(image_embed_dim=32, num_tokens=6, scale=0.8, seed=15)
+    m32.load_state_dict({k: v.float() for k, v in m16.state_dict().items()})
+    eng = UNet2DEngine.from_module(m16, _host=EmuHost())
+    assert eng.ip_external and eng.ip_proj == [(None, None, None)]
+    g = torch.Generator().manual_seed(16)
+    s = torch.randn(2, 4, 16, 16, generator=g).half()
+    e = torch.randn(2, 20, 64, generator=g).half()
+    patches = torch.randn(2, 1, 9, 32, generator=g).half()                      # [B, images, patches, D]
+    with torch.no_grad():
+        toks = m32.encoder_hid_proj([patches.float()])                           # what the compiled forward computes with the module
+        want = m32(s.float(), 700, e.float(), added_cond_kwargs={"image_embeds": [patches.float()]}).sample
+    assert tuple(toks[0].shape) == (2, 6, 64)
+    added = {"image_embeds": [patches], "ip_hidden_states": [t.half() for t in toks]}
+    y = eng.forward(s, 700, e, added_cond_kwargs=added)
+    assert rel_l2(y, want) < 3e-3
+    names = [op.name for op in next(iter(eng._plans.values())).ops]
+    assert not any(n.startswith("encoder_hid_proj") for n in names) and any(n.startswith("attn2.to_kv_ip.0[") for n in names)
+    with pytest.raises(UnsupportedUNet, match="ip_hidden_states"):
+        eng.forward(s, 700, e, added_cond_kwargs={"image_embeds": [patches]})    # tokens are required at this level

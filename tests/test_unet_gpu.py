@@ -747,3 +747,40 @@ def test_sd15_lora_step_cost(sd15):
     log_value("sd15 B=2 + un-fused lora r16 parity", engine_vs_fp32=e_engine, eager16_vs_fp32=e_eager, adapter_effect=rel_l2(y32_off, y32),
               merge_launch_us=a.elapsed_time(b) * 1e3 / 20, merged_mbytes=merge.bytes / 2e6)
     assert merge.name.startswith("lora.merge[128") and torch.isfinite(y).all() and e_engine < 2.5e-3, (e_engine, e_eager)
+
+
+def test_ip_adapter_plus_through_compile_projects_once():
+    """IP-Adapter Plus: the resampler is not a plan op -- the compiled forward runs the module's encoder_hid_proj once per distinct
+    image_embeds and hands the plan the projected tokens; replays with the same embeddings do not run it again."""
+    from sfast.compilers.diffusion_pipeline_compiler import CompilationConfig, compile_unet
+    cfg = U.tiny_config()
+    m = U.build(cfg, seed=41, dtype=torch.float16, device=DEV)
+    ref = U.build(cfg, seed=41, dtype=torch.float32, device=DEV)
+    for mm in (m, ref):
+        mm.load_ip_adapter_plus(image_embed_dim=32, num_tokens=6, scale=0.7, seed=42)
+    ref.load_state_dict({k: v.float() for k, v in m.state_dict().items()})
+    sample, ehs = _inputs(cfg, 2, seed=9, S=77)
+    g = torch.Generator().manual_seed(10)
+    patches = torch.randn(2, 1, 9, 32, generator=g).to(DEV, torch.float16)
+    with torch.no_grad():
+        want = ref(sample.float(), 400, ehs.float(), added_cond_kwargs={"image_embeds": [patches.float()]}).sample
+        ref.set_ip_adapter_scale(0.0)
+        text_only = ref(sample.float(), 400, ehs.float(), added_cond_kwargs={"image_embeds": [patches.float()]}).sample
+    config = CompilationConfig.Default()
+    config.enable_cuda_graph = True
+    cm = compile_unet(m, config)
+    calls = []
+    hook = m.encoder_hid_proj.register_forward_hook(lambda *a: calls.append(1))
+    kw = dict(encoder_hidden_states=ehs, added_cond_kwargs={"image_embeds": [patches]}, return_dict=False)
+    out = cm(sample, 400, **kw)[0]
+    out2 = cm(sample, 380, **kw)[0]
+    assert not cm.forward._warned and len(calls) == 1 and len(cm.forward._cached) == 1
+    log_value("tiny unet + ip-adapter plus (external projection) vs fp32 oracle", rel_l2=rel_l2(out, want), adapter_effect=rel_l2(text_only, want))
+    assert rel_l2(out, want) < 4e-3 and rel_l2(text_only, want) > 1e-2 and torch.isfinite(out2).all()
+    patches.mul_(-1.0)                                                            # new image: version counter moved -> projected again
+    with torch.no_grad():
+        ref.set_ip_adapter_scale(0.7)
+        want_neg = ref(sample.float(), 400, ehs.float(), added_cond_kwargs={"image_embeds": [patches.float()]}).sample
+    out3 = cm(sample, 400, **kw)[0]
+    hook.remove()
+    assert len(calls) == 2 and rel_l2(out3, want_neg) < 4e-3

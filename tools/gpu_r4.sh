@@ -155,5 +155,8 @@ final2)  # end of round 4: the whole GPU suite on HEAD, smoke, the default bench
   SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_images8.json run bench_images8 1200 python bench.py --images 8 --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants
   SFAST_TUNE_CACHE=$PWD/gpurun_out/tune_svd.json run bench_svd 1500 python bench.py --config svd --no-cpu-baseline
   ;;
+s17)  # IP-Adapter family after the external-projection mode
+  run t_ip 1200 $PYT tests/test_unet_gpu.py -k "ip_adapter or lora"
+  ;;
 esac
 cat gpurun_out/session.log
