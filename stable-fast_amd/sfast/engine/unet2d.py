@@ -746,8 +746,14 @@ class UNet2DEngine:
     def _pack(self, rec):
         L.check(self.lib.sfast_hip_pack_weight(rec["w"].data_ptr(), rec["buf"].data_ptr(), rec["N"], rec["K"], rec["ldw"], self.dt,
                                                self.host.stream_ptr(self.device)), "sfast_hip_pack_weight")
-        p = self._param_objs.get(rec["name"])
+        p = self._version_source(rec["name"])
         rec["version"] = p._version if p is not None else None
+
+    def _version_source(self, name):
+        """The object whose autograd version counter tells that parameter `name` was written: the module's nn.Parameter (from_module;
+        the engine's own `p.data` alias has a counter of its own), else the tensor the engine was constructed with."""
+        p = self._param_objs.get(name)
+        return p if p is not None else self.params.get(name)
 
     def sync_packed(self, force=False):
         """Re-pack every packed weight whose parameter changed since it was packed (version counter), or all of them (`force`).
@@ -756,7 +762,7 @@ class UNet2DEngine:
         for rec in list(self._pk.values()):  # a snapshot: another thread may be building a plan (new records) while this one replays
             if rec["users"] <= 0:
                 continue
-            p = self._param_objs.get(rec["name"])
+            p = self._version_source(rec["name"])
             if p is not None and p.data_ptr() != rec["w"].data_ptr() and not rec.get("warned"):
                 # `p.data = other` / load_state_dict(assign=True): the plan still reads the OLD storage (packed or not)
                 rec["warned"] = True

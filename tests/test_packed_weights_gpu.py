@@ -225,3 +225,31 @@ def test_lora_merge_matches_the_unfused_forward():
         for (w, down, up, out), s in zip(keep, scales):
             want = w.double() + s * (up.double() @ down.double())
             compare(f"lora_merge {tuple(w.shape)} r{down.shape[0]} {dtype}", out, want.float(), *tol(dtype), kernel=L.last_kernel())
+
+
+def test_engine_repacks_after_an_in_place_update():
+    """sync_packed() refreshes a packed copy when the parameter's version counter moved -- also for an engine built from a raw
+    parameter dict (the tensors' own counters) -- and is a no-op otherwise; a forward after it equals a fresh engine's."""
+    from oracle import unet_ref as U
+    from sfast.engine import UNet2DEngine
+    from sfast.engine.unet_spec import random_params
+    cfg = U.tiny_config()
+    params = random_params(cfg, seed=3, dtype=torch.float16, device=DEV)
+    eng = UNet2DEngine(cfg, params)
+    g = torch.Generator().manual_seed(4)
+    s = torch.randn(2, 4, 16, 16, generator=g).to(DEV, torch.float16)
+    e = torch.randn(2, 77, 64, generator=g).to(DEV, torch.float16)
+    y0 = eng.forward(s, 500, e)
+    name = "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_out.0.weight"
+    w = params[name]
+    rec = eng._packed_for(w)                                        # a record as the planner makes it for an op on pipe 4
+    assert rec is not None and rec["name"] == name
+    rec["users"] += 1
+    assert torch.equal(rec["buf"], F().pack_weight(w)) and eng.sync_packed() == 0
+    before = rec["buf"].clone()
+    w.mul_(-1.0)                                                    # in place, through the tensor the engine was given
+    assert eng.sync_packed() == 1 and eng.sync_packed() == 0
+    assert not torch.equal(rec["buf"], before) and torch.equal(rec["buf"], F().pack_weight(w))
+    y1 = eng.forward(s, 500, e)
+    assert torch.equal(y1, UNet2DEngine(cfg, params).forward(s, 500, e)) and not torch.equal(y1, y0)
+    assert eng._packed_for(torch.zeros(64, 64, dtype=torch.float16, device=DEV)) is None   # not one of the engine's parameters

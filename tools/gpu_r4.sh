@@ -158,5 +158,8 @@ final2)  # end of round 4: the whole GPU suite on HEAD, smoke, the default bench
 s17)  # IP-Adapter family after the external-projection mode
   run t_ip 1200 $PYT tests/test_unet_gpu.py -k "ip_adapter or lora"
   ;;
+s18)  # engine-level repack test; live-weight and LoRA switch through compile with packed copies on
+  run t_repack 900 $PYT tests/test_packed_weights_gpu.py -k "repack" tests/test_unet_gpu.py -k "live_weight or lora or repack"
+  ;;
 esac
 cat gpurun_out/session.log
