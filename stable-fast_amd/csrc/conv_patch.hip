@@ -81,6 +81,7 @@ __global__ void __launch_bounds__((WM * WN + PWW + PWP) * 64, (WM * WN + PWW + P
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const BlockTile bt = decode_block(a);
+    if (bt.tile_m < 0) return;  // surplus block of an xmap = 2 grid (wave-uniform, before any barrier)
     const int m0 = bt.tile_m * BM, n0 = bt.tile_n * BN;
     const int u_begin = bt.split * g.units_per_split;
     const int u_end = min(g.units, u_begin + g.units_per_split);

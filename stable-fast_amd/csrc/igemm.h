@@ -39,11 +39,15 @@ struct IgemmArgs {
     // xmap = 1: 1-D grid of tiles*splits blocks; XCD b%8 owns a box of x_sp K-splits x x_tm tile rows x x_tn tile columns
     // (2^x_lxn boxes along n, 2^x_lxm along m, the rest of the 8 along the K-splits). xmap = 0: grid (tiles, splits), every XCD a
     // contiguous run of row-major tiles.
-    int xmap, x_lxn, x_lxm, x_tn, x_tm, x_sp;
+    // xmap = 2 (round 4): the (split, tile_n, tile_m) triples in ONE linear order, XCD b%8 owns the contiguous run [xcd * x_per,
+    // (xcd + 1) * x_per) of it -- no divisibility needed; x_order 0: tile_m fastest (a run stays inside few (split, tile_n) pairs: the
+    // weight panel is fetched by ~one XCD), 1: tile_n fastest (the activation panel is). Grid = 8 * x_per blocks, the surplus exit at once.
+    int xmap, x_lxn, x_lxm, x_tn, x_tm, x_sp, x_per, x_order;
 };
 
 // launch grid of the MFMA kernels for the block map carried by `a`
 static inline dim3 igemm_grid(const IgemmArgs &a) {
+    if (a.xmap == 2) return dim3((unsigned)(8 * a.x_per), 1, 1);
     return a.xmap ? dim3((unsigned)(a.tiles_m * a.tiles_n * a.splits), 1, 1) : dim3((unsigned)(a.tiles_m * a.tiles_n), (unsigned)a.splits, 1);
 }
 

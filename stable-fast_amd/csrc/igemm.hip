@@ -29,6 +29,9 @@
 //     [M, 2N] intermediate never exists.
 //   * split-K (fp32 slabs + a reduce/epilogue kernel) for the weight-streaming 16x16 / 8x8 levels
 //     where M <= 512 gives too few tiles for 256 CUs.
+#include <algorithm>
+#include <vector>
+
 #include "igemm.h"
 #include "igemm_device.h"
 
@@ -62,6 +65,7 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs &a) {
     const int l31 = lane & 31, hi = lane >> 5;
 
     const BlockTile bt = decode_block(a);  // XCD-aware (tile, K-split) of this workgroup
+    if (bt.tile_m < 0) return;  // surplus block of an xmap = 2 grid (wave-uniform, before any barrier)
     const int tile_n = bt.tile_n, tile_m = bt.tile_m;
     const int m0 = tile_m * BM, n0 = tile_n * BNO;
     const int kt_begin = bt.split * a.ktiles_per_split;
@@ -727,7 +731,7 @@ static int set_attr_one() {
     OP(T, 64, 128, 2, 2, 0, true)
 
 static int g_pipe_pref = -1;  // -1 auto, 0 force register pipe, 1 force LDS-DMA pipe (SFAST_IGEMM_PIPE)
-static int g_xmap_pref = 1;   // SFAST_XCD_MAP=0: legacy block order everywhere (A/B of choose_xcd_map)
+static int g_xmap_pref = 1;   // SFAST_XCD_MAP=0: legacy block order everywhere; 1 (default): box maps; 2: + contiguous runs (A/B of choose_xcd_map)
 static int g_stage_pref = 0;  // 1: stage every eligible output tile through LDS (SFAST_STAGE_OUT=1), not only those that emit statistics
 
 int igemm_grouped_init();
@@ -750,7 +754,10 @@ int igemm_init() {
     const char *so = getenv("SFAST_STAGE_OUT");
     g_stage_pref = (so && so[0] == '1') ? 1 : 0;
     const char *xm = getenv("SFAST_XCD_MAP");
-    g_xmap_pref = (xm && xm[0] == '0') ? 0 : 1;
+    // 2: + contiguous runs (round 4). Measured and NOT the default: it cuts the modelled XCD-to-XCD duplication of the 32^2-level convs from
+    // 62 MB to ~25 MB and changes nothing in the step (184.07 vs 183.99 it/s, SDXL 41.74 vs 41.73: profiles/r04_xcd_run_map_ab_run25.log)
+    // -- the fabric duplication behind `roofline.traffic` = 3.9 x algorithmic is not what holds these launches.
+    g_xmap_pref = (xm && xm[0] == '0') ? 0 : (xm && xm[0] == '2') ? 2 : 1;
     const char *e = getenv("SFAST_IGEMM_PIPE");
     if (e && e[0] == 'r') g_pipe_pref = 0;
     if (e && e[0] == 'g') g_pipe_pref = 1;
@@ -1043,8 +1050,29 @@ int igemm_run_grouped(IgemmArgs &a, int dtype, int n_groups, const void *const *
 // factor to xs when they can (each XCD then streams only its K-slice of both operands: the 1280-channel convs of the 16x16 level
 // read their 29-59 MB of weights ONCE instead of once per XCD that owns a tile of the column). Ties go to fewer column boxes
 // (an activation panel stays in one L2, as in the legacy order). No dividing factorisation: legacy order (xmap = 0).
+// bytes the eight XCD L2s fetch under a block -> (tile, split) map: every distinct (split, tile_n) pair an XCD touches costs one weight
+// panel slice, every distinct (split, tile_m) pair one activation panel slice
+template <typename F> static double xcd_map_bytes(const IgemmArgs &a, double w_pair, double x_pair, int blocks_per_xcd, F &&decode) {
+    double bytes = 0.0;
+    std::vector<char> seen_n((size_t)a.splits * a.tiles_n), seen_m((size_t)a.splits * a.tiles_m);
+    for (int xcd = 0; xcd < 8; ++xcd) {
+        std::fill(seen_n.begin(), seen_n.end(), 0);
+        std::fill(seen_m.begin(), seen_m.end(), 0);
+        for (int k = 0; k < blocks_per_xcd; ++k) {
+            int tm, tn, sp;
+            if (!decode(xcd, k, tm, tn, sp)) continue;
+            char &n = seen_n[(size_t)sp * a.tiles_n + tn], &m = seen_m[(size_t)sp * a.tiles_m + tm];
+            if (!n) bytes += w_pair;
+            if (!m) bytes += x_pair;
+            n = m = 1;
+        }
+    }
+    return bytes;
+}
+
 static void choose_xcd_map(IgemmArgs &a, int mode, bool geglu) {
     a.xmap = 0;
+    a.x_per = a.x_order = 0;
     if (!g_xmap_pref) return;
     // unique operand bytes (a conv reads every input pixel once, whatever its im2col row count)
     const double act_bytes = mode ? (double)(a.M / (a.Ho * a.Wo)) * a.H * a.W * (a.ups ? 0.25 : 1.0) * (a.C1 + a.C2) * 2.0 : (double)a.M * a.K * 2.0;
@@ -1064,6 +1092,35 @@ static void choose_xcd_map(IgemmArgs &a, int mode, bool geglu) {
                 a.x_tn = a.tiles_n >> lxn;
                 a.x_tm = a.tiles_m >> lxm;
                 a.x_sp = a.splits >> lxs;
+            }
+        }
+    }
+    // round 4: contiguous runs of a linear (split, tile_n, tile_m) order -- no divisibility needed (5 tile columns x 3 splits of the
+    // 640 -> 640 @ 32^2 conv: the box map can only cut the 16 tile rows, every XCD fetches ALL weights: 62 MB against ~25 MB)
+    if (g_xmap_pref >= 2) {
+        const int total = a.tiles_m * a.tiles_n * a.splits;
+        if (total >= 16 && total <= 65536) {
+            const int per = ceil_div(total, 8);
+            const double w_pair = w_bytes / ((double)a.splits * a.tiles_n), x_pair = act_bytes / ((double)a.splits * a.tiles_m);
+            double cur = best;
+            if (a.xmap == 0) cur = 1e300;
+            for (int order = 0; order < 2; ++order) {
+                const double c = xcd_map_bytes(a, w_pair, x_pair, per, [&](int xcd, int k, int &tm, int &tn, int &sp) {
+                    const int lid = xcd * per + k;
+                    if (lid >= total) return false;
+                    const int d1 = order ? a.tiles_n : a.tiles_m, d2 = order ? a.tiles_m : a.tiles_n;
+                    const int q = lid / d1, s = q / d2, i1 = lid - q * d1, i2 = q - s * d2;
+                    tm = order ? i2 : i1;
+                    tn = order ? i1 : i2;
+                    sp = s;
+                    return true;
+                });
+                if (c < 0.85 * cur) {  // a clear win only: the box map keeps the tile order friendlier to the L2 within an XCD
+                    cur = c;
+                    a.xmap = 2;
+                    a.x_per = per;
+                    a.x_order = order;
+                }
             }
         }
     }
@@ -1122,7 +1179,8 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
     char pipe[8];
     snprintf(pipe, sizeof(pipe), p.v.pipe == 4 ? "pk%d" : p.v.pipe == 3 ? "patch%d" : p.v.pipe == 2 ? "ws%d" : p.v.pipe ? "dma%d" : "reg", p.v.ns);
     char xmap[24] = "";
-    if (a.xmap) snprintf(xmap, sizeof(xmap), "@xcd%dx%dx%d", 8 >> (a.x_lxm + a.x_lxn), 1 << a.x_lxm, 1 << a.x_lxn);  // K-split x row x column boxes
+    if (a.xmap == 2) snprintf(xmap, sizeof(xmap), "@xcdrun%c%d", a.x_order ? 'n' : 'm', a.x_per);  // contiguous runs, tile_m / tile_n fastest
+    else if (a.xmap) snprintf(xmap, sizeof(xmap), "@xcd%dx%dx%d", 8 >> (a.x_lxm + a.x_lxn), 1 << a.x_lxm, 1 << a.x_lxn);  // K-split x row x column boxes
     set_kernel_name("igemm_%s_%s%s[%dx%d,split=%d,%s]%s%s%s%s", mode ? "conv" : "lin", dtype == SFAST_F16 ? "f16" : "bf16",
                     geglu ? "_geglu" : "", p.v.BM, p.v.BN, p.splits, pipe, a.gn_stats ? "+gnstats" : (a.stage_out ? "+staged" : ""),
                     joins ? "+join" : "", a.gn_out ? "+gn" : "", xmap);  // +join: split-K finished inside this kernel (no reduce launch)

@@ -58,7 +58,7 @@ __device__ __forceinline__ void touch_args(const IgemmArgs &a) {
                  "s"(a.out), "s"(a.partial), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.ldx), "s"(a.ldw), "s"(a.ldo), "s"(a.ldr),
                  "s"(a.ld_rowbias), "s"(a.rows_per_seg), "s"(a.rows_per_batch), "s"(a.act), "s"(a.res_before_act), "s"(a.alpha));
     asm volatile("" ::"s"(a.tiles_m), "s"(a.tiles_n), "s"(a.ktiles), "s"(a.ktiles_per_split), "s"(a.splits), "s"(a.trace));
-    asm volatile("" ::"s"(a.xmap), "s"(a.x_lxn), "s"(a.x_lxm), "s"(a.x_tn), "s"(a.x_tm), "s"(a.x_sp));
+    asm volatile("" ::"s"(a.xmap), "s"(a.x_lxn), "s"(a.x_lxm), "s"(a.x_tn), "s"(a.x_tm), "s"(a.x_sp), "s"(a.x_per), "s"(a.x_order));
 }
 __device__ __forceinline__ void touch_conv_args(const IgemmArgs &a) {
     asm volatile("" ::"s"(a.H), "s"(a.W), "s"(a.C1), "s"(a.C2), "s"(a.Ho), "s"(a.Wo), "s"(a.KH), "s"(a.KW), "s"(a.stride_h), "s"(a.stride_w),
@@ -112,7 +112,20 @@ __device__ __forceinline__ BlockTile decode_block(const IgemmArgs &a) {
     BlockTile t;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, k = bid >> 3;
-    if (a.xmap) {
+    if (a.xmap == 2) {
+        const int lid = xcd * a.x_per + k;
+        if (lid >= a.tiles_m * a.tiles_n * a.splits) {  // surplus block of the last run(s): nothing to do (tile_m < 0, every kernel returns)
+            t.tile_m = t.tile_n = t.split = -1;
+            return t;
+        }
+        const int d1 = a.x_order ? a.tiles_n : a.tiles_m, d2 = a.x_order ? a.tiles_m : a.tiles_n;
+        const int q = fdiv22(lid, d1, __builtin_amdgcn_rcpf((float)d1));
+        const int s = fdiv22(q, d2, __builtin_amdgcn_rcpf((float)d2));
+        const int i1 = lid - q * d1, i2 = q - s * d2;
+        t.tile_m = a.x_order ? i2 : i1;
+        t.tile_n = a.x_order ? i1 : i2;
+        t.split = s;
+    } else if (a.xmap) {
         const int jn = xcd & ((1 << a.x_lxn) - 1);
         const int im = (xcd >> a.x_lxn) & ((1 << a.x_lxm) - 1);
         const int is = xcd >> (a.x_lxn + a.x_lxm);

@@ -67,6 +67,7 @@ __global__ void __launch_bounds__(WM *WN * 64, igemm_min_waves(WM *WN * 64, NS *
     const int l31 = lane & 31, hi = lane >> 5;
 
     const BlockTile bt = decode_block(a);  // XCD-aware (tile, K-split) of this workgroup
+    if (bt.tile_m < 0) return;  // surplus block of an xmap = 2 grid (wave-uniform, before any barrier)
     const int tile_n = bt.tile_n, tile_m = bt.tile_m;
     const int m0 = tile_m * BM, n0 = tile_n * BNO;
     const int kt_begin = bt.split * a.ktiles_per_split;

@@ -77,6 +77,7 @@ __global__ void __launch_bounds__((WM * WN + PW) * 64, ws_min_waves((WM * WN + P
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     const BlockTile bt = decode_block(a);  // XCD-aware (tile, K-split) of this workgroup
+    if (bt.tile_m < 0) return;  // surplus block of an xmap = 2 grid (wave-uniform, before any barrier)
     const int tile_n = bt.tile_n, tile_m = bt.tile_m;
     const int m0 = tile_m * BM, n0 = tile_n * BNO;
     const int kt_begin = bt.split * a.ktiles_per_split;

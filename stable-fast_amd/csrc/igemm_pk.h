@@ -63,6 +63,7 @@ __global__ void __launch_bounds__((WN + 1) * 64, 2) igemm_pk_kernel(const IgemmA
     const int l31 = lane & 31, hi = lane >> 5;
 
     const BlockTile bt = decode_block(a);
+    if (bt.tile_m < 0) return;  // surplus block of an xmap = 2 grid (wave-uniform, before any barrier)
     const int m0 = bt.tile_m * BM, n0 = bt.tile_n * BN;
     const int kt_begin = bt.split * a.ktiles_per_split;
     const int kt_end = min(a.ktiles, kt_begin + a.ktiles_per_split);

@@ -161,5 +161,14 @@ s17)  # IP-Adapter family after the external-projection mode
 s18)  # engine-level repack test; live-weight and LoRA switch through compile with packed copies on
   run t_repack 900 $PYT tests/test_packed_weights_gpu.py -k "repack" tests/test_unet_gpu.py -k "live_weight or lora or repack"
   ;;
+s19)  # XCD map with contiguous runs: parity over the GEMM / conv families, then the step with and without it
+  run t_ops 1500 $PYT tests/test_ops_gpu.py -k "linear or conv or geglu or split or statistics" tests/test_packed_weights_gpu.py
+  run bench_run 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --dump-kernels gpurun_out/kernels_xrun.json
+  SFAST_XCD_MAP=1 run bench_box 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  run bench_run2 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  SFAST_XCD_MAP=1 run bench_box2 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  run bench_sdxl_run 900 python bench.py --config sdxl --no-cpu-baseline --no-roofline
+  SFAST_XCD_MAP=1 run bench_sdxl_box 900 python bench.py --config sdxl --no-cpu-baseline --no-roofline
+  ;;
 esac
 cat gpurun_out/session.log
