@@ -86,12 +86,18 @@ class DenoiseLoop:
     def _stream_ptr(self):
         return torch.cuda.current_stream(self.engine.device).cuda_stream
 
-    def set_inputs(self, latents, ehs_uncond_cond):
+    def set_inputs(self, latents, ehs_uncond_cond, lora_scale=1.0):
         """latents [images,4,H,W]; ehs_uncond_cond [2*images, ctx, dim] ordered [uncond..., cond...]. Runs the text-side launches
-        (every cross-attention block's K/V projection) for this context."""
+        (every cross-attention block's K/V projection) for this context. `lora_scale`: diffusers' cross_attention_kwargs["scale"]
+        for a UNet with un-fused LoRA factors (an entry of the merge launch's scale table; ignored otherwise)."""
         self.latents.copy_(latents)
         si = self.plan.static_in
         self.engine.sync_packed()
+        if "lora_scale" in si:
+            vals = self.engine.lora_multipliers(lora_scale)
+            if vals != self.plan.lora["last"]:
+                si["lora_scale"].copy_(torch.tensor(vals, dtype=torch.float32))
+                self.plan.lora["last"] = vals
         si["sample"][: self.images].copy_(latents)
         si["sample"][self.images:].copy_(latents)
         si["encoder_hidden_states"].copy_(ehs_uncond_cond)
@@ -101,6 +107,10 @@ class DenoiseLoop:
         """hoist_text_kv only: re-run the text-side launches (every cross-attention block's K/V projection) on the current stream --
         after a new context (`set_inputs` calls this) or after an in-place update of to_k / to_v weights. A no-op otherwise."""
         sp = self._stream_ptr()
+        if self._ctx_ops and self.plan.lora is not None:
+            for op in self.plan.ops:  # the hoisted K/V projections read merged LoRA weights: rebuild those first
+                if op.name.startswith("lora.merge"):
+                    op.launch(sp)
         for op in self._ctx_ops:
             op.launch(sp)
 

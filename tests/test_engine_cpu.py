@@ -697,3 +697,47 @@ def test_ip_adapter_plus_takes_projected_tokens(built_lib):
     assert not any(n.startswith("encoder_hid_proj") for n in names) and any(n.startswith("attn2.to_kv_ip.0[") for n in names)
     with pytest.raises(UnsupportedUNet, match="ip_hidden_states"):
         eng.forward(s, 700, e, added_cond_kwargs={"image_embeds": [patches]})    # tokens are required at this level
+
+
+def test_lora_in_the_old_attention_processor_layout(built_lib):
+    """diffusers <= 0.20 kept the factors in the attention PROCESSOR (`<attn>.processor.to_q_lora.down.weight`, `to_out_lora`): the
+    same plan, recognised by name. Built here by renaming the keys of the LoRACompatibleLinear layout (no network_alpha: factor 1)."""
+    m16, m32 = _pair(U.tiny_config(), 17)
+    for m in (m16, m32):
+        m.load_lora(rank=4, network_alpha=None, seed=8, up_scale=0.05)
+    m32.load_state_dict({k: v.float() for k, v in m16.state_dict().items()})
+
+    def old_name(k):
+        for t in ("to_q", "to_k", "to_v"):
+            k = k.replace(f".{t}.lora_layer.", f".processor.{t}_lora.")
+        return k.replace(".to_out.0.lora_layer.", ".processor.to_out_lora.")
+
+    params = {old_name(k): v.data for k, v in m16.named_parameters()}
+    assert any(".processor.to_out_lora.up.weight" in k for k in params)
+    eng = UNet2DEngine(m16.config, params, _host=EmuHost())
+    assert len(eng.lora) == sum(1 for k in params if k.endswith("_lora.down.weight"))
+    assert all(".processor." in dn and ".processor." not in base for base, dn, _ in eng.lora)
+    g = torch.Generator().manual_seed(18)
+    s = torch.randn(2, 4, 16, 16, generator=g).half()
+    e = torch.randn(2, 20, 64, generator=g).half()
+    with torch.no_grad():
+        want = m32(s.float(), 400, e.float()).sample
+    assert rel_l2(eng.forward(s, 400, e), want) < 3e-3
+
+
+def test_lora_live_factors_of_peft_wrappers(built_lib):
+    """peft: scaling[adapter] is read at every call; a merged or disabled wrapper contributes nothing (its base weight already holds,
+    or must not hold, the delta)."""
+    from sfast.engine.unet2d import lora_multiplier_sources
+    m = U.build(U.tiny_config(), seed=3, dtype=torch.float16)
+    m.load_lora(rank=4, network_alpha=8.0, seed=1, style="peft")
+    src = lora_multiplier_sources(m)
+    name, mod = next((n, mm) for n, mm in m.named_modules() if hasattr(mm, "lora_A"))
+    f = src[name + ".weight"]
+    assert f() == 2.0
+    mod.scaling["default"] = 0.25
+    assert f() == 0.25
+    mod.merged = True
+    assert f() == 0.0
+    mod.merged, mod.disable_adapters = False, True
+    assert f() == 0.0
