@@ -741,3 +741,28 @@ def test_lora_live_factors_of_peft_wrappers(built_lib):
     assert f() == 0.0
     mod.merged, mod.disable_adapters = False, True
     assert f() == 0.0
+
+
+@pytest.mark.parametrize("hoist", [False, True])
+def test_denoise_loop_with_unfused_lora(built_lib, hoist):
+    """DenoiseLoop on a LoRA'd UNet: the scale table follows set_inputs(lora_scale=...), and with the text K/V projections hoisted out of
+    the step the merged weights they read are rebuilt first. Three fused CFG + DDIM steps == the same steps through engine.forward."""
+    from abi_emulator import emulated_denoise_loop
+    from oracle.ops_ref import cfg_ddim_ref, ddim_schedule
+    m16 = U.build(U.tiny_config(), seed=23, dtype=torch.float16)
+    m16.load_lora(rank=4, network_alpha=8.0, seed=4, up_scale=0.05)
+    eng = UNet2DEngine.from_module(m16, _host=EmuHost())
+    loop = emulated_denoise_loop(eng, images=1, height=16, width=16, ctx_len=20, guidance=7.5, num_steps=50, hoist_text_kv=hoist)
+    g = torch.Generator().manual_seed(24)
+    lat0 = torch.randn(1, 4, 16, 16, generator=g).half()
+    ehs = torch.randn(2, 20, 64, generator=g).half()
+    loop.set_inputs(lat0, ehs, lora_scale=0.5)
+    for i in range(3):
+        loop.step(i)
+    ts, coefs = ddim_schedule(50)
+    lat = lat0.clone()
+    for i in range(3):
+        eps = eng.forward(torch.cat([lat, lat]), float(ts[i]), ehs, lora_scale=0.5)
+        lat = cfg_ddim_ref(eps.flatten(), lat.flatten(), torch.tensor(coefs[i], dtype=torch.float32).tolist(), 7.5).to(torch.float16).reshape(lat.shape)
+    assert torch.equal(loop.latents, lat)
+    assert float(loop.plan.static_in["lora_scale"][0]) == 0.5 * 8.0 / 4
