@@ -170,5 +170,10 @@ s19)  # XCD map with contiguous runs: parity over the GEMM / conv families, then
   run bench_sdxl_run 900 python bench.py --config sdxl --no-cpu-baseline --no-roofline
   SFAST_XCD_MAP=1 run bench_sdxl_box 900 python bench.py --config sdxl --no-cpu-baseline --no-roofline
   ;;
+final3)  # HEAD after the last library change: the whole GPU suite, smoke, the default bench line
+  run pytest_full 2400 $PYT tests
+  run smoke 600 python __graft_entry__.py smoke
+  run bench_default 1200 python bench.py --dump-kernels gpurun_out/kernels.json
+  ;;
 esac
 cat gpurun_out/session.log
