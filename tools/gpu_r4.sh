@@ -175,5 +175,10 @@ final3)  # HEAD after the last library change: the whole GPU suite, smoke, the d
   run smoke 600 python __graft_entry__.py smoke
   run bench_default 1200 python bench.py --dump-kernels gpurun_out/kernels.json
   ;;
+extra)  # measurement only (no code change behind it): SDXL line with its roofline block, 2 / 4 images per GPU
+  run bench_sdxl 900 python bench.py --config sdxl --no-cpu-baseline
+  run bench_images2 600 python bench.py --images 2 --steps 50 --warmup 10 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants
+  run bench_images4 600 python bench.py --images 4 --steps 40 --warmup 8 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants
+  ;;
 esac
 cat gpurun_out/session.log
