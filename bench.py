@@ -179,7 +179,7 @@ def kernel_symbol(variant):
     of one tile shape share a symbol, so the split factor is dropped. A trailing "+staged" / "+gnstats" marks the
     instantiation with LDS-staged stores (last template argument)."""
     import re
-    m = re.match(r"igemm_(conv|lin)_(f16|bf16)(_geglu)?\[(\d+x\d+),split=(\d+),(reg|dma(\d)|ws(\d))\](\+staged|\+gnstats)?(\+join)?", variant)
+    m = re.match(r"igemm_(conv|lin)_(f16|bf16)(_geglu)?\[(\d+x\d+),split=(\d+),(reg|dma(\d)|ws(\d)|pk(\d))\](\+staged|\+gnstats)?(\+join)?", variant)
     if not m:
         ma = re.match(r"attn_fwd\[D=(\d+),BQ=(\d+)\](\+bias)?", variant)
         if ma:  # attn_fwd_kernel<T, D, NW, TRACE = 0, BIAS = false>: one wave per 32 queries
@@ -189,10 +189,16 @@ def kernel_symbol(variant):
     t = "DF16_" if m.group(2) == "f16" else "DF16b"
     geglu = m.group(3) is not None
     bm, bn = m.group(4).split("x")
-    wm, wn = _IGEMM_WAVES[(m.group(4), geglu)]
     # staged stores (and statistics from the tile flush) only when the GEMM kernel itself finishes the tile: unsplit, or split-K joined
     # inside the kernel ("+join"); otherwise a split GEMM writes fp32 slabs and splitk_reduce[_rows]_kernel finishes (igemm.hip igemm_run)
-    staged = int(m.group(9) is not None and (int(m.group(5)) == 1 or m.group(10) is not None))
+    staged = int(m.group(10) is not None and (int(m.group(5)) == 1 or m.group(11) is not None))
+    if m.group(6).startswith("pk"):
+        # igemm_pk_kernel<T, BM, BN, WN, NS, PD, MODE, STAGED> (csrc/igemm_pk.h): WN = 5 for the 160- / 320-row tiles, PD = 2 when a
+        # wave holds two 32-row weight blocks
+        wn_pk = 5 if int(bn) in (160, 320) else 4
+        pd = 2 if int(bn) // (wn_pk * 32) >= 2 else 3
+        return f"_ZN5sfast15igemm_pk_kernelI{t}Li{bm}ELi{bn}ELi{wn_pk}ELi{m.group(9)}ELi{pd}ELi{mode}ELb{staged}EEEvNS_9IgemmArgsE"
+    wm, wn = _IGEMM_WAVES[(m.group(4), geglu)]
     if m.group(6) == "reg":
         return f"_ZN5sfast12igemm_kernelI{t}Li{bm}ELi{bn}ELi{wm}ELi{wn}ELi{mode}ELb{int(geglu)}ELb{staged}EEEvNS_9IgemmArgsE"
     if m.group(6).startswith("ws"):

@@ -139,7 +139,11 @@ def test_bench_kernel_symbols_name_real_device_kernels(built_lib):
                 "igemm_lin_f16[128x128,split=4,ws4]", "igemm_lin_f16[64x64,split=1,reg]", "igemm_lin_f16[64x64,split=6,ws4]",
                 "igemm_lin_f16_geglu[128x128,split=1,dma2]", "igemm_lin_f16_geglu[64x128,split=1,ws3]", "igemm_lin_bf16[64x64,split=1,ws4]",
                 "igemm_conv_f16[128x128,split=1,ws4]+gnstats", "igemm_lin_f16[64x64,split=1,reg]+gnstats", "igemm_conv_f16[128x160,split=1,ws4]+staged",
-                "igemm_conv_f16[128x128,split=6,ws4]+join@xcd2x2x2", "igemm_conv_f16[128x128,split=3,ws4]+gnstats+join", "igemm_lin_f16[64x64,split=3,ws4]+join"]
+                "igemm_conv_f16[128x128,split=6,ws4]+join@xcd2x2x2", "igemm_conv_f16[128x128,split=3,ws4]+gnstats+join", "igemm_lin_f16[64x64,split=3,ws4]+join",
+                # pipe 4 (packed weights): every tile, linear and conv, staged and not, bf16
+                "igemm_lin_f16[64x160,split=1,pk4]@xcd1x8x1", "igemm_lin_f16[64x160,split=1,pk4]+gnstats@xcd1x4x2", "igemm_conv_f16[128x256,split=2,pk4]@xcd2x4x1",
+                "igemm_conv_f16[64x320,split=1,pk4]+gnstats", "igemm_lin_f16[128x160,split=1,pk4]", "igemm_conv_f16[64x256,split=6,pk4]",
+                "igemm_lin_bf16[128x128,split=1,pk4]+staged", "igemm_conv_bf16[128x128,split=12,pk4]@xcd4x1x2"]
     for v in variants:
         sym = bench.kernel_symbol(v)
         assert sym.startswith("_ZN5sfast"), (v, sym)
