@@ -180,5 +180,9 @@ extra)  # measurement only (no code change behind it): SDXL line with its roofli
   run bench_images2 600 python bench.py --images 2 --steps 50 --warmup 10 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants
   run bench_images4 600 python bench.py --images 4 --steps 40 --warmup 8 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants
   ;;
+extra2)  # the SDXL and SD1.5 lines again after bench.py learned the pipe-4 symbols (roofline grouping only; no library change)
+  run bench_sdxl 900 python bench.py --config sdxl --no-cpu-baseline
+  run bench_default 1200 python bench.py --dump-kernels gpurun_out/kernels.json
+  ;;
 esac
 cat gpurun_out/session.log
