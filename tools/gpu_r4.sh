@@ -184,5 +184,8 @@ extra2)  # the SDXL and SD1.5 lines again after bench.py learned the pipe-4 symb
   run bench_sdxl 900 python bench.py --config sdxl --no-cpu-baseline
   run bench_default 1200 python bench.py --dump-kernels gpurun_out/kernels.json
   ;;
+probes)  # the probe-build subset on HEAD (patch pipe, in-kernel join: they share decode_block / the epilogue with the product kernels)
+  SFAST_HIP_PROBES=1 run t_probes 1200 $PYT tests/test_ops_gpu.py -k "patch or join"
+  ;;
 esac
 cat gpurun_out/session.log
