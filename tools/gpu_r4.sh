@@ -187,5 +187,8 @@ extra2)  # the SDXL and SD1.5 lines again after bench.py learned the pipe-4 symb
 probes)  # the probe-build subset on HEAD (patch pipe, in-kernel join: they share decode_block / the epilogue with the product kernels)
   SFAST_HIP_PROBES=1 run t_probes 1200 $PYT tests/test_ops_gpu.py -k "patch or join"
   ;;
+nopk)  # the whole-model suites with packed copies switched off (the strictly-live-weights mode)
+  SFAST_PACKED_WEIGHTS=0 run t_models_nopk 1800 $PYT tests/test_unet_gpu.py tests/test_sdxl_gpu.py tests/test_vae_gpu.py tests/test_svd_gpu.py
+  ;;
 esac
 cat gpurun_out/session.log
