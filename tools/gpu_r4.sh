@@ -190,5 +190,12 @@ probes)  # the probe-build subset on HEAD (patch pipe, in-kernel join: they shar
 nopk)  # the whole-model suites with packed copies switched off (the strictly-live-weights mode)
   SFAST_PACKED_WEIGHTS=0 run t_models_nopk 1800 $PYT tests/test_unet_gpu.py tests/test_sdxl_gpu.py tests/test_vae_gpu.py tests/test_svd_gpu.py
   ;;
+dbg)  # the ControlNet -> UNet chain test that aborted with packed copies off: localise
+  SFAST_PACKED_WEIGHTS=0 run d_plain 600 $PYT tests/test_unet_gpu.py -k "controlnet_engine_and_compiled_chain" -x
+  SFAST_PACKED_WEIGHTS=0 HIP_LAUNCH_BLOCKING=1 AMD_SERIALIZE_KERNEL=3 run d_blocking 600 $PYT tests/test_unet_gpu.py -k "controlnet_engine_and_compiled_chain" -x
+  SFAST_PACKED_WEIGHTS=0 SFAST_AUTOTUNE=0 run d_notune 600 $PYT tests/test_unet_gpu.py -k "controlnet_engine_and_compiled_chain" -x
+  SFAST_PACKED_WEIGHTS=0 run d_file 900 $PYT tests/test_unet_gpu.py -x
+  for f in d_plain d_blocking d_notune d_file; do echo "--- $f"; head -c 1500 gpurun_out/$f.log; echo; done >> gpurun_out/session.log
+  ;;
 esac
 cat gpurun_out/session.log
