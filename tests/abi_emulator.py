@@ -391,6 +391,20 @@ class EmuLib:
         _strided(out, (p.B, p.Sq, p.H, p.D), tuple(p.os) + (1,), p.dtype).copy_(o)
         return 0
 
+    def sfast_hip_packed_weight_bytes(self, N, K):
+        return self.real.sfast_hip_packed_weight_bytes(N, K)  # host-only
+
+    def sfast_hip_pack_weight(self, w, packed, N, K, ldw, dtype, stream):
+        """packed[(nb * KS + s) * 64 + lane] = the 8 elements w[nb * 32 + lane % 32][s * 16 + (lane // 32) * 8 : + 8], zeros outside."""
+        self.calls.append("pack_weight")
+        KS, NB = (K + 63) // 64 * 4, (N + 31) // 32
+        src = _strided(w, (N, K), (ldw, 1), dtype)
+        full = torch.zeros(NB * 32, KS * 16, dtype=src.dtype)
+        full[:N, :K] = src
+        out = full.reshape(NB, 32, KS, 2, 8).permute(0, 2, 3, 1, 4).contiguous()   # [nb][s][g][r][8]
+        _flat(packed, NB * KS * 64 * 8, dtype).copy_(out.reshape(-1))
+        return 0
+
     def sfast_hip_lora_merge_plan(self, entries, n, total):
         return self.real.sfast_hip_lora_merge_plan(entries, n, total)  # host-only: validates the table, fills tile_begin
 

@@ -766,3 +766,61 @@ def test_denoise_loop_with_unfused_lora(built_lib, hoist):
         lat = cfg_ddim_ref(eps.flatten(), lat.flatten(), torch.tensor(coefs[i], dtype=torch.float32).tolist(), 7.5).to(torch.float16).reshape(lat.shape)
     assert torch.equal(loop.latents, lat)
     assert float(loop.plan.static_in["lora_scale"][0]) == 0.5 * 8.0 / 4
+
+
+def test_packed_weight_records_follow_version_counters(built_lib):
+    """The host logic of pipe 4's packed copies, on the emulator: a record per parameter, packed at once; sync_packed() re-packs when the
+    version counter of the module's nn.Parameter (from_module) or of the raw tensor (engine built from a dict) moved, and only then;
+    a re-assigned parameter is warned about; tensors that are not parameters of the engine are never packed."""
+    import logging
+    m16 = U.build(U.tiny_config(), seed=31, dtype=torch.float16)
+    emu = EmuLib()
+    eng = UNet2DEngine.from_module(m16, _host=EmuHost(emu))
+    name = "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_out.0.weight"
+    w = eng.params[name]
+    rec = eng._packed_for(w)
+    assert rec is not None and rec["name"] == name and emu.calls.count("pack_weight") == 1 and eng._packed_for(w) is rec
+    rec["users"] += 1
+
+    def expect(t):
+        N, K = t.shape
+        KS, NB = (K + 63) // 64 * 4, (N + 31) // 32
+        full = torch.zeros(NB * 32, KS * 16, dtype=t.dtype)
+        full[:N, :K] = t
+        return full.reshape(NB, 32, KS, 2, 8).permute(0, 2, 3, 1, 4).reshape(-1)
+
+    assert torch.equal(rec["buf"].view(torch.float16), expect(w)) and eng.sync_packed() == 0
+    p = dict(m16.named_parameters())[name]
+    with torch.no_grad():
+        m16.state_dict()[name].mul_(-1.0)            # the reference's recipe: in place through the state_dict tensor
+    assert eng.sync_packed() == 1 and eng.sync_packed() == 0 and torch.equal(rec["buf"].view(torch.float16), expect(p.data))
+    p.data.mul_(2.0)                                  # bypasses the version counter: invisible until forced
+    assert eng.sync_packed() == 0 and eng.sync_packed(force=True) == 1 and torch.equal(rec["buf"].view(torch.float16), expect(p.data))
+    assert eng._packed_for(torch.zeros(64, 64, dtype=torch.float16)) is None
+    # a 4-D conv weight packs as its [Cout][KH * KW * Cin] view; a weight the plan rewrites per step (not a parameter) does not pack
+    wc = eng.params["down_blocks.0.resnets.0.conv1.weight"]
+    rc = eng._packed_for(wc)
+    assert rc is not None and (rc["N"], rc["K"]) == (wc.shape[0], wc.shape[1] * 9)
+    assert torch.equal(rc["buf"].view(torch.float16), expect(wc.permute(0, 2, 3, 1).reshape(wc.shape[0], -1)))
+    # raw-dict engine: the tensors' own counters
+    params = {k: v.data.clone() for k, v in m16.named_parameters()}
+    for k, v in params.items():
+        if v.ndim == 4:
+            params[k] = v.contiguous(memory_format=torch.channels_last)
+    eng2 = UNet2DEngine(m16.config, params, _host=EmuHost())
+    r2 = eng2._packed_for(params[name])
+    r2["users"] += 1
+    params[name].add_(1.0)
+    assert eng2.sync_packed() == 1 and torch.equal(r2["buf"].view(torch.float16), expect(params[name]))
+    # re-assignment: the plan keeps reading the old storage -- said once, loudly
+    p.data = p.data.clone()
+    records = []
+    h = logging.Handler()
+    h.emit = lambda r: records.append(r.getMessage())
+    logging.getLogger("sfast.engine.unet2d").addHandler(h)
+    try:
+        eng.sync_packed()
+        eng.sync_packed()
+    finally:
+        logging.getLogger("sfast.engine.unet2d").removeHandler(h)
+    assert sum("re-assigned" in r for r in records) == 1
