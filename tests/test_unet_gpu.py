@@ -384,8 +384,54 @@ def test_tiny_unet_bf16():
     assert torch.isfinite(y).all() and e_eng < 3e-2 and e_eng < 1.5 * e_eager + 5e-3, (e_eng, e_eager)
 
 
+_INNER = "SFAST_ISOLATED_TEST_INNER"
+
+
+def _run_isolated(name, attempts=2):
+    """Run test `name` of this file in a pytest process of its own. A death by SIGSEGV / SIGABRT is retried once and REPORTED (parity
+    log + stderr); an ordinary failure is not retried. Why: DESIGN.md section 9, round 4, "Open at the end of the round" -- the
+    ControlNet -> UNet chain test died with a signal in a non-Python thread in 5 of 22 fresh runs of this file, never when it ran in a
+    process of its own; until the cause is pinned (RCCL teardown threads are the suspect) it must not take the other 1800 tests with it."""
+    import subprocess
+    import sys
+    died = []
+    for _ in range(attempts):
+        r = subprocess.run([sys.executable, "-m", "pytest", f"{os.path.abspath(__file__)}::{name}", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
+                           env=dict(os.environ, **{_INNER: name}), capture_output=True, text=True, timeout=1200,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        if r.returncode == 0:
+            if died:
+                log_value(f"{name}: an isolated attempt died with a signal and the retry passed", return_codes=died)
+                print(f"WARNING: {name} died with {died} before passing on retry", file=sys.stderr)
+            return
+        if r.returncode not in (-11, -6, 134, 139):
+            break
+        died.append(r.returncode)
+    raise AssertionError(f"{name} (isolated) failed: rc={r.returncode} died={died}\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}")
+
+
+def test_isolation_helper_selftest(tmp_path):
+    """The helper above, on a test that needs no GPU work: passes through, and a first attempt that dies with SIGSEGV is retried."""
+    if os.environ.get(_INNER) == "test_isolation_helper_selftest":
+        marker = os.environ.get("SFAST_SELFTEST_MARKER")
+        if marker and not os.path.exists(marker):
+            open(marker, "w").close()
+            import signal
+            os.kill(os.getpid(), signal.SIGSEGV)
+        return
+    _run_isolated("test_isolation_helper_selftest")
+    os.environ["SFAST_SELFTEST_MARKER"] = str(tmp_path / "died_once")
+    try:
+        _run_isolated("test_isolation_helper_selftest")
+        assert os.path.exists(os.environ["SFAST_SELFTEST_MARKER"])
+    finally:
+        del os.environ["SFAST_SELFTEST_MARKER"]
+
+
 def test_controlnet_engine_and_compiled_chain():
     """ControlNetModel on the native engine, behind compile_unet(), chained into the compiled UNet."""
+    if os.environ.get(_INNER) != "test_controlnet_engine_and_compiled_chain":
+        return _run_isolated("test_controlnet_engine_and_compiled_chain")
     from oracle import controlnet_ref as CN
     from sfast.compilers.diffusion_pipeline_compiler import CompilationConfig, compile_unet
     ccfg, ucfg = CN.tiny_config(), U.tiny_config()
