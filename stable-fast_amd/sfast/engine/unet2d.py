@@ -238,6 +238,10 @@ def capture_plan_graph(plan, stream, pool=None, tail=None, calibrate=True):
     graphs = [(False, cap(False))]
     if has_side:
         graphs.append((True, cap(True)))
+    # Both candidates stay referenced by the plan: the one that loses the calibration below is NOT destroyed while the process lives
+    # (a few hundred kernel nodes of host memory). hipGraphExecDestroy of a two-branch graph a moment after its last replay is one of the
+    # suspects of the intermittent crash described in DESIGN.md section 9, round 4 ("Open at the end of the round").
+    plan._graph_candidates = [g for _, g in graphs]
     if len(graphs) == 1 or not calibrate:
         return graphs[-1][1], graphs[-1][0]
     best = None
