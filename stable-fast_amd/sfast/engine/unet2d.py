@@ -140,6 +140,7 @@ class UNetPlan:
         self.ws = [None, 0]  # shared workspace [tensor, nbytes]; main-lane ops run serially on one stream
         self.ws_side = [None, 0]  # workspace of the side lanes (they may overlap main-lane kernels)
         self.side_stream = None
+        self._fork_events = None  # fork / lane / join events of run_forked: created once, never destroyed while the plan lives
         self.graph = None
         self.static_in = {}
         self.static_out = None
@@ -173,17 +174,23 @@ class UNetPlan:
         side = self.side_stream
         if side is None or not any(op.lane != LANE_MAIN for op in self.ops):
             return self.run(main.cuda_stream)
-        side.wait_stream(main)
-        events = {}
+        # The fork / join events live as long as the plan. They are recorded on streams that are being CAPTURED: an event object that is
+        # destroyed before hipStreamEndCapture (a local `torch.cuda.Event()`, or the temporary inside `Stream.wait_stream`) leaves the
+        # capturing streams' bookkeeping pointing at freed host memory.
+        ev = self._fork_events
+        if ev is None:
+            ev = self._fork_events = {k: torch.cuda.Event() for k in ("fork", LANE_TEMB, LANE_KV, "join")}
+        if FORK_EVENTS_LOCAL:  # A/B knob: the round-4 behaviour (events die inside the capture)
+            ev = {k: torch.cuda.Event() for k in ev}
+        ev["fork"].record(main)
+        side.wait_event(ev["fork"])
         with torch.cuda.stream(side):
             sp = side.cuda_stream
             for lane in (LANE_TEMB, LANE_KV):
                 for op in self.ops:
                     if op.lane == lane:
                         op.launch(sp)
-                ev = torch.cuda.Event()
-                ev.record(side)
-                events[lane] = ev
+                ev[lane].record(side)
         mp = main.cuda_stream
         joined = set()
         for op in self.ops:
@@ -192,10 +199,11 @@ class UNetPlan:
             if op.needs is not None and op.needs not in joined:
                 for lane in (LANE_TEMB, LANE_KV):  # joining KV implies the earlier temb work too
                     if lane <= op.needs and lane not in joined:
-                        main.wait_event(events[lane])
+                        main.wait_event(ev[lane])
                         joined.add(lane)
             op.launch(mp)
-        main.wait_stream(side)
+        ev["join"].record(side)
+        main.wait_event(ev["join"])
 
     def summary(self):
         agg = defaultdict(lambda: [0, 0.0, 0.0])
@@ -241,7 +249,8 @@ def capture_plan_graph(plan, stream, pool=None, tail=None, calibrate=True):
     # Both candidates stay referenced by the plan: the one that loses the calibration below is NOT destroyed while the process lives
     # (a few hundred kernel nodes of host memory). hipGraphExecDestroy of a two-branch graph a moment after its last replay is one of the
     # suspects of the intermittent crash described in DESIGN.md section 9, round 4 ("Open at the end of the round").
-    plan._graph_candidates = [g for _, g in graphs]
+    if not GRAPH_DESTROY_LOSER:
+        plan._graph_candidates = [g for _, g in graphs]
     if len(graphs) == 1 or not calibrate:
         return graphs[-1][1], graphs[-1][0]
     best = None
@@ -267,6 +276,9 @@ def capture_plan_graph(plan, stream, pool=None, tail=None, calibrate=True):
     return best[2], best[1]
 
 
+# A/B knobs of the round-5 crash hunt (tools/crash_repro.py): 1 = the round-4 behaviour
+FORK_EVENTS_LOCAL = os.environ.get("SFAST_FORK_EVENTS_LOCAL", "0") not in ("0", "false", "off", "")
+GRAPH_DESTROY_LOSER = os.environ.get("SFAST_GRAPH_DESTROY_LOSER", "0") not in ("0", "false", "off", "")
 # sfast_epilogue_ext.flags of every GEMM / conv launch of a plan. SFAST_SPLITK_JOIN=1: split-K problems finish inside the GEMM kernel
 # (ticket counters at the end of the plan's workspace) instead of a reduce launch -- off by default, it measured slower on the SD1.5
 # step (one workgroup per tile re-reads all slabs; DESIGN.md round 3, profiles/r03_splitk_join_*.json.log)

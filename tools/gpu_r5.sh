@@ -1,0 +1,44 @@
+#!/bin/bash
+# Round-5 GPU sessions (one gpurun call each): tools/gpu_r5.sh <stage> [budget seconds]
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+STAGE=${1:-crash1}
+BUDGET=${2:-780}
+export TMPDIR=/tmp
+T0=$(date +%s)
+left() { echo $(( BUDGET - ($(date +%s) - T0) )); }
+PYT="python -m pytest -q --no-header --tb=short -p no:cacheprovider --timeout=900 --maxfail=30 -m gpu"
+run() { # name, timeout, command...
+  local name=$1 to=$2; shift 2
+  echo "=== $name ===" | tee -a gpurun_out/session.log
+  local t0=$(date +%s)
+  timeout $to "$@" > gpurun_out/$name.log 2>&1
+  echo "exit=$? $(( $(date +%s) - t0 ))s $(tail -n 1 gpurun_out/$name.log | cut -c1-300)" | tee -a gpurun_out/session.log
+}
+# crash hunt: every process under the backtrace shim; glibc's abort text to stderr; Python stacks of all threads
+HUNT="env LD_PRELOAD=$PWD/tools/_crashbt.so LIBC_FATAL_STDERR_=1 PYTHONFAULTHANDLER=1"
+R4SEL="tiny or sd15_unet_parity or compile_drop_in or lcm or live_weight or rccl or add_strided or controlnet"
+hunt() { # tag, per-process timeout, count, command...  -- stops early when the session budget is nearly spent
+  local tag=$1 to=$2 n=$3; shift 3
+  for i in $(seq 1 $n); do
+    [ $(left) -lt $(( to / 2 )) ] && { echo "$tag: budget spent before run $i" >> gpurun_out/session.log; break; }
+    local t0=$(date +%s)
+    timeout $to "$@" > gpurun_out/${tag}_$i.log 2>&1
+    local rc=$?
+    echo "$tag run $i exit=$rc $(( $(date +%s) - t0 ))s $(grep -a -m1 -E 'crashbt\] signal|SENTINEL' gpurun_out/${tag}_$i.log | cut -c1-120) | $(tail -n 1 gpurun_out/${tag}_$i.log | cut -c1-80)" >> gpurun_out/session.log
+    [ $rc -eq 0 ] && rm -f gpurun_out/${tag}_$i.log
+  done
+}
+rm -f gpurun_out/parity.jsonl gpurun_out/session.log
+rocminfo 2>/dev/null | grep -E "gfx|Compute Unit" | head -2 >> gpurun_out/session.log
+case $STAGE in
+crash1)  # (a) the round-4 arrangement, literally: process group inside pytest, chain test inline, events die inside the capture, loser destroyed
+  export SFAST_TEST_INPROC=1
+  SFAST_FORK_EVENTS_LOCAL=1 SFAST_GRAPH_DESTROY_LOSER=1 hunt r4py 300 4 $HUNT $PYT tests/test_unet_gpu.py -k "$R4SEL"
+  # (b) the amplified reproducer, round-4 behaviour vs this round's
+  SFAST_FORK_EVENTS_LOCAL=1 SFAST_GRAPH_DESTROY_LOSER=1 hunt amp_old 240 3 $HUNT python tools/crash_repro.py --rccl 1 --iters 12 --budget 150
+  hunt amp_new 240 3 $HUNT python tools/crash_repro.py --rccl 1 --iters 12 --budget 150
+  SFAST_FORK_EVENTS_LOCAL=1 SFAST_GRAPH_DESTROY_LOSER=1 hunt r4py_b 300 4 $HUNT $PYT tests/test_unet_gpu.py -k "$R4SEL"
+  ;;
+esac
+cat gpurun_out/session.log
