@@ -20,11 +20,18 @@
 //     add their accumulators through LDS at the end.
 //   * fp32 partial tiles go to the split-K slab [slice][pixel][Cout]; the existing splitk_reduce_kernel (igemm.hip) sums the slices
 //     in order 0 .. S-1 and runs the epilogue (bias, time-embedding row bias, residual, activation) -- bitwise reproducible.
+//
+// Round 5: this file is EVIDENCE, not product. In the SD1.5 step the fused launch measured 1 % SLOWER than the two operators it
+// replaces (180.1 vs 182.2 it/s, profiles/r04_gnconv_step_ab_run6.log), so it is compiled only
+// into the probe build (-DSFAST_PROBES: build.py --probes -> libsfast_hip_probes.so, what the gn_conv2d tests and tools/gnconv_ab.py
+// load). The product library carries the stubs at the bottom: sfast_hip_gn_conv2d_supported() == 0, workspace 0,
+// sfast_hip_gn_conv2d() == SFAST_ERR_UNSUPPORTED.
 #include <type_traits>
 
 #include "igemm_device.h"
 
 namespace sfast {
+#ifdef SFAST_PROBES
 
 struct GnConvArgs {
     const void *x, *x2, *gamma, *beta, *w;
@@ -509,4 +516,14 @@ int gnconv_init() {
     return SFAST_OK;
 }
 
+#else  // !SFAST_PROBES: the product library has no fused GroupNorm -> conv launch
+
+bool gnconv_plan(int, int, int, int, int, int, int, GnConvPlan &) { return false; }
+int gnconv_run(IgemmArgs &, int, int, const void *, const void *, int, float, int, void *, size_t, hipStream_t) {
+    set_error("gn_conv2d: this library was built without -DSFAST_PROBES (the fused launch is a measured, slower candidate)");
+    return SFAST_ERR_UNSUPPORTED;
+}
+int gnconv_init() { return SFAST_OK; }
+
+#endif
 }  // namespace sfast

@@ -398,6 +398,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const IgemmArgs a) {
     *reinterpret_cast<u32x2 *>((T *)a.out + (int64_t)m * a.ldo + n) = pack4<T>(o[0], o[1], o[2], o[3]);
 }
 
+#ifdef SFAST_PROBES  // measured SLOWER than reduce + separate GroupNorm in the SD1.5 step (profiles/r04_reduce_gn_ab_run{7,8,9}.log): probe build only
 // Split-K reduce + epilogue + the GroupNorm(+SiLU) that CONSUMES the output, in one launch (round 4): workgroup (g, b) owns group g of
 // sample b -- every pixel, the group's N / G channels -- sums the K-split slabs in order 0 .. S-1, runs the conv / GEMM epilogue (bias,
 // row bias, residual, activation), stores the f16 / bf16 output as the plain reduce does, and then normalises exactly those stored
@@ -530,6 +531,8 @@ __global__ void __launch_bounds__(512) splitk_reduce_gn_kernel(const IgemmArgs a
         }
     }
 }
+
+#endif  // SFAST_PROBES
 
 // can the split-K reduce of an [M, N] problem also run the GroupNorm of its output? (host-side rule shared by igemm_run and the API query)
 bool igemm_reduce_gn_ok(int M, int N, int rows_per_batch, int groups) {
@@ -757,7 +760,11 @@ int igemm_init() {
     // 2: + contiguous runs (round 4). Measured and NOT the default: it cuts the modelled XCD-to-XCD duplication of the 32^2-level convs from
     // 62 MB to ~25 MB and changes nothing in the step (184.07 vs 183.99 it/s, SDXL 41.74 vs 41.73: profiles/r04_xcd_run_map_ab_run25.log)
     // -- the fabric duplication behind `roofline.traffic` = 3.9 x algorithmic is not what holds these launches.
+#ifdef SFAST_PROBES
     g_xmap_pref = (xm && xm[0] == '0') ? 0 : (xm && xm[0] == '2') ? 2 : 1;
+#else
+    g_xmap_pref = (xm && xm[0] == '0') ? 0 : 1;  // the run map is a probe-build candidate: "2" means "1" here
+#endif
     const char *e = getenv("SFAST_IGEMM_PIPE");
     if (e && e[0] == 'r') g_pipe_pref = 0;
     if (e && e[0] == 'g') g_pipe_pref = 1;
@@ -1097,6 +1104,7 @@ static void choose_xcd_map(IgemmArgs &a, int mode, bool geglu) {
     }
     // round 4: contiguous runs of a linear (split, tile_n, tile_m) order -- no divisibility needed (5 tile columns x 3 splits of the
     // 640 -> 640 @ 32^2 conv: the box map can only cut the 16 tile rows, every XCD fetches ALL weights: 62 MB against ~25 MB)
+#ifdef SFAST_PROBES
     if (g_xmap_pref >= 2) {
         const int total = a.tiles_m * a.tiles_n * a.splits;
         if (total >= 16 && total <= 65536) {
@@ -1124,6 +1132,7 @@ static void choose_xcd_map(IgemmArgs &a, int mode, bool geglu) {
             }
         }
     }
+#endif
 }
 
 // entry used by api_gemm_conv.hip. mode: 0 linear, 1 conv. Fills plan fields of `a`.
@@ -1176,6 +1185,17 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
         SFAST_REQUIRE(ws && ws_bytes >= need, SFAST_ERR_WORKSPACE, "igemm: workspace %zu < %zu", ws_bytes, need);
         a.partial = (float *)ws;
     }
+    if (a.gn_out) {
+        // sfast_epilogue_ext.gn_out -- the consumer GroupNorm inside the split-K reduce launch. Refused BEFORE anything is launched: an error
+        // after the main kernel would leave `out` written, `gn_out` untouched and, inside a capture, a dangling node.
+#ifdef SFAST_PROBES
+        SFAST_REQUIRE(p.splits > 1 && !joins && !geglu && igemm_reduce_gn_ok(a.M, a.N, a.rows_per_batch, a.gn_groups) && a.ldo % 4 == 0, SFAST_ERR_UNSUPPORTED,
+                      "igemm: the fused GroupNorm epilogue needs a split-K plan (got %d splits) and N / G %% 4 == 0, H*W * N / G <= 16384", p.splits);
+#else
+        SFAST_REQUIRE(false, SFAST_ERR_UNSUPPORTED, "igemm: the fused GroupNorm epilogue (sfast_epilogue_ext.gn_out) measured slower than reduce + "
+                      "GroupNorm and lives in the probe build only (-DSFAST_PROBES); %d splits planned, nothing launched", p.splits);
+#endif
+    }
     char pipe[8];
     snprintf(pipe, sizeof(pipe), p.v.pipe == 4 ? "pk%d" : p.v.pipe == 3 ? "patch%d" : p.v.pipe == 2 ? "ws%d" : p.v.pipe ? "dma%d" : "reg", p.v.ns);
     char xmap[24] = "";
@@ -1198,9 +1218,8 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
     else
         rc = mode ? dispatch_variant<bf16, 1>(a, p.v, geglu, st) : dispatch_variant<bf16, 0>(a, p.v, geglu, st);
     if (rc || joins) return rc;
-    if (a.gn_out) {  // the GroupNorm that consumes this output rides in the reduce launch
-        SFAST_REQUIRE(p.splits > 1 && !geglu && igemm_reduce_gn_ok(a.M, a.N, a.rows_per_batch, a.gn_groups) && a.ldo % 4 == 0, SFAST_ERR_UNSUPPORTED,
-                      "igemm: the fused GroupNorm epilogue needs a split-K plan (got %d splits) and N / G %% 4 == 0, H*W * N / G <= 16384", p.splits);
+#ifdef SFAST_PROBES
+    if (a.gn_out) {  // the GroupNorm that consumes this output rides in the reduce launch (coverage checked BEFORE the main launch, above)
         const int items = ceil_div(a.rows_per_batch * (a.N / a.gn_groups / 4), 512);
         const dim3 grid((unsigned)a.gn_groups, (unsigned)(a.M / a.rows_per_batch)), block(512);
 #define RG_LAUNCH(T, I) hipLaunchKernelGGL((splitk_reduce_gn_kernel<T, I>), grid, block, 0, st, a)
@@ -1212,6 +1231,7 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
 #undef RG_LAUNCH
         return check_launch("splitk_reduce_gn");
     }
+#endif
     if (p.splits > 1 && a.gn_stats) {
         const int R = red_ty * red_rt, CPR = a.N / 8;
         const dim3 grid((unsigned)ceil_div(a.M, R)), block((unsigned)(((CPR * red_ty + 63) / 64) * 64));

@@ -112,6 +112,7 @@ __device__ __forceinline__ BlockTile decode_block(const IgemmArgs &a) {
     BlockTile t;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, k = bid >> 3;
+#ifdef SFAST_PROBES
     if (a.xmap == 2) {
         const int lid = xcd * a.x_per + k;
         if (lid >= a.tiles_m * a.tiles_n * a.splits) {  // surplus block of the last run(s): nothing to do (tile_m < 0, every kernel returns)
@@ -125,7 +126,9 @@ __device__ __forceinline__ BlockTile decode_block(const IgemmArgs &a) {
         t.tile_m = a.x_order ? i2 : i1;
         t.tile_n = a.x_order ? i1 : i2;
         t.split = s;
-    } else if (a.xmap) {
+    } else
+#endif
+    if (a.xmap) {
         const int jn = xcd & ((1 << a.x_lxn) - 1);
         const int im = (xcd >> a.x_lxn) & ((1 << a.x_lxm) - 1);
         const int is = xcd >> (a.x_lxn + a.x_lxm);

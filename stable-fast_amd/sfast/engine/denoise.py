@@ -46,7 +46,9 @@ class DenoiseLoop:
     step is literally one `unet.forward` + guidance + scheduler update -- the unit the reference's it/s counts and what
     `bench.py`'s headline measures; the hoisted form is reported beside it. With the hoist, in-place updates of `to_k` / `to_v`
     weights (the live-weight / LoRA contract) become visible at the next `set_inputs()` or `refresh_text_kv()`, not at the next
-    step -- every other weight stays live.
+    step -- every other weight stays live: read from the parameter's storage by the launch itself, or (packed-weight pipe, the
+    default) re-packed by `step()` when the parameter's autograd version counter moved (`UNet2DEngine.sync_packed`; writes that
+    bypass the counter, e.g. `p.data.copy_`, need `engine.sync_packed(force=True)`).
 
     The loop owns a PRIVATE plan (`engine.build_plan`, not the engine's cached plan of the same signature): its static inputs
     and K/V buffers cannot be overwritten by `engine.forward()` / `compile()` calls that share the engine between two steps."""
@@ -107,6 +109,8 @@ class DenoiseLoop:
         """hoist_text_kv only: re-run the text-side launches (every cross-attention block's K/V projection) on the current stream --
         after a new context (`set_inputs` calls this) or after an in-place update of to_k / to_v weights. A no-op otherwise."""
         sp = self._stream_ptr()
+        if self._ctx_ops:
+            self.engine.sync_packed()
         if self._ctx_ops and self.plan.lora is not None:
             for op in self.plan.ops:  # the hoisted K/V projections read merged LoRA weights: rebuild those first
                 if op.name.startswith("lora.merge"):
@@ -165,6 +169,9 @@ class DenoiseLoop:
         if idx != self._next:
             self.cursor.fill_(idx)
         self._next = (idx + 1) % self.num_steps
+        # pipe-4 launches read PACKED copies of their weights: an in-place parameter update (the live-LoRA switch) between two steps is
+        # picked up here through the parameters' version counters (a host-side compare per packed weight when nothing changed)
+        self.engine.sync_packed()
         if self.graph is not None:
             self.graph.replay()
         else:

@@ -406,6 +406,7 @@ class SVDUNetEngine(UNet2DEngine):
         if encoder_hidden_states.shape[1] != 1:
             raise UnsupportedUNet("the spatio-temporal plan takes one context token per video (CLIP image embedding)")
         plan = self.get_plan(B, Fr, H, W)
+        self.sync_packed()  # pipe-4 launches read packed copies: follow the live parameters' version counters
         self.load_inputs(plan, sample, timestep, encoder_hidden_states, added_time_ids)
         plan.run(self.host.stream_ptr(self.device))
         return plan.static_out.clone()

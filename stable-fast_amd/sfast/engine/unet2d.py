@@ -15,7 +15,14 @@ plan into a hipGraph. The fusion spec is the reference's pass list, applied by c
     (never materialised), NHWC everywhere so [B,C,H,W] <-> [B,HW,C] is free.
 
 Weights are read from the live parameter storage at every launch (the reference's
-`preserve_parameters=True` / LoRA in-place update contract, README.md:228-265): nothing is baked.
+`preserve_parameters=True` / LoRA in-place update contract, README.md:228-265) -- with ONE exception,
+the packed-weight pipe (pipe 4, on by default): a GEMM / conv whose autotuned kernel reads a packed
+copy of its weight depends on `sync_packed()`, which every engine `forward`, every compiled forward and
+`DenoiseLoop.set_inputs / step / refresh_text_kv` call before they launch; it re-packs a parameter
+whose autograd VERSION COUNTER moved since the copy was made. In-place updates through the parameter
+(`p.add_`, `p.copy_`, `state_dict()[k].copy_`) are therefore seen at the next call; writes that bypass
+the counter (`p.data.copy_`, raw pointers, foreign kernels) need `engine.sync_packed(force=True)`,
+re-assigned parameters `engine.refresh_parameters(module)`. `SFAST_PACKED_WEIGHTS=0`: no copies at all.
 """
 import ctypes as C
 import logging
@@ -283,19 +290,16 @@ GRAPH_DESTROY_LOSER = os.environ.get("SFAST_GRAPH_DESTROY_LOSER", "0") not in ("
 # (ticket counters at the end of the plan's workspace) instead of a reduce launch -- off by default, it measured slower on the SD1.5
 # step (one workgroup per tile re-reads all slabs; DESIGN.md round 3, profiles/r03_splitk_join_*.json.log)
 EXT_FLAGS = L.EXT_WS_TICKETS if os.environ.get("SFAST_SPLITK_JOIN", "0") not in ("0", "false", "off", "") else 0
-# GroupNorm+SiLU -> 3x3 conv as one weight-streaming launch where the library covers the shape (B*H*W <= 128: SD1.5's 8x8 level;
-# csrc/gnconv.hip, sfast_hip_gn_conv2d). OFF by default: measured in the SD1.5 step it is 1 % SLOWER than the two operators it
-# replaces (180.1 vs 182.2 it/s, 25.5 us against 16.8 + 4.7 us per 1280 -> 1280 layer: profiles/r04_gnconv_step_ab_run6.log) --
-# every one of the 40 output-channel tiles re-normalises the same activation slice (~4 us of SiLU arithmetic on the critical path of
-# each workgroup) and a wave that streams weights straight into its own registers stalls at the memory queue instead of computing
-# (DESIGN.md section 9, round 4, item 1). SFAST_FUSE_GN_CONV=1 switches it on (A/B knob; the operator itself is parity-green).
-FUSE_GN_CONV = os.environ.get("SFAST_FUSE_GN_CONV", "0") not in ("0", "false", "off", "")
-# the GroupNorm(+SiLU) behind a split-K conv / GEMM rides in that problem's reduce launch (UNet2DEngine._fuse_gn_into_reduce,
-# sfast_epilogue_ext.gn_out). OFF by default: 22 launches fewer per SD1.5 step and still 0.6 - 1.1 % SLOWER (180.2 vs 181.2 it/s,
-# profiles/r04_reduce_gn_ab_run{7,8,9}.log) -- the statistics need a whole (sample, group) in ONE workgroup, i.e. 64 workgroups, and 64
-# CUs pull a 16x16 level's 15.7 MB of fp32 slabs at ~16 GB/s each: 43 us for conv + fused reduce against 31 + 7 us for the
-# chip-wide reduce and the separate 64-workgroup GroupNorm of a 1.3 MB tensor; at the 8x8 level it is a wash (21.5 vs 21.4 us).
-GN_IN_REDUCE = os.environ.get("SFAST_GN_IN_REDUCE", "0") not in ("0", "false", "off", "")
+# Two fusions that were built to parity in round 4, measured SLOWER in the SD1.5 step than what they replace, and therefore live in the
+# PROBE build of the library only (build.py --probes, loaded with SFAST_HIP_PROBES=1): the product library answers
+# SFAST_ERR_UNSUPPORTED for both, and without the probe library these knobs do nothing.
+#  * SFAST_FUSE_GN_CONV=1: GroupNorm+SiLU -> 3x3 conv as one weight-streaming launch (B*H*W <= 128: SD1.5's 8x8 level; csrc/gnconv.hip,
+#    sfast_hip_gn_conv2d): 180.1 vs 182.2 it/s (profiles/r04_gnconv_step_ab_run6.log).
+#  * SFAST_GN_IN_REDUCE=1: the GroupNorm(+SiLU) behind a split-K conv / GEMM rides in that problem's reduce launch
+#    (UNet2DEngine._fuse_gn_into_reduce, sfast_epilogue_ext.gn_out): 180.2 vs 181.2 it/s (profiles/r04_reduce_gn_ab_run{7,8,9}.log).
+_PROBE_LIB = os.environ.get("SFAST_HIP_PROBES", "0") == "1"
+FUSE_GN_CONV = _PROBE_LIB and os.environ.get("SFAST_FUSE_GN_CONV", "0") not in ("0", "false", "off", "")
+GN_IN_REDUCE = _PROBE_LIB and os.environ.get("SFAST_GN_IN_REDUCE", "0") not in ("0", "false", "off", "")
 # Packed weights (pipe 4, csrc/igemm_pk.h): every GEMM / conv whose weight is a parameter of the engine is offered a packed copy (1 KB
 # MFMA fragments, sfast_hip_pack_weight); the autotuner then times the pipe-4 kernels beside the ring kernels and keeps a copy only
 # where one of them won. The copies are re-packed when the parameter's version counter moved (UNet2DEngine.sync_packed, called by
@@ -400,9 +404,19 @@ class UNet2DEngine:
 
     def refresh_parameters(self, m):
         """Re-bind after parameters were re-assigned (not needed for in-place `copy_` updates)."""
-        new = type(self).from_module(m)
-        self.params = new.params
-        self._plans.clear()
+        new = type(self).from_module(m, _host=self.host)
+        with self._lock:
+            self.params = new.params
+            self.norm_eps = new.norm_eps
+            # everything that is keyed by the OLD storage goes with it: version sources, LoRA factor sources, IP-Adapter processors, and the
+            # packed-weight caches (data_ptr -> name map, records). A record that survived would pin the freed tensor and its packed copy,
+            # keep being re-packed from it, and a plan-owned buffer that later lands on the freed address would be taken for a parameter.
+            self._param_objs = new._param_objs
+            self.lora, self._lora_mult = new.lora, new._lora_mult
+            self._ip_processors = new._ip_processors
+            self._plans.clear()
+            self._pk.clear()
+            self.__dict__.pop("_ptr_names", None)
 
     def _parse_config(self):
         g = lambda k, d=None: _cfg_get(self.cfg, k, d)
@@ -1881,6 +1895,7 @@ class ControlNetEngine(UNet2DEngine):
         as fresh NCHW tensors, ready to be passed to UNet2DConditionModel.forward / UNet2DEngine.forward."""
         B, _, H, W = sample.shape
         plan = self.get_plan(B, H, W, encoder_hidden_states.shape[1])
+        self.sync_packed()  # pipe-4 launches read packed copies: follow the live parameters' version counters
         self.load_inputs(plan, sample, timestep, encoder_hidden_states, controlnet_cond, added_cond_kwargs)
         plan.run(self.host.stream_ptr(self.device))
         return self.outputs(plan, conditioning_scale, guess_mode)

@@ -280,6 +280,7 @@ class VaeDecoderEngine(UNet2DEngine):
         """Eager (no graph) execution on the current stream; returns a fresh NCHW image tensor."""
         B, _, H, W = z.shape
         plan = self.get_plan(B, H, W)
+        self.sync_packed()  # pipe-4 launches read packed copies: follow the live parameters' version counters
         self.load_inputs(plan, z)
         plan.run(self.host.stream_ptr(self.device))
         return plan.static_out.clone()

@@ -216,6 +216,17 @@ def softmax_rows(x, scale=1.0, out=None):
     return y
 
 
+def _check_packed(who, lib, pk, rows, K, like):
+    """A packed copy handed to linear() / conv2d() is indexed by the pipe-4 kernels up to ceil(rows / 32) * ceil(K / 64) * 4 KB
+    unconditionally: a buffer of another size, dtype or device would be read out of bounds on the GPU. (That it was packed from THIS
+    weight cannot be checked here; pack_weight() is the only producer.)"""
+    need = int(lib.sfast_hip_packed_weight_bytes(int(rows), int(K)))
+    if not (torch.is_tensor(pk) and pk.dtype == torch.uint8 and pk.device == like.device and pk.is_contiguous() and pk.numel() == need):
+        got = (tuple(pk.shape), pk.dtype, str(pk.device)) if torch.is_tensor(pk) else type(pk).__name__
+        raise L.SfastHipError(f"{who}: w_packed must be the uint8 tensor pack_weight() returns for this [{rows}, {K}] weight "
+                              f"({need} bytes on {like.device}), got {got}")
+
+
 @_on_device
 def pack_weight(weight):
     """Packed copy of a [N, K] linear weight or a [Cout, Cin, KH, KW] channels_last conv weight for the pipe-4 kernels
@@ -314,6 +325,8 @@ def linear(x, weight, bias=None, *, act=None, residual=None, alpha=1.0, res_befo
         pk_list = list(w_packed) if isinstance(w_packed, (list, tuple)) else [w_packed]
         if len(pk_list) != len(ws_list):
             raise L.SfastHipError("linear: one packed copy per weight segment is required")
+        for t in pk_list:
+            _check_packed("linear", lib, t, ws_list[0].shape[0], K, x)
         pk_arr = (C.c_void_p * len(pk_list))(*[t.data_ptr() for t in pk_list])
         ext.w_packed = C.cast(pk_arr, C.c_void_p)
     stats, lay = None, None
@@ -484,6 +497,9 @@ def conv2d(x, weight, bias=None, *, z=None, alpha=1.0, stride=1, padding=0, dila
     wsb, nb, flags = _ws_tickets(nb, x)
     ext = L.EpilogueExt(float(out_scale), int(gn_unit), Ho * Wo, flags)
     if w_packed is not None:  # pack_weight(weight): the pipe-4 kernels (variant 41 ..) become eligible
+        _check_packed("conv2d", lib, w_packed, p.Cout, p.KH * p.KW * p.Cin, x)
+        if not (weight.stride(1) == 1 and (p.KW == 1 or weight.stride(3) == p.Cin) and (p.KH == 1 or weight.stride(2) == p.KW * p.Cin)):
+            raise L.SfastHipError("conv2d: w_packed needs the channels_last ([Cout][KH][KW][Cin]) weight it was packed from")
         pk_arr = (C.c_void_p * 1)(w_packed.data_ptr())
         ext.w_packed = C.cast(pk_arr, C.c_void_p)
     gn_y = None

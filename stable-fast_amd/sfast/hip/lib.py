@@ -266,6 +266,27 @@ def load():
     return _lib
 
 
+_probes_lib = None
+
+
+def load_probes():
+    """A SECOND handle, on the probe build (libsfast_hip_probes.so), whatever library load() returns -- for tests / tools that ask the
+    host-only queries of a measured-and-not-shipped candidate (sfast_hip_gn_conv2d_supported, ...). Raises when it was not built."""
+    global _probes_lib
+    if _probes_lib is None:
+        with _lock:
+            if _probes_lib is None:
+                if not os.path.exists(PROBES_LIB_PATH):
+                    raise SfastHipError(f"{PROBES_LIB_PATH} not found: build it with `python stable-fast_amd/build.py --probes`")
+                import torch  # noqa: F401
+                lib = C.CDLL(PROBES_LIB_PATH)
+                _declare(lib)
+                if lib.sfast_hip_abi_version() != ABI_VERSION or not lib.sfast_hip_has_probes():
+                    raise SfastHipError("libsfast_hip_probes.so is stale; rebuild with --probes")
+                _probes_lib = lib
+    return _probes_lib
+
+
 _inited = set()
 
 

@@ -50,8 +50,8 @@ def _p(ref):
 class EmuLib:
     """Duck-typed stand-in for the ctypes library handle."""
 
-    def __init__(self):
-        self.real = L.load()
+    def __init__(self, real=None):
+        self.real = real if real is not None else L.load()   # host-only queries (plans, layouts, coverage) go to a real library
         self.calls = []
         self.err = b""
 

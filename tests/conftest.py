@@ -23,6 +23,19 @@ def built_lib():
     return mod.build(verbose=False)
 
 
+@pytest.fixture(scope="session")
+def built_probe_lib(built_lib):
+    """libsfast_hip_probes.so (-DSFAST_PROBES): the measured-and-not-shipped candidates (fused GroupNorm -> conv, GroupNorm in the split-K
+    reduce, patch conv pipe, ...). The planner tests of those candidates ask ITS host-only queries; returns the loaded handle."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sfast_build", os.path.join(ROOT, "stable-fast_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build(verbose=False, probes=True)
+    from sfast.hip import lib as L
+    return L.load_probes()
+
+
 @pytest.fixture(scope="session", autouse=True)
 def eager_references_without_miopen():
     """The torch-eager reference legs of the GPU tests (fp32 oracles, eager-fp16 stand-ins) run ATen's im2col / vol2col + rocBLAS

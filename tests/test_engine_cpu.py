@@ -446,20 +446,21 @@ def test_engine_on_the_emulator_matches_round3_goldens(built_lib):
     assert int(cur[0]) == ops["cursor_after"]
 
 
-def test_gn_conv_fusion_at_the_low_resolution_level(built_lib, monkeypatch):
+def test_gn_conv_fusion_at_the_low_resolution_level(built_probe_lib, monkeypatch):
     """Round 4: where B*H*W <= 128 and the channel slices are whole GroupNorm groups, a resnet's GroupNorm+SiLU -> conv3x3 pairs are ONE
     sfast_hip_gn_conv2d launch each (csrc/gnconv.hip). The plan built on the emulator must (a) ask the REAL library which layers it
     covers, (b) wire raw inputs / concat sources / time-embedding offsets / residuals of the fused op correctly -- parity with the
     oracle UNet -- and (c) fall back to the two operators when the knob is off, with identical results on the emulator."""
     import sfast.engine.unet2d as E
-    monkeypatch.setattr(E, "FUSE_GN_CONV", True)   # opt-in since round 4 measured it slower in the SD1.5 step
+    # round 4 measured it slower in the SD1.5 step; since round 5 the launch exists in the PROBE build only: the planner asks that library
+    monkeypatch.setattr(E, "FUSE_GN_CONV", True)
     cfg = U.tiny_config(sample_size=16, block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
                         up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), attention_head_dim=8, norm_num_groups=16)
     m = U.build(cfg, seed=31, dtype=torch.float16)
     g = torch.Generator().manual_seed(32)
     sample = torch.randn(2, 4, 16, 16, generator=g).half()
     ehs = torch.randn(2, 20, cfg["cross_attention_dim"], generator=g).half()
-    emu = EmuLib()
+    emu = EmuLib(real=built_probe_lib)
     eng = UNet2DEngine.from_module(m, _host=EmuHost(emu))
     y = eng.forward(sample, 500, ehs)
     n_fused = emu.calls.count("gn_conv2d")
@@ -476,7 +477,7 @@ def test_gn_conv_fusion_at_the_low_resolution_level(built_lib, monkeypatch):
     assert rel_l2(y2, y.float()) < 1e-3
 
 
-def test_groupnorm_inside_the_split_k_reduce_launch(built_lib, monkeypatch):
+def test_groupnorm_inside_the_split_k_reduce_launch(built_probe_lib, monkeypatch):
     """Round 4, opt-in (SFAST_GN_IN_REDUCE=1; measured slower in the SD1.5 step, so off by default): a GroupNorm right behind a split-K
     conv / GEMM is computed by that problem's reduce launch (sfast_epilogue_ext.gn_out) and leaves the plan. Parity with the oracle
     UNet on the emulator, which refuses -- like the library -- a fused GroupNorm on a plan without a reduce launch."""
@@ -484,7 +485,7 @@ def test_groupnorm_inside_the_split_k_reduce_launch(built_lib, monkeypatch):
     monkeypatch.setattr(E, "GN_IN_REDUCE", True)
     cfg = U.tiny_config()
     m = U.build(cfg, seed=41, dtype=torch.float16)
-    emu = EmuLib()
+    emu = EmuLib(real=built_probe_lib)
     eng = UNet2DEngine.from_module(m, _host=EmuHost(emu))
     g = torch.Generator().manual_seed(42)
     sample = torch.randn(2, 4, 16, 16, generator=g).half()

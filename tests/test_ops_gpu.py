@@ -1034,6 +1034,7 @@ GNCONV_CASES = [
 ]
 
 
+@needs_probes
 @pytest.mark.parametrize("case", GNCONV_CASES, ids=[c[0] for c in GNCONV_CASES])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_gn_conv2d_fused(case, dtype):
@@ -1063,6 +1064,7 @@ def test_gn_conv2d_fused(case, dtype):
     compare(f"gn_conv2d vs two operators {name} {dtype}", y, y2.float(), *tol(dtype, 3.0), kernel=k)
 
 
+@needs_probes
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_gn_conv2d_without_groupnorm_is_the_plain_conv(dtype):
     """groups = 0: the same weight-streaming launch without the normalisation ("wsconv") -- measured against the tuned ring kernels and not
@@ -1077,7 +1079,14 @@ def test_gn_conv2d_without_groupnorm_is_the_plain_conv(dtype):
 
 
 def test_gn_conv2d_refuses_what_it_does_not_cover():
+    """Probe build: shapes outside the fused kernel's coverage are refused. Product build (round 5: the fused launch measured slower and
+    lives in the probe library only): EVERYTHING is refused -- supported() == 0, the call raises SFAST_ERR_UNSUPPORTED, nothing launches."""
     from sfast.hip import lib
+    if not _probes_loaded():
+        x8, w8 = cl(rnd(2, 1280, 8, 8, seed=318)), cl(rnd(1280, 1280, 3, 3, seed=319, scale=0.01))
+        assert not F().gn_conv2d_supported(x8, w8, 32)
+        with pytest.raises(lib.SfastHipError):
+            F().gn_conv2d(x8, 32, None, None, w8)
     x = cl(rnd(2, 1280, 16, 16, seed=311))               # 512 pixels
     w = cl(rnd(1280, 1280, 3, 3, seed=312, scale=0.01))
     assert not F().gn_conv2d_supported(x, w, 32)
@@ -1089,6 +1098,7 @@ def test_gn_conv2d_refuses_what_it_does_not_cover():
     assert not F().gn_conv2d_supported(x1, cl(rnd(1280, 1920, 3, 3, seed=317, scale=0.01)), 32, x2=x2)
 
 
+@needs_probes
 # ---- round 4: the consumer GroupNorm(+SiLU) computed by the split-K reduce launch (sfast_epilogue_ext.gn_out) -------------------------------
 @pytest.mark.parametrize("case", [
     # name, B, Cin, H, W, Cout, split, groups, act, extras
@@ -1127,7 +1137,20 @@ def test_conv_split_k_reduce_carries_the_consumer_groupnorm(case, dtype):
 
 
 def test_fused_groupnorm_epilogue_refuses_unsplit_plans():
+    """sfast_epilogue_ext.gn_out is refused BEFORE the conv is launched (no partial side effects): `out` stays untouched. In the
+    product build (the fused reduce lives in the probe library) that holds for split plans too."""
     from sfast.hip import lib
+    x, w = cl(rnd(2, 1280, 8, 8, seed=415)), cl(rnd(1280, 1280, 3, 3, seed=416, scale=0.02))
+    sentinel = torch.full((2, 1280, 8, 8), 7.0, dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+    with pytest.raises(lib.SfastHipError):   # split 1: no reduce launch to ride in, whichever build
+        F().conv2d(x, w, None, padding=1, split_k=1, gn=(32, None, None, 1e-5, "silu"), out=sentinel)
+    torch.cuda.synchronize()
+    assert bool((sentinel == 7.0).all()), "the conv was launched before the fused GroupNorm epilogue was refused"
+    if not _probes_loaded():
+        with pytest.raises(lib.SfastHipError):
+            F().conv2d(x, w, None, padding=1, split_k=12, gn=(32, None, None, 1e-5, "silu"), out=sentinel)
+        torch.cuda.synchronize()
+        assert bool((sentinel == 7.0).all())
     x, w = cl(rnd(2, 320, 32, 32, seed=411)), cl(rnd(320, 320, 3, 3, seed=412, scale=0.02))
     with pytest.raises(lib.SfastHipError):   # 32x32: 1024 pixels x 10 channels per group: fine, but split 1 has no reduce launch to ride in
         F().conv2d(x, w, None, padding=1, split_k=1, variant=4, gn=(32, None, None, 1e-5, "silu"))

@@ -10,13 +10,16 @@
  */
 #define _GNU_SOURCE
 #include <execinfo.h>
+#include <fcntl.h>
 #include <signal.h>
+#include <ucontext.h>
 #include <stdio.h>
 #include <string.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 
-static void put(const char *s) { (void)!write(2, s, strlen(s)); }
+static int g_fd = 2; /* a private duplicate of the ORIGINAL stderr, taken in the constructor: pytest redirects fd 2 into its capture file later */
+static void put(const char *s) { (void)!write(g_fd, s, strlen(s)); }
 
 static void put_hex(unsigned long v) {
     char b[2 + 16 + 1];
@@ -29,7 +32,6 @@ static void put_hex(unsigned long v) {
 }
 
 static void handler(int sig, siginfo_t *si, void *uc) {
-    (void)uc;
     void *frames[96];
     put("\n[crashbt] signal ");
     put_hex((unsigned long)sig);
@@ -39,9 +41,23 @@ static void handler(int sig, siginfo_t *si, void *uc) {
     put_hex((unsigned long)getpid());
     put(" fault address ");
     put_hex((unsigned long)(si ? si->si_addr : 0));
+    put(" rip ");
+    put_hex(uc ? (unsigned long)((ucontext_t *)uc)->uc_mcontext.gregs[REG_RIP] : 0);
     put("\n");
+    {   /* the dying thread's name (hsa / rccl / torch helper threads name themselves) */
+        char path[64], name[64] = "";
+        snprintf(path, sizeof path, "/proc/self/task/%ld/comm", (long)syscall(SYS_gettid));
+        int cf = open(path, O_RDONLY);
+        if (cf >= 0) {
+            ssize_t r = read(cf, name, sizeof name - 1);
+            if (r > 0) name[r] = 0;
+            close(cf);
+        }
+        put("[crashbt] thread name: ");
+        put(name);
+    }
     int n = backtrace(frames, 96);
-    backtrace_symbols_fd(frames, n, 2);
+    backtrace_symbols_fd(frames, n, g_fd);
     put("[crashbt] end of backtrace\n");
     /* a copy of the memory map makes the offsets resolvable later */
     FILE *f = fopen("/proc/self/maps", "r");
@@ -113,6 +129,8 @@ static void *churn(void *arg) {
 }
 
 __attribute__((constructor)) static void crashbt_install(void) {
+    int d = fcntl(2, F_DUPFD_CLOEXEC, 200);
+    if (d >= 0) g_fd = d;
     static char alt[1 << 16];
     stack_t ss = {.ss_sp = alt, .ss_size = sizeof alt, .ss_flags = 0};
     sigaltstack(&ss, 0);

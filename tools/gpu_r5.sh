@@ -40,5 +40,23 @@ crash1)  # (a) the round-4 arrangement, literally: process group inside pytest, 
   hunt amp_new 240 3 $HUNT python tools/crash_repro.py --rccl 1 --iters 12 --budget 150
   SFAST_FORK_EVENTS_LOCAL=1 SFAST_GRAPH_DESTROY_LOSER=1 hunt r4py_b 300 4 $HUNT $PYT tests/test_unet_gpu.py -k "$R4SEL"
   ;;
+crash2)  # backtraces: the round-4 arrangement until it dies twice (once with Python's faulthandler chained in front, once without, so
+  # that the shim sees the original fault address), then this round's default behaviour for the rest of the budget
+  export SFAST_TEST_INPROC=1
+  HUNT_RAW="env LD_PRELOAD=$PWD/tools/_crashbt.so LIBC_FATAL_STDERR_=1"
+  died=0
+  for i in $(seq 1 10); do
+    [ $died -ge 2 ] && break
+    [ $(left) -lt 400 ] && break
+    if [ $(( i % 2 )) -eq 1 ]; then
+      SFAST_FORK_EVENTS_LOCAL=1 SFAST_GRAPH_DESTROY_LOSER=1 hunt r4raw$i 300 1 $HUNT_RAW $PYT -p no:faulthandler tests/test_unet_gpu.py -k "$R4SEL"
+      [ -f gpurun_out/r4raw${i}_1.log ] && died=$(( died + 1 ))
+    else
+      SFAST_FORK_EVENTS_LOCAL=1 SFAST_GRAPH_DESTROY_LOSER=1 hunt r4fh$i 300 1 $HUNT $PYT tests/test_unet_gpu.py -k "$R4SEL"
+      [ -f gpurun_out/r4fh${i}_1.log ] && died=$(( died + 1 ))
+    fi
+  done
+  hunt r5new 300 20 $HUNT $PYT tests/test_unet_gpu.py -k "$R4SEL"
+  ;;
 esac
 cat gpurun_out/session.log
