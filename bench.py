@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the extra lines of the same run: text-K/V hoisted out of the step graph, the literal B = 1 (no-CFG) step, "
                          "and (N = 8 or --bs64-sharded) BASELINE configs[3]: bs = 64 sharded over the ranks")
+    ap.add_argument("--no-sdxl-variant", action="store_true",
+                    help="skip `variants.sdxl` of the default N = 1 SD1.5 run: the 1x4x128x128-latent step (BASELINE configs[2]) timed by a child "
+                         "process of this script (bench.py --config sdxl --steps 20), so that the driver-run record carries both latent sizes")
     ap.add_argument("--bs64-sharded", action="store_true",
                     help="run the configs[3] leg (64 images split over the N ranks, 64 / N per GPU) for any N, not only N = 8")
     ap.add_argument("--dump-kernels", default=None, help="write the per-op timing table to this JSON file")
@@ -252,11 +255,21 @@ def roofline_from(rows, plan=None, config="sd15"):
                 launches_per_step=dom["launches"], avg_launch_us=dom["seconds"] / dom["launches"] * 1e6,
                 share_of_step=share, timing=timing, **extra, **split_note, algorithmic_gflop_per_launch=dom["flops"] / dom["launches"] / 1e9,
                 algorithmic_mbytes_per_launch=dom["bytes"] / dom["launches"] / 1e6, traffic=None)
-    # HBM-side bytes per launch from the PMC counters: collected in their own rocprofv3 --pmc passes over this same
-    # command (tools/gpu_pmc_bench.sh: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB units) and committed under profiles/
-    # (file named by SFAST_TRAFFIC_PROFILE, else the newest profiles/rNN_pmc_traffic_by_symbol.json; its run id is stated)
+    # Two named fractions so that the line is reproducible from profiles/ alone:
+    #  * frac_interval    -- live, this run: algorithmic work / HIP-event interval around the C-ABI call. For a split-K problem the call is
+    #                        TWO launches (main kernel + splitk_reduce*), and the interval also holds the event pair's own overhead.
+    #  * frac_kernel_only -- algorithmic work / the rocprofv3 per-dispatch average of THIS symbol, from the committed counter / trace passes
+    #                        over this same command (profiles/rNN_pmc_traffic_by_symbol*.json: `avg_us`), i.e. what `rocprofv3 --stats` shows.
+    # `frac` / `achieved` stay the live interval figures (the conservative ones).
+    roof["frac_interval"] = roof["frac"]
+    roof["frac_kernel_only"] = None
+    # HBM-side bytes per launch from the PMC counters: collected in their own rocprofv3 --pmc passes over this same command
+    # (tools/gpu_pmc_bench.sh: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB units) and committed under profiles/. A file is used only when its
+    # `_meta` block says it was taken with the kernel choices in use now (sha256 of the packaged tune cache); otherwise `traffic` is null
+    # and `traffic_note` says why (round 4 silently quoted a round-3 file).
     try:
         import glob
+        import hashlib
         here = os.path.dirname(os.path.abspath(__file__))
         path = os.environ.get("SFAST_TRAFFIC_PROFILE")
         if not path:
@@ -266,13 +279,33 @@ def roofline_from(rows, plan=None, config="sd15"):
             path = cands[-1] if cands else None
         if path:
             with open(path) as f:
-                t = json.load(f).get(dom_name)
-            if t:
+                doc = json.load(f)
+            meta = doc.get("_meta") or {}
+            with open(os.path.join(here, "stable-fast_amd", "sfast", "engine", "tune_gfx950.json"), "rb") as f:
+                tune_sha = hashlib.sha256(f.read()).hexdigest()[:16]
+            rel = os.path.relpath(path, here)
+            t = doc.get(dom_name)
+            if not meta:
+                roof["traffic_note"] = f"{rel} carries no _meta block (taken before round 5): not quoted"
+            elif meta.get("tune_cache_sha256") != tune_sha:
+                roof["traffic_note"] = (f"{rel} (round {meta.get('round')}, commit {meta.get('commit')}) was taken with other kernel choices "
+                                        f"(tune cache {meta.get('tune_cache_sha256')} != {tune_sha}): not quoted")
+            elif not t:
+                roof["traffic_note"] = f"{rel} has no row for this symbol"
+            else:
                 roof["traffic"] = t["bytes_per_launch"]
-                roof["traffic_source"] = (f"{os.path.relpath(path, here)} (counters from separate rocprofv3 --pmc passes over this command, not "
-                                          "re-measured in this run; FETCH_SIZE x2 + WRITE_SIZE, includes Infinity-Cache hits)")
-    except (OSError, ValueError):
-        pass
+                roof["traffic_over_algorithmic"] = t["bytes_per_launch"] / max(dom["bytes"] / dom["launches"], 1.0)
+                roof["traffic_source"] = (f"{rel} (round {meta.get('round')}, commit {meta.get('commit')}, {meta.get('command')}; counters from "
+                                          "separate rocprofv3 --pmc passes over this command, not re-measured in this run; FETCH_SIZE x2 + "
+                                          "WRITE_SIZE, includes Infinity-Cache hits)")
+                if t.get("avg_us"):
+                    per_launch = (dom["flops"] if mfma else dom["bytes"]) / dom["launches"]
+                    rate = per_launch / (t["avg_us"] * 1e-6) / (1e12 if mfma else 1e9)
+                    roof["frac_kernel_only"] = rate / (MFMA_PEAK_TFLOPS if mfma else HBM_PEAK_GBS)
+                    roof["kernel_only_avg_us"] = t["avg_us"]
+                    roof["kernel_only_source"] = f"{rel}: rocprofv3 per-dispatch average of this symbol over {t.get('launches')} steady-window dispatches"
+    except (OSError, ValueError, KeyError) as e:
+        roof["traffic_note"] = f"traffic file unreadable: {type(e).__name__}: {e}"
     fam = {}
     for r in rows:
         f = fam.setdefault(r["kind"], dict(seconds=0.0, flops=0.0, bytes=0.0, launches=0))
@@ -517,6 +550,32 @@ def step_variants(args, engine, cfg, hw, dev, latents, ehs, headline_ms):
             ms1 = _time_steps(lambda i: graph.replay(), steps, warm, dev) * 1e3
         out["literal_b1"] = {"value": 1e3 / ms1, "unit": "it/s", "ms_per_step": ms1, "unet_batch": 1, "kernel_launches_per_step": len(plan.ops) + 1,
                              "note": "UNet forward at batch 1 (no classifier-free guidance) + DDIM update, one hipGraph -- SURVEY 8d config 2, B = 1"}
+    return out
+
+
+def sdxl_variant(steps=20, warmup=5, timeout=240):
+    """north_star asks for it/s on BOTH latent sizes; the driver times `python bench.py` only. So the default SD1.5 run ends by timing
+    the 1x4x128x128-latent step (BASELINE configs[2]: SDXL 1024x1024 bs=1 fp16, CFG batch-2 UNet + guidance + DDIM update as one
+    hipGraph, packaged kernel choices) in a CHILD process of this same script -- its own 5 GB of weights, its own plan, its own
+    `roofline` block -- and embeds the child's JSON line. A failure is reported, never raised: the contract line must survive."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", "sdxl", "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup),
+           "--no-cpu-baseline", "--no-end-to-end", "--no-variants"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
+        if r.returncode != 0 or line is None:
+            return {"error": f"child exited {r.returncode}", "stderr_tail": r.stderr[-400:], "seconds": time.perf_counter() - t0}
+        child = json.loads(line)
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}", "seconds": time.perf_counter() - t0}
+    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "gpu_ms_per_step_events", "outputs_finite",
+            "kernel_launches_per_step", "packed_weight_launches", "roofline", "kernel_families", "sum_of_kernel_ms_eager")
+    out = {k: child[k] for k in keep if k in child}
+    out["wall_seconds_of_child_process"] = time.perf_counter() - t0
+    out["command"] = " ".join(["python", "bench.py"] + cmd[2:])
     return out
 
 
@@ -996,6 +1055,9 @@ def main():
                 out["variants"] = step_variants(args, engine, cfg, hw, dev, latents, ehs, elapsed / args.steps * 1e3)
             except Exception as e:   # extra lines must never take the contract line down
                 out["variants"] = {"error": f"{type(e).__name__}: {e}"}
+        if (world == 1 and args.config == "sd15" and args.images == 1 and not args.no_variants and not args.no_sdxl_variant
+                and not args.no_graph and isinstance(out.get("variants"), dict)):
+            out["variants"]["sdxl"] = sdxl_variant()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.config, args.images)
     # BASELINE configs[3] (bs = 64 sharded over the ranks): every rank runs its shard; a leg of the N = 8 run (or --bs64-sharded)

@@ -156,6 +156,9 @@ class DenoiseLoop:
             with torch.cuda.stream(side):
                 with torch.cuda.graph(g, stream=side):
                     self._launch_all(torch.cuda.current_stream(dev).cuda_stream)
+            if self.graph is not None:   # a re-capture: the old graph is retired, never destroyed in the same breath as its last replay
+                from .unet2d import retire_graph
+                retire_graph(self.graph, dev)
             self.graph = g
             torch.cuda.synchronize(dev)
         self.latents.copy_(keep_lat)

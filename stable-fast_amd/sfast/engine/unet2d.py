@@ -27,6 +27,7 @@ re-assigned parameters `engine.refresh_parameters(module)`. `SFAST_PACKED_WEIGHT
 import ctypes as C
 import logging
 import os
+import collections
 import threading
 from collections import defaultdict
 
@@ -222,6 +223,27 @@ class UNetPlan:
         return {k: {"count": v[0], "gflop": v[1] / 1e9, "mbytes": v[2] / 1e6} for k, v in agg.items()}
 
 
+# hipGraphExec objects that are no longer wanted. A graph is never destroyed in the same breath as its last replay: the HIP runtime releases
+# the kernel commands of a launch on its asynchronous completion thread (ROCclr NDRangeKernelCommand::releaseResources -> free of the
+# captured kernel arguments), and a graph torn down under it ends in an invalid free() on that thread a few milliseconds later -- the
+# backtrace of the round-4 crash (profiles/r05_crash_backtrace_run2.log). Retired graphs are dropped oldest-first, only when more than
+# 2 * _RETIRED_KEEP have piled up, only from capture_plan_graph's own (non-capturing, non-GC) context and only after a device synchronise.
+_RETIRED = collections.deque()
+_RETIRED_KEEP = 8
+
+
+def retire_graph(g, device=None):
+    _RETIRED.append((g, device))
+
+
+def _trim_retired():
+    if len(_RETIRED) > 2 * _RETIRED_KEEP:
+        for dev in {d for _, d in _RETIRED}:
+            torch.cuda.synchronize(dev)
+        while len(_RETIRED) > _RETIRED_KEEP:
+            _RETIRED.popleft()
+
+
 def capture_plan_graph(plan, stream, pool=None, tail=None, calibrate=True):
     """Capture `plan` (+ an optional `tail(stream_ptr)` launch) into a hipGraph on `stream`.
 
@@ -234,6 +256,7 @@ def capture_plan_graph(plan, stream, pool=None, tail=None, calibrate=True):
     (5.60 vs 5.42 ms: with the side lanes reduced to ~8 grouped launches the fork / join edges cost more than the
     overlap returns; tools/replay_gap_probe.py, profiles/r02_replay_gap_probe.log)."""
     dev = plan.engine.device
+    _trim_retired()
 
     def cap(forked):
         g = torch.cuda.CUDAGraph()
@@ -253,11 +276,8 @@ def capture_plan_graph(plan, stream, pool=None, tail=None, calibrate=True):
     graphs = [(False, cap(False))]
     if has_side:
         graphs.append((True, cap(True)))
-    # Both candidates stay referenced by the plan: the one that loses the calibration below is NOT destroyed while the process lives
-    # (a few hundred kernel nodes of host memory). hipGraphExecDestroy of a two-branch graph a moment after its last replay is one of the
-    # suspects of the intermittent crash described in DESIGN.md section 9, round 4 ("Open at the end of the round").
-    if not GRAPH_DESTROY_LOSER:
-        plan._graph_candidates = [g for _, g in graphs]
+    # The candidate that loses the calibration below is RETIRED, not destroyed on the spot (see retire_graph): hipGraphExecDestroy in the
+    # same breath as the graph's last replay is one of the two triggers of the round-4 crash.
     if len(graphs) == 1 or not calibrate:
         return graphs[-1][1], graphs[-1][0]
     best = None
@@ -280,6 +300,10 @@ def capture_plan_graph(plan, stream, pool=None, tail=None, calibrate=True):
             plan.graph_calibration_ms = cal
             if best is None or t < best[0]:
                 best = (t, forked, g)
+    if not GRAPH_DESTROY_LOSER:
+        for _, g in graphs:
+            if g is not best[2]:
+                retire_graph(g, dev)
     return best[2], best[1]
 
 

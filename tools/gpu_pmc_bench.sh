@@ -2,6 +2,8 @@
 # HBM-side traffic per kernel symbol of the bench step: FETCH_SIZE and WRITE_SIZE in separate --pmc passes
 # (counters only with --kernel-trace, as the pool requires) over the SAME bench command, autotune results cached.
 # usage: tools/gpu_pmc_bench.sh [sd15|sdxl|svd] [steps]   -> gpurun_out/pmcb/traffic_by_symbol[_<config>].json
+# The file carries a `_meta` block (round, commit = $SFAST_COMMIT as passed by the caller -- the GPU box has no .git --, sha256 of the
+# packaged tune cache, the command): bench.py quotes `traffic` from it only while the kernel choices are the ones it was taken with.
 cd "$(dirname "$0")/.."
 CFG=${1:-sd15}
 STEPS=${2:-6}
@@ -9,7 +11,7 @@ SUF=""; [ "$CFG" != "sd15" ] && SUF="_$CFG"
 rm -rf gpurun_out/pmcb; mkdir -p gpurun_out/pmcb
 export TMPDIR=/tmp
 R=$PWD
-export SFAST_TUNE_CACHE=$R/gpurun_out/tune_cache.json
+# round 5: the passes run on the PACKAGED kernel choices (sfast/engine/tune_gfx950.json), exactly like the driver's `python bench.py`
 python bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-roofline --no-end-to-end > gpurun_out/pmcb/warm.log 2>&1
 pass() { # name, counters...
   local name=$1; shift
@@ -19,8 +21,8 @@ pass() { # name, counters...
 }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
-SUF=$SUF python - <<'PY'
-import json, os
+SUF=$SUF CFG=$CFG STEPS=$STEPS python - <<'PY'
+import hashlib, json, os
 f = {r["kernel"]: r for r in json.load(open("gpurun_out/pmcb/fetch.json"))["rows"]}
 w = {r["kernel"]: r for r in json.load(open("gpurun_out/pmcb/write.json"))["rows"]}
 out = {}
@@ -30,7 +32,12 @@ for k, r in f.items():
     # gfx950: FETCH_SIZE counts 128-B fabric requests as 64 B (MI355X_MICROARCH.md, HBM section) -> x2; unit KB
     out[k] = dict(bytes_per_launch=(2.0 * fetch_kb + write_kb) * 1024.0, fetch_kb_raw=fetch_kb, write_kb_raw=write_kb,
                   launches=r["dispatches"], avg_us=r.get("avg_us"))
+sha = hashlib.sha256(open("stable-fast_amd/sfast/engine/tune_gfx950.json", "rb").read()).hexdigest()[:16]
+out["_meta"] = dict(round=5, commit=os.environ.get("SFAST_COMMIT", "unknown"), tune_cache_sha256=sha,
+                    command=f"python bench.py --config {os.environ['CFG']} --steps {os.environ['STEPS']} --warmup 2 --no-cpu-baseline --no-roofline --no-end-to-end",
+                    method="separate rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE; WRITE_SIZE); last 40 % of the dispatches; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB")
 json.dump(out, open("gpurun_out/pmcb/traffic_by_symbol" + os.environ.get("SUF", "") + ".json", "w"), indent=1)
+del out["_meta"]
 for k, v in sorted(out.items(), key=lambda kv: -(kv[1]["avg_us"] or 0) * kv[1]["launches"])[:12]:
     print(f"{k[:90]:90s} n={v['launches']:5d} {v['avg_us'] or 0:7.1f} us  {v['bytes_per_launch'] / 1e6:8.2f} MB/launch")
 PY

@@ -58,5 +58,23 @@ crash2)  # backtraces: the round-4 arrangement until it dies twice (once with Py
   done
   hunt r5new 300 20 $HUNT $PYT tests/test_unet_gpu.py -k "$R4SEL"
   ;;
+crash3)  # this round's default behaviour in the round-4 arrangement, two fresh pytest processes at a time (the crash is a host-side race:
+  # a second process competing for the cores is a harder test, and the loop takes half the box time), then the norm micro-benchmark
+  export SFAST_TEST_INPROC=1
+  N=${3:-10}
+  for i in $(seq 1 $N); do
+    [ $(left) -lt 200 ] && { echo "r5v: budget spent before round $i" >> gpurun_out/session.log; break; }
+    t0=$(date +%s)
+    ( MASTER_PORT=29533 timeout 400 $HUNT $PYT tests/test_unet_gpu.py -k "$R4SEL" > gpurun_out/r5v_a$i.log 2>&1; echo $? > gpurun_out/r5v_a$i.rc ) &
+    ( cd . && SFAST_PACKED_WEIGHTS=0 MASTER_PORT=29534 timeout 400 $HUNT $PYT tests/test_unet_gpu.py -k "$R4SEL" > gpurun_out/r5v_b$i.log 2>&1; echo $? > gpurun_out/r5v_b$i.rc ) &
+    wait
+    for v in a b; do
+      rc=$(cat gpurun_out/r5v_$v$i.rc); rm -f gpurun_out/r5v_$v$i.rc
+      echo "r5v $v$i exit=$rc $(( $(date +%s) - t0 ))s $(grep -a -m1 -E 'crashbt\] signal' gpurun_out/r5v_$v$i.log | cut -c1-120) | $(tail -n 1 gpurun_out/r5v_$v$i.log | cut -c1-80)" >> gpurun_out/session.log
+      [ "$rc" = "0" ] && rm -f gpurun_out/r5v_$v$i.log
+    done
+  done
+  run micro_norm 200 python tools/micro_norm.py
+  ;;
 esac
 cat gpurun_out/session.log
