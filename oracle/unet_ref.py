@@ -290,10 +290,16 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, x, ctx):
-        cross_bias, ip = None, None
-        if isinstance(ctx, tuple):  # (encoder_hidden_states, additive cross-attention bias [B, 1, S_ctx] or None[, IP-Adapter image tokens])
-            ctx, cross_bias, ip = (tuple(ctx) + (None,))[:3]
-        x = self.attn1(self.norm1(x)) + x
+        cross_bias, ip, self_bias = None, None, None
+        if isinstance(ctx, tuple):  # (encoder_hidden_states, additive cross-attention bias [B, 1, S_ctx] or None[, IP-Adapter image tokens[, self-attention bias]])
+            ctx, cross_bias, ip, self_bias = (tuple(ctx) + (None, None))[:4]
+        if self_bias is not None and self_bias.shape[-1] != x.shape[1]:
+            # diffusers Attention.prepare_attention_mask: a mask whose length differs from the layer's key count is padded by
+            # F.pad(mask, (0, target_length)) -- to current + target keys, not to target -- and scaled_dot_product_attention then refuses
+            # the shape. A UNet-level `attention_mask` is therefore usable only when every self-attention layer has exactly that many tokens.
+            raise RuntimeError(f"attention_mask of {self_bias.shape[-1]} keys on a self-attention layer with {x.shape[1]} tokens "
+                               "(diffusers pads it to the sum of both and scaled_dot_product_attention rejects the shape)")
+        x = self.attn1(self.norm1(x), None, self_bias) + x
         x = self.attn2(self.norm2(x), ctx, cross_bias, ip) + x
         return self.ff(self.norm3(x)) + x
 
@@ -543,7 +549,7 @@ class UNet2DConditionModel(nn.Module):
 
     def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, return_dict=True,
                 down_block_additional_residuals=None, mid_block_additional_residual=None, encoder_attention_mask=None,
-                timestep_cond=None, class_labels=None, cross_attention_kwargs=None, **_):
+                timestep_cond=None, class_labels=None, cross_attention_kwargs=None, attention_mask=None, **_):
         # cross_attention_kwargs: only {"scale": s} is meaningful here: diffusers scales the LoRA layers by it for this call
         # (load_lora(); a no-op without them)
         assert not cross_attention_kwargs or set(cross_attention_kwargs) <= {"scale"}
@@ -575,6 +581,12 @@ class UNet2DConditionModel(nn.Module):
                 ip.append(self.encoder_hid_proj(t_.reshape(b_ * n_, -1)).reshape(b_, -1, c.cross_attention_dim).to(sample.dtype))
             base = encoder_hidden_states if isinstance(encoder_hidden_states, tuple) else (encoder_hidden_states, None)
             encoder_hidden_states = (base[0], base[1], ip)
+        if attention_mask is not None:
+            # diffusers UNet2DConditionModel.forward: a keep-mask [B, L] -> additive bias (1 - mask) * -10000, unsqueezed to [B, 1, L], handed to
+            # the SELF-attention (attn1) of every transformer block
+            sb = ((1 - attention_mask.to(sample.dtype)) * -10000.0).unsqueeze(1)
+            base = encoder_hidden_states if isinstance(encoder_hidden_states, tuple) else (encoder_hidden_states, None)
+            encoder_hidden_states = (tuple(base) + (None, None))[:3] + (sb,)
         t = timestep
         if not torch.is_tensor(t):
             t = torch.tensor([t], dtype=torch.float32, device=sample.device)

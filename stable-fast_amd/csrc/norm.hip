@@ -317,6 +317,89 @@ __global__ void gn_nhwc_apply_kernel(const T *__restrict__ x, const T *__restric
     gn_apply_rows<T, SILU>(x, x2, gamma, beta, y, g, rows_per_block, mean, rstd, ga_raw, be_raw);
 }
 
+// One-pass apply over producer-emitted statistics, second form of the merge prologue (round 5). The records of one sample -- per concat
+// source n_rb row blocks x S slots of {mean, M2}, one contiguous block of memory -- are copied into LDS by all threads with coalesced
+// loads (ONE exposed memory round trip), then LPG lanes per group (a power of two, groups never straddle a wave) combine the group's
+// records with the weighted two-pass formulas
+//      mean = sum(n_i * mean_i) / sum(n_i),     M2 = sum(M2_i) + sum(n_i * (mean_i - mean)^2)
+// each lane over its strided share, xor butterflies inside the lane group: fixed order, bitwise reproducible, no serial Chan chain and no
+// division per record. The first form (gn_nhwc_apply_kernel<.., PRE = true>) walks three dependent stages -- per-lane Chan merges, a
+// 16-long serial merge per slot, a serial merge per group -- and costs ~3 us more than a LayerNorm over the same bytes (7.5 vs 4.65 us
+// at [2, 320, 64, 64], profiles/r05_micro_norm_run3.log). Same contract and record layout; kept for sample sizes whose records
+// exceed the LDS budget and as the A/B partner (SFAST_GN_MERGE=chain).
+template <typename T, bool SILU>
+__global__ void gn_nhwc_apply2_kernel(const T *__restrict__ x, const T *__restrict__ x2, const T *__restrict__ gamma, const T *__restrict__ beta,
+                                      T *__restrict__ y, GnGeom g, int rows_per_block, float eps, const GnPre pre, int lpg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *mean = smem;                                      // [G]
+    float *rstd = smem + g.G;                                // [G]
+    float2 *rec = reinterpret_cast<float2 *>(smem + 2 * g.G + (g.G & 1) * 2);  // [R0 + R1] (8-byte aligned)
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int tx0 = tid % g.TXB;
+    const bool pre_ok = tx0 < g.CX && tid < g.TXB * g.TY;
+    u32x4 ga_raw = {0u, 0u, 0u, 0u}, be_raw = {0u, 0u, 0u, 0u};
+    if (pre_ok && gamma) ga_raw = *reinterpret_cast<const u32x4 *>(gamma + tx0 * 8);
+    if (pre_ok && beta) be_raw = *reinterpret_cast<const u32x4 *>(beta + tx0 * 8);
+    const int S0 = pre.tiles_n[0] * pre.slots[0];
+    const int S1 = g.C1 < g.C ? pre.tiles_n[1] * pre.slots[1] : 0;
+    const int R0 = S0 * pre.n_rb[0], R1 = S1 * pre.n_rb[1];
+    for (int w = tid; w < R0 + R1; w += blockDim.x) {
+        const int s_ = w < R0 ? 0 : 1;
+        const int lw = w - (s_ ? R0 : 0);
+        rec[w] = *reinterpret_cast<const float2 *>(pre.p[s_] + ((int64_t)b * (s_ ? R1 : R0) + lw) * 2);
+    }
+    __syncthreads();
+    if (tid < g.G * lpg) {
+        const int grp = tid / lpg, j = tid - grp * lpg;
+        // every {slot, count} of this group, in channel order; f(record base of the slot, records stride, row blocks, count)
+        auto for_each_slot = [&](auto &&f) {
+            int c = grp * g.cpg;
+            const int cend = c + g.cpg;
+            while (c < cend) {
+                const int s_ = c < g.C1 ? 0 : 1;
+                const int cl = c - pre.coff[s_];
+                const int Ul = cl / pre.unit[s_];
+                const int uend = min((Ul + 1) * pre.unit[s_], pre.nch[s_]);
+                for (int tn = cl / pre.bno[s_]; tn <= (uend - 1) / pre.bno[s_]; ++tn) {
+                    const int jj = Ul - (tn * pre.bno[s_]) / pre.unit[s_];
+                    const int lo = max(tn * pre.bno[s_], Ul * pre.unit[s_]), hi = min(min((tn + 1) * pre.bno[s_], pre.nch[s_]), (Ul + 1) * pre.unit[s_]);
+                    if (hi > lo)
+                        f((s_ ? R0 : 0) + tn * pre.slots[s_] + jj, s_ ? S1 : S0, pre.n_rb[s_], (float)(hi - lo) * (float)pre.rb_rows[s_]);
+                }
+                c = uend + pre.coff[s_];
+            }
+        };
+        float sw = 0.f, sm = 0.f;
+        for_each_slot([&](int base, int stride, int nrb, float cnt) {
+            for (int rb = j; rb < nrb; rb += lpg) {
+                sw += cnt;
+                sm = fmaf(cnt, rec[base + rb * stride].x, sm);
+            }
+        });
+        for (int off = lpg >> 1; off >= 1; off >>= 1) {
+            sw += __shfl_xor(sw, off, 64);
+            sm += __shfl_xor(sm, off, 64);
+        }
+        const float mu = sm / sw;
+        float m2 = 0.f;
+        for_each_slot([&](int base, int stride, int nrb, float cnt) {
+            for (int rb = j; rb < nrb; rb += lpg) {
+                const float2 r = rec[base + rb * stride];
+                const float d = r.x - mu;
+                m2 += fmaf(cnt * d, d, r.y);
+            }
+        });
+        for (int off = lpg >> 1; off >= 1; off >>= 1) m2 += __shfl_xor(m2, off, 64);
+        if (j == 0) {
+            mean[grp] = mu;
+            rstd[grp] = rsqrtf(fmaxf(m2 / sw, 0.f) + eps);  // biased variance (group_norm.py:48)
+        }
+    }
+    __syncthreads();
+    gn_apply_rows<T, SILU>(x, x2, gamma, beta, y, g, rows_per_block, mean, rstd, ga_raw, be_raw);
+}
+
 template <typename T, bool SILU>
 __device__ __forceinline__ void gn_apply_rows(const T *__restrict__ x, const T *__restrict__ x2, const T *__restrict__ gamma,
                                               const T *__restrict__ beta, T *__restrict__ y, const GnGeom &g, int rows_per_block,
@@ -710,6 +793,70 @@ static int gn_launch_small(const void *x, const void *x2, const void *gamma, con
     return check_launch("group_norm_small");
 }
 
+// LayerNorm rows whose 16-byte chunk count is LPR * CPL with LPR < 64 (round 5): LPR lanes own a row, CPL chunks each, 64 / LPR rows per wave.
+// The UNet's widths are 320 / 640 / 1280 = 40 / 80 / 160 chunks = (8 | 16 | 32 lanes) x 5: with one row per wave (ln_rows_kernel) a 320-wide
+// row keeps 40 of 64 lanes busy and a 64 x 64 level launches 8192 waves of 640 bytes each -- 4.65 us against 2.7 us for a plain copy of
+// the same bytes (profiles/r05_micro_norm_run3.log). Here every lane is busy, a wave has 64 / LPR rows x CPL loads in flight, and a load
+// instruction touches whole 128-byte lines (lane l of a row reads chunks l, l + LPR, ...: consecutive lanes, consecutive 16 bytes).
+// Same arithmetic as ln_rows_kernel (two exact passes over the cached row, fp32), reduction = xor butterfly inside the lane group.
+template <typename T, int LPR, int CPL>
+__global__ void __launch_bounds__(256) ln_group_kernel(const T *__restrict__ x, const T *__restrict__ gamma, const T *__restrict__ beta,
+                                                       T *__restrict__ y, int M, int N, float eps) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l = lane % LPR;
+    const int row = (blockIdx.x * 4 + wave) * RPW + lane / LPR;
+    const bool live = row < M;
+    const T *xr = x + (int64_t)(live ? row : 0) * N;
+    u32x4 cache[CPL], gar[CPL], ber[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) cache[j] = live ? *reinterpret_cast<const u32x4 *>(xr + (l + j * LPR) * 8) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        gar[j] = u32x4{0u, 0u, 0u, 0u};
+        ber[j] = u32x4{0u, 0u, 0u, 0u};
+        if (gamma) gar[j] = *reinterpret_cast<const u32x4 *>(gamma + (l + j * LPR) * 8);
+        if (beta) ber[j] = *reinterpret_cast<const u32x4 *>(beta + (l + j * LPR) * 8);
+    }
+    float sacc = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        float f[8];
+        unpack8<T>(cache[j], f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sacc += f[i];
+    }
+#pragma unroll
+    for (int off = LPR / 2; off >= 1; off >>= 1) sacc += __shfl_xor(sacc, off, 64);
+    const float mean = sacc / (float)N;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        float f[8];
+        unpack8<T>(cache[j], f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float d = f[i] - mean;
+            q += d * d;
+        }
+    }
+#pragma unroll
+    for (int off = LPR / 2; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = rsqrtf(q / (float)N + eps);
+    if (!live) return;
+    T *yr = y + (int64_t)row * N;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        float f[8], ga[8], be[8];
+        unpack8<T>(cache[j], f);
+        unpack8<T>(gar[j], ga);
+        unpack8<T>(ber[j], be);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (f[i] - mean) * rstd * (gamma ? ga[i] : 1.f) + (beta ? be[i] : 0.f);
+        *reinterpret_cast<u32x4 *>(yr + (l + j * LPR) * 8) = pack8<T>(f);
+    }
+}
+
 // ---- host-side planning ----------------------------------------------------------------------
 struct GnPlan {
     bool fast;
@@ -787,6 +934,16 @@ static int gn_launch_fast(const void *x, const void *x2, const void *gamma, cons
     return check_launch("group_norm_nhwc");
 }
 
+// SFAST_GN_MERGE=chain: the first-form merge prologue (three dependent stages of Chan merges) everywhere -- the A/B partner of round 5's
+// two-pass lane-group prologue (default)
+static bool gn_merge_two_pass() {
+    static const bool v = [] {
+        const char *e = getenv("SFAST_GN_MERGE");
+        return !(e && e[0] == 'c');
+    }();
+    return v;
+}
+
 // one normalisation pass over statistics the producers left behind
 template <typename T>
 static int gn_launch_pre(const void *x, const void *x2, const void *gamma, const void *beta, void *y, const sfast_gn_params *p,
@@ -800,6 +957,20 @@ static int gn_launch_pre(const void *x, const void *x2, const void *gamma, const
     pr.kl = threads / (s_tot > 0 ? s_tot : 1);
     if (pr.kl < 1) pr.kl = 1;
     if (pr.kl > 16) pr.kl = 16;
+    // second-form prologue (gn_nhwc_apply2_kernel): all records of the sample in LDS, lane groups per GroupNorm group
+    const int64_t recs = (int64_t)pr.tiles_n[0] * pr.slots[0] * pr.n_rb[0] + (g.C1 < g.C ? (int64_t)pr.tiles_n[1] * pr.slots[1] * pr.n_rb[1] : 0);
+    const size_t smem2 = (size_t)(2 * g.G + 2) * sizeof(float) + (size_t)recs * 8;
+    int lpg = 64;
+    while (lpg > 1 && lpg * g.G > threads) lpg >>= 1;
+    if (gn_merge_two_pass() && smem2 <= 48 * 1024 && lpg * g.G <= threads) {
+        if (p->act == SFAST_ACT_SILU)
+            hipLaunchKernelGGL((gn_nhwc_apply2_kernel<T, true>), dim3(pl.napply, p->N), dim3(threads), smem2, st, (const T *)x, (const T *)x2,
+                               (const T *)gamma, (const T *)beta, (T *)y, g, pl.rows_apply, p->eps, pr, lpg);
+        else
+            hipLaunchKernelGGL((gn_nhwc_apply2_kernel<T, false>), dim3(pl.napply, p->N), dim3(threads), smem2, st, (const T *)x, (const T *)x2,
+                               (const T *)gamma, (const T *)beta, (T *)y, g, pl.rows_apply, p->eps, pr, lpg);
+        return check_launch("group_norm_apply2");
+    }
     const size_t smem_apply = (size_t)(2 * g.G + (size_t)s_tot * pr.kl * 3 + (size_t)s_tot * 3) * sizeof(float);
     if (smem_apply > 60 * 1024) {
         set_error("group_norm_apply: %d record slots per sample exceed the merge scratch", s_tot);
@@ -1068,6 +1239,17 @@ __global__ void __launch_bounds__(256) ln_wide_kernel(const T *__restrict__ x, c
     }
 }
 
+// lanes per row of ln_group_kernel<T, LPR, 5> for an N-wide row (0: not that family). SFAST_LN_GROUP=0 keeps one row per wave (A/B knob).
+static int ln_group_lanes(int N) {
+    static const int on = [] {
+        const char *e = getenv("SFAST_LN_GROUP");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    if (!on || N % 40 != 0) return 0;
+    const int lpr = N / 40;
+    return (lpr == 8 || lpr == 16 || lpr == 32) ? lpr : 0;
+}
+
 template <typename T>
 static int ln_launch(const void *x, const void *gamma, const void *beta, void *y, const sfast_ln_params *p,
                      hipStream_t st, bool fast) {
@@ -1085,6 +1267,14 @@ static int ln_launch(const void *x, const void *gamma, const void *beta, void *y
             hipLaunchKernelGGL((ln_wide_kernel<T, 16>), dim3(p->M), block, 0, st, (const T *)x, (const T *)gamma, (const T *)beta, (T *)y,
                                p->M, p->N, p->eps);
         return check_launch("layer_norm_wide");
+      }
+      if (fast && ln_group_lanes(p->N) && p->M >= 64) {   // 320 / 640 / 1280-wide rows (the UNet's): lane groups, every lane busy
+        const int lpr = ln_group_lanes(p->N);
+        const dim3 gg(ceil_div(p->M, 4 * (64 / lpr)));
+#define LNG_LAUNCH(LPR_) hipLaunchKernelGGL((ln_group_kernel<T, LPR_, 5>), gg, block, 0, st, (const T *)x, (const T *)gamma, (const T *)beta, (T *)y, p->M, p->N, p->eps)
+        if (lpr == 8) LNG_LAUNCH(8); else if (lpr == 16) LNG_LAUNCH(16); else LNG_LAUNCH(32);
+#undef LNG_LAUNCH
+        return check_launch("layer_norm_group");
       }
       if (fast) {
         const int nch = p->N / 8;
@@ -1117,7 +1307,7 @@ extern "C" int sfast_hip_layer_norm(const void *x, const void *gamma, const void
     hipStream_t st = (hipStream_t)stream;
     const bool fast = p->dtype != SFAST_F32 && p->N % 8 == 0 && p->N <= 32768 && aligned16(x) && aligned16(y) &&
                       (!gamma || aligned16(gamma)) && (!beta || aligned16(beta));
-    set_kernel_name(fast ? (p->N > 4096 ? "ln_wide" : "ln_rows") : "ln_generic");
+    set_kernel_name(fast ? (p->N > 4096 ? "ln_wide" : (ln_group_lanes(p->N) && p->M >= 64 ? "ln_group" : "ln_rows")) : "ln_generic");
     switch (p->dtype) {
     case SFAST_F16: return ln_launch<f16>(x, gamma, beta, y, p, st, fast);
     case SFAST_BF16: return ln_launch<bf16>(x, gamma, beta, y, p, st, fast);

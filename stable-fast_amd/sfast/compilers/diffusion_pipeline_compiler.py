@@ -119,20 +119,20 @@ class _NativeUNetForward:
             self._warned = True
         return self.orig_forward(*args, **kwargs)
 
-    def _prepare(self, key, sample, timestep, ehs, added, down_res, mid_res, emask=None, tcond=None, clabels=None, lora_scale=1.0):
+    def _prepare(self, key, sample, timestep, ehs, added, down_res, mid_res, emask=None, tcond=None, clabels=None, lora_scale=1.0, amask=None):
         eng = self.engine
-        B, H, W, S, ctrl, has_mask, has_tcond, ip = key
+        B, H, W, S, ctrl, has_mask, has_tcond, ip, amask_len = key
         # everything below (kernel-attribute setup, autotune launches and their event timing, warm-up, capture) must run with
         # the MODEL's device current, whatever device the caller has selected (reference: graphs.py wraps capture and replay
         # in torch.cuda.device(execution_env.device))
         with torch.cuda.device(eng.device):
-            plan = eng.get_plan(B, H, W, S, ctrl, has_mask, has_tcond, ip)
+            plan = eng.get_plan(B, H, W, S, ctrl, has_mask, has_tcond, ip, self_mask=amask_len)
         env = get_per_device_graph_execution_env(eng.device)
         graph = None
         # warm-up: runs the whole plan eagerly (also validates every launch before capture)
         torch.cuda.synchronize(eng.device)
         with torch.cuda.device(eng.device), torch.cuda.stream(torch.cuda.Stream(device=eng.device)):
-            eng.load_inputs(plan, sample, timestep, ehs, added, down_res, mid_res, emask, tcond, clabels, lora_scale)
+            eng.load_inputs(plan, sample, timestep, ehs, added, down_res, mid_res, emask, tcond, clabels, lora_scale, amask)
             for _ in range(self.warmups if self.enable_graph else 1):
                 plan.run(torch.cuda.current_stream(eng.device).cuda_stream)
         torch.cuda.synchronize(eng.device)
@@ -148,9 +148,17 @@ class _NativeUNetForward:
                  attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
                  down_block_additional_residuals=None, mid_block_additional_residual=None,
                  down_intrablock_additional_residuals=None, encoder_attention_mask=None, return_dict=True):
-        extra = dict(attention_mask=attention_mask, down_intrablock_additional_residuals=down_intrablock_additional_residuals)
+        extra = dict(down_intrablock_additional_residuals=down_intrablock_additional_residuals)
         bad = [k for k, v in extra.items() if v is not None]
         eng = self.engine
+        # attention_mask (a keep-mask over the SELF-attention keys) is an input of the native plan: an additive key bias of every attn1
+        # launch, as diffusers builds it; the reference hands attn_bias straight to the kernel (libs/xformers/xformers_attention.py:26-48).
+        # A mask whose length differs from some layer's token count has no plan (diffusers itself fails on it): that signature keeps the
+        # module's own forward, which raises diffusers' own error.
+        amask = attention_mask
+        if amask is not None and not (torch.is_tensor(amask) and amask.device.type == "cuda" and amask.ndim == 2
+                                      and torch.is_tensor(sample) and amask.shape[0] == sample.shape[0]):
+            bad.append("attention_mask (need a [B, keys] keep-mask on the GPU)")
         # encoder_attention_mask (text padding) is an input of the native plan: an additive key bias of every cross-attention
         # launch (reference passes attn_bias through, libs/xformers/xformers_attention.py:30-47)
         emask = encoder_attention_mask
@@ -211,7 +219,7 @@ class _NativeUNetForward:
                                   **{k: v for k, v in given.items() if v is not None})
         B, _, H, W = sample.shape
         lora_scale = float((cross_attention_kwargs or {}).get("scale", 1.0))
-        key = (B, H, W, encoder_hidden_states.shape[1], ctrl, emask is not None, tcond is not None, ip)
+        key = (B, H, W, encoder_hidden_states.shape[1], ctrl, emask is not None, tcond is not None, ip, int(amask.shape[1]) if amask is not None else 0)
         entry = self._cached.get(key)
         if entry is None:
             with self._lock:
@@ -220,7 +228,7 @@ class _NativeUNetForward:
                     logger.info("sfast: building native UNet plan for %s (graph=%s)", key, self.enable_graph)
                     try:
                         entry = self._prepare(key, sample, timestep, encoder_hidden_states, added_cond_kwargs,
-                                              down_block_additional_residuals, mid_block_additional_residual, emask, tcond, clabels, lora_scale)
+                                              down_block_additional_residuals, mid_block_additional_residual, emask, tcond, clabels, lora_scale, amask)
                     except (NotImplementedError, KeyError) as e:
                         # this signature is outside the plan's coverage (e.g. a latent size the levels do not divide, a
                         # parameter the planner expected but a wrapper renamed): keep the module's own forward for it
@@ -231,14 +239,15 @@ class _NativeUNetForward:
         if entry is _FALLBACK:
             given = dict(added_cond_kwargs=added_cond_kwargs, down_block_additional_residuals=down_block_additional_residuals,
                          mid_block_additional_residual=mid_block_additional_residual, encoder_attention_mask=encoder_attention_mask,
-                         timestep_cond=timestep_cond, class_labels=class_labels, cross_attention_kwargs=cross_attention_kwargs)
+                         timestep_cond=timestep_cond, class_labels=class_labels, cross_attention_kwargs=cross_attention_kwargs,
+                         attention_mask=attention_mask)
             return self.orig_forward(sample, timestep, encoder_hidden_states=encoder_hidden_states, return_dict=return_dict,
                                      **{k: v for k, v in given.items() if v is not None})
         plan, graph, env = entry
         with env.lock, torch.cuda.device(eng.device):
             eng.sync_packed()  # packed weight copies follow the live parameters (version counters); a no-op when nothing changed
             eng.load_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs,
-                            down_block_additional_residuals, mid_block_additional_residual, emask, tcond, clabels, lora_scale)
+                            down_block_additional_residuals, mid_block_additional_residual, emask, tcond, clabels, lora_scale, amask)
             if graph is not None:
                 graph.replay()
             else:

@@ -1241,8 +1241,14 @@ class UNet2DEngine:
                                                           P[bp + ".attn1.to_v.weight"]], None, qkv, M, 3 * Cc, Cc, Cc, 3 * Cc)
             a = pool.get(M * Cc)
             st = (S * 3 * Cc, 3 * Cc, D)
+            sbias = plan.static_in.get("attention_bias")
+            if sbias is not None and sbias.shape[1] != S:
+                # diffusers hands the UNet-level attention_mask to EVERY self-attention layer; one whose token count differs pads it to the
+                # sum of both lengths and fails in scaled_dot_product_attention (Attention.prepare_attention_mask) -- nothing to restate
+                raise UnsupportedUNet(f"attention_mask of {sbias.shape[1]} keys on a self-attention layer with {S} tokens")
             self._op_attn(plan, bp + ".attn1", qkv, qkv, qkv, a, B, heads, S, S, D, st, st, st, (S * Cc, Cc, D),
-                          q_off=0, k_off=Cc, v_off=2 * Cc)
+                          q_off=0, k_off=Cc, v_off=2 * Cc, bias=sbias, bias_strides=(sbias.stride(0), 0, 0) if sbias is not None else None,
+                          kind="attn_self")
             pool.put(qkv)
             self._op_gemm(plan, bp + ".attn1.to_out", a, [P[bp + ".attn1.to_out.0.weight"]], P[bp + ".attn1.to_out.0.bias"], t,
                           M, Cc, Cc, Cc, Cc, residual=t, ldr=Cc)
@@ -1307,7 +1313,7 @@ class UNet2DEngine:
         return names
 
     # ------------------------------------------------------------------------------------------
-    def build_plan(self, B, H, W, S_ctx, ctrl=False, enc_mask=False, tcond=False, ip=None):
+    def build_plan(self, B, H, W, S_ctx, ctrl=False, enc_mask=False, tcond=False, ip=None, self_mask=0):
         """`ctrl`: the plan also takes ControlNet residuals (one NCHW tensor per skip connection + one for the mid block,
         diffusers `down_block_additional_residuals` / `mid_block_additional_residual`) as static inputs.
         `tcond`: the plan takes `timestep_cond` [B, time_cond_proj_dim] (LCM-distilled UNets).
@@ -1345,6 +1351,10 @@ class UNet2DEngine:
             # UNet2DConditionModel.forward builds it, [B, S_ctx] broadcast over heads and queries (row padded to 8 halves)
             ld = (S_ctx + 7) // 8 * 8
             plan.static_in["encoder_attention_bias"] = torch.zeros((B, ld), dtype=dt, device=dev)[:, :S_ctx]
+        if self_mask:
+            # additive key bias of the SELF-attention layers (diffusers `attention_mask`, a keep-mask of `self_mask` keys): same form
+            ld = (int(self_mask) + 7) // 8 * 8
+            plan.static_in["attention_bias"] = torch.zeros((B, ld), dtype=dt, device=dev)[:, :int(self_mask)]
         plan.static_out = out
         lib = self.lib
         if ip is not None:
@@ -1801,10 +1811,10 @@ class UNet2DEngine:
         return out
 
     # ------------------------------------------------------------------------------------------
-    def get_plan(self, B, H, W, S_ctx, ctrl=False, enc_mask=False, tcond=False, ip=None):
+    def get_plan(self, B, H, W, S_ctx, ctrl=False, enc_mask=False, tcond=False, ip=None, self_mask=0):
         if ip is None and self.ip_proj and not self.ip_external:
             ip = ((1,) * len(self.ip_proj), self.ip_scales())
-        key = (B, H, W, S_ctx, bool(ctrl), bool(enc_mask), bool(tcond), ip)
+        key = (B, H, W, S_ctx, bool(ctrl), bool(enc_mask), bool(tcond), ip) + ((int(self_mask),) if self_mask else ())
         plan = self._plans.get(key)
         if plan is None:
             with self._lock:
@@ -1819,6 +1829,8 @@ class UNet2DEngine:
                         kw["tcond"] = True
                     if ip is not None:
                         kw["ip"] = ip
+                    if self_mask:
+                        kw["self_mask"] = int(self_mask)
                     plan = self.build_plan(B, H, W, S_ctx, **kw)
                     self._plans[key] = plan
         return plan
@@ -1835,8 +1847,12 @@ class UNet2DEngine:
 
     def load_inputs(self, plan, sample, timestep, encoder_hidden_states, added_cond_kwargs=None,
                     down_block_additional_residuals=None, mid_block_additional_residual=None, encoder_attention_mask=None,
-                    timestep_cond=None, class_labels=None, lora_scale=1.0):
+                    timestep_cond=None, class_labels=None, lora_scale=1.0, attention_mask=None):
         si = plan.static_in
+        if "attention_bias" in si:
+            if attention_mask is None or attention_mask.ndim != 2:
+                raise ValueError("this plan takes an attention_mask [B, keys] (1 = keep, 0 = discard)")
+            si["attention_bias"].copy_(((1 - attention_mask.to(self.dtype)) * -10000.0).to(self.dtype))
         if "lora_scale" in si:
             vals = self.lora_multipliers(lora_scale)
             if vals != plan.lora["last"]:  # cross_attention_kwargs["scale"] / set_adapters() moved: one small copy, no re-capture
@@ -1882,15 +1898,16 @@ class UNet2DEngine:
             si["mid_block_additional_residual"].copy_(mid_block_additional_residual)
 
     def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, down_block_additional_residuals=None,
-                mid_block_additional_residual=None, encoder_attention_mask=None, timestep_cond=None, class_labels=None, lora_scale=1.0):
+                mid_block_additional_residual=None, encoder_attention_mask=None, timestep_cond=None, class_labels=None, lora_scale=1.0,
+                attention_mask=None):
         """Eager (no graph) execution on the current stream; returns a fresh NCHW tensor."""
         B, _, H, W = sample.shape
         ctrl = down_block_additional_residuals is not None
         plan = self.get_plan(B, H, W, encoder_hidden_states.shape[1], ctrl, encoder_attention_mask is not None, timestep_cond is not None,
-                             self.ip_signature(added_cond_kwargs))
+                             self.ip_signature(added_cond_kwargs), self_mask=attention_mask.shape[1] if attention_mask is not None else 0)
         self.sync_packed()
         self.load_inputs(plan, sample, timestep, encoder_hidden_states, added_cond_kwargs, down_block_additional_residuals,
-                         mid_block_additional_residual, encoder_attention_mask, timestep_cond, class_labels, lora_scale)
+                         mid_block_additional_residual, encoder_attention_mask, timestep_cond, class_labels, lora_scale, attention_mask)
         plan.run(self.host.stream_ptr(self.device))
         return plan.static_out.clone()
 

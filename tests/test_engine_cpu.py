@@ -314,6 +314,46 @@ def test_encoder_attention_mask_is_a_plan_input(built_lib):
     assert torch.equal(y3, y)
 
 
+def _one_level_config():
+    """A UNet whose self-attention layers all see the same number of tokens (one resolution level: the last down block has no
+    downsampler, the mid block runs at the same size) -- the only topology on which diffusers' UNet-level attention_mask works."""
+    return U.tiny_config(block_out_channels=(64,), down_block_types=("CrossAttnDownBlock2D",), up_block_types=("CrossAttnUpBlock2D",),
+                         sample_size=8)
+
+
+def test_self_attention_mask_is_a_plan_input(built_lib):
+    """UNet-level `attention_mask` (keep-mask over the SELF-attention keys) -> additive key bias of every attn1
+    launch, (1 - mask) * -10000 as diffusers' UNet2DConditionModel.forward builds it; own plan-cache key. A mask whose length differs
+    from a layer's token count has no plan (diffusers fails on it too: prepare_attention_mask pads to the SUM of both lengths)."""
+    cfg = _one_level_config()
+    m = U.build(cfg, seed=33, dtype=torch.float16)
+    eng = UNet2DEngine.from_module(m, _host=EmuHost())
+    g = torch.Generator().manual_seed(34)
+    sample = torch.randn(2, 4, 8, 8, generator=g).half()
+    ehs = torch.randn(2, 20, cfg["cross_attention_dim"], generator=g).half()
+    mask = torch.ones(2, 64)
+    mask[0, 40:] = 0
+    mask[1, ::3] = 0
+    y = eng.forward(sample, 700, ehs, attention_mask=mask)
+    with torch.no_grad():
+        want = m.float()(sample.float(), 700, ehs.float(), attention_mask=mask).sample
+        plain = m(sample.float(), 700, ehs.float()).sample
+    err = float((y.float() - want).norm() / want.norm())
+    assert err < 4e-3, err
+    assert float((plain - want).norm() / want.norm()) > 1e-2  # the mask matters for this input
+    assert len(eng._plans) == 1 and list(eng._plans)[0][-1] == 64   # the key carries the mask length
+    assert torch.equal(eng.forward(sample, 700, ehs), eng.forward(sample, 700, ehs)) and len(eng._plans) == 2   # unmasked: its own plan
+    # two resolution levels: level 0 has 256 tokens, level 1 and the mid block 64 -> no plan, and the oracle (= diffusers) refuses too
+    cfg2 = U.tiny_config()
+    m2 = U.build(cfg2, seed=35, dtype=torch.float16)
+    eng2 = UNet2DEngine.from_module(m2, _host=EmuHost())
+    s2 = torch.randn(2, 4, 16, 16, generator=g).half()
+    with pytest.raises(NotImplementedError):
+        eng2.forward(s2, 700, ehs, attention_mask=torch.ones(2, 256))
+    with pytest.raises(RuntimeError), torch.no_grad():
+        m2.float()(s2.float(), 700, ehs.float(), attention_mask=torch.ones(2, 256))
+
+
 # ---- VERDICT r02 "eager cliffs": timestep_cond (LCM), class_labels, cross_attention_kwargs={"scale": s} are native plan inputs ----
 def test_plan_takes_timestep_cond_like_an_lcm_unet(built_lib):
     """LCM-distilled UNets (`time_cond_proj_dim`, /root/reference/examples/optimize_lcm_pipeline.py): the guidance embedding w goes

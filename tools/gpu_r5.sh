@@ -76,5 +76,20 @@ crash3)  # this round's default behaviour in the round-4 arrangement, two fresh 
   done
   run micro_norm 200 python tools/micro_norm.py
   ;;
+perf1)  # round-5 norm kernels (LayerNorm lane groups, GroupNorm two-pass merge): parity first, then per-op and whole-step A/B; the default
+  # bench line with the SDXL child (first run of that path); the self-attention mask and the refusal tests
+  run t_norm 900 $PYT tests/test_ops_gpu.py -k "group_norm or layer_norm or gn_ or gnstats or stats or fused_groupnorm"
+  run t_reftriton 900 $PYT tests/test_ref_triton_gpu.py -k "group_norm or layer_norm"
+  run t_unet 900 $PYT tests/test_unet_gpu.py -k "tiny or sd15_unet_parity or attention_mask or isolation or controlnet"
+  run micro_new 200 python tools/micro_norm.py
+  SFAST_GN_MERGE=chain SFAST_LN_GROUP=0 run micro_old 200 python tools/micro_norm.py
+  AB="python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline"
+  for i in 1 2; do
+    run ab_new$i 300 $AB
+    SFAST_GN_MERGE=chain SFAST_LN_GROUP=0 run ab_old$i 300 $AB
+  done
+  for f in ab_new1 ab_old1 ab_new2 ab_old2; do echo "$f $(grep -a -o '"value": [0-9.]*' gpurun_out/$f.log | head -1) $(grep -a -o '"ms_per_step": [0-9.]*' gpurun_out/$f.log | head -1)" >> gpurun_out/session.log; done
+  [ $(left) -gt 200 ] && run bench_default 400 python bench.py
+  ;;
 esac
 cat gpurun_out/session.log
