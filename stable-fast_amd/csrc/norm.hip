@@ -317,6 +317,7 @@ __global__ void gn_nhwc_apply_kernel(const T *__restrict__ x, const T *__restric
     gn_apply_rows<T, SILU>(x, x2, gamma, beta, y, g, rows_per_block, mean, rstd, ga_raw, be_raw);
 }
 
+#ifdef SFAST_PROBES
 // One-pass apply over producer-emitted statistics, second form of the merge prologue (round 5). The records of one sample -- per concat
 // source n_rb row blocks x S slots of {mean, M2}, one contiguous block of memory -- are copied into LDS by all threads with coalesced
 // loads (ONE exposed memory round trip), then LPG lanes per group (a power of two, groups never straddle a wave) combine the group's
@@ -326,7 +327,11 @@ __global__ void gn_nhwc_apply_kernel(const T *__restrict__ x, const T *__restric
 // division per record. The first form (gn_nhwc_apply_kernel<.., PRE = true>) walks three dependent stages -- per-lane Chan merges, a
 // 16-long serial merge per slot, a serial merge per group -- and costs ~3 us more than a LayerNorm over the same bytes (7.5 vs 4.65 us
 // at [2, 320, 64, 64], profiles/r05_micro_norm_run3.log). Same contract and record layout; kept for sample sizes whose records
-// exceed the LDS budget and as the A/B partner (SFAST_GN_MERGE=chain).
+// exceed the LDS budget.
+// MEASURED (profiles/r05_norm_ab_run4.log, 40 dependent launches in one hipGraph): 7.33 vs 7.59 us at [2, 320, 64, 64], 6.15 vs 6.38 us at
+// [2, 640, 32, 32], 5.52 vs 6.74 us at [2, 1280, 8, 8] (where the plan runs gn_small anyway) -- the merge arithmetic is ~0.25 us of the ~3 us
+// that separate this launch from a LayerNorm over the same bytes; the rest is the dependent round trip for the records and its barrier.
+// Not measured on its own in the step: it lives in the PROBE build (-DSFAST_PROBES, SFAST_GN_MERGE=two-pass), the product keeps the first form.
 template <typename T, bool SILU>
 __global__ void gn_nhwc_apply2_kernel(const T *__restrict__ x, const T *__restrict__ x2, const T *__restrict__ gamma, const T *__restrict__ beta,
                                       T *__restrict__ y, GnGeom g, int rows_per_block, float eps, const GnPre pre, int lpg) {
@@ -399,6 +404,8 @@ __global__ void gn_nhwc_apply2_kernel(const T *__restrict__ x, const T *__restri
     __syncthreads();
     gn_apply_rows<T, SILU>(x, x2, gamma, beta, y, g, rows_per_block, mean, rstd, ga_raw, be_raw);
 }
+
+#endif  // SFAST_PROBES
 
 template <typename T, bool SILU>
 __device__ __forceinline__ void gn_apply_rows(const T *__restrict__ x, const T *__restrict__ x2, const T *__restrict__ gamma,
@@ -793,69 +800,10 @@ static int gn_launch_small(const void *x, const void *x2, const void *gamma, con
     return check_launch("group_norm_small");
 }
 
-// LayerNorm rows whose 16-byte chunk count is LPR * CPL with LPR < 64 (round 5): LPR lanes own a row, CPL chunks each, 64 / LPR rows per wave.
-// The UNet's widths are 320 / 640 / 1280 = 40 / 80 / 160 chunks = (8 | 16 | 32 lanes) x 5: with one row per wave (ln_rows_kernel) a 320-wide
-// row keeps 40 of 64 lanes busy and a 64 x 64 level launches 8192 waves of 640 bytes each -- 4.65 us against 2.7 us for a plain copy of
-// the same bytes (profiles/r05_micro_norm_run3.log). Here every lane is busy, a wave has 64 / LPR rows x CPL loads in flight, and a load
-// instruction touches whole 128-byte lines (lane l of a row reads chunks l, l + LPR, ...: consecutive lanes, consecutive 16 bytes).
-// Same arithmetic as ln_rows_kernel (two exact passes over the cached row, fp32), reduction = xor butterfly inside the lane group.
-template <typename T, int LPR, int CPL>
-__global__ void __launch_bounds__(256) ln_group_kernel(const T *__restrict__ x, const T *__restrict__ gamma, const T *__restrict__ beta,
-                                                       T *__restrict__ y, int M, int N, float eps) {
-    constexpr int RPW = 64 / LPR;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l = lane % LPR;
-    const int row = (blockIdx.x * 4 + wave) * RPW + lane / LPR;
-    const bool live = row < M;
-    const T *xr = x + (int64_t)(live ? row : 0) * N;
-    u32x4 cache[CPL], gar[CPL], ber[CPL];
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) cache[j] = live ? *reinterpret_cast<const u32x4 *>(xr + (l + j * LPR) * 8) : u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-        gar[j] = u32x4{0u, 0u, 0u, 0u};
-        ber[j] = u32x4{0u, 0u, 0u, 0u};
-        if (gamma) gar[j] = *reinterpret_cast<const u32x4 *>(gamma + (l + j * LPR) * 8);
-        if (beta) ber[j] = *reinterpret_cast<const u32x4 *>(beta + (l + j * LPR) * 8);
-    }
-    float sacc = 0.f;
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-        float f[8];
-        unpack8<T>(cache[j], f);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) sacc += f[i];
-    }
-#pragma unroll
-    for (int off = LPR / 2; off >= 1; off >>= 1) sacc += __shfl_xor(sacc, off, 64);
-    const float mean = sacc / (float)N;
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-        float f[8];
-        unpack8<T>(cache[j], f);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float d = f[i] - mean;
-            q += d * d;
-        }
-    }
-#pragma unroll
-    for (int off = LPR / 2; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
-    const float rstd = rsqrtf(q / (float)N + eps);
-    if (!live) return;
-    T *yr = y + (int64_t)row * N;
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-        float f[8], ga[8], be[8];
-        unpack8<T>(cache[j], f);
-        unpack8<T>(gar[j], ga);
-        unpack8<T>(ber[j], be);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) f[i] = (f[i] - mean) * rstd * (gamma ? ga[i] : 1.f) + (beta ? be[i] : 0.f);
-        *reinterpret_cast<u32x4 *>(yr + (l + j * LPR) * 8) = pack8<T>(f);
-    }
-}
+// (Round 5 measured and REMOVED a lane-group LayerNorm -- LPR lanes per row x 5 chunks each, 64 / LPR rows per wave, every lane busy for the
+// 320 / 640 / 1280-wide rows: 4.9 vs 4.5 us at [8192, 320], 4.6 vs 3.4 us at [2048, 640], 180.2 vs 183.4 it/s in the step
+// (profiles/r05_norm_ab_run4.log). One row per wave with 8x more waves in flight hides the exposed load -> reduce -> store chain better
+// than fewer, fatter waves with 212 registers.)
 
 // ---- host-side planning ----------------------------------------------------------------------
 struct GnPlan {
@@ -934,15 +882,16 @@ static int gn_launch_fast(const void *x, const void *x2, const void *gamma, cons
     return check_launch("group_norm_nhwc");
 }
 
-// SFAST_GN_MERGE=chain: the first-form merge prologue (three dependent stages of Chan merges) everywhere -- the A/B partner of round 5's
-// two-pass lane-group prologue (default)
+#ifdef SFAST_PROBES
+// probe build only: SFAST_GN_MERGE=two-pass selects round 5's lane-group merge prologue (gn_nhwc_apply2_kernel) for the A/B
 static bool gn_merge_two_pass() {
     static const bool v = [] {
         const char *e = getenv("SFAST_GN_MERGE");
-        return !(e && e[0] == 'c');
+        return e && e[0] == 't';
     }();
     return v;
 }
+#endif
 
 // one normalisation pass over statistics the producers left behind
 template <typename T>
@@ -957,6 +906,7 @@ static int gn_launch_pre(const void *x, const void *x2, const void *gamma, const
     pr.kl = threads / (s_tot > 0 ? s_tot : 1);
     if (pr.kl < 1) pr.kl = 1;
     if (pr.kl > 16) pr.kl = 16;
+#ifdef SFAST_PROBES
     // second-form prologue (gn_nhwc_apply2_kernel): all records of the sample in LDS, lane groups per GroupNorm group
     const int64_t recs = (int64_t)pr.tiles_n[0] * pr.slots[0] * pr.n_rb[0] + (g.C1 < g.C ? (int64_t)pr.tiles_n[1] * pr.slots[1] * pr.n_rb[1] : 0);
     const size_t smem2 = (size_t)(2 * g.G + 2) * sizeof(float) + (size_t)recs * 8;
@@ -971,6 +921,7 @@ static int gn_launch_pre(const void *x, const void *x2, const void *gamma, const
                                (const T *)gamma, (const T *)beta, (T *)y, g, pl.rows_apply, p->eps, pr, lpg);
         return check_launch("group_norm_apply2");
     }
+#endif
     const size_t smem_apply = (size_t)(2 * g.G + (size_t)s_tot * pr.kl * 3 + (size_t)s_tot * 3) * sizeof(float);
     if (smem_apply > 60 * 1024) {
         set_error("group_norm_apply: %d record slots per sample exceed the merge scratch", s_tot);
@@ -1239,17 +1190,6 @@ __global__ void __launch_bounds__(256) ln_wide_kernel(const T *__restrict__ x, c
     }
 }
 
-// lanes per row of ln_group_kernel<T, LPR, 5> for an N-wide row (0: not that family). SFAST_LN_GROUP=0 keeps one row per wave (A/B knob).
-static int ln_group_lanes(int N) {
-    static const int on = [] {
-        const char *e = getenv("SFAST_LN_GROUP");
-        return (e && e[0] == '0') ? 0 : 1;
-    }();
-    if (!on || N % 40 != 0) return 0;
-    const int lpr = N / 40;
-    return (lpr == 8 || lpr == 16 || lpr == 32) ? lpr : 0;
-}
-
 template <typename T>
 static int ln_launch(const void *x, const void *gamma, const void *beta, void *y, const sfast_ln_params *p,
                      hipStream_t st, bool fast) {
@@ -1267,14 +1207,6 @@ static int ln_launch(const void *x, const void *gamma, const void *beta, void *y
             hipLaunchKernelGGL((ln_wide_kernel<T, 16>), dim3(p->M), block, 0, st, (const T *)x, (const T *)gamma, (const T *)beta, (T *)y,
                                p->M, p->N, p->eps);
         return check_launch("layer_norm_wide");
-      }
-      if (fast && ln_group_lanes(p->N) && p->M >= 64) {   // 320 / 640 / 1280-wide rows (the UNet's): lane groups, every lane busy
-        const int lpr = ln_group_lanes(p->N);
-        const dim3 gg(ceil_div(p->M, 4 * (64 / lpr)));
-#define LNG_LAUNCH(LPR_) hipLaunchKernelGGL((ln_group_kernel<T, LPR_, 5>), gg, block, 0, st, (const T *)x, (const T *)gamma, (const T *)beta, (T *)y, p->M, p->N, p->eps)
-        if (lpr == 8) LNG_LAUNCH(8); else if (lpr == 16) LNG_LAUNCH(16); else LNG_LAUNCH(32);
-#undef LNG_LAUNCH
-        return check_launch("layer_norm_group");
       }
       if (fast) {
         const int nch = p->N / 8;
@@ -1307,7 +1239,7 @@ extern "C" int sfast_hip_layer_norm(const void *x, const void *gamma, const void
     hipStream_t st = (hipStream_t)stream;
     const bool fast = p->dtype != SFAST_F32 && p->N % 8 == 0 && p->N <= 32768 && aligned16(x) && aligned16(y) &&
                       (!gamma || aligned16(gamma)) && (!beta || aligned16(beta));
-    set_kernel_name(fast ? (p->N > 4096 ? "ln_wide" : (ln_group_lanes(p->N) && p->M >= 64 ? "ln_group" : "ln_rows")) : "ln_generic");
+    set_kernel_name(fast ? (p->N > 4096 ? "ln_wide" : "ln_rows") : "ln_generic");
     switch (p->dtype) {
     case SFAST_F16: return ln_launch<f16>(x, gamma, beta, y, p, st, fast);
     case SFAST_BF16: return ln_launch<bf16>(x, gamma, beta, y, p, st, fast);
