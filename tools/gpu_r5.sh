@@ -67,14 +67,14 @@ crash3)  # this round's default behaviour in the round-4 arrangement, two fresh 
     t0=$(date +%s)
     ( MASTER_PORT=29533 timeout 400 $HUNT $PYT tests/test_unet_gpu.py -k "$R4SEL" > gpurun_out/r5v_a$i.log 2>&1; echo $? > gpurun_out/r5v_a$i.rc ) &
     ( cd . && SFAST_PACKED_WEIGHTS=0 MASTER_PORT=29534 timeout 400 $HUNT $PYT tests/test_unet_gpu.py -k "$R4SEL" > gpurun_out/r5v_b$i.log 2>&1; echo $? > gpurun_out/r5v_b$i.rc ) &
+    ( cd . && SFAST_PACKED_WEIGHTS=0 MASTER_PORT=29535 timeout 400 $HUNT $PYT tests/test_unet_gpu.py -k "$R4SEL" > gpurun_out/r5v_c$i.log 2>&1; echo $? > gpurun_out/r5v_c$i.rc ) &
     wait
-    for v in a b; do
+    for v in a b c; do
       rc=$(cat gpurun_out/r5v_$v$i.rc); rm -f gpurun_out/r5v_$v$i.rc
       echo "r5v $v$i exit=$rc $(( $(date +%s) - t0 ))s $(grep -a -m1 -E 'crashbt\] signal' gpurun_out/r5v_$v$i.log | cut -c1-120) | $(tail -n 1 gpurun_out/r5v_$v$i.log | cut -c1-80)" >> gpurun_out/session.log
       [ "$rc" = "0" ] && rm -f gpurun_out/r5v_$v$i.log
     done
   done
-  run micro_norm 200 python tools/micro_norm.py
   ;;
 perf1)  # round-5 norm kernels (LayerNorm lane groups, GroupNorm two-pass merge): parity first, then per-op and whole-step A/B; the default
   # bench line with the SDXL child (first run of that path); the self-attention mask and the refusal tests
