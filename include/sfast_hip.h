@@ -273,7 +273,10 @@ int sfast_hip_conv2d(const void *x, const void *x2, const void *w, const void *b
  *             of sfast_hip_group_norm on `out`. Replaces the separate launch of the reference's fused GroupNorm
  *             (triton/torch_ops.py:179-189) behind a split-K conv / GEMM at the low-resolution levels. Only for problems that run
  *             split-K (ask sfast_hip_conv2d_plan / sfast_hip_igemm_plan: out[2] > 1) with (N / gn_groups) % 4 == 0 and
- *             gn_rows_per_sample * N / gn_groups <= 16384; otherwise SFAST_ERR_UNSUPPORTED. Not combinable with gn_unit / gn_stats.  */
+ *             gn_rows_per_sample * N / gn_groups <= 16384; otherwise SFAST_ERR_UNSUPPORTED. Not combinable with gn_unit / gn_stats.
+ *             ROUND 5: measured slower in the SD1.5 step than reduce + separate GroupNorm (profiles/r04_reduce_gn_ab_run{7,8,9}.log), so
+ *             the launch exists in the PROBE build only (libsfast_hip_probes.so); the product library answers SFAST_ERR_UNSUPPORTED for
+ *             any non-NULL gn_out BEFORE it launches anything (`out` is left untouched).                                            */
 /* w_packed (ABI 9): packed copies of the weight segments, made by sfast_hip_pack_weight from the live parameters. With them the
  *             planner may pick a pipe-4 kernel (variant ids 41 ..: weight fragments global -> VGPR in MFMA order, activations through
  *             the LDS ring; csrc/igemm_pk.h) -- the reference's vendor GEMMs / convs re-lay out filters inside the call as well.
@@ -330,7 +333,10 @@ int sfast_hip_conv2d_ex(const void *x, const void *x2, const void *w, const void
  * Coverage (sfast_hip_gn_conv2d_supported == 1): f16 / bf16; 3x3, stride 1, padding 1, no dilation / upsample / extra padding;
  * dense NHWC sources, [Cout][3][3][Cin] weights, dense NHWC output; B*H*W <= 128; (Cin / groups) % 8 == 0; Cout % 32 == 0; a channel
  * slice of >= 80 channels that is a whole number of groups and of 16-channel steps and divides both concat sources. Everything
- * else: SFAST_ERR_UNSUPPORTED -- callers run the two operators. workspace: sfast_hip_gn_conv2d_workspace_bytes (fp32 slabs). */
+ * else: SFAST_ERR_UNSUPPORTED -- callers run the two operators. workspace: sfast_hip_gn_conv2d_workspace_bytes (fp32 slabs).
+ * ROUND 5: measured 1 % slower in the SD1.5 step than the two operators (profiles/r04_gnconv_step_ab_run6.log): the kernel lives in the
+ * PROBE build only. In the product library sfast_hip_gn_conv2d_supported() == 0 for every problem, the workspace query returns 0 and
+ * sfast_hip_gn_conv2d() returns SFAST_ERR_UNSUPPORTED -- the entry points stay so that one binding serves both builds. */
 typedef struct {
     sfast_conv_params conv; /* geometry, strides and epilogue of the convolution (of the NORMALISED input) */
     int32_t groups;         /* GroupNorm groups over conv.Cin channels; 0: no normalisation (the weight-streaming conv alone, a measured

@@ -423,3 +423,44 @@ def test_auto_graph_compiler_walk_matches_patch_module():
     assert wrapped(net) and not wrapped(net[0])
     with pytest.raises(TypeError):
         AutoGraphCraphCompiler(warmups=1)
+
+
+def test_bench_quotes_pmc_traffic_only_with_matching_provenance(tmp_path, monkeypatch):
+    """BENCH_r04's roofline.traffic silently came from a round-3 file. bench.roofline_from() quotes a PMC traffic
+    file only when its `_meta` block names the kernel choices in use (sha256 of the packaged tune cache) and says which round / commit /
+    command produced it; otherwise `traffic` is null and `traffic_note` says why. `frac_kernel_only` (rocprofv3 per-dispatch average
+    from the same file) sits beside `frac_interval` (live HIP events around the C-ABI call, reduce launch included)."""
+    import hashlib
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sym_variant = "igemm_conv_f16[128x128,split=3,ws4]+gnstats@xcd1x8x1"
+    rows = [dict(kind="conv3x3", name=f"c{i}", kernel=sym_variant, seconds=40e-6, flops=18.874e9, bytes=25.5e6) for i in range(4)]
+    rows.append(dict(kind="ln", name="ln", kernel="ln_rows", seconds=5e-6, flops=0.0, bytes=10.5e6))
+    sym = bench.kernel_symbol(sym_variant)
+    with open(os.path.join(root, "stable-fast_amd", "sfast", "engine", "tune_gfx950.json"), "rb") as f:
+        sha = hashlib.sha256(f.read()).hexdigest()[:16]
+    path = tmp_path / "r05_pmc_traffic_by_symbol.json"
+    monkeypatch.setenv("SFAST_TRAFFIC_PROFILE", str(path))
+
+    def write(meta):
+        doc = {sym: dict(bytes_per_launch=85.6e6, avg_us=31.2, launches=192)}
+        if meta is not None:
+            doc["_meta"] = meta
+        path.write_text(json.dumps(doc))
+
+    write(None)                                             # a pre-round-5 file: no provenance
+    roof, _, _ = bench.roofline_from(rows, None, "sd15")
+    assert roof["kernel"] == sym and roof["traffic"] is None and "no _meta" in roof["traffic_note"] and roof["frac_kernel_only"] is None
+    write(dict(round=5, commit="abc1234", tune_cache_sha256="0" * 16, command="python bench.py"))   # other kernel choices
+    roof, _, _ = bench.roofline_from(rows, None, "sd15")
+    assert roof["traffic"] is None and "other kernel choices" in roof["traffic_note"]
+    write(dict(round=5, commit="abc1234", tune_cache_sha256=sha, command="python bench.py"))
+    roof, _, _ = bench.roofline_from(rows, None, "sd15")
+    assert roof["traffic"] == 85.6e6 and "round 5, commit abc1234" in roof["traffic_source"]
+    assert abs(roof["traffic_over_algorithmic"] - 85.6 / 25.5) < 1e-6
+    assert abs(roof["frac_interval"] - 18.874e9 / 40e-6 / 1e12 / 2500.0) < 1e-9 and roof["frac"] == roof["frac_interval"]
+    assert abs(roof["frac_kernel_only"] - 18.874e9 / 31.2e-6 / 1e12 / 2500.0) < 1e-9   # what rocprofv3 --stats reproduces (0.24 in round 4)

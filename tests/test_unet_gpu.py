@@ -200,12 +200,16 @@ def test_compile_drop_in_surface():
     # LoRA layers: accepted natively, same plan, same result
     o2s = pipe.unet(lat2, torch.tensor(500, device=DEV), encoder_hidden_states=ehs[:, :40], cross_attention_kwargs={"scale": 0.5}, return_dict=False)[0]
     assert torch.equal(o2s, o2) and not pipe.unet.forward._warned and len(pipe.unet.forward._cached) == 2
-    # unsupported call forms fall back to the original forward instead of computing something else
-    # (`attention_mask` -- the self-attention mask -- is not a plan input; the oracle module ignores it, so both eager runs agree)
-    o3 = pipe.unet(lat2, 500, encoder_hidden_states=ehs[:, :40], attention_mask=torch.ones(2, 1, 512, device=DEV, dtype=torch.float16),
+    # unsupported call forms fall back to the original forward instead of computing something else (T2I-Adapter residuals are not a plan
+    # input; the oracle module ignores the keyword, so both eager runs agree)
+    o3 = pipe.unet(lat2, 500, encoder_hidden_states=ehs[:, :40], down_intrablock_additional_residuals=[torch.zeros(1, device=DEV)],
                    return_dict=False)[0]
     assert pipe.unet.forward._warned  # took the eager path (two eager fp16 runs differ by conv algorithm noise)
     assert rel_l2(o3, w2) < 1e-2 and len(pipe.unet.forward._cached) == 2
+    # a UNet-level attention_mask whose length cannot match every self-attention level (512 keys at the top, 128 / 32 below) has no
+    # plan: that signature is handed to the module's own forward, which refuses it as diffusers does (round 5)
+    with pytest.raises(RuntimeError):
+        pipe.unet(lat2, 500, encoder_hidden_states=ehs[:, :40], attention_mask=torch.ones(2, 512, device=DEV), return_dict=False)
 
 
 @pytest.mark.parametrize("option", ["timestep_cond", "class_timestep", "class_projection", "all"])

@@ -91,5 +91,29 @@ perf1)  # round-5 norm kernels (LayerNorm lane groups, GroupNorm two-pass merge)
   for f in ab_new1 ab_old1 ab_new2 ab_old2; do echo "$f $(grep -a -o '"value": [0-9.]*' gpurun_out/$f.log | head -1) $(grep -a -o '"ms_per_step": [0-9.]*' gpurun_out/$f.log | head -1)" >> gpurun_out/session.log; done
   [ $(left) -gt 200 ] && run bench_default 400 python bench.py
   ;;
+final)  # the round's evidence set on HEAD, most important first; SFAST_COMMIT=<sha> in the environment names the commit in the PMC files
+  run pytest_full 1500 $PYT tests
+  cp gpurun_out/parity.jsonl gpurun_out/parity_full.jsonl 2>/dev/null
+  run smoke 300 python __graft_entry__.py smoke
+  # PMC traffic by symbol (separate --pmc passes, packaged kernel choices): copied into profiles/ on this box so that the bench lines of this
+  # session already quote them (the same files come back through gpurun_out/)
+  run pmc_sd15 900 bash tools/gpu_pmc_bench.sh sd15 6
+  cp gpurun_out/pmcb/traffic_by_symbol.json profiles/r05_pmc_traffic_by_symbol.json && cp gpurun_out/pmcb/traffic_by_symbol.json gpurun_out/r05_pmc_traffic_by_symbol.json
+  for f in fetch write; do cp gpurun_out/pmcb/$f.log gpurun_out/pmc_sd15_$f.log 2>/dev/null; done
+  if [ $(left) -gt 700 ]; then
+    run pmc_sdxl 900 bash tools/gpu_pmc_bench.sh sdxl 4
+    cp gpurun_out/pmcb/traffic_by_symbol_sdxl.json profiles/r05_pmc_traffic_by_symbol_sdxl.json && cp gpurun_out/pmcb/traffic_by_symbol_sdxl.json gpurun_out/r05_pmc_traffic_by_symbol_sdxl.json
+  fi
+  rm -rf gpurun_out/pmcb
+  run bench_default 600 python bench.py --dump-kernels gpurun_out/kernels.json
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -o bench -- python $OLDPWD/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants > $OLDPWD/gpurun_out/rocprof.log 2>&1 )
+  echo "rocprof exit=$?" >> gpurun_out/session.log
+  for db in $(find gpurun_out/prof -name "*.db"); do python tools/rocpd_summary.py $db --csv gpurun_out/kernel_stats.csv --top 60 --step-marker cfg_ddim --steps 12 > gpurun_out/kernel_stats.txt; done
+  rm -rf gpurun_out/prof
+  [ $(left) -gt 300 ] && run bench_sdxl 600 python bench.py --config sdxl --no-cpu-baseline --dump-kernels gpurun_out/kernels_sdxl.json
+  [ $(left) -gt 300 ] && run bench_svd 900 python bench.py --config svd --no-cpu-baseline
+  [ $(left) -gt 150 ] && run bench_torchrun 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 50 --warmup 10 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants
+  [ $(left) -gt 120 ] && run bench_images8 600 python bench.py --images 8 --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  ;;
 esac
 cat gpurun_out/session.log
