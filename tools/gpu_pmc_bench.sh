@@ -11,11 +11,13 @@ SUF=""; [ "$CFG" != "sd15" ] && SUF="_$CFG"
 rm -rf gpurun_out/pmcb; mkdir -p gpurun_out/pmcb
 export TMPDIR=/tmp
 R=$PWD
-# round 5: the passes run on the PACKAGED kernel choices (sfast/engine/tune_gfx950.json), exactly like the driver's `python bench.py`
-python bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-roofline --no-end-to-end > gpurun_out/pmcb/warm.log 2>&1
+# round 5: the passes run on the PACKAGED kernel choices (sfast/engine/tune_gfx950.json), exactly like the driver's `python bench.py`, and
+# WITHOUT the variants: the literal B = 1 step is not in the packaged cache, its autotuning launches (thousands, under counters) flooded
+# the first round-5 pass and the "last 40 %" window (profiles/r05_pmc_traffic_contaminated_run6.log); the SDXL pass timed out on them
+python bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants > gpurun_out/pmcb/warm.log 2>&1
 pass() { # name, counters...
   local name=$1; shift
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc "$@" -d $R/gpurun_out/pmcb -o $name -- python $R/bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-roofline --no-end-to-end > $R/gpurun_out/pmcb/$name.log 2>&1 )
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc "$@" -d $R/gpurun_out/pmcb -o $name -- python $R/bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants > $R/gpurun_out/pmcb/$name.log 2>&1 )
   echo "pmc $name exit=$? $(tail -n 1 $R/gpurun_out/pmcb/$name.log | cut -c1-100)"
   for db in $(find $R/gpurun_out/pmcb -name "*.db"); do python $R/tools/pmc_extract.py $db $R/gpurun_out/pmcb/$name.json --by-symbol --last-frac 0.4; rm -f $db; done
 }
@@ -34,7 +36,7 @@ for k, r in f.items():
                   launches=r["dispatches"], avg_us=r.get("avg_us"))
 sha = hashlib.sha256(open("stable-fast_amd/sfast/engine/tune_gfx950.json", "rb").read()).hexdigest()[:16]
 out["_meta"] = dict(round=5, commit=os.environ.get("SFAST_COMMIT", "unknown"), tune_cache_sha256=sha,
-                    command=f"python bench.py --config {os.environ['CFG']} --steps {os.environ['STEPS']} --warmup 2 --no-cpu-baseline --no-roofline --no-end-to-end",
+                    command=f"python bench.py --config {os.environ['CFG']} --steps {os.environ['STEPS']} --warmup 2 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants",
                     method="separate rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE; WRITE_SIZE); last 40 % of the dispatches; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB")
 json.dump(out, open("gpurun_out/pmcb/traffic_by_symbol" + os.environ.get("SUF", "") + ".json", "w"), indent=1)
 del out["_meta"]

@@ -91,6 +91,23 @@ perf1)  # round-5 norm kernels (LayerNorm lane groups, GroupNorm two-pass merge)
   for f in ab_new1 ab_old1 ab_new2 ab_old2; do echo "$f $(grep -a -o '"value": [0-9.]*' gpurun_out/$f.log | head -1) $(grep -a -o '"ms_per_step": [0-9.]*' gpurun_out/$f.log | head -1)" >> gpurun_out/session.log; done
   [ $(left) -gt 200 ] && run bench_default 400 python bench.py
   ;;
+armA)  # which of the two round-4 behaviours is sufficient? ONE arm: the fork / join events die inside the capture again
+  # (SFAST_FORK_EVENTS_LOCAL=1), the losing graph is retired as in this round's product -- sequential fresh processes, round-4 arrangement
+  export SFAST_TEST_INPROC=1
+  SFAST_FORK_EVENTS_LOCAL=1 hunt armA 300 40 $HUNT $PYT tests/test_unet_gpu.py -k "$R4SEL"
+  ;;
+final2)  # the PMC passes again without the variants (first attempt: B = 1 autotuning under counters), then the lines that did not fit
+  run pmc_sd15 400 bash tools/gpu_pmc_bench.sh sd15 6
+  cp gpurun_out/pmcb/traffic_by_symbol.json profiles/r05_pmc_traffic_by_symbol.json && cp gpurun_out/pmcb/traffic_by_symbol.json gpurun_out/r05_pmc_traffic_by_symbol.json
+  run bench_default 400 python bench.py --dump-kernels gpurun_out/kernels.json
+  run pmc_sdxl 330 bash tools/gpu_pmc_bench.sh sdxl 4
+  cp gpurun_out/pmcb/traffic_by_symbol_sdxl.json profiles/r05_pmc_traffic_by_symbol_sdxl.json && cp gpurun_out/pmcb/traffic_by_symbol_sdxl.json gpurun_out/r05_pmc_traffic_by_symbol_sdxl.json
+  rm -rf gpurun_out/pmcb
+  [ $(left) -gt 60 ] && run bench_sdxl 300 python bench.py --config sdxl --no-cpu-baseline --no-variants --dump-kernels gpurun_out/kernels_sdxl.json
+  [ $(left) -gt 150 ] && run bench_svd 400 python bench.py --config svd --no-cpu-baseline
+  [ $(left) -gt 60 ] && run bench_torchrun 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 50 --warmup 10 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants
+  [ $(left) -gt 50 ] && run bench_images8 300 python bench.py --images 8 --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  ;;
 final)  # the round's evidence set on HEAD, most important first; SFAST_COMMIT=<sha> in the environment names the commit in the PMC files
   run pytest_full 1500 $PYT tests
   cp gpurun_out/parity.jsonl gpurun_out/parity_full.jsonl 2>/dev/null
