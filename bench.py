@@ -298,12 +298,15 @@ def roofline_from(rows, plan=None, config="sd15"):
                 roof["traffic_source"] = (f"{rel} (round {meta.get('round')}, commit {meta.get('commit')}, {meta.get('command')}; counters from "
                                           "separate rocprofv3 --pmc passes over this command, not re-measured in this run; FETCH_SIZE x2 + "
                                           "WRITE_SIZE, includes Infinity-Cache hits)")
-                if t.get("avg_us"):
+                # the --kernel-trace-only pass of the same session (kernels run ~10-15 % slower while counters are collected: `avg_us` of the
+                # --pmc passes is not a duration to price a roofline fraction with)
+                if t.get("avg_us_trace"):
                     per_launch = (dom["flops"] if mfma else dom["bytes"]) / dom["launches"]
-                    rate = per_launch / (t["avg_us"] * 1e-6) / (1e12 if mfma else 1e9)
+                    rate = per_launch / (t["avg_us_trace"] * 1e-6) / (1e12 if mfma else 1e9)
                     roof["frac_kernel_only"] = rate / (MFMA_PEAK_TFLOPS if mfma else HBM_PEAK_GBS)
-                    roof["kernel_only_avg_us"] = t["avg_us"]
-                    roof["kernel_only_source"] = f"{rel}: rocprofv3 per-dispatch average of this symbol over {t.get('launches')} steady-window dispatches"
+                    roof["kernel_only_avg_us"] = t["avg_us_trace"]
+                    roof["kernel_only_source"] = (f"{rel}: rocprofv3 --kernel-trace (no counters) per-dispatch average of this symbol over "
+                                                  f"{t.get('launches_trace')} dispatches of the steady window of graph replays, same session as the counters")
     except (OSError, ValueError, KeyError) as e:
         roof["traffic_note"] = f"traffic file unreadable: {type(e).__name__}: {e}"
     fam = {}

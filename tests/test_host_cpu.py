@@ -447,7 +447,7 @@ def test_bench_quotes_pmc_traffic_only_with_matching_provenance(tmp_path, monkey
     monkeypatch.setenv("SFAST_TRAFFIC_PROFILE", str(path))
 
     def write(meta):
-        doc = {sym: dict(bytes_per_launch=85.6e6, avg_us=31.2, launches=192)}
+        doc = {sym: dict(bytes_per_launch=85.6e6, avg_us=36.0, launches=192, avg_us_trace=31.2, launches_trace=48)}
         if meta is not None:
             doc["_meta"] = meta
         path.write_text(json.dumps(doc))

@@ -14,7 +14,11 @@ R=$PWD
 # round 5: the passes run on the PACKAGED kernel choices (sfast/engine/tune_gfx950.json), exactly like the driver's `python bench.py`, and
 # WITHOUT the variants: the literal B = 1 step is not in the packaged cache, its autotuning launches (thousands, under counters) flooded
 # the first round-5 pass and the "last 40 %" window (profiles/r05_pmc_traffic_contaminated_run6.log); the SDXL pass timed out on them
-python bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants > gpurun_out/pmcb/warm.log 2>&1
+# pass 0: --kernel-trace ONLY (no counters): the per-dispatch durations `rocprofv3 --stats` shows. Kernels run ~10-15 % slower while counters
+# are collected, so the durations of the --pmc passes (`avg_us`) are not the ones a roofline fraction may be priced with: `avg_us_trace` is.
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $R/gpurun_out/pmcb -o trace -- python $R/bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants > $R/gpurun_out/pmcb/trace.log 2>&1 )
+echo "trace pass exit=$?"
+for db in $(find gpurun_out/pmcb -name "*.db"); do python tools/rocpd_summary.py $db --csv gpurun_out/pmcb/trace.csv --top 200 --step-marker cfg_ddim --steps $(( STEPS - 1 )) > gpurun_out/pmcb/trace.txt; rm -f $db; done
 pass() { # name, counters...
   local name=$1; shift
   ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc "$@" -d $R/gpurun_out/pmcb -o $name -- python $R/bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants > $R/gpurun_out/pmcb/$name.log 2>&1 )
@@ -27,6 +31,14 @@ SUF=$SUF CFG=$CFG STEPS=$STEPS python - <<'PY'
 import hashlib, json, os
 f = {r["kernel"]: r for r in json.load(open("gpurun_out/pmcb/fetch.json"))["rows"]}
 w = {r["kernel"]: r for r in json.load(open("gpurun_out/pmcb/write.json"))["rows"]}
+import csv
+trace = {}
+try:
+    with open("gpurun_out/pmcb/trace.csv") as fh:
+        for row in csv.DictReader(l for l in fh if not l.startswith("#")):
+            trace[row["kernel"]] = (float(row["avg_us"]), int(row["calls"]))
+except OSError:
+    pass
 out = {}
 for k, r in f.items():
     fetch_kb = r["counters"].get("FETCH_SIZE", 0.0)
@@ -34,10 +46,14 @@ for k, r in f.items():
     # gfx950: FETCH_SIZE counts 128-B fabric requests as 64 B (MI355X_MICROARCH.md, HBM section) -> x2; unit KB
     out[k] = dict(bytes_per_launch=(2.0 * fetch_kb + write_kb) * 1024.0, fetch_kb_raw=fetch_kb, write_kb_raw=write_kb,
                   launches=r["dispatches"], avg_us=r.get("avg_us"))
+    t = trace.get(k[:110])   # tools/rocpd_summary.py cuts names at 110 characters
+    if t:
+        out[k]["avg_us_trace"], out[k]["launches_trace"] = t
 sha = hashlib.sha256(open("stable-fast_amd/sfast/engine/tune_gfx950.json", "rb").read()).hexdigest()[:16]
 out["_meta"] = dict(round=5, commit=os.environ.get("SFAST_COMMIT", "unknown"), tune_cache_sha256=sha,
                     command=f"python bench.py --config {os.environ['CFG']} --steps {os.environ['STEPS']} --warmup 2 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants",
-                    method="separate rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE; WRITE_SIZE); last 40 % of the dispatches; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB")
+                    method="separate rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE; WRITE_SIZE); last 40 % of the dispatches; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB; "
+                           "avg_us = per-dispatch average UNDER counter collection, avg_us_trace = the same from a --kernel-trace-only pass (steady window of graph replays)")
 json.dump(out, open("gpurun_out/pmcb/traffic_by_symbol" + os.environ.get("SUF", "") + ".json", "w"), indent=1)
 del out["_meta"]
 for k, v in sorted(out.items(), key=lambda kv: -(kv[1]["avg_us"] or 0) * kv[1]["launches"])[:12]:
