@@ -96,6 +96,20 @@ armA)  # which of the two round-4 behaviours is sufficient? ONE arm: the fork / 
   export SFAST_TEST_INPROC=1
   SFAST_FORK_EVENTS_LOCAL=1 hunt armA 300 40 $HUNT $PYT tests/test_unet_gpu.py -k "$R4SEL"
   ;;
+final3)  # the default bench line FIRST on a fresh box (two final2 sessions in a row measured 150 it/s where every other session of the round
+  # measured 180 - 184: is it the box, or what ran before?), then --kernel-trace-only passes (no counters) for the per-symbol durations
+  run bench_default 300 python bench.py --dump-kernels gpurun_out/kernels.json
+  for cfg in sd15 sdxl; do
+    [ $(left) -lt 60 ] && break
+    ( cd /tmp && timeout 200 rocprofv3 --kernel-trace -d $OLDPWD/gpurun_out/prof_$cfg -o trace -- python $OLDPWD/bench.py --config $cfg --steps 8 --warmup 2 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants > $OLDPWD/gpurun_out/trace_$cfg.log 2>&1 )
+    for db in $(find gpurun_out/prof_$cfg -name "*.db"); do python tools/rocpd_summary.py $db --csv gpurun_out/trace_$cfg.csv --top 200 --step-marker cfg_ddim --steps 6 > gpurun_out/trace_$cfg.txt; done
+    rm -rf gpurun_out/prof_$cfg
+    echo "trace $cfg: $(head -1 gpurun_out/trace_$cfg.txt)" >> gpurun_out/session.log
+  done
+  [ $(left) -gt 40 ] && run bench_sdxl 200 python bench.py --config sdxl --no-cpu-baseline --no-variants --dump-kernels gpurun_out/kernels_sdxl.json
+  [ $(left) -gt 30 ] && run bench_images8 200 python bench.py --images 8 --steps 50 --warmup 10 --no-cpu-baseline --no-end-to-end --no-variants --no-roofline
+  [ $(left) -gt 130 ] && run bench_svd 300 python bench.py --config svd --no-cpu-baseline
+  ;;
 final2)  # the PMC passes again without the variants (first attempt: B = 1 autotuning under counters), then the lines that did not fit
   run pmc_sd15 400 bash tools/gpu_pmc_bench.sh sd15 6
   cp gpurun_out/pmcb/traffic_by_symbol.json profiles/r05_pmc_traffic_by_symbol.json && cp gpurun_out/pmcb/traffic_by_symbol.json gpurun_out/r05_pmc_traffic_by_symbol.json
