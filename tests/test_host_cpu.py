@@ -464,3 +464,32 @@ def test_bench_quotes_pmc_traffic_only_with_matching_provenance(tmp_path, monkey
     assert abs(roof["traffic_over_algorithmic"] - 85.6 / 25.5) < 1e-6
     assert abs(roof["frac_interval"] - 18.874e9 / 40e-6 / 1e12 / 2500.0) < 1e-9 and roof["frac"] == roof["frac_interval"]
     assert abs(roof["frac_kernel_only"] - 18.874e9 / 31.2e-6 / 1e12 / 2500.0) < 1e-9   # what rocprofv3 --stats reproduces (0.24 in round 4)
+
+
+def test_unwanted_graphs_are_retired_oldest_first_after_a_synchronise(monkeypatch):
+    """Round 5 (the fix of the round-4 crash): a hipGraphExec that is no longer wanted is never destroyed in the same breath as its last
+    replay. `retire_graph` parks it; `_trim_retired` -- called from capture_plan_graph's own context only -- lets the oldest entries go
+    once more than 2 x _RETIRED_KEEP have piled up, and only after it synchronised every device that owns one."""
+    import sfast.engine.unet2d as E
+    synced = []
+    monkeypatch.setattr(E.torch.cuda, "synchronize", lambda dev=None: synced.append(dev))
+    monkeypatch.setattr(E, "_RETIRED", type(E._RETIRED)())
+    dropped = []
+
+    class G:
+        def __init__(self, i):
+            self.i = i
+
+        def __del__(self):
+            dropped.append((self.i, len(synced)))
+
+    for i in range(2 * E._RETIRED_KEEP):
+        E.retire_graph(G(i), "dev0")
+        E._trim_retired()
+    assert not dropped and not synced and len(E._RETIRED) == 2 * E._RETIRED_KEEP      # nothing leaves while the queue is short
+    E.retire_graph(G(99), "dev1")
+    E._trim_retired()
+    assert sorted(synced) == ["dev0", "dev1"]                                              # every owning device, before anything is dropped
+    assert [i for i, _ in dropped] == list(range(E._RETIRED_KEEP + 1))                      # oldest first ...
+    assert all(n == 2 for _, n in dropped) and len(E._RETIRED) == E._RETIRED_KEEP          # ... and only after both synchronisations
+    assert E._RETIRED[-1][0].i == 99
