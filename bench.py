@@ -30,6 +30,10 @@ sys.path.insert(0, os.path.join(ROOT, "stable-fast_amd"))
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+# hipGraphs this script is done with stay referenced until the process exits: a graph is never destroyed in the same breath as its last replay
+# (the trigger of the round-4 crash, DESIGN.md section 9, round 5, item 1 -- the product retires its graphs the same way)
+_KEEP_GRAPHS = []
+
 MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
@@ -169,6 +173,7 @@ def differential_graph_timing(plan, idxs, replays=30, rounds=3):
                 t = a.elapsed_time(b) * 1e-3 / replays
                 best[k] = t if best[k] is None or t < best[k] else best[k]
     torch.cuda.current_stream().wait_stream(s)
+    _KEEP_GRAPHS.extend(graphs)
     return max(best[0] - best[1], 0.0), best[0], best[1]
 
 
@@ -528,7 +533,7 @@ def step_variants(args, engine, cfg, hw, dev, latents, ehs, headline_ms):
     out["text_kv_hoisted"] = {"value": 1e3 / ms, "unit": "it/s", "ms_per_step": ms, "kernel_launches_per_step": len(loop._step_ops) + 2,
                               "gain_vs_headline": headline_ms / ms,
                               "note": "cross-attention K/V projections of the text context run once per prompt (DenoiseLoop(hoist_text_kv=True)), not per step"}
-    del loop
+    _KEEP_GRAPHS.append(loop)   # (not `del loop`: its graph was replayed a moment ago)
     if args.images == 1:
         plan = engine.get_plan(1, hw, hw, 77)
         kw = {}
