@@ -65,6 +65,36 @@ def test_live_unet_parameters_are_read_at_every_run(built_lib):
     assert rel_l2(y1, want) < 3e-3 and rel_l2(y0, want) > 1e-2
 
 
+def test_refresh_parameters_rebinds_everything_keyed_by_the_old_storage(built_lib):
+    """after parameters were RE-ASSIGNED (`p.data = other`, load_state_dict(assign=True)) refresh_parameters() must leave no
+    trace of the old storage -- plans, the data-pointer -> name map of the packed-weight pipe, its records (which would pin the freed
+    tensors and keep re-packing from them) and the version sources -- and the next forward must compute with the new weights."""
+    cfg = U.tiny_config()
+    m16, m32 = _pair(cfg, 19)
+    eng = UNet2DEngine.from_module(m16, _host=EmuHost())
+    g = torch.Generator().manual_seed(5)
+    s = torch.randn(2, 4, 16, 16, generator=g).half()
+    e = torch.randn(2, 77, 64, generator=g).half()
+    y0 = eng.forward(s, 300, e)
+    old_ptrs = {p.data_ptr() for p in m16.parameters()}
+    with torch.no_grad():
+        for n, p in m16.named_parameters():
+            if n.endswith(("attn1.to_q.weight", "attn2.to_out.0.weight", "conv1.weight", "proj_in.weight")):
+                p.data = (p.data.float() * 0.5 + 0.03 * torch.randn(p.shape, generator=g)).to(p.dtype)   # new storage
+    eng.refresh_parameters(m16)
+    assert not eng._plans and not eng._pk and "_ptr_names" not in eng.__dict__
+    assert all(eng._param_objs[n] is p for n, p in m16.named_parameters())
+    y1 = eng.forward(s, 300, e)
+    m32.load_state_dict({k: v.float() for k, v in m16.state_dict().items()})
+    with torch.no_grad():
+        want = m32(s.float(), 300, e.float()).sample
+    assert rel_l2(y1, want) < 3e-3 and rel_l2(y0, want) > 1e-2
+    live = {t.data_ptr() for t in eng.params.values() if torch.is_tensor(t)}
+    assert all(rec["w"].data_ptr() in live for rec in eng._pk.values())          # packed records (if any) belong to live parameters
+    changed = {p.data_ptr() for p in m16.parameters()} - old_ptrs
+    assert changed and changed <= live
+
+
 def test_plan_executes_tiny_sd2_topology(built_lib):
     # SD2.x = the SD1.5 block layout with Linear proj_in / proj_out and a per-level head count
     cfg = U.tiny_config(use_linear_projection=True, attention_head_dim=(2, 4, 4), cross_attention_dim=48)
