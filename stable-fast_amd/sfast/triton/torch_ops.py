@@ -62,8 +62,13 @@ def layer_norm(input, normalized_shape, weight=None, bias=None, eps=1e-5):
 
 def _convolution(input, weight, bias, stride, padding, dilation, transposed, output_padding, groups, benchmark,
                  deterministic, cudnn_enabled, allow_tf32):
-    if transposed or groups != 1:
-        raise RuntimeError("sfast_triton::_convolution on ROCm supports groups == 1, non-transposed convolutions only")
+    if transposed:
+        raise RuntimeError("sfast_triton::_convolution on ROCm supports non-transposed convolutions only")
+    if groups != 1:
+        # the reference hands grouped convolutions to ATen (triton/torch_ops.py:116-125); here they stay on the HIP library: one native
+        # launch per group writing its channel slice of one output (the wrapper behind sfast::cudnn_convolution_bias, round 5)
+        from ..torch_ops import _conv
+        return _conv(input, weight, bias, None, None, list(stride), list(padding), list(dilation), False, [0] * len(stride), int(groups), None)
     return F.conv2d(input, weight, bias, stride=tuple(stride), padding=tuple(padding), dilation=tuple(dilation))
 
 
