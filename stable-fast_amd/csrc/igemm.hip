@@ -686,11 +686,14 @@ static const Variant kVariants[] = {
     // autotuner candidates, only when the caller hands over packed copies (caps bit 1)
     {41, 128, 256, 1, 4, 4, 4, 1.10f}, {42, 64, 256, 1, 4, 4, 4, 0.90f},  {43, 64, 320, 1, 5, 4, 4, 0.90f},
     {44, 128, 160, 1, 5, 4, 4, 0.90f}, {45, 64, 160, 1, 5, 4, 4, 0.70f},  {46, 128, 128, 1, 4, 4, 4, 0.90f},
+    // pipe 5 (round 6): 256-row ping-pong tiles, 8 waves in two alternating groups (igemm_pp.h); autotuner candidates for large M
+    {51, 256, 128, 4, 2, 5, 3, 1.30f}, {52, 256, 160, 4, 2, 5, 3, 1.30f}, {53, 256, 256, 2, 4, 5, 2, 1.40f},
 };
 static const Variant kGegluVariants[] = {
     {1, 128, 128, 2, 2, 0, 2, 1.00f},  {3, 64, 128, 2, 2, 0, 2, 0.75f},  {11, 128, 128, 2, 2, 1, 4, 1.00f},
     {13, 64, 128, 2, 2, 1, 5, 0.75f},  {16, 128, 128, 2, 2, 1, 2, 1.00f}, {18, 64, 128, 2, 2, 1, 3, 0.75f},
     {21, 128, 128, 2, 2, 2, 4, 1.00f}, {23, 64, 128, 2, 2, 2, 3, 0.75f},
+    {53, 256, 256, 2, 4, 5, 2, 1.40f},  // pipe 5: 256 pixels x (128 h + 128 g) weight rows
 };
 
 extern unsigned long long *g_igemm_trace;  // igemm_glds.hip
@@ -698,6 +701,8 @@ int igemm_glds_ws_init();  // igemm_glds_ws.hip
 int igemm_glds_ws_launch(const IgemmArgs &a, int dtype, int mode, bool geglu, int BM, int BN, int NS, hipStream_t st);
 int igemm_pk_init();                                                                                 // igemm_pk.hip
 int igemm_pk_launch(const IgemmArgs &a, int dtype, int mode, int BM, int BN, hipStream_t st);       // igemm_pk.hip
+int igemm_pp_init();                                                                                 // igemm_pp.hip
+int igemm_pp_launch(const IgemmArgs &a, int dtype, int mode, bool geglu, int BN, hipStream_t st);    // igemm_pp.hip
 int igemm_glds_init();                                                                               // igemm_glds.hip
 int igemm_glds_launch(const IgemmArgs &a, int dtype, int mode, bool geglu, int BM, int BN, int NS, hipStream_t st);  // igemm_glds.hip
 
@@ -754,6 +759,7 @@ int igemm_init() {
     if (!rc) rc = igemm_glds_init();
     if (!rc) rc = igemm_glds_ws_init();
     if (!rc) rc = igemm_pk_init();
+    if (!rc) rc = igemm_pp_init();
     const char *so = getenv("SFAST_STAGE_OUT");
     g_stage_pref = (so && so[0] == '1') ? 1 : 0;
     const char *xm = getenv("SFAST_XCD_MAP");
@@ -838,6 +844,7 @@ static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, 
         }
         if (v.pipe >= 1 && !glds_ok) continue;
         if (v.pipe == 4 && !(caps & 2)) continue;
+        if (v.pipe == 5 && (K % 64 != 0 || M < 256)) continue;  // no K tail in the ping-pong pipe; one full tile of rows at least
         if (v.pipe == 3 && !(patch_w > 0 && K % 576 == 0 && conv_patch_fits(patch_h, patch_w, M, v.BM, v.BN))) continue;
         const int bno = geglu ? v.BN / 2 : v.BN;
         const int tm = ceil_div(M, v.BM), tn = ceil_div(N, bno);
@@ -1197,7 +1204,7 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
 #endif
     }
     char pipe[8];
-    snprintf(pipe, sizeof(pipe), p.v.pipe == 4 ? "pk%d" : p.v.pipe == 3 ? "patch%d" : p.v.pipe == 2 ? "ws%d" : p.v.pipe ? "dma%d" : "reg", p.v.ns);
+    snprintf(pipe, sizeof(pipe), p.v.pipe == 5 ? "pp%d" : p.v.pipe == 4 ? "pk%d" : p.v.pipe == 3 ? "patch%d" : p.v.pipe == 2 ? "ws%d" : p.v.pipe ? "dma%d" : "reg", p.v.ns);
     char xmap[24] = "";
     if (a.xmap == 2) snprintf(xmap, sizeof(xmap), "@xcdrun%c%d", a.x_order ? 'n' : 'm', a.x_per);  // contiguous runs, tile_m / tile_n fastest
     else if (a.xmap) snprintf(xmap, sizeof(xmap), "@xcd%dx%dx%d", 8 >> (a.x_lxm + a.x_lxn), 1 << a.x_lxm, 1 << a.x_lxn);  // K-split x row x column boxes
@@ -1205,7 +1212,9 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
                     geglu ? "_geglu" : "", p.v.BM, p.v.BN, p.splits, pipe, a.gn_stats ? "+gnstats" : (a.stage_out ? "+staged" : ""),
                     joins ? "+join" : "", a.gn_out ? "+gn" : "", xmap);  // +join: split-K finished inside this kernel (no reduce launch)
     int rc;
-    if (p.v.pipe == 4)
+    if (p.v.pipe == 5)
+        rc = igemm_pp_launch(a, dtype, mode, geglu, p.v.BN, st);
+    else if (p.v.pipe == 4)
         rc = igemm_pk_launch(a, dtype, mode, p.v.BM, p.v.BN, st);
     else if (p.v.pipe == 3)
         rc = conv_patch_launch(a, dtype, p.v.BM, p.v.BN, st);
