@@ -688,6 +688,7 @@ static const Variant kVariants[] = {
     {44, 128, 160, 1, 5, 4, 4, 0.90f}, {45, 64, 160, 1, 5, 4, 4, 0.70f},  {46, 128, 128, 1, 4, 4, 4, 0.90f},
     // pipe 5 (round 6): 256-row ping-pong tiles, 8 waves in two alternating groups (igemm_pp.h); autotuner candidates for large M
     {51, 256, 128, 4, 2, 5, 3, 1.30f}, {52, 256, 160, 4, 2, 5, 3, 1.30f}, {53, 256, 256, 2, 4, 5, 2, 1.40f},
+    {55, 256, 128, 4, 2, 5, 3, 1.30f}, {56, 256, 160, 4, 2, 5, 3, 1.30f},  // + four producer waves (12 waves per workgroup)
 };
 static const Variant kGegluVariants[] = {
     {1, 128, 128, 2, 2, 0, 2, 1.00f},  {3, 64, 128, 2, 2, 0, 2, 0.75f},  {11, 128, 128, 2, 2, 1, 4, 1.00f},
@@ -702,7 +703,7 @@ int igemm_glds_ws_launch(const IgemmArgs &a, int dtype, int mode, bool geglu, in
 int igemm_pk_init();                                                                                 // igemm_pk.hip
 int igemm_pk_launch(const IgemmArgs &a, int dtype, int mode, int BM, int BN, hipStream_t st);       // igemm_pk.hip
 int igemm_pp_init();                                                                                 // igemm_pp.hip
-int igemm_pp_launch(const IgemmArgs &a, int dtype, int mode, bool geglu, int BN, hipStream_t st);    // igemm_pp.hip
+int igemm_pp_launch(const IgemmArgs &a, int dtype, int mode, bool geglu, int BN, int pw, hipStream_t st);  // igemm_pp.hip
 int igemm_glds_init();                                                                               // igemm_glds.hip
 int igemm_glds_launch(const IgemmArgs &a, int dtype, int mode, bool geglu, int BM, int BN, int NS, hipStream_t st);  // igemm_glds.hip
 
@@ -1185,7 +1186,11 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
             a.gn_slots = ceil_div(a.N, a.gn_unit);
         }
     }
-    a.stage_out = ((p.splits == 1 || joins) && !geglu && stage_ok && (a.gn_stats != nullptr || g_stage_pref > 0)) ? 1 : 0;
+    // pipe 5 stages every eligible tile: its six-fragment waves would otherwise run the one-fragment-ahead epilogue with 8-byte global
+    // stores between the operand fetches, and gfx950 counts loads and stores in ONE vmcnt -- the wait for fragment f + 1's operands also
+    // waits for fragment f's stores to be acknowledged (~1.15 us per fragment on a busy chip: 7 us of epilogue behind a 70 us K loop,
+    // profiles/r06_pp_loop_probe_run8_timeline.log). Staged, the fragment loop only writes LDS and the tile leaves as 16-byte segments.
+    a.stage_out = ((p.splits == 1 || joins) && !geglu && stage_ok && (a.gn_stats != nullptr || g_stage_pref > 0 || p.v.pipe == 5)) ? 1 : 0;
     if (p.splits > 1) {
         const size_t need = joins ? (size_t)p.splits * p.tiles_m * p.tiles_n * p.v.BM * p.v.BN * sizeof(float)
                                   : (size_t)p.splits * a.M * (geglu ? 2 * (size_t)a.N : (size_t)a.N) * sizeof(float);
@@ -1204,7 +1209,7 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
 #endif
     }
     char pipe[8];
-    snprintf(pipe, sizeof(pipe), p.v.pipe == 5 ? "pp%d" : p.v.pipe == 4 ? "pk%d" : p.v.pipe == 3 ? "patch%d" : p.v.pipe == 2 ? "ws%d" : p.v.pipe ? "dma%d" : "reg", p.v.ns);
+    snprintf(pipe, sizeof(pipe), p.v.pipe == 5 ? (p.v.id >= 55 ? "ppw%d" : "pp%d") : p.v.pipe == 4 ? "pk%d" : p.v.pipe == 3 ? "patch%d" : p.v.pipe == 2 ? "ws%d" : p.v.pipe ? "dma%d" : "reg", p.v.ns);
     char xmap[24] = "";
     if (a.xmap == 2) snprintf(xmap, sizeof(xmap), "@xcdrun%c%d", a.x_order ? 'n' : 'm', a.x_per);  // contiguous runs, tile_m / tile_n fastest
     else if (a.xmap) snprintf(xmap, sizeof(xmap), "@xcd%dx%dx%d", 8 >> (a.x_lxm + a.x_lxn), 1 << a.x_lxm, 1 << a.x_lxn);  // K-split x row x column boxes
@@ -1213,7 +1218,7 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
                     joins ? "+join" : "", a.gn_out ? "+gn" : "", xmap);  // +join: split-K finished inside this kernel (no reduce launch)
     int rc;
     if (p.v.pipe == 5)
-        rc = igemm_pp_launch(a, dtype, mode, geglu, p.v.BN, st);
+        rc = igemm_pp_launch(a, dtype, mode, geglu, p.v.BN, p.v.id >= 55 ? 4 : 0, st);  // ids 55..: four producer waves
     else if (p.v.pipe == 4)
         rc = igemm_pk_launch(a, dtype, mode, p.v.BM, p.v.BN, st);
     else if (p.v.pipe == 3)

@@ -404,7 +404,8 @@ __device__ __forceinline__ void epilogue_finish(const IgemmArgs &a, const StageC
 // fragment AHEAD of the one being finished (12 vectors each), which keeps the epilogue inside the register budget
 // of two waves per SIMD while still overlapping every operand round trip but the first with math and stores.
 // (Program order = load(f+1), store(f): legal for in-place residuals because fragments never overlap.)
-template <typename T, int FN, int FM, bool STAGED>
+// AHEAD = false (the 12-wave form of igemm_pp.h: 168 registers, 96 of them accumulators): one operand set, fetched and consumed per fragment
+template <typename T, int FN, int FM, bool STAGED, bool AHEAD = true>
 __device__ __forceinline__ void epilogue_late(const IgemmArgs &a, const StageCtx &sc, f32x16 (&acc)[FN][FM], int mbase, int nbase, int l31,
                                               int hi, int split_idx, bool whole) {
     typedef const u32x2 __attribute__((address_space(1))) * g2_ptr;
@@ -414,7 +415,7 @@ __device__ __forceinline__ void epilogue_late(const IgemmArgs &a, const StageCtx
         return;
     }
     const BatchOfRow batch_of(a);
-    u32x2 vb[2][4], vb2[2][4], vr[2][4];
+    u32x2 vb[AHEAD ? 2 : 1][4], vb2[AHEAD ? 2 : 1][4], vr[AHEAD ? 2 : 1][4];
     const EpiRow<T> bias(a.bias, 0, true);
     auto fetch = [&](int f, int buf) {
         const int fm = f / FN, fh = f % FN;
@@ -431,13 +432,18 @@ __device__ __forceinline__ void epilogue_late(const IgemmArgs &a, const StageCtx
             vr[buf][g] = res.load(n, nok);
         }
     };
-    fetch(0, 0);
+    if constexpr (AHEAD) fetch(0, 0);
 #pragma unroll
     for (int f = 0; f < FN * FM; ++f) {
         const int fm = f / FN, fh = f % FN;
-        if (f + 1 < FN * FM) fetch(f + 1, (f + 1) & 1);
+        if constexpr (AHEAD) {
+            if (f + 1 < FN * FM) fetch(f + 1, (f + 1) & 1);
+        } else {
+            fetch(f, 0);
+        }
         const int m = mbase + fm * 32 + l31;
-        fragment_pass1<T, STAGED>(a, sc, acc[fh][fm], vb[f & 1], vb2[f & 1], vr[f & 1], m < a.M, m, nbase + fh * 32, hi);
+        constexpr int B1 = AHEAD ? 1 : 0;
+        fragment_pass1<T, STAGED>(a, sc, acc[fh][fm], vb[f & B1], vb2[f & B1], vr[f & B1], m < a.M, m, nbase + fh * 32, hi);
     }
     if (a.act != SFAST_ACT_NONE) epilogue_act_tail<T, FN, FM, STAGED>(a, sc, acc, mbase, nbase, l31, hi);
 }
@@ -627,7 +633,7 @@ constexpr bool kJoinDefault = true;
 #else
 constexpr bool kJoinDefault = false;
 #endif
-template <typename T, int BM, int BNO, int FN, int FM, bool GEGLU, bool EPI_EARLY, int NTC, bool STAGED, bool JOIN = kJoinDefault>
+template <typename T, int BM, int BNO, int FN, int FM, bool GEGLU, bool EPI_EARLY, int NTC, bool STAGED, bool JOIN = kJoinDefault, bool LATE_AHEAD = true>
 __device__ __forceinline__ void run_epilogue(const IgemmArgs &a, f32x16 (&acc)[FN][FM],
                                              EpiOperands<(EPI_EARLY ? (GEGLU ? FN / 2 : FN) : 1), (EPI_EARLY ? FM : 1)> &epi, char *smem,
                                              int m0, int n0, int mbase, int nbase, int l31, int hi, int ctid, int split_idx) {
@@ -645,13 +651,13 @@ __device__ __forceinline__ void run_epilogue(const IgemmArgs &a, f32x16 (&acc)[F
         if constexpr (EPI_EARLY)
             epilogue_finish<T, FN, FM, GEGLU, true>(a, sc, acc, epi, mbase, nbase, l31, hi, split_idx, whole);
         else
-            epilogue_late<T, FN, FM, true>(a, sc, acc, mbase, nbase, l31, hi, split_idx, whole);
+            epilogue_late<T, FN, FM, true, LATE_AHEAD>(a, sc, acc, mbase, nbase, l31, hi, split_idx, whole);
         flush_staged_tile<T, BM, BNO, NTC>(a, smem, m0, n0, ctid);
     } else {
         if constexpr (EPI_EARLY)
             epilogue_finish<T, FN, FM, GEGLU, false>(a, sc, acc, epi, mbase, nbase, l31, hi, split_idx, whole);
         else
-            epilogue_late<T, FN, FM, false>(a, sc, acc, mbase, nbase, l31, hi, split_idx, whole);
+            epilogue_late<T, FN, FM, false, LATE_AHEAD>(a, sc, acc, mbase, nbase, l31, hi, split_idx, whole);
     }
 }
 

@@ -27,6 +27,12 @@ VARIANTS = (1, 2, 3, 5, 11, 12, 13, 15, 16, 17, 18, 21, 22, 23, 24, 25, 26)
 GEGLU_VARIANTS = (1, 3, 11, 13, 16, 18, 21, 23)
 PK_VARIANTS = (41, 42, 43, 44, 45, 46)  # igemm_pk.h: packed weights global -> VGPR; only for ops that were handed packed copies
 CONV_PATCH_VARIANTS = (31, 32, 34)   # conv_patch.hip: 3x3 / stride 1 / pad 1 convs only (sfast_hip_conv2d_plan says whether a problem fits)
+# igemm_pp.h (round 6): 256-row ping-pong tiles -- 256 x 128 / 160 / 256 with the consumer groups issuing the LDS-DMA requests (51 - 53)
+# or four producer waves (55, 56); candidates only where the tiles alone put work on at least PP_MIN_TILES of the 256 CUs
+PP_VARIANTS = (51, 52, 53, 55, 56)
+PP_GEGLU_VARIANTS = (53,)
+PP_BN = {51: 128, 52: 160, 53: 256, 55: 128, 56: 160}
+PP_MIN_TILES = 96
 MAX_SLAB_BYTES = 192 << 20
 
 
@@ -76,6 +82,16 @@ def _save_file(path):
         pass
 
 
+def _pp_candidates(M, N, K, geglu):
+    if K % 64 != 0 or M < 1024:
+        return ()
+    return tuple(v for v in (PP_GEGLU_VARIANTS if geglu else PP_VARIANTS)
+                 if -(-M // 256) * -(-N // (PP_BN[v] // 2 if geglu else PP_BN[v])) >= PP_MIN_TILES)
+
+
+_extended = set()  # SFAST_TUNE_EXTEND=1: cached problems already re-timed against the pipe-5 candidates in this process
+
+
 def problem_key(p, dtype_tag, device_name):
     if isinstance(p, L.GemmParams):
         epi = (int(p.geglu), int(p.act), int(p.n_wseg))
@@ -123,6 +139,8 @@ def tune_plan(plan, device, dtype_tag="f16", verbose=False):
             _load_file(PACKAGED_CACHE)  # choices measured on an MI355X for the SD1.5 / SDXL shapes; anything else is timed here
     devname = getattr(torch.cuda.get_device_properties(device), "gcnArchName", "gpu").split(":")[0]
     todo = {}
+    ext_base = {}
+    extend = os.environ.get("SFAST_TUNE_EXTEND", "0") not in ("0", "false", "off", "")
     for op in plan.ops:
         if op.tune is None:
             continue
@@ -134,6 +152,11 @@ def tune_plan(plan, device, dtype_tag="f16", verbose=False):
         hit = _cache.get(key)
         if hit is not None:
             p.variant, p.split_k = int(hit[0]), int(hit[1])
+            # SFAST_TUNE_EXTEND=1 (tools/retune_pp.py): a cached choice made before the 256-row tiles existed is timed once more against
+            # them -- how sfast/engine/tune_gfx950.json was brought up to date in round 6 without re-timing 360 problems x 17 variants
+            if extend and 0 < int(hit[0]) < 50 and key not in _extended and _pp_candidates(M, N, K, geglu):
+                ext_base[key] = (int(hit[0]), int(hit[1]))
+                todo.setdefault(key, []).append(op)
         else:
             todo.setdefault(key, []).append(op)
     if not todo:
@@ -154,11 +177,15 @@ def tune_plan(plan, device, dtype_tag="f16", verbose=False):
         best = None
         is_conv = not isinstance(p, L.GemmParams)
         cands = GEGLU_VARIANTS if geglu else (VARIANTS + CONV_PATCH_VARIANTS if is_conv else VARIANTS)
+        cands = cands + _pp_candidates(M, N, K, geglu)
         only = None
-        if key.endswith("|pk"):
+        if key in ext_base:
+            _extended.add(key)
+            cands, only = (ext_base[key][0],) + _pp_candidates(M, N, K, geglu), ext_base[key]
+        elif key.endswith("|pk"):
             base = _cache.get(key[:-3])
             if base is not None and int(base[0]) > 0:
-                cands, only = (int(base[0]),) + PK_VARIANTS, (int(base[0]), int(base[1]))  # the known best ring kernel against the packed pipe
+                cands, only = (int(base[0]),) + PK_VARIANTS, (int(base[0]), int(base[1]))  # the known best kernel against the packed pipe
             else:
                 cands = cands + PK_VARIANTS
         for v in cands:
@@ -167,6 +194,8 @@ def tune_plan(plan, device, dtype_tag="f16", verbose=False):
                     continue
                 if s > 1 and ktiles // s < 2:
                     continue
+                if v >= 50 and s > 2:
+                    continue  # the 256-row tiles are candidates where the tiles alone fill the chip
                 if s > 1 and s * M * wrows * 4 > MAX_SLAB_BYTES:
                     continue
                 if is_conv:
@@ -186,7 +215,7 @@ def tune_plan(plan, device, dtype_tag="f16", verbose=False):
                 if launch_with(sp, ws.data_ptr(), ws.numel()) != 0:
                     continue
                 k = L.last_kernel()
-                if ("pk" if v >= 40 else "patch" if v >= 30 else "ws" if v >= 20 else "dma" if v >= 10 else "reg") not in k.split(",")[-1]:
+                if ("pp" if v >= 50 else "pk" if v >= 40 else "patch" if v >= 30 else "ws" if v >= 20 else "dma" if v >= 10 else "reg") not in k.split(",")[-1]:
                     continue  # pipe not applicable to this problem: the library substituted another
                 t = _time(lambda: launch_with(sp, ws.data_ptr(), ws.numel()), stream)
                 if best is None or t < best[0]:

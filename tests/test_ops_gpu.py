@@ -438,6 +438,134 @@ def test_conv_patch_pipe_emits_groupnorm_statistics(variant, split, cin, cout, h
     compare(f"gn_apply conv patch {cin}->{cout}@{hw} v{variant} s{split}", yn, R.group_norm_ref(y, 32, gam, bet, 1e-5, True), *tol(y.dtype, 2.0), kernel=k)
 
 
+# ---- pipe 5 (round 6): 256-row ping-pong tiles, csrc/igemm_pp.h -- ids 51 - 53 (8 waves), 55 / 56 (+ 4 producer waves) ------------------
+PP_VARIANTS = [51, 52, 53, 55, 56]
+
+
+def _pp_applies(M, K):
+    return M >= 256 and K % 64 == 0
+
+
+@pytest.mark.parametrize("M,K,N", [(8192, 320, 320), (8192, 320, 960), (2048, 2560, 640), (512, 1280, 1280), (4095, 320, 324), (300, 64, 36),
+                                   (256, 1280, 1280), (8192, 328, 320), (130, 1280, 1280)])
+@pytest.mark.parametrize("variant", PP_VARIANTS)
+def test_linear_pp_variants(M, K, N, variant):
+    x = rnd(M, K, seed=40)
+    w = rnd(N, K, seed=41, scale=K ** -0.5)
+    b = rnd(N, seed=42, scale=0.1)
+    y = F().linear(x, w, b, variant=variant)
+    k = last_kernel()
+    assert "igemm_lin" in k and (("pp" in k.split(",")[-1]) == _pp_applies(M, K)), k  # K tail / fewer than 256 rows: another pipe takes the call
+    compare(f"linear M{M} K{K} N{N} v{variant}", y, R.linear_ref(x, w, b), *tol(x.dtype), kernel=k)
+
+
+@pytest.mark.parametrize("M,K,N", [(8192, 320, 1280), (2048, 640, 2560), (512, 1280, 5120), (700, 1280, 320), (256, 64, 64)])
+def test_geglu_pp_variant(M, K, N):
+    x = rnd(M, K, seed=33)
+    w = rnd(2 * N, K, seed=34, scale=K ** -0.5)
+    b = rnd(2 * N, seed=35, scale=0.1)
+    y = F().linear(x, w, b, geglu=True, variant=53)
+    assert "geglu[256x256" in last_kernel() and "pp2" in last_kernel(), last_kernel()
+    compare(f"geglu M{M} K{K} N{N} v53", y, R.linear_ref(x, w, b, geglu=True), *tol(x.dtype), kernel=last_kernel())
+    ws = [w[:N].contiguous(), w[N:].contiguous()]  # two live weight tensors (h rows, g rows), as the engine passes them
+    y2 = F().linear(x, ws, b, geglu=True, variant=53)
+    assert torch.equal(y, y2), last_kernel()
+
+
+@pytest.mark.parametrize("variant,split", [(51, 2), (52, 2), (52, 3), (53, 2), (53, 5), (55, 2), (56, 4)])
+def test_linear_pp_split_k(variant, split):
+    x, w, b = rnd(600, 5120, seed=43), rnd(1280, 5120, seed=44, scale=5120 ** -0.5), rnd(1280, seed=45)
+    r = rnd(600, 1280, seed=46)
+    y = F().linear(x, w, b, residual=r, variant=variant, split_k=split)
+    assert f"split={split},pp" in last_kernel(), last_kernel()
+    compare(f"linear split{split} v{variant}", y, R.linear_ref(x, w, b, residual=r), *tol(x.dtype), kernel=last_kernel())
+
+
+@pytest.mark.parametrize("variant", PP_VARIANTS)
+def test_pp_epilogues_bf16(variant):
+    M, K, N = 700, 1280, 640
+    dt = torch.bfloat16
+    x, w, b = rnd(M, K, dtype=dt, seed=56), rnd(N, K, dtype=dt, seed=57, scale=K ** -0.5), rnd(N, dtype=dt, seed=58, scale=0.1)
+    r, rb = rnd(M, N, dtype=dt, seed=59), rnd(4, N, dtype=dt, seed=60)
+    y = F().linear(x, w, b, residual=r, alpha=0.5, act="gelu", rowbias=rb, rows_per_batch=175, variant=variant)
+    assert "pp" in last_kernel().split(",")[-1], last_kernel()
+    want = R.linear_ref(x, w, b, residual=r, alpha=0.5, act="gelu", rowbias=rb, rows_per_batch=175)
+    compare(f"pp epilogue bf16 v{variant}", y, want, *tol(dt, 2.0), kernel=last_kernel())
+    buf = r.clone()
+    F().linear(x, w, b, residual=buf, out=buf, variant=variant)
+    compare(f"pp inplace residual bf16 v{variant}", buf, R.linear_ref(x, w, b, residual=r), *tol(dt, 2.0), kernel=last_kernel())
+    big = torch.zeros(M, 3 * N, dtype=dt, device=DEV)
+    ws = [rnd(N // 2, K, dtype=dt, seed=61 + i, scale=K ** -0.5) for i in range(2)]  # stacked weight segments + a strided output
+    y = F().linear(x, ws, b, out=big[:, N:2 * N], variant=variant)
+    compare(f"pp segments / strided out bf16 v{variant}", y, R.linear_ref(x, torch.cat(ws, 0), b), *tol(dt, 2.0), kernel=last_kernel())
+    assert float(big[:, :N].abs().max()) == 0 and float(big[:, 2 * N:].abs().max()) == 0
+
+
+PP_CONV_CASES = [c for c in CONV_CASES if c[0] in ("res 320@64", "res2 320@64 +z", "down 320@64 s2", "640@32", "1280@16", "1280@8", "cat 640+320@64",
+                                                   "cat1x1 1280+640@32", "1x1 320@64", "5x5 pad2")] + [
+    ("3 images 128@24 ragged", 3, 128, 24, 24, 200, 3, 1, 1, dict(z=True)),          # M = 1728: a ragged last row tile, Cout % 32 != 0
+    ("dilated 64@40", 1, 64, 40, 40, 96, 3, 1, 2, dict(dil=2)),
+]
+
+
+@pytest.mark.parametrize("case", PP_CONV_CASES, ids=[c[0] for c in PP_CONV_CASES])
+@pytest.mark.parametrize("variant", PP_VARIANTS)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_conv_pp_variants(case, variant, dtype):
+    name, B, Cin, H, W, Cout, k, stride, pad, ex = case
+    if dtype == torch.bfloat16 and variant not in (52, 53, 56):
+        pytest.skip("bf16: one tile shape per wave layout")
+    x = cl(rnd(B, Cin, H, W, seed=70, dtype=dtype))
+    c2 = ex.get("c2", 0)
+    dil = ex.get("dil", 1)
+    x2 = cl(rnd(B, c2, H, W, seed=71, dtype=dtype)) if c2 else None
+    w = cl(rnd(Cout, Cin + c2, k, k, seed=72, scale=((Cin + c2) * k * k) ** -0.5, dtype=dtype))
+    b = rnd(Cout, seed=73, scale=0.1, dtype=dtype)
+    Ho, Wo = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    z = cl(rnd(B, Cout, Ho, Wo, seed=74, dtype=dtype)) if ex.get("z") else None
+    rb = rnd(B, Cout, seed=75, dtype=dtype) if ex.get("rowbias") else None
+    y = F().conv2d(x, w, b, z=z, stride=stride, padding=pad, dilation=dil, x2=x2, rowbias=rb, variant=variant)
+    kname = last_kernel()
+    assert "igemm_conv" in kname and (("pp" in kname.split(",")[-1]) == (B * Ho * Wo >= 256)), kname
+    want = R.conv2d_ref(x, w, b, z, 1.0, stride, pad, dil, x2=x2, rowbias=rb)
+    compare(f"conv {name} v{variant} {dtype}", y, want, *tol(dtype, 2.0), kernel=kname)
+
+
+@pytest.mark.parametrize("variant,split", [(52, 1), (53, 1), (56, 1), (51, 1), (55, 1), (52, 2), (56, 3)])
+@pytest.mark.parametrize("cin,cout,hw,unit", [(320, 320, 32, 10), (640, 1280, 16, 20), (320, 640, 64, 20)])
+def test_conv_pp_emits_groupnorm_statistics(variant, split, cin, cout, hw, unit):
+    import numpy as np
+    x = rnd(2, cin, hw, hw, seed=200, shift=0.5).contiguous(memory_format=torch.channels_last)
+    w = rnd(cout, cin, 3, 3, seed=201, scale=(9 * cin) ** -0.5).contiguous(memory_format=torch.channels_last)
+    b = rnd(cout, seed=202, shift=2.0)
+    z = rnd(2, cout, hw, hw, seed=203).contiguous(memory_format=torch.channels_last)
+    y, stats, lay = F().conv2d(x, w, b, z=z, padding=1, variant=variant, split_k=split, gn_unit=unit)
+    k = last_kernel()
+    assert "pp" in k.split(",")[-1] and "+gnstats" in k, k
+    plain = F().conv2d(x, w, b, z=z, padding=1, variant=variant, split_k=split)
+    assert torch.equal(y, plain), k
+    want = _stats_reference(y.permute(0, 2, 3, 1).reshape(-1, cout), lay)
+    got = stats.double().cpu().numpy().reshape(want.shape)
+    used = ~np.isnan(want)
+    assert np.allclose(got[..., 0][used[..., 0]], want[..., 0][used[..., 0]], rtol=1e-4, atol=1e-4), k
+    assert np.allclose(got[..., 1][used[..., 1]], want[..., 1][used[..., 1]], rtol=2e-3, atol=1e-2), k
+    gam, bet = rnd(cout, seed=204, shift=1.0, scale=0.2), rnd(cout, seed=205, scale=0.2)
+    yn = F().group_norm_apply(y, 32, gam, bet, 1e-5, "silu", stats, lay)
+    compare(f"gn_apply conv pp {cin}->{cout}@{hw} v{variant} s{split}", yn, R.group_norm_ref(y, 32, gam, bet, 1e-5, True), *tol(y.dtype, 2.0), kernel=k)
+
+
+def test_pp_matches_the_other_pipes_on_identical_inputs():
+    # same products, different fp32 summation order (channel-slice-major K traversal): results agree to f16 rounding, and a second call is bit-equal
+    x, w, b = cl(rnd(4, 320, 64, 64, seed=90)), cl(rnd(320, 320, 3, 3, seed=91, scale=2880 ** -0.5)), rnd(320, seed=92)
+    y_ws = F().conv2d(x, w, b, padding=1, variant=22)
+    for v in PP_VARIANTS:
+        y1 = F().conv2d(x, w, b, padding=1, variant=v)
+        k = last_kernel()
+        assert "pp" in k.split(",")[-1], k
+        assert torch.equal(y1, F().conv2d(x, w, b, padding=1, variant=v)), k  # deterministic
+        compare(f"pp v{v} vs ws 128x160", y1, y_ws.float(), *tol(x.dtype), kernel=k)
+
+
 @pytest.mark.parametrize("split", [2, 4, 12])
 def test_conv_split_k(split):
     x, w, b = cl(rnd(2, 1280, 8, 8, seed=76)), cl(rnd(1280, 1280, 3, 3, seed=77, scale=11520 ** -0.5)), rnd(1280, seed=78)
