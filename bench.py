@@ -30,9 +30,8 @@ sys.path.insert(0, os.path.join(ROOT, "stable-fast_amd"))
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-# hipGraphs this script is done with stay referenced until the process exits: a graph is never destroyed in the same breath as its last replay
-# (the trigger of the round-4 crash, DESIGN.md section 9, round 5, item 1 -- the product retires its graphs the same way)
-_KEEP_GRAPHS = []
+# (round 6: no `_KEEP_GRAPHS` list any more -- every graph the product hands out is an OwnedGraph whose teardown is deferred to a
+# synchronised point, sfast/engine/unet2d.py; the raw torch.cuda.CUDAGraph objects this script captures itself are retired the same way)
 
 MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
@@ -173,7 +172,9 @@ def differential_graph_timing(plan, idxs, replays=30, rounds=3):
                 t = a.elapsed_time(b) * 1e-3 / replays
                 best[k] = t if best[k] is None or t < best[k] else best[k]
     torch.cuda.current_stream().wait_stream(s)
-    _KEEP_GRAPHS.extend(graphs)
+    from sfast.engine.unet2d import retire_graph
+    for g in graphs:  # never destroyed in the same breath as the last replay
+        retire_graph(g, None)
     return max(best[0] - best[1], 0.0), best[0], best[1]
 
 
@@ -320,7 +321,9 @@ def roofline_from(rows, plan=None, config="sd15"):
                     roof["frac_kernel_only"] = rate / (MFMA_PEAK_TFLOPS if mfma else HBM_PEAK_GBS)
                     roof["kernel_only_avg_us"] = t["avg_us_trace"]
                     roof["kernel_only_source"] = (f"{rel}: rocprofv3 --kernel-trace (no counters) per-dispatch average of this symbol over "
-                                                  f"{t.get('launches_trace')} dispatches of the steady window of graph replays, same session as the counters")
+                                                  f"{t.get('launches_trace')} dispatches of the steady window of graph replays, "
+                                                  + (f"durations from {meta['avg_us_trace_from']}" if meta.get("avg_us_trace_from")
+                                                     else "same session as the counters"))
     except (OSError, ValueError, KeyError) as e:
         roof["traffic_note"] = f"traffic file unreadable: {type(e).__name__}: {e}"
     fam = {}
@@ -542,7 +545,7 @@ def step_variants(args, engine, cfg, hw, dev, latents, ehs, headline_ms):
     out["text_kv_hoisted"] = {"value": 1e3 / ms, "unit": "it/s", "ms_per_step": ms, "kernel_launches_per_step": len(loop._step_ops) + 2,
                               "gain_vs_headline": headline_ms / ms,
                               "note": "cross-attention K/V projections of the text context run once per prompt (DenoiseLoop(hoist_text_kv=True)), not per step"}
-    _KEEP_GRAPHS.append(loop)   # (not `del loop`: its graph was replayed a moment ago)
+    del loop   # its graph retires through its OwnedGraph handle
     if args.images == 1:
         plan = engine.get_plan(1, hw, hw, 77)
         kw = {}
@@ -570,14 +573,16 @@ def step_variants(args, engine, cfg, hw, dev, latents, ehs, headline_ms):
     return out
 
 
-def sdxl_variant(steps=20, warmup=5, timeout=240):
-    """north_star asks for it/s on BOTH latent sizes; the driver times `python bench.py` only. So the default SD1.5 run ends by timing
-    the 1x4x128x128-latent step (BASELINE configs[2]: SDXL 1024x1024 bs=1 fp16, CFG batch-2 UNet + guidance + DDIM update as one
-    hipGraph, packaged kernel choices) in a CHILD process of this same script -- its own 5 GB of weights, its own plan, its own
-    `roofline` block -- and embeds the child's JSON line. A failure is reported, never raised: the contract line must survive."""
+def child_variant(extra, steps=20, warmup=5, timeout=150):
+    """north_star asks for it/s on BOTH latent sizes and BASELINE configs[3] runs 8 images per GPU; the driver times `python bench.py`
+    only. So the default SD1.5 run ends by timing (a) the 1x4x128x128-latent step (BASELINE configs[2]: SDXL 1024x1024 bs=1 fp16) and
+    (b) the per-GPU shape of configs[3] (SD1.5, 8 images = UNet batch 16) -- CFG UNet + guidance + DDIM update as one hipGraph,
+    packaged kernel choices -- each in a CHILD process of this same script (its own weights, plan and `roofline` block) and embeds the
+    children's JSON lines. A failure is reported, never raised, and a hung child costs at most `timeout` seconds (240 s
+    before): the contract line must survive."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--config", "sdxl", "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup),
-           "--no-cpu-baseline", "--no-end-to-end", "--no-variants"]
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(extra) + ["--gpus", "1", "--steps", str(steps), "--warmup", str(warmup),
+                                                                       "--no-cpu-baseline", "--no-end-to-end", "--no-variants"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
     t0 = time.perf_counter()
     try:
@@ -594,6 +599,14 @@ def sdxl_variant(steps=20, warmup=5, timeout=240):
     out["wall_seconds_of_child_process"] = time.perf_counter() - t0
     out["command"] = " ".join(["python", "bench.py"] + cmd[2:])
     return out
+
+
+def sdxl_variant(steps=20, warmup=5, timeout=150):
+    return child_variant(["--config", "sdxl"], steps, warmup, timeout)
+
+
+def bs8_variant(steps=20, warmup=5, timeout=150):
+    return child_variant(["--config", "sd15", "--images", "8"], steps, warmup, timeout)
 
 
 def bs64_sharded(args, engine, cfg, hw, dev, rank, world, use_dist):
@@ -1075,6 +1088,7 @@ def main():
         if (world == 1 and args.config == "sd15" and args.images == 1 and not args.no_variants and not args.no_sdxl_variant
                 and not args.no_graph and isinstance(out.get("variants"), dict)):
             out["variants"]["sdxl"] = sdxl_variant()
+            out["variants"]["bs8"] = bs8_variant()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.config, args.images)
     # BASELINE configs[3] (bs = 64 sharded over the ranks): every rank runs its shard; a leg of the N = 8 run (or --bs64-sharded)
@@ -1098,6 +1112,15 @@ def main():
             out["end_to_end"] = e2e
             if "ms_per_image_end_to_end" in e2e:
                 out["ms_per_image_end_to_end"] = e2e["ms_per_image_end_to_end"]
+        # headline values of the variant legs at the FRONT of the line: the driver keeps a truncated tail of long lines
+        v = out.get("variants") if isinstance(out.get("variants"), dict) else {}
+        summ = {k: {"value": v[k]["value"], "unit": v[k].get("unit"), "ms_per_step": v[k].get("ms_per_step"),
+                    "workload": (v[k].get("config") or {}).get("workload", k)}
+                for k in v if isinstance(v[k], dict) and "value" in v[k]}
+        if summ:
+            head = {k: out[k] for k in ("metric", "value", "unit") if k in out}
+            head["variants_summary"] = summ
+            out = {**head, **{k: val for k, val in out.items() if k not in head}}
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -404,6 +404,7 @@ __device__ __forceinline__ void pp_consumer(const IgemmArgs &a, char *smem, cons
         constexpr bool last = ph == NP - 1;
         // ---------------- memory part: fragment reads (issuing consumers: the requests spread between the k-steps' reads) --------
         if (ph == 0) stamp(0);
+        if constexpr ((EXP & 8) != 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int q = 0; q < KSP; ++q) {
             const int coff = (((ph * KSP + q) * 2 + hi) ^ swz) << 4;
@@ -432,7 +433,7 @@ __device__ __forceinline__ void pp_consumer(const IgemmArgs &a, char *smem, cons
         __builtin_amdgcn_s_barrier();
         if (ph == 0) stamp(4);
         // ---------------- MFMA part ----------------
-        if constexpr ((EXP & 8) != 0) __builtin_amdgcn_s_setprio(1);
+        if constexpr ((EXP & 8) != 0) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int q = 0; q < KSP; ++q)
 #pragma unroll
@@ -444,7 +445,6 @@ __device__ __forceinline__ void pp_consumer(const IgemmArgs &a, char *smem, cons
                     else
                         asm volatile("" ::"v"(af[q][fn]), "v"(bf[q][fm]));  // the fragment reads stay
                 }
-        if constexpr ((EXP & 8) != 0) __builtin_amdgcn_s_setprio(0);
         if (ph == 0) stamp(5);
         if constexpr (ISSUER && last && NS == 2 && G == 0) pp_wait_vmcnt<0>();  // two-stage ring: group 0's share of the next tile
         __builtin_amdgcn_sched_barrier(0);

@@ -84,6 +84,20 @@ def _device_of(m):
 _FALLBACK = object()  # plan-cache entry of a signature that must run the module's original forward
 
 
+def _drop_stale_plans(fwd):
+    """`engine.refresh_parameters(module)` re-binds the engine to RE-ASSIGNED parameters (new storage) and bumps `engine.generation`.
+    A compiled forward's (plan, graph) entries built before it would go on replaying the old storage and the old packed copies,
+    silently: they are dropped here, at the next call -- the graphs retire through their OwnedGraph handles, the next call
+    of each signature rebuilds its plan against the new parameters."""
+    gen = getattr(fwd.engine, "generation", 0)
+    if fwd.__dict__.get("_gen", gen) != gen:
+        with fwd._lock:
+            if fwd._cached:
+                logger.info("sfast: engine parameters were re-bound (generation %d): dropping %d cached plan(s)", gen, len(fwd._cached))
+            fwd._cached.clear()
+    fwd._gen = gen
+
+
 class _NativeUNetForward:
     """Replacement for `unet.forward`: per-signature plan cache + hipGraph replay."""
 
@@ -151,6 +165,7 @@ class _NativeUNetForward:
         extra = dict(down_intrablock_additional_residuals=down_intrablock_additional_residuals)
         bad = [k for k, v in extra.items() if v is not None]
         eng = self.engine
+        _drop_stale_plans(self)
         # attention_mask (a keep-mask over the SELF-attention keys) is an input of the native plan: an additive key bias of every attn1
         # launch, as diffusers builds it; the reference hands attn_bias straight to the kernel (libs/xformers/xformers_attention.py:26-48).
         # A mask whose length differs from some layer's token count has no plan (diffusers itself fails on it): that signature keeps the
@@ -307,6 +322,7 @@ class _NativeControlNetForward:
                  class_labels=None, timestep_cond=None, attention_mask=None, added_cond_kwargs=None, cross_attention_kwargs=None,
                  guess_mode=False, return_dict=True):
         eng = self.engine
+        _drop_stale_plans(self)
         bad = [k for k, v in dict(class_labels=class_labels, timestep_cond=timestep_cond, attention_mask=attention_mask).items() if v is not None]
         # added_cond_kwargs: SDXL ControlNets (addition_embed_type "text_time") take text_embeds + time_ids natively; any other key, or
         # extra conditioning handed to a ControlNet without the addition embedding (diffusers ignores it there), keeps diffusers' forward
@@ -396,6 +412,7 @@ class _NativeSVDForward:
 
     def __call__(self, sample, timestep, encoder_hidden_states, added_time_ids, return_dict=True):
         eng = self.engine
+        _drop_stale_plans(self)
         ok = (torch.is_tensor(sample) and sample.ndim == 5 and sample.device.type == "cuda" and sample.dtype == eng.dtype
               and torch.is_tensor(encoder_hidden_states) and encoder_hidden_states.ndim == 3 and encoder_hidden_states.shape[1] == 1
               and torch.is_tensor(added_time_ids))
@@ -583,6 +600,7 @@ class _NativeVaeDecoderForward:
 
     def __call__(self, sample, latent_embeds=None, *args, **kwargs):
         eng = self.engine
+        _drop_stale_plans(self)
         if (latent_embeds is not None or args or kwargs or not torch.is_tensor(sample) or sample.device.type != "cuda"
                 or sample.dtype != eng.dtype or sample.ndim != 4 or sample.shape[1] != eng.in_ch):
             if not self._warned:

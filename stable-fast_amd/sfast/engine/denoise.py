@@ -57,6 +57,8 @@ class DenoiseLoop:
                  hoist_text_kv=False):
         self.engine = engine
         self.images = images
+        self._shape = (height, width, ctx_len)
+        self._gen = getattr(engine, "generation", 0)
         self.guidance = float(guidance)
         self.lib = self._library(engine)
         dev, dt = engine.device, engine.dtype
@@ -118,6 +120,31 @@ class DenoiseLoop:
         for op in self._ctx_ops:
             op.launch(sp)
 
+    def _follow_engine(self):
+        """`engine.refresh_parameters()` re-bound the engine to re-assigned parameters since this loop built its private plan: rebuild the
+        plan against the new storage (static inputs and the schedule position carried over), re-run the text-side launches and re-capture
+        the graph when there was one -- the old graph retires through its OwnedGraph handle."""
+        gen = getattr(self.engine, "generation", 0)
+        if gen == self._gen:
+            return
+        self._gen = gen
+        old_in = {k: v.clone() for k, v in self.plan.static_in.items() if torch.is_tensor(v)}
+        h, w, ctx = self._shape
+        self.plan = self.engine.build_plan(2 * self.images, h, w, ctx)
+        if self.hoist_text_kv:
+            self._step_ops = [op for op in self.plan.ops if op.lane != self._kv_lane]
+            self._ctx_ops = [op for op in self.plan.ops if op.lane == self._kv_lane]
+        else:
+            self._step_ops, self._ctx_ops = list(self.plan.ops), []
+        for k, v in old_in.items():
+            if k in self.plan.static_in and self.plan.static_in[k].shape == v.shape:
+                self.plan.static_in[k].copy_(v)
+        self.refresh_text_kv()
+        if self.graph is not None:
+            nxt = self._next
+            self.capture(warmups=1)
+            self.set_step(nxt)
+
     def set_step(self, i):
         """Next iteration to run (0-based, modulo the schedule length)."""
         self._next = i % self.num_steps
@@ -156,10 +183,12 @@ class DenoiseLoop:
             with torch.cuda.stream(side):
                 with torch.cuda.graph(g, stream=side):
                     self._launch_all(torch.cuda.current_stream(dev).cuda_stream)
-            if self.graph is not None:   # a re-capture: the old graph is retired, never destroyed in the same breath as its last replay
-                from .unet2d import retire_graph
-                retire_graph(self.graph, dev)
-            self.graph = g
+            from .unet2d import OwnedGraph, _trim_retired
+            # a re-capture: dropping the old handle RETIRES its graph (OwnedGraph), never destroys it in the same breath as its last replay;
+            # the retired queue is trimmed here as well (a process that only re-captures loops never reached capture_plan_graph)
+            self.graph = None
+            _trim_retired()
+            self.graph = OwnedGraph(g, dev)
             torch.cuda.synchronize(dev)
         self.latents.copy_(keep_lat)
         self.plan.static_in["sample"].copy_(keep_in)
@@ -168,6 +197,7 @@ class DenoiseLoop:
     def step(self, i):
         """Run denoise iteration i (0-based) on the current stream: one graph launch. The host touches the device cursor only when
         `i` is not the iteration the cursor already points at (a restart, a skipped step)."""
+        self._follow_engine()
         idx = i % self.num_steps
         if idx != self._next:
             self.cursor.fill_(idx)

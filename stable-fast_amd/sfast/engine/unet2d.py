@@ -27,7 +27,9 @@ re-assigned parameters `engine.refresh_parameters(module)`. `SFAST_PACKED_WEIGHT
 import ctypes as C
 import logging
 import os
+import atexit
 import collections
+import weakref
 import threading
 from collections import defaultdict
 
@@ -236,6 +238,50 @@ def retire_graph(g, device=None):
     _RETIRED.append((g, device))
 
 
+class OwnedGraph:
+    """A captured hipGraph whose teardown is deferred (round 6). Everything that keeps a live graph -- the plan /
+    graph cache of a compiled wrapper, DenoiseLoop, the engines' own plans -- holds it through this handle. When the last reference
+    goes (`del pipe`, garbage collection of a compiled model, interpreter exit) the finalizer does NOT destroy the hipGraphExec: it
+    moves it to the retired queue, which is trimmed only from a non-capturing context after a device synchronise (`_trim_retired`)
+    or, at interpreter exit, by `_drain_retired_at_exit`. Before this the WINNING graph of every plan was destroyed by plain
+    reference counting -- the trigger of the round-4 crash for any user who dropped a pipeline right after its last replay -- and
+    bench.py kept its graphs alive by hand (`_KEEP_GRAPHS`). The reference never evicts a captured graph at all
+    (/root/reference/src/sfast/cuda/graphs.py:31-49, :139-164: a per-callable cache under one lock)."""
+    __slots__ = ("_g", "_fin", "__weakref__")
+
+    def __init__(self, g, device=None):
+        self._g = g
+        self._fin = weakref.finalize(self, retire_graph, g, device)
+
+    def replay(self):
+        self._g.replay()
+
+    def pool(self):
+        return self._g.pool()
+
+    @property
+    def raw(self):
+        return self._g
+
+    def __getattr__(self, name):  # anything else of torch.cuda.CUDAGraph (debug dumps, ...)
+        return getattr(object.__getattribute__(self, "_g"), name)
+
+
+def _drain_retired_at_exit():
+    """atexit (registered at import, so it runs AFTER the weakref finalizers of still-live OwnedGraphs): the device is idle before the
+    interpreter tears the retired graphs down."""
+    try:
+        if _RETIRED and torch.cuda.is_initialized():
+            for dev in {d for _, d in _RETIRED}:
+                torch.cuda.synchronize(dev)
+    except Exception:
+        pass
+    _RETIRED.clear()
+
+
+atexit.register(_drain_retired_at_exit)
+
+
 def _trim_retired():
     if len(_RETIRED) > 2 * _RETIRED_KEEP:
         for dev in {d for _, d in _RETIRED}:
@@ -279,7 +325,9 @@ def capture_plan_graph(plan, stream, pool=None, tail=None, calibrate=True):
     # The candidate that loses the calibration below is RETIRED, not destroyed on the spot (see retire_graph): hipGraphExecDestroy in the
     # same breath as the graph's last replay is one of the two triggers of the round-4 crash.
     if len(graphs) == 1 or not calibrate:
-        return graphs[-1][1], graphs[-1][0]
+        for _, g in graphs[:-1]:  # (the serial candidate of an uncalibrated forked capture)
+            retire_graph(g, dev)
+        return OwnedGraph(graphs[-1][1], dev), graphs[-1][0]
     best = None
     with torch.cuda.stream(stream):
         for forked, g in graphs:
@@ -304,7 +352,7 @@ def capture_plan_graph(plan, stream, pool=None, tail=None, calibrate=True):
         for _, g in graphs:
             if g is not best[2]:
                 retire_graph(g, dev)
-    return best[2], best[1]
+    return OwnedGraph(best[2], dev), best[1]
 
 
 # A/B knobs of the round-5 crash hunt (tools/crash_repro.py): 1 = the round-4 behaviour
@@ -441,6 +489,9 @@ class UNet2DEngine:
             self._plans.clear()
             self._pk.clear()
             self.__dict__.pop("_ptr_names", None)
+            # plans held OUTSIDE the engine (a compiled forward's per-signature cache, a DenoiseLoop's private plan) compare this counter at
+            # their next call and rebuild: they would otherwise replay graphs over the old storage and the old packed copies
+            self.generation = getattr(self, "generation", 0) + 1
 
     def _parse_config(self):
         g = lambda k, d=None: _cfg_get(self.cfg, k, d)
@@ -1332,6 +1383,15 @@ class UNet2DEngine:
         nlev = len(self.boc)
         if H % (1 << (nlev - 1)) or W % (1 << (nlev - 1)):
             raise UnsupportedUNet(f"latent {H}x{W} not divisible by {1 << (nlev - 1)}")
+        if self_mask:
+            # checked BEFORE any op is emitted: the same refusal from inside _transformer left the packed-weight records of
+            # the ops emitted so far with users > 0 -- pinned buffers that sync_packed() kept re-packing for a plan that never existed
+            lv = {i for i, t in enumerate(self.down_types) if t.startswith("CrossAttn")} | {nlev - 1 - j for j, t in enumerate(self.up_types) if t.startswith("CrossAttn")}
+            lv.add(nlev - 1)  # the mid block
+            for i in sorted(lv):
+                S = (H >> i) * (W >> i)
+                if S != self_mask:
+                    raise UnsupportedUNet(f"attention_mask of {self_mask} keys on a self-attention layer with {S} tokens")
         P = self.params
         dev, dt = self.device, self.dtype
         plan = UNetPlan(self, B, H, W, S_ctx)

@@ -19,7 +19,7 @@ CASES = [  # B, Cin, C2, H, W, Cout, variant, split
 ]
 NAMES = {0: "full", 1: "no MFMA", 2: "no fragment reads", 3: "no MFMA, no fragment reads", 4: "no in-loop DMA", 7: "loop skeleton (barriers only)",
          6: "MFMAs + barriers only (no fragment reads, no in-loop DMA)", 5: "fragment reads + barriers only (no MFMA, no in-loop DMA)",
-         8: "full, s_setprio 1 around the MFMAs"}
+         8: "full, s_setprio 1 in the memory part"}
 SKEL = 7
 stream = torch.cuda.Stream()
 lib = L.load()
