@@ -250,7 +250,7 @@ def test_packaged_tune_cache_is_well_formed():
     with open(autotune.PACKAGED_CACHE) as f:
         d = json.load(f)
     assert len(d) > 100
-    n_pk = 0
+    n_pk = n_pp = 0
     for k, (v, s) in d.items():
         arch, dt, kind, mnk, epi = k.split("|")[:5]
         packed = k.endswith("|pk")   # the same problem with a packed copy of the weight at hand: pipe-4 variants are candidates too
@@ -258,10 +258,14 @@ def test_packaged_tune_cache_is_well_formed():
         assert arch == "gfx950" and dt in ("f16", "bf16") and kind in ("gemm", "conv"), k
         assert len(mnk.split("x")) == 3
         geglu = kind == "gemm" and epi.startswith("(1,")
-        allowed = autotune.GEGLU_VARIANTS if geglu else (autotune.VARIANTS + (autotune.PK_VARIANTS if packed else ()))
+        allowed = autotune.GEGLU_VARIANTS if geglu else (autotune.VARIANTS + autotune.CONV_PATCH_VARIANTS + (autotune.PK_VARIANTS if packed else ()))
+        M, N, K = (int(x) for x in mnk.split("x"))
+        allowed = allowed + autotune._pp_candidates(M, N, K, geglu)   # round 6: the 256-row tiles, only where their tiles fill >= 96 CUs
         assert v in allowed and s in autotune.SPLITS, (k, v, s)
         n_pk += packed
+        n_pp += v >= 50
     assert n_pk > 50   # round 4: the SD1.5 / SDXL problems were re-timed with the packed-weight pipe among the candidates
+    assert n_pp > 50   # round 6: ... and the large-M problems (8 images per GPU, SDXL 128^2, SVD-XT, VAE) against the 256-row tiles
     n0 = len(autotune.export_cache())
     assert autotune.import_cache(d) >= 0 and len(autotune.export_cache()) >= max(n0, len(d))
 
