@@ -47,6 +47,9 @@ def parse():
                          "svd (SVD-XT 576x1024, 25 frames, BASELINE configs[4])")
     ap.add_argument("--frames", type=int, default=25, help="--config svd: frames per video")
     ap.add_argument("--images", type=int, default=1, help="images per GPU (UNet batch is 2x this: CFG)")
+    ap.add_argument("--weights", default=os.environ.get("SFAST_SD15_DIR") or None,
+                    help="diffusers model directory (or unet .safetensors file) to load REAL UNet weights from (sd15 / sdxl configs; default: "
+                         "$SFAST_SD15_DIR, else seeded random-init weights -- there is no checkpoint on the driver's box)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--through-compile", action="store_true",
                     help="also time the same step through sfast.compilers.compile() + a pipeline-shaped loop (N=1)")
@@ -989,7 +992,11 @@ def main():
 
     cfg = SD15_CONFIG if args.config == "sd15" else SDXL_CONFIG
     # rank 0 owns the weights; replicas receive them with one bucketed RCCL broadcast over xGMI
-    params = random_params(cfg, seed=0 if rank == 0 else 1000 + rank, dtype=torch.float16, device=dev)
+    if args.weights and rank == 0:
+        from sfast.engine.unet_spec import load_params
+        params = load_params(args.weights, cfg, dtype=torch.float16, device=dev)   # the other ranks receive them by the broadcast below
+    else:
+        params = random_params(cfg, seed=0 if rank == 0 else 1000 + rank, dtype=torch.float16, device=dev)
     t0 = time.perf_counter()
     bytes_bcast = broadcast_parameters(params, src=0) if world > 1 else 0
     torch.cuda.synchronize()
@@ -1049,7 +1056,7 @@ def main():
             "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_image_50_steps_unet_and_scheduler": elapsed / args.steps * 1e3 * 50 / max(1, args.images), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
+            "dtype": "f16", "data": ("synthetic latents / text embeddings, weights from " + args.weights) if args.weights else "synthetic",
             "config": {"workload": f"{'SD1.5 512x512' if args.config == 'sd15' else 'SDXL 1024x1024'} bs={args.images} fp16, 50-step DDIM "
                                    f"schedule, one step = CFG batch-{2 * args.images} UNet forward + guidance combine + DDIM update, "
                                    f"hipGraph {'off' if args.no_graph else 'on'}, seeded random-init weights, {world} replica(s) "

@@ -7,6 +7,7 @@ Names follow the public diffusers layout recorded in SURVEY.md Appendix A (the r
 never spells them out: it traces whatever module it is given).
 """
 import math
+import os
 from typing import Dict, Tuple
 
 import torch
@@ -153,6 +154,44 @@ def random_params(cfg: dict, seed: int = 0, dtype=torch.float16, device="cuda") 
         if t.ndim == 4:
             t = t.contiguous(memory_format=torch.channels_last)
         params[name] = t
+    return params
+
+
+def find_unet_weights(path: str) -> str:
+    """`path`: a diffusers model directory (…/unet/diffusion_pytorch_model[.fp16].safetensors inside it or in its `unet/`), or the
+    weight file itself (.safetensors, or a torch-pickled .bin / .pt state dict)."""
+    if os.path.isfile(path):
+        return path
+    for sub in ("unet", ""):
+        for name in ("diffusion_pytorch_model.fp16.safetensors", "diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.bin"):
+            cand = os.path.join(path, sub, name)
+            if os.path.isfile(cand):
+                return cand
+    raise FileNotFoundError(f"no diffusers UNet weights under {path!r} (looked for unet/diffusion_pytorch_model[.fp16].safetensors / .bin)")
+
+
+def load_params(path: str, cfg: dict, dtype=torch.float16, device="cuda") -> Dict[str, torch.Tensor]:
+    """Real weights behind the same interface as `random_params` (round 6): a diffusers-layout UNet checkpoint is read
+    into the {state-dict name: tensor} form the engines and `oracle/unet_ref.py` take -- the parameter names of `unet2d_param_shapes`
+    ARE diffusers' state-dict keys, so the first real checkpoint that becomes reachable also checks that appendix:
+    a missing / unexpected key or a shape mismatch raises with the offending names. 4-D weights come back channels_last."""
+    f = find_unet_weights(path)
+    if f.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        sd = load_file(f, device="cpu")
+    else:
+        sd = torch.load(f, map_location="cpu", weights_only=True)
+    want = unet2d_param_shapes(cfg)
+    missing = sorted(k for k in want if k not in sd)
+    extra = sorted(k for k in sd if k not in want)
+    wrong = sorted(k for k in want if k in sd and tuple(sd[k].shape) != tuple(want[k]))
+    if missing or extra or wrong:
+        raise ValueError(f"{f} does not match this UNet config: {len(missing)} missing (e.g. {missing[:3]}), {len(extra)} unexpected "
+                         f"(e.g. {extra[:3]}), {len(wrong)} shape mismatches (e.g. {[(k, tuple(sd[k].shape), want[k]) for k in wrong[:2]]})")
+    params = {}
+    for k in want:
+        t = sd[k].to(device=device, dtype=dtype)
+        params[k] = t.contiguous(memory_format=torch.channels_last) if t.ndim == 4 else t.contiguous()
     return params
 
 

@@ -497,3 +497,32 @@ def test_unwanted_graphs_are_retired_oldest_first_after_a_synchronise(monkeypatc
     assert [i for i, _ in dropped] == list(range(E._RETIRED_KEEP + 1))                      # oldest first ...
     assert all(n == 2 for _, n in dropped) and len(E._RETIRED) == E._RETIRED_KEEP          # ... and only after both synchronisations
     assert E._RETIRED[-1][0].i == 99
+
+
+def test_real_weight_hook_round_trip(tmp_path):
+    """`load_params` (what bench.py --weights and SFAST_SD15_DIR use) reads a diffusers-layout checkpoint into the
+    engines' {state-dict name: tensor} form and refuses one that does not match the config. No real checkpoint is reachable offline,
+    so the file is written here from the oracle module of the tiny config -- names come from the MODULE, shapes from the inventory."""
+    from safetensors.torch import save_file
+    from oracle import unet_ref as U
+    from sfast.engine.unet_spec import find_unet_weights, load_params
+    cfg = U.tiny_config()
+    m = U.build(cfg, seed=3)
+    sd = {k: v.detach().clone().contiguous() for k, v in m.state_dict().items()}
+    (tmp_path / "unet").mkdir()
+    f = tmp_path / "unet" / "diffusion_pytorch_model.safetensors"
+    save_file(sd, str(f))
+    assert find_unet_weights(str(tmp_path)) == str(f) and find_unet_weights(str(f)) == str(f)
+    p = load_params(str(tmp_path), cfg, dtype=torch.float32, device="cpu")
+    assert set(p) == set(sd) and all(torch.equal(p[k], sd[k]) for k in sd)
+    assert all(v.is_contiguous(memory_format=torch.channels_last) for v in p.values() if v.ndim == 4)
+    m2 = U.build(cfg, seed=99)
+    m2.load_state_dict(p)   # the loaded dict drops into the oracle (and, on a GPU, into UNet2DEngine(cfg, params))
+    bad = dict(sd)
+    bad.pop("conv_in.bias")
+    bad["conv_out.weight"] = torch.zeros(1, 2, 3, 3)
+    save_file(bad, str(f))
+    with pytest.raises(ValueError, match="1 missing.*conv_in.bias.*1 shape mismatches"):
+        load_params(str(tmp_path), cfg, dtype=torch.float32, device="cpu")
+    with pytest.raises(FileNotFoundError):
+        find_unet_weights(str(tmp_path / "nothing"))

@@ -78,8 +78,16 @@ def test_tiny_sdxl_style_unet():
 
 @pytest.fixture(scope="module")
 def sd15():
+    """Seeded random-init weights of the published architecture -- or, when SFAST_SD15_DIR names a diffusers model directory (or a unet
+    .safetensors file), the REAL runwayml/stable-diffusion-v1-5 weights, loaded into the module every test of this file compares against
+    (engine, fp32 oracle and eager fp16 all receive the same state dict; sfast.engine.unet_spec.load_params checks names and shapes)."""
     torch.manual_seed(0)
     m = U.build("sd15", seed=0, dtype=torch.float16, device=DEV)
+    real = os.environ.get("SFAST_SD15_DIR")
+    if real:
+        from sfast.engine.unet_spec import SD15_CONFIG, load_params
+        m.load_state_dict(load_params(real, SD15_CONFIG, dtype=torch.float16, device=DEV))
+        log_value("sd15 fixture", weights=real)
     return m
 
 
