@@ -66,7 +66,7 @@ def build(force=False, jobs=None, verbose=True, probes=False):
     objs = []
     for s in srcs:
         src = os.path.join(CSRC, s)
-        flags = FLAGS + EXTRA_FLAGS.get(s, []) + (["-DSFAST_PROBES"] if probes else [])
+        flags = FLAGS + EXTRA_FLAGS.get(s, []) + (["-DSFAST_PROBES"] if probes else []) + os.environ.get("SFAST_EXTRA_CFLAGS", "").split()
         tag = _digest([src] + headers, flags)
         obj = os.path.join(OBJ_DIR, f"{os.path.splitext(s)[0]}.{'p.' if probes else ''}{tag}.o")
         objs.append(obj)

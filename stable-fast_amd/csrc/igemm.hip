@@ -689,6 +689,7 @@ static const Variant kVariants[] = {
     // pipe 5 (round 6): 256-row ping-pong tiles, 8 waves in two alternating groups (igemm_pp.h); autotuner candidates for large M
     {51, 256, 128, 4, 2, 5, 3, 1.30f}, {52, 256, 160, 4, 2, 5, 3, 1.30f}, {53, 256, 256, 2, 4, 5, 2, 1.40f},
     {55, 256, 128, 4, 2, 5, 3, 1.30f}, {56, 256, 160, 4, 2, 5, 3, 1.30f},  // + four producer waves (12 waves per workgroup)
+    {57, 256, 128, 4, 2, 5, 3, 1.30f}, {58, 256, 160, 4, 2, 5, 3, 1.30f},  // producers + LOCKSTEP consumers (one barrier per K-tile)
 };
 static const Variant kGegluVariants[] = {
     {1, 128, 128, 2, 2, 0, 2, 1.00f},  {3, 64, 128, 2, 2, 0, 2, 0.75f},  {11, 128, 128, 2, 2, 1, 4, 1.00f},
@@ -1209,7 +1210,7 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
 #endif
     }
     char pipe[8];
-    snprintf(pipe, sizeof(pipe), p.v.pipe == 5 ? (p.v.id >= 55 ? "ppw%d" : "pp%d") : p.v.pipe == 4 ? "pk%d" : p.v.pipe == 3 ? "patch%d" : p.v.pipe == 2 ? "ws%d" : p.v.pipe ? "dma%d" : "reg", p.v.ns);
+    snprintf(pipe, sizeof(pipe), p.v.pipe == 5 ? (p.v.id >= 57 ? "ppl%d" : p.v.id >= 55 ? "ppw%d" : "pp%d") : p.v.pipe == 4 ? "pk%d" : p.v.pipe == 3 ? "patch%d" : p.v.pipe == 2 ? "ws%d" : p.v.pipe ? "dma%d" : "reg", p.v.ns);
     char xmap[24] = "";
     if (a.xmap == 2) snprintf(xmap, sizeof(xmap), "@xcdrun%c%d", a.x_order ? 'n' : 'm', a.x_per);  // contiguous runs, tile_m / tile_n fastest
     else if (a.xmap) snprintf(xmap, sizeof(xmap), "@xcd%dx%dx%d", 8 >> (a.x_lxm + a.x_lxn), 1 << a.x_lxm, 1 << a.x_lxn);  // K-split x row x column boxes
@@ -1218,7 +1219,7 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
                     joins ? "+join" : "", a.gn_out ? "+gn" : "", xmap);  // +join: split-K finished inside this kernel (no reduce launch)
     int rc;
     if (p.v.pipe == 5)
-        rc = igemm_pp_launch(a, dtype, mode, geglu, p.v.BN, p.v.id >= 55 ? 4 : 0, st);  // ids 55..: four producer waves
+        rc = igemm_pp_launch(a, dtype, mode, geglu, p.v.BN, p.v.id >= 57 ? 104 : p.v.id >= 55 ? 4 : 0, st);  // ids 55..: four producer waves; 57..: lockstep
     else if (p.v.pipe == 4)
         rc = igemm_pk_launch(a, dtype, mode, p.v.BM, p.v.BN, st);
     else if (p.v.pipe == 3)

@@ -448,6 +448,95 @@ __device__ __forceinline__ void epilogue_late(const IgemmArgs &a, const StageCtx
     if (a.act != SFAST_ACT_NONE) epilogue_act_tail<T, FN, FM, STAGED>(a, sc, acc, mbase, nbase, l31, hi);
 }
 
+// By-operand-type form (round 6, the 256-row tiles of igemm_pp.h): instead of walking the fragments with all three operand kinds in
+// flight per fragment, every kind is requested for the WHOLE wave tile at once -- bias (FN * 4 vectors, shared by the pixel fragments),
+// then the row bias, then the residual (FN * FM * 4 vectors = 48 registers for a six-fragment wave, beside 96 accumulator registers) --
+// and an ABSENT kind is skipped (a wave-uniform branch) instead of being fetched from the zero block. Memory round trips per workgroup:
+// one for the bias + FM per further operand kind that exists (typically three) instead of one per fragment (six, serialised: ~12 us of epilogue
+// behind a 52 us K loop in the 12-wave form, profiles/r06_pp_loop_probe_run19.log). Same arithmetic sequence per element as
+// fragment_pass1: v = fma(acc, out_scale, bias); v += row bias; v += alpha * residual.
+template <typename T, int FN, int FM, bool STAGED>
+__device__ __forceinline__ void epilogue_by_type(const IgemmArgs &a, const StageCtx &sc, f32x16 (&acc)[FN][FM], int mbase, int nbase, int l31,
+                                                 int hi, int split_idx, bool whole) {
+    if (a.splits > 1 && !whole) {
+        store_partial<FN, FM, false>(a, acc, mbase, nbase, l31, hi, split_idx);
+        return;
+    }
+    {
+        u32x2 vb[FN][4];
+        const EpiRow<T> bias(a.bias, 0, true);
+#pragma unroll
+        for (int fh = 0; fh < FN; ++fh)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nbase + fh * 32 + 8 * g + 4 * hi;
+                vb[fh][g] = bias.load(n, n < a.N);
+            }
+#pragma unroll
+        for (int fh = 0; fh < FN; ++fh)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float b0[4];
+                unpack4<T>(vb[fh][g], b0);
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[fh][fm][4 * g + i] = fmaf(acc[fh][fm][4 * g + i], a.out_scale, b0[i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+    const bool res_now = a.res_before_act || a.act == SFAST_ACT_NONE;
+    // one pixel fragment row (FN fragments, FN * 4 vectors) per round trip: all FM rows at once is 48 data + 48 address registers for a
+    // six-fragment wave -- past the 168-register budget of the 12-wave kernels (measured: 150 spilled registers)
+    auto add_rows = [&](const void *base_ptr, bool per_batch, float scale) __attribute__((always_inline)) {
+        const BatchOfRow batch_of(a);
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            u32x2 v[FN][4];
+            const int m = mbase + fm * 32 + l31;
+            const int64_t row_off = per_batch ? (int64_t)batch_of(m) * a.ld_rowbias : (int64_t)m * a.ldr;
+            const EpiRow<T> row(base_ptr, row_off, m < a.M);
+#pragma unroll
+            for (int fh = 0; fh < FN; ++fh)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = nbase + fh * 32 + 8 * g + 4 * hi;
+                    v[fh][g] = row.load(n, n < a.N);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int fh = 0; fh < FN; ++fh)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float r[4];
+                    unpack4<T>(v[fh][g], r);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[fh][fm][4 * g + i] += r[i] * scale;
+                    __builtin_amdgcn_sched_barrier(0);  // one vector at a time: unpacking all of them first costs 4 registers per vector
+                }
+        }
+    };
+    if (a.rowbias != nullptr) add_rows(a.rowbias, true, 1.0f);
+    if (a.res != nullptr && res_now) add_rows(a.res, false, a.alpha);
+    if (a.act != SFAST_ACT_NONE) {
+        epilogue_act_tail<T, FN, FM, STAGED>(a, sc, acc, mbase, nbase, l31, hi);
+        return;
+    }
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+        const int m = mbase + fm * 32 + l31;
+#pragma unroll
+        for (int fh = 0; fh < FN; ++fh)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nbase + fh * 32 + 8 * g + 4 * hi;
+                put4<T, STAGED>(a, sc, m, n, m < a.M && n < a.N,
+                                pack4<T>(acc[fh][fm][4 * g], acc[fh][fm][4 * g + 1], acc[fh][fm][4 * g + 2], acc[fh][fm][4 * g + 3]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+}
+
 // ---- staged tile -> global memory (+ GroupNorm partial statistics) ------------------------------------------------
 // Thread t of the NTC consumer threads owns chunk column t % (BNO/8) (8 output channels = 16 bytes) of rows t / (BNO/8) + k*RPP:
 // 16 consecutive lanes write 256 contiguous bytes of one output row. On request the same pass reduces the tile to the
@@ -628,12 +717,17 @@ __device__ __forceinline__ bool splitk_join(const IgemmArgs &a, f32x16 (&acc)[FN
 // Round 4: the join is EVIDENCE code (measured slower than the reduce launch; its ticket protocol rests on
 // sc1 cache behaviour rather than on release / acquire) -- it is compiled only into the probe build (-DSFAST_PROBES, build.py
 // --probes -> libsfast_hip_probes.so); the product library ignores SFAST_EXT_WS_TICKETS and always runs the reduce launch.
+// which late epilogue run_epilogue uses unless a kernel says otherwise: 2 = by operand type (round 6), 0 = one fragment ahead (rounds 1 - 5;
+// `SFAST_EXTRA_CFLAGS=-DSFAST_LATE_FORM_DEFAULT=0 python stable-fast_amd/build.py` rebuilds that arm for an A/B)
+#ifndef SFAST_LATE_FORM_DEFAULT
+#define SFAST_LATE_FORM_DEFAULT 2
+#endif
 #ifdef SFAST_PROBES
 constexpr bool kJoinDefault = true;
 #else
 constexpr bool kJoinDefault = false;
 #endif
-template <typename T, int BM, int BNO, int FN, int FM, bool GEGLU, bool EPI_EARLY, int NTC, bool STAGED, bool JOIN = kJoinDefault, bool LATE_AHEAD = true>
+template <typename T, int BM, int BNO, int FN, int FM, bool GEGLU, bool EPI_EARLY, int NTC, bool STAGED, bool JOIN = kJoinDefault, int LATE_FORM = SFAST_LATE_FORM_DEFAULT>
 __device__ __forceinline__ void run_epilogue(const IgemmArgs &a, f32x16 (&acc)[FN][FM],
                                              EpiOperands<(EPI_EARLY ? (GEGLU ? FN / 2 : FN) : 1), (EPI_EARLY ? FM : 1)> &epi, char *smem,
                                              int m0, int n0, int mbase, int nbase, int l31, int hi, int ctid, int split_idx) {
@@ -651,13 +745,19 @@ __device__ __forceinline__ void run_epilogue(const IgemmArgs &a, f32x16 (&acc)[F
         if constexpr (EPI_EARLY)
             epilogue_finish<T, FN, FM, GEGLU, true>(a, sc, acc, epi, mbase, nbase, l31, hi, split_idx, whole);
         else
-            epilogue_late<T, FN, FM, true, LATE_AHEAD>(a, sc, acc, mbase, nbase, l31, hi, split_idx, whole);
+            if constexpr (LATE_FORM == 2)
+                epilogue_by_type<T, FN, FM, true>(a, sc, acc, mbase, nbase, l31, hi, split_idx, whole);
+            else
+                epilogue_late<T, FN, FM, true, LATE_FORM == 0>(a, sc, acc, mbase, nbase, l31, hi, split_idx, whole);
         flush_staged_tile<T, BM, BNO, NTC>(a, smem, m0, n0, ctid);
     } else {
         if constexpr (EPI_EARLY)
             epilogue_finish<T, FN, FM, GEGLU, false>(a, sc, acc, epi, mbase, nbase, l31, hi, split_idx, whole);
         else
-            epilogue_late<T, FN, FM, false, LATE_AHEAD>(a, sc, acc, mbase, nbase, l31, hi, split_idx, whole);
+            if constexpr (LATE_FORM == 2)
+                epilogue_by_type<T, FN, FM, false>(a, sc, acc, mbase, nbase, l31, hi, split_idx, whole);
+            else
+                epilogue_late<T, FN, FM, false, LATE_FORM == 0>(a, sc, acc, mbase, nbase, l31, hi, split_idx, whole);
     }
 }
 

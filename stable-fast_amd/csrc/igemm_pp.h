@@ -472,8 +472,138 @@ __device__ __forceinline__ void pp_consumer(const IgemmArgs &a, char *smem, cons
     // The 12-wave form (168 registers) fetches and consumes one fragment's operands at a time: two sets in flight spilled 38 - 50 registers.
     EpiOperands<(GEGLU ? FN / 2 : 1), (GEGLU ? FM : 1)> epi;
     if constexpr (GEGLU) epilogue_prefetch<T, FN, FM, true>(a, epi, m0 + xr0, n0 + wr0 / 2, l31, hi);
-    run_epilogue<T, BM, BNO, FN, FM, GEGLU, GEGLU, 512, STAGED, kJoinDefault, (S::PW == 0)>(a, acc, epi, smem, m0, n0, m0 + xr0, n0 + (GEGLU ? wr0 / 2 : wr0), l31,
+    run_epilogue<T, BM, BNO, FN, FM, GEGLU, GEGLU, 512, STAGED, kJoinDefault, 2>(a, acc, epi, smem, m0, n0, m0 + xr0, n0 + (GEGLU ? wr0 / 2 : wr0), l31,
                                                                                             hi, tid, bt.split);
+}
+
+// ---- KSP = 0: the LOCKSTEP form (round 6, third form) -----------------------------------------------------------------------------------
+// Same tile, same wave layout (incl. the uneven 96 + 64 split of the 160-wide tile), same producers, but the eight consumer waves do NOT
+// alternate: every wave reads the fragments of k-step q + 1 while its OWN MFMAs of k-step q run (two fragment sets), across the tile
+// boundary, and there is ONE barrier per K-tile -- the loop of igemm_glds_ws.hip on a 256-row tile. Why: on gfx950 an LDS read overlaps
+// the MFMAs of the SAME wave but barely those of the other wave of its SIMD -- the ablations of the ping-pong loop ADD UP (skeleton 34
+// + MFMAs 46 + fragment reads 28 = 108 us against 111 measured with both), and in its timeline the younger group's eight reads take 470
+// clocks beside the older group's 384 clocks of MFMAs (profiles/r06_pp_loop_probe_run9.log, _run10.log).
+template <typename T, typename S, int MODE, bool GEGLU, int EXP>
+__device__ __forceinline__ void pp_producer_ls(const IgemmArgs &a, char *smem, const BlockTile &bt, const int tid, const int wave, const u32x2 *meta) {
+    using LD = PPLoader<T, S, MODE, GEGLU, false>;
+    constexpr int L = LD::L, NS = S::NS;
+    static_assert(!S::TAIL && NS >= 3 && L * (NS - 1) <= 63, "ring");
+    const int kt_begin = bt.split * a.ktiles_per_split;
+    const int kt_end = min(a.ktiles, kt_begin + a.ktiles_per_split);
+    LD ld;
+    ld.init(a, smem, tid - 512, wave - 8, bt.tile_m * S::BM, bt.tile_n * S::BNO, kt_begin, kt_end, meta);
+    auto issue_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) ld.issue(l);
+        ld.advance(a);
+    };
+    // Ring protocol of igemm_glds_ws.hip -- the consumers meet barrier k + 1 with every fragment of tile k in registers, so that barrier
+    // releases the stage of tile k and it is refilled with tile k + NS -- with two differences: (a) only NS - 1 tiles are requested ahead
+    // of the first barrier (the consumers start as soon as tile 0 has landed; the NS-th tile goes out right behind that barrier instead of
+    // queueing 52 KB in front of it), and (b) NO surplus tiles are requested at the end of the K range: the consumers' first epilogue
+    // barrier waits until the producer waves have terminated, i.e. until everything they requested has landed -- two surplus tiles were
+    // 104 KB of transfers nobody reads, awaited at the top of every workgroup's epilogue. The waits of the last NS - 2 tiles are therefore
+    // counted by hand (NS == 3: vmcnt(L) while one more tile is in flight, vmcnt(0) for the last).
+    static_assert(NS == 3, "tail waits are written out for a three-stage ring");
+    const int ntiles = kt_end - kt_begin;
+    issue_tile();  // T0
+    issue_tile();  // T1 (a one-tile K range requests its tile twice: the copy lands in a stage nobody reads)
+    pp_wait_vmcnt<L>();  // T0 has landed (this wave's share)
+    __builtin_amdgcn_s_barrier();
+    if constexpr ((EXP & 4) == 0) {
+        if (2 < ntiles) issue_tile();  // T2
+    }
+    for (int kt = 1; kt < ntiles; ++kt) {
+        if constexpr ((EXP & 4) != 0) {
+            pp_wait_vmcnt<0>();
+        } else if (kt + 1 < ntiles) {
+            pp_wait_vmcnt<L>();  // T_kt has landed; T_kt+1 may be in flight
+        } else {
+            pp_wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();  // the consumers hold all of T_kt-1 in registers: its stage is free
+        if constexpr ((EXP & 4) == 0) {
+            if (kt + 2 < ntiles) issue_tile();  // T_kt+2 -> that stage
+        }
+    }
+    pp_wait_vmcnt<0>();
+}
+
+template <typename T, typename S, int MODE, bool GEGLU, bool STAGED, int G, int EXP>
+__device__ __forceinline__ void pp_consumer_ls(const IgemmArgs &a, char *smem, const BlockTile &bt, const int tid, const int wave) {
+    using vec8 = typename Elem<T>::vec8;
+    constexpr int BM = S::BM, NS = S::NS, FM = S::FM, FN = G ? S::FN1 : S::FN0, STAGE = S::STAGE, BNO = S::BNO;
+    constexpr int WNB = FN * 32;
+    const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wq = wave & 3;
+    const int xr0 = S::SPLIT_M ? G * 128 : wq * 64;
+    const int wr0 = S::SPLIT_M ? wq * WNB : (G ? S::FN0 * 32 : 0);
+    const int m0 = bt.tile_m * BM, n0 = bt.tile_n * BNO;
+    const int kt_begin = bt.split * a.ktiles_per_split;
+    const int kt_end = min(a.ktiles, kt_begin + a.ktiles_per_split);
+    f32x16 acc[FN][FM];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[fn][fm][r] = 0.f;
+    trace_mark(a, 1);
+    trace_mark(a, 2);
+    const int swz = (l31 >> 1) & 7;
+    const int xoff = (xr0 + l31) * 128, woff = BM * 128 + (wr0 + l31) * 128;
+    const char *cstage = smem;
+    vec8 af[2][FN], bf[2][FM];
+    if constexpr ((EXP & 2) != 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) af[q][fn] = vec8{};
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) bf[q][fm] = vec8{};
+        }
+    }
+    auto read_frags = [&](const char *st, int ks, int set) __attribute__((always_inline)) {
+        if constexpr ((EXP & 2) != 0) return;
+        const int coff = (((ks * 2) + hi) ^ swz) << 4;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) af[set][fn] = *reinterpret_cast<const vec8 *>(st + woff + fn * 4096 + coff);
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) bf[set][fm] = *reinterpret_cast<const vec8 *>(st + xoff + fm * 4096 + coff);
+    };
+    __builtin_amdgcn_s_barrier();  // tile kt_begin has landed
+    trace_mark(a, 3);
+    read_frags(cstage, 0, 0);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const char *st = cstage;
+        cstage = (cstage + STAGE == smem + NS * STAGE) ? smem : cstage + STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) {
+                read_frags(st, ks + 1, (ks + 1) & 1);
+            } else if (kt + 1 < kt_end) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment of tile kt is in registers
+                __builtin_amdgcn_s_barrier();                       // tile kt + 1 has landed, the stage of tile kt is released
+                asm volatile("" ::: "memory");
+                read_frags(cstage, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // the reads stay above the MFMAs they run beside
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm) {
+                    if constexpr ((EXP & 1) == 0)
+                        acc[fn][fm] = mfma32(af[ks & 1][fn], bf[ks & 1][fm], acc[fn][fm]);
+                    else
+                        asm volatile("" ::"v"(af[ks & 1][fn]), "v"(bf[ks & 1][fm]));
+                }
+        }
+    }
+    trace_mark(a, 4);
+    EpiOperands<(GEGLU ? FN / 2 : 1), (GEGLU ? FM : 1)> epi;
+    if constexpr (GEGLU) epilogue_prefetch<T, FN, FM, true>(a, epi, m0 + xr0, n0 + wr0 / 2, l31, hi);
+    run_epilogue<T, BM, BNO, FN, FM, GEGLU, GEGLU, 512, STAGED, kJoinDefault, 2>(a, acc, epi, smem, m0, n0, m0 + xr0, n0 + (GEGLU ? wr0 / 2 : wr0), l31, hi,
+                                                                                    tid, bt.split);
 }
 
 template <typename T, int BN, int NS, int KSP, int PW, int MODE, bool GEGLU, bool STAGED, int EXP = 0>
@@ -505,14 +635,25 @@ __global__ void __launch_bounds__(512 + PW * 64, (PW ? 3 : 2)) igemm_pp_kernel(c
             meta = mt;
         }
         if (wave >= 8) {
-            pp_producer<T, S, KSP, MODE, GEGLU, EXP>(a, smem, bt, tid, wave, meta);
+            if constexpr (KSP == 0)
+                pp_producer_ls<T, S, MODE, GEGLU, EXP>(a, smem, bt, tid, wave, meta);
+            else
+                pp_producer<T, S, KSP, MODE, GEGLU, EXP>(a, smem, bt, tid, wave, meta);
             return;
         }
     }
-    if (wave < 4)
-        pp_consumer<T, S, KSP, MODE, GEGLU, STAGED, 0, EXP>(a, smem, bt, tid, wave);
-    else
-        pp_consumer<T, S, KSP, MODE, GEGLU, STAGED, 1, EXP>(a, smem, bt, tid, wave);
+    if constexpr (KSP == 0) {
+        static_assert(PW > 0, "the lockstep form has producer waves");
+        if (wave < 4)
+            pp_consumer_ls<T, S, MODE, GEGLU, STAGED, 0, EXP>(a, smem, bt, tid, wave);
+        else
+            pp_consumer_ls<T, S, MODE, GEGLU, STAGED, 1, EXP>(a, smem, bt, tid, wave);
+    } else {
+        if (wave < 4)
+            pp_consumer<T, S, KSP, MODE, GEGLU, STAGED, 0, EXP>(a, smem, bt, tid, wave);
+        else
+            pp_consumer<T, S, KSP, MODE, GEGLU, STAGED, 1, EXP>(a, smem, bt, tid, wave);
+    }
     trace_finish(a);
 }
 
@@ -523,7 +664,9 @@ __global__ void __launch_bounds__(512 + PW * 64, (PW ? 3 : 2)) igemm_pp_kernel(c
     OP(T, 160, 3, 4, 0, MODE, false)       \
     OP(T, 256, 2, 2, 0, MODE, false)       \
     OP(T, 128, 3, 2, 4, MODE, false)       \
-    OP(T, 160, 3, 2, 4, MODE, false)
+    OP(T, 160, 3, 2, 4, MODE, false)       \
+    OP(T, 128, 3, 0, 4, MODE, false)       \
+    OP(T, 160, 3, 0, 4, MODE, false)
 
 #define SFAST_FOR_PP_GEGLU_VARIANTS(T, OP) OP(T, 256, 2, 2, 0, 0, true)
 
@@ -561,11 +704,13 @@ extern int g_igemm_exp;  // igemm_glds.hip (SFAST_IGEMM_EXP, latched by sfast_hi
 
 // pw: producer waves of the variant (0: the consumer groups issue the requests themselves)
 template <typename T, int MODE> static int pp_dispatch(const IgemmArgs &a, int BN_, int pw, bool geglu, hipStream_t st) {
+    const bool lockstep = pw >= 100;  // pw = 100 + producer waves: the lockstep form (KSP = 0)
+    pw %= 100;
 #ifdef SFAST_PROBES  // timing-only instantiations (results are garbage): probe build only (build.py --probes)
     if constexpr (std::is_same<T, f16>::value && MODE == 1) {
         if (g_igemm_exp != 0 && !geglu && a.stage_out) {
 #define LAUNCH_EXP(BN, NS, KSP, PW, E)                                                                                                 \
-    if (BN_ == BN && pw == PW && g_igemm_exp == E) {                                                                                   \
+    if (BN_ == BN && pw == PW && g_igemm_exp == E && lockstep == (KSP == 0)) {                                                         \
         auto kern = igemm_pp_kernel<f16, BN, NS, KSP, PW, 1, false, true, E>;                                                         \
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pp_smem_bytes(BN, NS, false, true)); \
         hipLaunchKernelGGL(kern, igemm_grid(a), dim3(512 + PW * 64), pp_smem_bytes(BN, NS, false, true), st, a);                      \
@@ -575,14 +720,14 @@ template <typename T, int MODE> static int pp_dispatch(const IgemmArgs &a, int B
     LAUNCH_EXP(BN, NS, KSP, PW, 1) LAUNCH_EXP(BN, NS, KSP, PW, 2) LAUNCH_EXP(BN, NS, KSP, PW, 3) LAUNCH_EXP(BN, NS, KSP, PW, 4)      \
     LAUNCH_EXP(BN, NS, KSP, PW, 5) LAUNCH_EXP(BN, NS, KSP, PW, 6) LAUNCH_EXP(BN, NS, KSP, PW, 7) LAUNCH_EXP(BN, NS, KSP, PW, 8)      \
     LAUNCH_EXP(BN, NS, KSP, PW, 16)
-            LAUNCH_EXPS(160, 3, 4, 0) LAUNCH_EXPS(160, 3, 2, 4) LAUNCH_EXPS(256, 2, 2, 0)
+            LAUNCH_EXPS(160, 3, 4, 0) LAUNCH_EXPS(160, 3, 2, 4) LAUNCH_EXPS(256, 2, 2, 0) LAUNCH_EXPS(160, 3, 0, 4)
 #undef LAUNCH_EXPS
 #undef LAUNCH_EXP
         }
     }
 #endif
 #define LAUNCH_OP(TT, BN, NS, KSP, PW, MODE_, G)                                                                                    \
-    if (BN_ == BN && pw == PW && geglu == G) {                                                                                      \
+    if (BN_ == BN && pw == PW && geglu == G && lockstep == (KSP == 0)) {                                                            \
         if constexpr (!G) {                                                                                                         \
             if (a.stage_out) {                                                                                                      \
                 hipLaunchKernelGGL((igemm_pp_kernel<TT, BN, NS, KSP, PW, MODE_, false, true>), igemm_grid(a), dim3(512 + PW * 64),  \

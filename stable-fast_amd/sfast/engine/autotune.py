@@ -28,10 +28,10 @@ GEGLU_VARIANTS = (1, 3, 11, 13, 16, 18, 21, 23)
 PK_VARIANTS = (41, 42, 43, 44, 45, 46)  # igemm_pk.h: packed weights global -> VGPR; only for ops that were handed packed copies
 CONV_PATCH_VARIANTS = (31, 32, 34)   # conv_patch.hip: 3x3 / stride 1 / pad 1 convs only (sfast_hip_conv2d_plan says whether a problem fits)
 # igemm_pp.h (round 6): 256-row ping-pong tiles -- 256 x 128 / 160 / 256 with the consumer groups issuing the LDS-DMA requests (51 - 53)
-# or four producer waves (55, 56); candidates only where the tiles alone put work on at least PP_MIN_TILES of the 256 CUs
-PP_VARIANTS = (51, 52, 53, 55, 56)
+# or four producer waves (55, 56: ping-pong consumers; 57, 58: lockstep consumers, one barrier per K-tile); candidates only where the tiles alone put work on at least PP_MIN_TILES of the 256 CUs
+PP_VARIANTS = (51, 52, 53, 55, 56, 57, 58)
 PP_GEGLU_VARIANTS = (53,)
-PP_BN = {51: 128, 52: 160, 53: 256, 55: 128, 56: 160}
+PP_BN = {51: 128, 52: 160, 53: 256, 55: 128, 56: 160, 57: 128, 58: 160}
 PP_MIN_TILES = 96
 MAX_SLAB_BYTES = 192 << 20
 
@@ -154,7 +154,7 @@ def tune_plan(plan, device, dtype_tag="f16", verbose=False):
             p.variant, p.split_k = int(hit[0]), int(hit[1])
             # SFAST_TUNE_EXTEND=1 (tools/retune_pp.py): a cached choice made before the 256-row tiles existed is timed once more against
             # them -- how sfast/engine/tune_gfx950.json was brought up to date in round 6 without re-timing 360 problems x 17 variants
-            if extend and 0 < int(hit[0]) < 50 and key not in _extended and _pp_candidates(M, N, K, geglu):
+            if extend and int(hit[0]) > 0 and key not in _extended and _pp_candidates(M, N, K, geglu):
                 ext_base[key] = (int(hit[0]), int(hit[1]))
                 todo.setdefault(key, []).append(op)
         else:
@@ -181,7 +181,7 @@ def tune_plan(plan, device, dtype_tag="f16", verbose=False):
         only = None
         if key in ext_base:
             _extended.add(key)
-            cands, only = (ext_base[key][0],) + _pp_candidates(M, N, K, geglu), ext_base[key]
+            cands, only = (ext_base[key][0],) + tuple(v for v in _pp_candidates(M, N, K, geglu) if v != ext_base[key][0]), ext_base[key]
         elif key.endswith("|pk"):
             base = _cache.get(key[:-3])
             if base is not None and int(base[0]) > 0:

@@ -438,8 +438,8 @@ def test_conv_patch_pipe_emits_groupnorm_statistics(variant, split, cin, cout, h
     compare(f"gn_apply conv patch {cin}->{cout}@{hw} v{variant} s{split}", yn, R.group_norm_ref(y, 32, gam, bet, 1e-5, True), *tol(y.dtype, 2.0), kernel=k)
 
 
-# ---- pipe 5 (round 6): 256-row ping-pong tiles, csrc/igemm_pp.h -- ids 51 - 53 (8 waves), 55 / 56 (+ 4 producer waves) ------------------
-PP_VARIANTS = [51, 52, 53, 55, 56]
+# ---- pipe 5 (round 6): 256-row tiles, csrc/igemm_pp.h -- ids 51 - 53 (8 waves, ping-pong), 55 / 56 (+ 4 producer waves), 57 / 58 (producers + lockstep consumers)
+PP_VARIANTS = [51, 52, 53, 55, 56, 57, 58]
 
 
 def _pp_applies(M, K):
@@ -472,7 +472,7 @@ def test_geglu_pp_variant(M, K, N):
     assert torch.equal(y, y2), last_kernel()
 
 
-@pytest.mark.parametrize("variant,split", [(51, 2), (52, 2), (52, 3), (53, 2), (53, 5), (55, 2), (56, 4)])
+@pytest.mark.parametrize("variant,split", [(51, 2), (52, 2), (52, 3), (53, 2), (53, 5), (55, 2), (56, 4), (57, 3), (58, 2)])
 def test_linear_pp_split_k(variant, split):
     x, w, b = rnd(600, 5120, seed=43), rnd(1280, 5120, seed=44, scale=5120 ** -0.5), rnd(1280, seed=45)
     r = rnd(600, 1280, seed=46)
@@ -513,7 +513,7 @@ PP_CONV_CASES = [c for c in CONV_CASES if c[0] in ("res 320@64", "res2 320@64 +z
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_conv_pp_variants(case, variant, dtype):
     name, B, Cin, H, W, Cout, k, stride, pad, ex = case
-    if dtype == torch.bfloat16 and variant not in (52, 53, 56):
+    if dtype == torch.bfloat16 and variant not in (52, 53, 56, 58):
         pytest.skip("bf16: one tile shape per wave layout")
     x = cl(rnd(B, Cin, H, W, seed=70, dtype=dtype))
     c2 = ex.get("c2", 0)
@@ -531,7 +531,7 @@ def test_conv_pp_variants(case, variant, dtype):
     compare(f"conv {name} v{variant} {dtype}", y, want, *tol(dtype, 2.0), kernel=kname)
 
 
-@pytest.mark.parametrize("variant,split", [(52, 1), (53, 1), (56, 1), (51, 1), (55, 1), (52, 2), (56, 3)])
+@pytest.mark.parametrize("variant,split", [(52, 1), (53, 1), (56, 1), (51, 1), (55, 1), (52, 2), (56, 3), (57, 1), (58, 1), (58, 2)])
 @pytest.mark.parametrize("cin,cout,hw,unit", [(320, 320, 32, 10), (640, 1280, 16, 20), (320, 640, 64, 20)])
 def test_conv_pp_emits_groupnorm_statistics(variant, split, cin, cout, hw, unit):
     import numpy as np

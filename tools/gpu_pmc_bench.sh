@@ -1,13 +1,16 @@
 #!/bin/bash
 # HBM-side traffic per kernel symbol of the bench step: FETCH_SIZE and WRITE_SIZE in separate --pmc passes
 # (counters only with --kernel-trace, as the pool requires) over the SAME bench command, autotune results cached.
-# usage: tools/gpu_pmc_bench.sh [sd15|sdxl|svd] [steps]   -> gpurun_out/pmcb/traffic_by_symbol[_<config>].json
+# usage: tools/gpu_pmc_bench.sh [sd15|sdxl|svd|bs8] [steps]   -> gpurun_out/pmcb/traffic_by_symbol[_<config>].json
+# (bs8 = SD1.5 at 8 images per GPU, the per-GPU shape of BASELINE configs[3]: `bench.py --config sd15 --images 8`)
 # The file carries a `_meta` block (round, commit = $SFAST_COMMIT as passed by the caller -- the GPU box has no .git --, sha256 of the
 # packaged tune cache, the command): bench.py quotes `traffic` from it only while the kernel choices are the ones it was taken with.
 cd "$(dirname "$0")/.."
 CFG=${1:-sd15}
 STEPS=${2:-6}
 SUF=""; [ "$CFG" != "sd15" ] && SUF="_$CFG"
+BARGS="--config $CFG"; [ "$CFG" = "bs8" ] && BARGS="--config sd15 --images 8"
+export BARGS
 rm -rf gpurun_out/pmcb; mkdir -p gpurun_out/pmcb
 export TMPDIR=/tmp
 R=$PWD
@@ -16,12 +19,12 @@ R=$PWD
 # the first round-5 pass and the "last 40 %" window (profiles/r05_pmc_traffic_contaminated_run6.log); the SDXL pass timed out on them
 # pass 0: --kernel-trace ONLY (no counters): the per-dispatch durations `rocprofv3 --stats` shows. Kernels run ~10-15 % slower while counters
 # are collected, so the durations of the --pmc passes (`avg_us`) are not the ones a roofline fraction may be priced with: `avg_us_trace` is.
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $R/gpurun_out/pmcb -o trace -- python $R/bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants > $R/gpurun_out/pmcb/trace.log 2>&1 )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $R/gpurun_out/pmcb -o trace -- python $R/bench.py $BARGS --steps $STEPS --warmup 2 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants > $R/gpurun_out/pmcb/trace.log 2>&1 )
 echo "trace pass exit=$?"
 for db in $(find gpurun_out/pmcb -name "*.db"); do python tools/rocpd_summary.py $db --csv gpurun_out/pmcb/trace.csv --top 200 --step-marker cfg_ddim --steps $(( STEPS - 1 )) > gpurun_out/pmcb/trace.txt; rm -f $db; done
 pass() { # name, counters...
   local name=$1; shift
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc "$@" -d $R/gpurun_out/pmcb -o $name -- python $R/bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants > $R/gpurun_out/pmcb/$name.log 2>&1 )
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc "$@" -d $R/gpurun_out/pmcb -o $name -- python $R/bench.py $BARGS --steps $STEPS --warmup 2 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants > $R/gpurun_out/pmcb/$name.log 2>&1 )
   echo "pmc $name exit=$? $(tail -n 1 $R/gpurun_out/pmcb/$name.log | cut -c1-100)"
   for db in $(find $R/gpurun_out/pmcb -name "*.db"); do python $R/tools/pmc_extract.py $db $R/gpurun_out/pmcb/$name.json --by-symbol --last-frac 0.4; rm -f $db; done
 }
@@ -50,8 +53,8 @@ for k, r in f.items():
     if t:
         out[k]["avg_us_trace"], out[k]["launches_trace"] = t
 sha = hashlib.sha256(open("stable-fast_amd/sfast/engine/tune_gfx950.json", "rb").read()).hexdigest()[:16]
-out["_meta"] = dict(round=5, commit=os.environ.get("SFAST_COMMIT", "unknown"), tune_cache_sha256=sha,
-                    command=f"python bench.py --config {os.environ['CFG']} --steps {os.environ['STEPS']} --warmup 2 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants",
+out["_meta"] = dict(round=6, commit=os.environ.get("SFAST_COMMIT", "unknown"), tune_cache_sha256=sha,
+                    command=f"python bench.py {os.environ['BARGS']} --steps {os.environ['STEPS']} --warmup 2 --no-cpu-baseline --no-roofline --no-end-to-end --no-variants",
                     method="separate rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE; WRITE_SIZE); last 40 % of the dispatches; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB; "
                            "avg_us = per-dispatch average UNDER counter collection, avg_us_trace = the same from a --kernel-trace-only pass (steady window of graph replays)")
 json.dump(out, open("gpurun_out/pmcb/traffic_by_symbol" + os.environ.get("SUF", "") + ".json", "w"), indent=1)

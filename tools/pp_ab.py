@@ -20,7 +20,7 @@ REPS = 10
 OLD = [21, 22, 23, 24, 25, 1, 2, 5, 11, 12, 15]
 OLD_GEGLU = [1, 11, 21, 23]
 PK = [41, 44, 46]
-PP = [51, 52, 53, 55, 56]
+PP = [51, 52, 53, 55, 56, 57, 58]
 SPLITS = [1, 2, 3]
 
 # name, B, Cin, hw, Cout, k

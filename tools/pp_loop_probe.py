@@ -15,7 +15,7 @@ from sfast.hip import functional as F  # noqa: E402
 from sfast.hip import lib as L  # noqa: E402
 
 CASES = [  # B, Cin, C2, H, W, Cout, variant, split
-    (16, 320, 0, 64, 64, 320, 52, 1), (16, 320, 0, 64, 64, 320, 56, 1), (16, 640, 0, 32, 32, 640, 56, 1), (16, 640, 0, 32, 32, 640, 53, 1),
+    (16, 320, 0, 64, 64, 320, 52, 1), (16, 320, 0, 64, 64, 320, 56, 1), (16, 320, 0, 64, 64, 320, 58, 1), (16, 640, 0, 32, 32, 640, 58, 1), (16, 640, 0, 32, 32, 640, 53, 1),
 ]
 NAMES = {0: "full", 1: "no MFMA", 2: "no fragment reads", 3: "no MFMA, no fragment reads", 4: "no in-loop DMA", 7: "loop skeleton (barriers only)",
          6: "MFMAs + barriers only (no fragment reads, no in-loop DMA)", 5: "fragment reads + barriers only (no MFMA, no in-loop DMA)",
@@ -97,5 +97,5 @@ for (B, Cin, C2, H, W, Cout, v, s) in CASES:
     for ex, t in best.items():
         print(f"   {NAMES[ex]:58s} {t:7.1f} us   {flops / t / 1e6:6.0f} 'TF/s'", flush=True)
     bm = 256
-    bn = 160 if v in (52, 56) else 256 if v == 53 else 128
+    bn = 160 if v in (52, 56, 58) else 256 if v == 53 else 128
     timeline(run, (M // bm) * ((Cout + bn - 1) // bn))
