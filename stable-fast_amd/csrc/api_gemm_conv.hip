@@ -179,7 +179,9 @@ static int conv_caps(const sfast_conv_params *p) {
     const bool patch = glds_ok && p->KH == 3 && p->KW == 3 && p->stride_h == 1 && p->stride_w == 1 && p->pad_h == 1 && p->pad_w == 1 &&
                        p->pad_h_extra == 0 && p->pad_w_extra == 0 && p->dil_h == 1 && p->dil_w == 1;
     // forced pipe-4 variants (41..): the query assumes the packed copy the launch will be handed (sfast_epilogue_ext.w_packed)
-    return igemm_caps(glds_ok, patch ? p->H : 0, patch ? p->W : 0, p->variant >= 40 && p->variant < 100);
+    const bool pp_ups = p->upsample2x && C2 == 0 && p->C1 % 64 == 0 && p->KH * p->KW <= 30 && p->dil_h == 1 && p->dil_w == 1 &&
+                        (int64_t)p->B * p->H * p->W * p->C1 < (1ll << 31);
+    return igemm_caps(glds_ok, patch ? p->H : 0, patch ? p->W : 0, p->variant >= 40 && p->variant < 100, pp_ups);
 }
 
 }  // namespace

@@ -58,8 +58,9 @@ static inline int stats_slots(int bno, int unit) { return (bno - 1) / unit + 2; 
 // bit 1 = packed copies of the weights are at hand (pipe 4, igemm_pk.hip);
 // for convs the patch pipe (conv_patch.hip) may be chosen can: 3x3, stride 1, padding 1, dense NHWC, C1 / C2 multiples of 64 -- then
 // bits 8..19 = image width W, bits 20..31 = image height H (the tile has to cover whole image rows).
-static inline int igemm_caps(bool glds_ok, int patch_h, int patch_w, bool packed = false) {
-    return (glds_ok ? 1 : 0) | (packed ? 2 : 0) | ((patch_h > 0 && patch_w > 0 && patch_h < 4096 && patch_w < 4096) ? ((patch_w << 8) | (patch_h << 20)) : 0);
+// bit 2 (round 6) = a conv with a fused nearest-2x upsample that the 12-wave forms of pipe 5 (variants 55 ..) can take although no other LDS-DMA pipe can
+static inline int igemm_caps(bool glds_ok, int patch_h, int patch_w, bool packed = false, bool pp_ups = false) {
+    return (glds_ok ? 1 : 0) | (packed ? 2 : 0) | (pp_ups ? 4 : 0) | ((patch_h > 0 && patch_w > 0 && patch_h < 4096 && patch_w < 4096) ? ((patch_w << 8) | (patch_h << 20)) : 0);
 }
 bool conv_patch_fits(int H, int W, int M, int BM, int BN);                                 // conv_patch.hip
 int conv_patch_launch(const IgemmArgs &a, int dtype, int BM, int BN, hipStream_t st);       // conv_patch.hip

@@ -844,7 +844,11 @@ static IgemmPlan igemm_plan(int M, int N, int K, bool geglu, int force_variant, 
             if (v.pipe >= 1 && (!glds_ok || g_pipe_pref == 0)) continue;
             if (v.pipe == 0 && glds_ok && g_pipe_pref == 1) continue;
         }
-        if (v.pipe >= 1 && !glds_ok) continue;
+        if (v.pipe == 5 && !glds_ok && (caps & 4) && v.id >= 55) {
+            // fused-upsample conv: the producer waves of pipe 5 address it (igemm_pp.h pp_decode_row); nothing else with LDS-DMA does
+        } else if (v.pipe >= 1 && !glds_ok) {
+            continue;
+        }
         if (v.pipe == 4 && !(caps & 2)) continue;
         if (v.pipe == 5 && (K % 64 != 0 || M < 256)) continue;  // no K tail in the ping-pong pipe; one full tile of rows at least
         if (v.pipe == 3 && !(patch_w > 0 && K % 576 == 0 && conv_patch_fits(patch_h, patch_w, M, v.BM, v.BN))) continue;
@@ -1154,7 +1158,11 @@ int igemm_run(IgemmArgs &a, int dtype, int mode, bool geglu, int variant, int sp
     const int nseg = a.rows_per_seg > 0 ? ceil_div(a.N, a.rows_per_seg) : 1;
     bool packed = glds_elig && !geglu && !a.w_int8 && nseg <= SFAST_MAX_WSEG && (nseg == 1 || a.rows_per_seg % 32 == 0);
     for (int i = 0; i < nseg && packed; ++i) packed = a.wpk[i] != nullptr;
-    const int glds_ok = igemm_caps(glds_elig, patch_elig ? a.H : 0, patch_elig ? a.W : 0, packed);
+    // pipe 5's producer waves also take a single-source 3x3-style conv with the nearest-2x upsample fused into the gather
+    const int64_t ups_elems = (a.Ho > 0 && a.Wo > 0) ? (int64_t)a.M / ((int64_t)a.Ho * a.Wo) * a.H * a.W * a.C1 : 0;
+    const bool pp_ups = mode == 1 && a.ups && a.x2 == nullptr && a.C2 == 0 && a.C1 % 64 == 0 && a.dil_h == 1 && a.dil_w == 1 && a.KH * a.KW <= 30 &&
+                        ups_elems < (1ll << 31);
+    const int glds_ok = igemm_caps(glds_elig, patch_elig ? a.H : 0, patch_elig ? a.W : 0, packed, pp_ups);
     a.pk_ksteps = ceil_div(a.K, 64) * 4;
     IgemmPlan p = igemm_plan(a.M, a.N, a.K, geglu, variant, split, glds_ok);
     const bool want_staged = !geglu && (a.gn_stats != nullptr || g_stage_pref > 0);

@@ -102,10 +102,14 @@ __device__ __forceinline__ void pp_decode_row(const IgemmArgs &a, const PixelDec
     int b, ho, wo;
     decode(m, b, ho, wo);
     const int h0 = ho * a.stride_h - a.pad_h, w0 = wo * a.stride_w - a.pad_w;
-    pix = (b * a.H + h0) * a.W + w0;
+    // fused nearest-2x upsample (12-wave forms only): taps address the UPSAMPLED image [2H, 2W], tap (r, s) of this row reads source pixel
+    // ((h0 + r) >> 1, (w0 + s) >> 1) = (h0 >> 1, w0 >> 1) + (((h0 & 1) + r) >> 1, ((w0 & 1) + s) >> 1): `pix` is the first term, the two
+    // parities ride in bits 30 / 31 of the mask (KH * KW <= 30) and the loader adds the second term per K-tile (PPLoader::tile_state)
+    const int Hin = a.ups ? 2 * a.H : a.H, Win = a.ups ? 2 * a.W : a.W;
+    pix = a.ups ? (b * a.H + (h0 >> 1)) * a.W + (w0 >> 1) : (b * a.H + h0) * a.W + w0;
     if (a.dil_h == 1 && a.dil_w == 1) {
-        const int s_lo = max(0, -w0), s_hi = min(a.KW, a.W - w0);
-        const int r_lo = max(0, -h0), r_hi = min(a.KH, a.H - h0);
+        const int s_lo = max(0, -w0), s_hi = min(a.KW, Win - w0);
+        const int r_lo = max(0, -h0), r_hi = min(a.KH, Hin - h0);
         if (s_hi > s_lo && r_hi > r_lo) {
             const unsigned cols = ((1u << s_hi) - 1u) & ~((1u << s_lo) - 1u);
             const unsigned lo_bits = r_lo * a.KW, hi_bits = r_hi * a.KW;
@@ -114,9 +118,10 @@ __device__ __forceinline__ void pp_decode_row(const IgemmArgs &a, const PixelDec
         }
     } else {
         unsigned cols = 0;
-        for (int s = 0; s < a.KW; ++s) cols |= ((unsigned)(w0 + s * a.dil_w) < (unsigned)a.W ? 1u : 0u) << s;
-        for (int r = 0; r < a.KH; ++r) mask |= ((unsigned)(h0 + r * a.dil_h) < (unsigned)a.H ? cols : 0u) << (r * a.KW);
+        for (int s = 0; s < a.KW; ++s) cols |= ((unsigned)(w0 + s * a.dil_w) < (unsigned)Win ? 1u : 0u) << s;
+        for (int r = 0; r < a.KH; ++r) mask |= ((unsigned)(h0 + r * a.dil_h) < (unsigned)Hin ? cols : 0u) << (r * a.KW);
     }
+    if (a.ups) mask = (mask & 0x3fffffffu) | ((unsigned)(h0 & 1) << 30) | ((unsigned)(w0 & 1) << 31);
 }
 __device__ __forceinline__ unsigned pp_rep_all(const IgemmArgs &a) {
     unsigned rep_all = 0;
@@ -129,6 +134,9 @@ template <typename T, typename S, int MODE, bool GEGLU, bool UPPER> struct PPLoa
     const char *xptr[XP];    // MODE 0: row pointer at chunk kc
     int xoffB[XP], xdAB[XP];  // MODE 1: BYTE offset of (tap (0,0), chunk kc) in source 2; (the same in source 1) - xoffB
     unsigned xmask[XP];      // MODE 1: bit (r * KW + s) set when that tap is inside the image
+    static constexpr bool UPS = S::PW > 0 && MODE == 1;  // the producer waves take convs with a fused nearest-2x upsample (registers to spare)
+    int xph[UPS ? XP : 1], xpw[UPS ? XP : 1];  // ups: byte step of one source row / one source pixel where the row's parity is odd, else 0
+    int mh, mw;                                 // ups: -1 where this K-tile's tap row / column index is odd (the parity term applies)
     const char *wptr[WCH];
     __amdgpu_buffer_rsrc_t rsrc1, rsrc2;
     int cin, ntaps, t_tap, t_r, t_s, t_c, issued, kt_end, tapoff, fmask, tapsh, iwave;
@@ -144,6 +152,11 @@ template <typename T, typename S, int MODE, bool GEGLU, bool UPPER> struct PPLoa
             tapoff = first ? (pixoff * a.C1 + t_c) * 2 : (pixoff * a.C2 + (t_c - a.C1)) * 2;
             fmask = first ? -1 : 0;
             tapsh = 31 - (t_tap & 31);
+            if (UPS && a.ups) {  // (single source, no dilation: host-side conditions)
+                tapoff = (((t_r >> 1) * a.W + (t_s >> 1)) * a.C1 + t_c) * 2;
+                mh = (t_r & 1) ? -1 : 0;
+                mw = (t_s & 1) ? -1 : 0;
+            }
         }
     }
     // itid: index among the issuing threads, iwave: its wave among the issuing waves; meta: per-tile-row {pixel index, tap mask} in LDS, or
@@ -184,6 +197,10 @@ template <typename T, typename S, int MODE, bool GEGLU, bool UPPER> struct PPLoa
                     xoffB[i] = (pix * a.C2 + kc * 8) * 2;
                     xdAB[i] = pix * (a.C1 - a.C2) * 2;
                     xmask[i] = mask;
+                    if constexpr (UPS) {
+                        xph[i] = (a.ups && (mask & (1u << 30))) ? a.W * a.C1 * 2 : 0;
+                        xpw[i] = (a.ups && (mask & (1u << 31))) ? a.C1 * 2 : 0;
+                    }
                 }
             }
         }
@@ -215,7 +232,7 @@ template <typename T, typename S, int MODE, bool GEGLU, bool UPPER> struct PPLoa
             t_s = t_tap - t_r * a.KW;
         }
         issued = kt_begin;
-        tapoff = fmask = tapsh = 0;
+        tapoff = fmask = tapsh = mh = mw = 0;
         first = true;
         tile_state(a);
     }
@@ -227,7 +244,9 @@ template <typename T, typename S, int MODE, bool GEGLU, bool UPPER> struct PPLoa
                 __builtin_amdgcn_global_load_lds((pp_src_t)(const void *)(xptr[l] + kb), dst, 16, 0, 0);
             } else {
                 const int valid = (int)(xmask[l] << tapsh) >> 31;  // -1: the tap is inside the image
-                const int voff = (xoffB[l] + (xdAB[l] & fmask) + tapoff) | ~valid;
+                int off = xoffB[l] + (xdAB[l] & fmask) + tapoff;
+                if constexpr (UPS) off += (xph[l] & mh) + (xpw[l] & mw);
+                const int voff = off | ~valid;
                 if (first)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, dst, 16, voff, 0, 0, 0);
                 else

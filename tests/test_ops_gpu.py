@@ -502,7 +502,8 @@ def test_pp_epilogues_bf16(variant):
 
 
 PP_CONV_CASES = [c for c in CONV_CASES if c[0] in ("res 320@64", "res2 320@64 +z", "down 320@64 s2", "640@32", "1280@16", "1280@8", "cat 640+320@64",
-                                                   "cat1x1 1280+640@32", "1x1 320@64", "5x5 pad2")] + [
+                                                   "cat1x1 1280+640@32", "1x1 320@64", "5x5 pad2", "up 1280@16 ups")] + [
+    ("up 320@24 ups B3", 3, 320, 24, 24, 192, 3, 1, 1, dict(ups=True, z=True)),      # fused nearest-2x upsample: the 12-wave forms only (55 ..)
     ("3 images 128@24 ragged", 3, 128, 24, 24, 200, 3, 1, 1, dict(z=True)),          # M = 1728: a ragged last row tile, Cout % 32 != 0
     ("dilated 64@40", 1, 64, 40, 40, 96, 3, 1, 2, dict(dil=2)),
 ]
@@ -521,13 +522,15 @@ def test_conv_pp_variants(case, variant, dtype):
     x2 = cl(rnd(B, c2, H, W, seed=71, dtype=dtype)) if c2 else None
     w = cl(rnd(Cout, Cin + c2, k, k, seed=72, scale=((Cin + c2) * k * k) ** -0.5, dtype=dtype))
     b = rnd(Cout, seed=73, scale=0.1, dtype=dtype)
-    Ho, Wo = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    ups = ex.get("ups", False)
+    Hin, Win = (2 * H, 2 * W) if ups else (H, W)
+    Ho, Wo = (Hin + 2 * pad - dil * (k - 1) - 1) // stride + 1, (Win + 2 * pad - dil * (k - 1) - 1) // stride + 1
     z = cl(rnd(B, Cout, Ho, Wo, seed=74, dtype=dtype)) if ex.get("z") else None
     rb = rnd(B, Cout, seed=75, dtype=dtype) if ex.get("rowbias") else None
-    y = F().conv2d(x, w, b, z=z, stride=stride, padding=pad, dilation=dil, x2=x2, rowbias=rb, variant=variant)
+    y = F().conv2d(x, w, b, z=z, stride=stride, padding=pad, dilation=dil, x2=x2, upsample2x=ups, rowbias=rb, variant=variant)
     kname = last_kernel()
-    assert "igemm_conv" in kname and (("pp" in kname.split(",")[-1]) == (B * Ho * Wo >= 256)), kname
-    want = R.conv2d_ref(x, w, b, z, 1.0, stride, pad, dil, x2=x2, rowbias=rb)
+    assert "igemm_conv" in kname and (("pp" in kname.split(",")[-1]) == (B * Ho * Wo >= 256 and (not ups or variant >= 55))), kname
+    want = R.conv2d_ref(x, w, b, z, 1.0, stride, pad, dil, x2=x2, upsample2x=ups, rowbias=rb)
     compare(f"conv {name} v{variant} {dtype}", y, want, *tol(dtype, 2.0), kernel=kname)
 
 
