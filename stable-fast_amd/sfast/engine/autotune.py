@@ -32,7 +32,8 @@ CONV_PATCH_VARIANTS = (31, 32, 34)   # conv_patch.hip: 3x3 / stride 1 / pad 1 co
 PP_VARIANTS = (51, 52, 53, 55, 56, 57, 58)
 PP_GEGLU_VARIANTS = (53,)
 PP_BN = {51: 128, 52: 160, 53: 256, 55: 128, 56: 160, 57: 128, 58: 160}
-PP_MIN_TILES = 96
+PP_MIN_TILES = 32   # tiles alone; with split-K the workgroups (tiles x splits) must reach PP_MIN_WGS
+PP_MIN_WGS = 96
 MAX_SLAB_BYTES = 192 << 20
 
 
@@ -194,8 +195,8 @@ def tune_plan(plan, device, dtype_tag="f16", verbose=False):
                     continue
                 if s > 1 and ktiles // s < 2:
                     continue
-                if v >= 50 and s > 2:
-                    continue  # the 256-row tiles are candidates where the tiles alone fill the chip
+                if v >= 50 and (s > 4 or -(-M // 256) * -(-N // (PP_BN[v] // 2 if geglu else PP_BN[v])) * s < PP_MIN_WGS):
+                    continue  # the 256-row tiles are candidates where tiles x (a small) split-K put work on a good part of the chip
                 if s > 1 and s * M * wrows * 4 > MAX_SLAB_BYTES:
                     continue
                 if is_conv:
