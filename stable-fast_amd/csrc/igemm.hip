@@ -696,6 +696,7 @@ static const Variant kGegluVariants[] = {
     {13, 64, 128, 2, 2, 1, 5, 0.75f},  {16, 128, 128, 2, 2, 1, 2, 1.00f}, {18, 64, 128, 2, 2, 1, 3, 0.75f},
     {21, 128, 128, 2, 2, 2, 4, 1.00f}, {23, 64, 128, 2, 2, 2, 3, 0.75f},
     {53, 256, 256, 2, 4, 5, 2, 1.40f},  // pipe 5: 256 pixels x (128 h + 128 g) weight rows
+    {57, 256, 128, 4, 2, 5, 3, 1.20f},  // pipe 5, producers + lockstep consumers: 256 pixels x (64 h + 64 g) weight rows
 };
 
 extern unsigned long long *g_igemm_trace;  // igemm_glds.hip

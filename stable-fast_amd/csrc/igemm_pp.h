@@ -687,7 +687,9 @@ __global__ void __launch_bounds__(512 + PW * 64, (PW ? 3 : 2)) igemm_pp_kernel(c
     OP(T, 128, 3, 0, 4, MODE, false)       \
     OP(T, 160, 3, 0, 4, MODE, false)
 
-#define SFAST_FOR_PP_GEGLU_VARIANTS(T, OP) OP(T, 256, 2, 2, 0, 0, true)
+#define SFAST_FOR_PP_GEGLU_VARIANTS(T, OP) \
+    OP(T, 256, 2, 2, 0, 0, true)           \
+    OP(T, 128, 3, 0, 4, 0, true)
 
 constexpr int pp_smem_bytes(int BN, int NS, bool geglu, bool staged) {
     const int ring = NS * (256 + BN) * 128;

@@ -30,7 +30,7 @@ CONV_PATCH_VARIANTS = (31, 32, 34)   # conv_patch.hip: 3x3 / stride 1 / pad 1 co
 # igemm_pp.h (round 6): 256-row ping-pong tiles -- 256 x 128 / 160 / 256 with the consumer groups issuing the LDS-DMA requests (51 - 53)
 # or four producer waves (55, 56: ping-pong consumers; 57, 58: lockstep consumers, one barrier per K-tile); candidates only where the tiles alone put work on at least PP_MIN_TILES of the 256 CUs
 PP_VARIANTS = (51, 52, 53, 55, 56, 57, 58)
-PP_GEGLU_VARIANTS = (53,)
+PP_GEGLU_VARIANTS = (53, 57)
 PP_BN = {51: 128, 52: 160, 53: 256, 55: 128, 56: 160, 57: 128, 58: 160}
 PP_MIN_TILES = 32   # tiles alone; with split-K the workgroups (tiles x splits) must reach PP_MIN_WGS
 PP_MIN_WGS = 96

@@ -460,16 +460,19 @@ def test_linear_pp_variants(M, K, N, variant):
 
 
 @pytest.mark.parametrize("M,K,N", [(8192, 320, 1280), (2048, 640, 2560), (512, 1280, 5120), (700, 1280, 320), (256, 64, 64)])
-def test_geglu_pp_variant(M, K, N):
+@pytest.mark.parametrize("variant,tag", [(53, "geglu[256x256,"), (57, "geglu[256x128,")])
+def test_geglu_pp_variant(M, K, N, variant, tag):
     x = rnd(M, K, seed=33)
     w = rnd(2 * N, K, seed=34, scale=K ** -0.5)
     b = rnd(2 * N, seed=35, scale=0.1)
-    y = F().linear(x, w, b, geglu=True, variant=53)
-    assert "geglu[256x256" in last_kernel() and "pp2" in last_kernel(), last_kernel()
-    compare(f"geglu M{M} K{K} N{N} v53", y, R.linear_ref(x, w, b, geglu=True), *tol(x.dtype), kernel=last_kernel())
+    y = F().linear(x, w, b, geglu=True, variant=variant)
+    assert tag in last_kernel() and ",pp" in last_kernel(), last_kernel()  # (the planner may add a split-K of its own)
+    compare(f"geglu M{M} K{K} N{N} v{variant}", y, R.linear_ref(x, w, b, geglu=True), *tol(x.dtype), kernel=last_kernel())
     ws = [w[:N].contiguous(), w[N:].contiguous()]  # two live weight tensors (h rows, g rows), as the engine passes them
-    y2 = F().linear(x, ws, b, geglu=True, variant=53)
+    y2 = F().linear(x, ws, b, geglu=True, variant=variant)
     assert torch.equal(y, y2), last_kernel()
+    yb = F().linear(x.bfloat16(), w.bfloat16(), b.bfloat16(), geglu=True, variant=variant)
+    compare(f"geglu bf16 M{M} K{K} N{N} v{variant}", yb, R.linear_ref(x.bfloat16(), w.bfloat16(), b.bfloat16(), geglu=True), *tol(torch.bfloat16, 2.0), kernel=last_kernel())
 
 
 @pytest.mark.parametrize("variant,split", [(51, 2), (52, 2), (52, 3), (53, 2), (53, 5), (55, 2), (56, 4), (57, 3), (58, 2)])

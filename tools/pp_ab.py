@@ -18,7 +18,7 @@ from sfast.hip import lib as L  # noqa: E402
 
 REPS = 10
 OLD = [21, 22, 23, 24, 25, 1, 2, 5, 11, 12, 15]
-OLD_GEGLU = [1, 11, 21, 23]
+OLD_GEGLU = [1, 11, 16, 21, 23]
 PK = [41, 44, 46]
 PP = [51, 52, 53, 55, 56, 57, 58]
 SPLITS = [1, 2, 3]
@@ -129,9 +129,10 @@ def correctness(dev):
         b = torch.randn(2 * N, generator=gen, device=dev).half()
         h = x.float() @ w.float().t() + b.float()
         want = h[:, :N] * torch.nn.functional.gelu(h[:, N:])
-        y = F.linear(x, w, b, geglu=True, variant=53)
-        if "pp" in L.last_kernel():
-            ok &= check(f"geglu {M}x{N}x{K} v53", y, want)
+        for v in (53, 57):
+            y = F.linear(x, w, b, geglu=True, variant=v)
+            if "pp" in L.last_kernel():
+                ok &= check(f"geglu {M}x{N}x{K} v{v}", y, want)
     return ok
 
 
