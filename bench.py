@@ -576,7 +576,7 @@ def step_variants(args, engine, cfg, hw, dev, latents, ehs, headline_ms):
     return out
 
 
-def child_variant(extra, steps=20, warmup=5, timeout=150):
+def child_variant(extra, steps=20, warmup=5, timeout=150, env_extra=None):
     """north_star asks for it/s on BOTH latent sizes and BASELINE configs[3] runs 8 images per GPU; the driver times `python bench.py`
     only. So the default SD1.5 run ends by timing (a) the 1x4x128x128-latent step (BASELINE configs[2]: SDXL 1024x1024 bs=1 fp16) and
     (b) the per-GPU shape of configs[3] (SD1.5, 8 images = UNet batch 16) -- CFG UNet + guidance + DDIM update as one hipGraph,
@@ -587,6 +587,7 @@ def child_variant(extra, steps=20, warmup=5, timeout=150):
     cmd = [sys.executable, os.path.abspath(__file__)] + list(extra) + ["--gpus", "1", "--steps", str(steps), "--warmup", str(warmup),
                                                                        "--no-cpu-baseline", "--no-end-to-end", "--no-variants"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(env_extra or {})
     t0 = time.perf_counter()
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
@@ -610,6 +611,21 @@ def sdxl_variant(steps=20, warmup=5, timeout=150):
 
 def bs8_variant(steps=20, warmup=5, timeout=150):
     return child_variant(["--config", "sd15", "--images", "8"], steps, warmup, timeout)
+
+
+def batch_invariant_variant(bs8, steps=20, warmup=5, timeout=150):
+    """the cost of SFAST_BATCH_INVARIANT=1 (every kernel choice and statistics partition follows the per-sample
+    problem at the reference batch 2, so a sample's latents are bit-equal at any batch: tests/test_unet_gpu.py
+    test_batch_invariant_mode_is_bit_exact_across_batch_sizes) where it costs most -- 8 images per GPU (UNet batch 16), whose
+    measured choices are the 256-row tiles the mode gives up. At batch 2 (the headline) the mode changes nothing."""
+    out = child_variant(["--config", "sd15", "--images", "8"], steps, warmup, timeout, env_extra={"SFAST_BATCH_INVARIANT": "1"})
+    if "value" in out:
+        out["env"] = "SFAST_BATCH_INVARIANT=1"
+        if isinstance(out.get("config"), dict) and "workload" in out["config"]:
+            out["config"]["workload"] += " [SFAST_BATCH_INVARIANT=1]"
+        if isinstance(bs8, dict) and bs8.get("value"):
+            out["relative_to_variants_bs8"] = out["value"] / bs8["value"]
+    return out
 
 
 def bs64_sharded(args, engine, cfg, hw, dev, rank, world, use_dist):
@@ -1096,6 +1112,7 @@ def main():
                 and not args.no_graph and isinstance(out.get("variants"), dict)):
             out["variants"]["sdxl"] = sdxl_variant()
             out["variants"]["bs8"] = bs8_variant()
+            out["variants"]["batch_invariant"] = batch_invariant_variant(out["variants"]["bs8"])
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.config, args.images)
     # BASELINE configs[3] (bs = 64 sharded over the ranks): every rank runs its shard; a leg of the N = 8 run (or --bs64-sharded)

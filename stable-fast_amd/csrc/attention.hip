@@ -691,7 +691,7 @@ extern "C" int sfast_hip_attention_bias(const void *q, const void *k, const void
         //   * beyond 1024 units the launch takes ceil(units / 1024) rounds: a last round that is less than half full costs a whole T
         //     (SDXL's 10-head 64x64 level: 1280 units = 2 rounds, 137 vs 132 us) unless there are many rounds to spread it over.
         // variant 64 / 62: forced, 4 / 2 waves per workgroup; variant 32 (and 2 / 4): the 32-row kernel.
-        const int64_t units = (int64_t)ceil_div(p->Sq, 64) * p->H * p->B;
+        const int64_t units = (int64_t)ceil_div(p->Sq, 64) * p->H * (g_batch_ref > 0 ? g_batch_ref : p->B);  // (SFAST_BATCH_INVARIANT: common.h)
         const int64_t tail = units % 1024;
         const bool fills = units <= 1024 ? units >= (p->D == 80 ? 1024 : 512) : (units >= 3072 || tail == 0 || tail >= 512);
         int use = (p->variant == 64 || p->variant == 62) ? 1 : (p->variant != 0 ? 0 : (g_attn_q64 >= 0 ? g_attn_q64 : (fills ? 1 : 0)));
@@ -710,7 +710,7 @@ extern "C" int sfast_hip_attention_bias(const void *q, const void *k, const void
     }
     if (vec && p->variant != 100 && p->scale > 0.f) {
         int nw = 4;
-        const int64_t blocks4 = (int64_t)ceil_div(p->Sq, 128) * p->H * p->B;
+        const int64_t blocks4 = (int64_t)ceil_div(p->Sq, 128) * p->H * (g_batch_ref > 0 ? g_batch_ref : p->B);
         if (blocks4 < 256) nw = 2;
         if (p->variant == 2 || p->variant == 4) nw = p->variant;  // (variant 32: the automatic choice of this kernel)
         if (bias || p->D >= 128) nw = 4;  // wide heads and the biased instantiation: four waves per workgroup only

@@ -24,6 +24,12 @@ int check_launch(const char *what);
         }                               \
     } while (0)
 
+// SFAST_BATCH_INVARIANT=1 (read once in sfast_hip_init; round 6): launch heuristics that size a grid from the
+// BATCH -- statistics splits of the GroupNorm, the row blocks of the split-K reduce, the 32- vs 64-row attention kernel -- are evaluated
+// for a reference batch of this many samples instead, so a sample's arithmetic does not depend on how many samples ride with it.
+// 0 = off (every heuristic sees the real batch).
+extern int g_batch_ref;
+
 // ---- element types ------------------------------------------------------------------------------
 using f16 = _Float16;
 using bf16 = __bf16;

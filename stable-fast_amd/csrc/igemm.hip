@@ -656,6 +656,7 @@ static void reduce_rows_geometry(int M, int N, int rows_per_sample, int &TY, int
     TY = 1;
     while (TY < 8 && CPR * TY * 2 <= 512) TY *= 2;
     RT = 1;
+    if (g_batch_ref > 0 && rows_per_sample > 0) M = rows_per_sample * g_batch_ref;  // SFAST_BATCH_INVARIANT: row blocks of a sample do not follow the batch
     while (RT < 4 && M / (TY * RT * 2) >= 128) RT *= 2;  // >= 128 workgroups; fewer, larger row blocks = fewer records to merge
     while (TY * RT > 1 && rows_per_sample % (TY * RT) != 0) {
         if (RT > 1) RT /= 2; else TY /= 2;

@@ -33,6 +33,7 @@ int check_launch(const char *what) {
 extern unsigned long long *g_igemm_trace;  // igemm_glds.hip
 extern int g_igemm_exp;                    // igemm_glds.hip
 int igemm_init();      // igemm.hip
+int g_batch_ref = 0;    // common.h
 int attention_init();  // attention.hip
 int gnconv_init();     // gnconv.hip
 
@@ -53,6 +54,10 @@ int sfast_hip_init(void) {
         return SFAST_ERR_LAUNCH;
     }
     std::lock_guard<std::mutex> lock(mu);
+    {
+        const char *bi = getenv("SFAST_BATCH_INVARIANT");
+        sfast::g_batch_ref = (bi && bi[0] != '0' && bi[0] != '\0') ? 2 : 0;  // reference batch = the CFG pair of one image
+    }
     if (state[dev] == 0) {
         int rc = sfast::igemm_init();
         if (rc == 0) rc = sfast::attention_init();

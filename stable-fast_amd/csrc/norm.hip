@@ -781,7 +781,7 @@ static bool gn_small_ok(const sfast_gn_params *p) {
     const int cpg = p->C / p->G;
     if ((cpg & 1) || (p->C1 & 1)) return false;
     const int64_t group_bytes = (int64_t)p->HW * cpg * 2;
-    const int64_t tensor_bytes = (int64_t)p->N * p->HW * p->C * 2;
+    const int64_t tensor_bytes = (int64_t)(g_batch_ref > 0 ? g_batch_ref : p->N) * p->HW * p->C * 2;  // (SFAST_BATCH_INVARIANT: common.h)
     return group_bytes <= 32 * 1024 && tensor_bytes <= (4 << 20);
 }
 
@@ -845,13 +845,14 @@ static GnPlan gn_plan(const sfast_gn_params *p, int apply_wgs = 256) {
     // ~one workgroup per CU in the apply pass, half that in the stats pass: every apply workgroup re-reads
     // all G x nsplit partial sums in its prologue (16 KB at 64 splits, two batched loads per thread); with
     // 128 splits and 684 apply workgroups that prologue traffic exceeded the tensor itself.
-    int want = ceil_div(256, p->N);
+    const int nb = g_batch_ref > 0 ? g_batch_ref : p->N;  // SFAST_BATCH_INVARIANT: the statistics partition of a sample must not follow the batch
+    int want = ceil_div(256, nb);
     if (want > 64) want = 64;
     pl.nsplit = want < max_split ? want : max_split;
     if (pl.nsplit < 1) pl.nsplit = 1;
     pl.rows_stats = ceil_div(p->HW, pl.nsplit);
     pl.nsplit = ceil_div(p->HW, pl.rows_stats);
-    int wanta = ceil_div(apply_wgs, p->N);
+    int wanta = ceil_div(apply_wgs, nb);  // (rows per apply workgroup select the 4-row-batched or the single-row loop body: not bit-identical code)
     int na = wanta < max_split ? wanta : max_split;
     if (na < 1) na = 1;
     pl.rows_apply = ceil_div(p->HW, na);

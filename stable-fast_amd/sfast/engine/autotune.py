@@ -130,8 +130,73 @@ def _time(fn, stream, inner=4, groups=3):
     return best
 
 
+BATCH_INVARIANT = os.environ.get("SFAST_BATCH_INVARIANT", "0") not in ("0", "false", "off", "")
+BATCH_REF = 2   # the reference batch: the CFG pair of one image (csrc/common.h g_batch_ref uses the same number)
+
+
+def _ref_problem(p, batch):
+    """Copy of a GEMM / conv params struct with the batch replaced by BATCH_REF, or None when the rows do not divide by the batch."""
+    q = type(p).from_buffer_copy(p)
+    if isinstance(p, L.GemmParams):
+        if batch <= 0 or p.M % batch:
+            return None
+        q.M = p.M // batch * BATCH_REF
+    else:
+        q.B = BATCH_REF
+    return q
+
+
+def pin_plan_to_reference_batch(plan, device, dtype_tag="f16"):
+    """SFAST_BATCH_INVARIANT=1 (opt-in): every GEMM / conv of the plan runs the (variant, split-K) that the
+    SAME per-sample problem gets at the reference batch (BATCH_REF = 2) -- the packaged / measured choice when there is one, else the
+    library's analytic plan for that shape -- whatever the plan's own batch is. Tile shapes of pipes 0 - 4 accumulate K in the same order
+    (64-wide K-tiles, 16-wide MFMA steps, fp32), so what must not follow the batch is (a) the split-K factor (partial sums are added in
+    split order) and (b) anything that changes the partition of a sample's GroupNorm statistics (tile rows of a statistics-emitting
+    conv): pinning both to the reference batch makes row i of a batch-B run bit-equal to the same sample run at any other batch.
+    Pipe 5 visits a conv's K-tiles channel-slice-major, i.e. in another order: a reference choice that names it is replaced by the
+    analytic (pipes 0 - 2) variant of the reference shape. Costs throughput at large batches (reported by bench.py as
+    `variants.batch_invariant`). Returns the number of ops pinned."""
+    lib = L.load()
+    with _cache_lock:
+        _load_file(os.environ.get("SFAST_TUNE_CACHE"))
+        if os.environ.get("SFAST_TUNE_PACKAGED", "1") not in ("0", "false", "off", ""):
+            _load_file(PACKAGED_CACHE)
+    devname = getattr(torch.cuda.get_device_properties(device), "gcnArchName", "gpu").split(":")[0]
+    o = (C.c_int32 * 5)()
+    n = 0
+    for op in plan.ops:
+        if op.tune is None:
+            continue
+        p, _ = op.tune
+        M, N, K, geglu = _mnk(p)
+        if M <= 16 or (not isinstance(p, L.GemmParams) and (p.Cout < 16 or p.Cin % 8)):
+            continue
+        q = _ref_problem(p, plan.B)
+        if q is None:
+            continue
+        is_conv = not isinstance(p, L.GemmParams)
+        key = problem_key(q, dtype_tag, devname) + ("|pk" if getattr(op, "packed", None) else "")
+        hit = _cache.get(key) or _cache.get(key[:-3] if key.endswith("|pk") else key)
+        v, s = (int(hit[0]), int(hit[1])) if hit is not None else (0, 0)
+        Mq = _mnk(q)[0]
+        if v <= 0 or s <= 0 or (v >= 50 and is_conv) or (40 <= v < 50 and not getattr(op, "packed", None)):
+            # no usable reference choice: the analytic plan of the REFERENCE shape (variant and split), never of this plan's own shape
+            q.variant, q.split_k = 0, (s if s > 0 else 0)
+            if is_conv:
+                lib.sfast_hip_conv2d_plan(C.byref(q), 0, q.split_k, o)
+            else:
+                lib.sfast_hip_igemm_plan(Mq, N, K, int(geglu), 0, q.split_k, C.byref(o))
+            v, s = int(o[4]), int(o[2])
+        p.variant, p.split_k = v, max(s, 1)
+        n += 1
+    return n
+
+
 def tune_plan(plan, device, dtype_tag="f16", verbose=False):
     """Choose (variant, split_k) for every tunable op of `plan` in place. Returns #problems measured."""
+    if BATCH_INVARIANT:
+        pin_plan_to_reference_batch(plan, device, dtype_tag)
+        return 0
     lib = L.load()
     cache_path = os.environ.get("SFAST_TUNE_CACHE")
     with _cache_lock:

@@ -1713,6 +1713,7 @@ class UNet2DEngine:
         if mode in ("0", "false", "off", ""):
             return
         import math
+        from . import autotune
         lib = self.lib
         # one statistics unit for the whole plan: the widest channel count that divides every GroupNorm's channels-per-group and
         # every concat boundary (SD / SDXL: 320 / 32 = 10), so that the records of a tensor serve all of its consumers
@@ -1731,7 +1732,8 @@ class UNet2DEngine:
             srcs = [c["xw"]] + ([c["x2w"]] if c["concat"] else [])
             if any(w is None for w in srcs) or cpg % unit or p.C1 % unit or p.C % 8 or p.C1 % 8:
                 continue
-            if p.HW * cpg * 2 <= 32 * 1024 and p.N * p.HW * p.C * 2 <= (4 << 20):
+            n_small = autotune.BATCH_REF if autotune.BATCH_INVARIANT else p.N  # (the library's gn_small_ok sees the same number)
+            if p.HW * cpg * 2 <= 32 * 1024 and n_small * p.HW * p.C * 2 <= (4 << 20):
                 continue  # the library runs these as one single-pass kernel already (norm.hip gn_small)
             lays = []
             for w in srcs:

@@ -475,6 +475,42 @@ def test_controlnet_engine_and_compiled_chain():
     assert not cnet.forward._warned
 
 
+def test_batch_invariant_mode_is_bit_exact_across_batch_sizes():
+    """with SFAST_BATCH_INVARIANT=1 (opt-in, read when the library and the tuner are first loaded -- hence a
+    process of its own) every kernel choice and every statistics partition follows the PER-SAMPLE problem at the reference batch, so
+    the same image gives the same latents whether it runs alone (B = 1), as the CFG pair (B = 2) or as one of 8 images per GPU
+    (B = 16, the per-GPU shape of BASELINE configs[3]): bit-equal rows, full-size SD1.5 UNet. Without the mode the rows differ by
+    ~2e-3 (different split-K factors per batch: `test_sd15_unet_parity_and_graph` logs it)."""
+    name = "test_batch_invariant_mode_is_bit_exact_across_batch_sizes"
+    if os.environ.get(_INNER) != name:
+        old = os.environ.get("SFAST_BATCH_INVARIANT")
+        os.environ["SFAST_BATCH_INVARIANT"] = "1"
+        try:
+            return _run_isolated(name)
+        finally:
+            if old is None:
+                os.environ.pop("SFAST_BATCH_INVARIANT", None)
+            else:
+                os.environ["SFAST_BATCH_INVARIANT"] = old
+    from sfast.engine import autotune
+    assert autotune.BATCH_INVARIANT
+    m = U.build("sd15", seed=0, dtype=torch.float16, device=DEV)
+    eng = _engine(m)
+    sample, ehs = _inputs(U.SD15_CONFIG, 16, seed=3)
+    outs = {}
+    for B in (2, 1, 16):
+        outs[B] = eng.forward(sample[:B], 981, ehs[:B]).clone()
+    with torch.no_grad():
+        ref = U.build("sd15", seed=0, dtype=torch.float32, device=DEV)
+        ref.load_state_dict({k: v.float() for k, v in m.state_dict().items()})
+        y32 = ref(sample[:2].float(), 981, ehs[:2].float()).sample
+    log_value("sd15 batch-invariant mode", engine_vs_fp32_B2=rel_l2(outs[2], y32), b1_vs_b2_row0=rel_l2(outs[1], outs[2][:1]),
+              b16_vs_b2_rows01=rel_l2(outs[16][:2], outs[2]))
+    assert rel_l2(outs[2], y32) < 2.5e-3
+    assert torch.equal(outs[1][0], outs[2][0])
+    assert torch.equal(outs[16][:2], outs[2])
+
+
 def test_graph_teardown_survives_del_and_gc():
     """a user who drops a compiled model right after its last replay (`del pipe; gc.collect()`) hit the trigger of
     the round-4 crash -- the winning graph of every plan was destroyed by plain reference counting, a few microseconds after its last
