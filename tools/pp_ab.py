@@ -21,6 +21,7 @@ OLD = [21, 22, 23, 24, 25, 1, 2, 5, 11, 12, 15]
 OLD_GEGLU = [1, 11, 16, 21, 23]
 PK = [41, 44, 46]
 PP = [51, 52, 53, 55, 56, 57, 58]
+PP_GEGLU = [53, 57]
 SPLITS = [1, 2, 3]
 
 # name, B, Cin, hw, Cout, k
@@ -67,7 +68,7 @@ def tag(v):
 
 def sweep(label, flops, call, pk, old, quick):
     res = {}
-    for v in old + (PK if pk is not None else []) + PP:
+    for v in old + (PK if pk is not None else []) + (PP_GEGLU if "geglu" in label else PP):
         for s in ([1] if (quick or v >= 50) else SPLITS):
             t, name = timed(lambda: call(v, s, pk if 40 <= v < 50 else None))
             if t is None or f"split={s}," not in name or tag(v) not in name.split(",")[-1]:
@@ -78,7 +79,7 @@ def sweep(label, flops, call, pk, old, quick):
     base = min(olds, key=lambda r: r[0]) if olds else None
     if base:
         print(f"{label:34s} best old {base[0]:8.1f} us {flops / base[0] / 1e6:6.0f} TF/s  [{base[2]}]", flush=True)
-    for v in PP:
+    for v in (PP_GEGLU if "geglu" in label else PP):
         if v in res:
             t, s, name = res[v]
             print(f"{'':34s}   pp v{v} {t:8.1f} us {flops / t / 1e6:6.0f} TF/s  x{(base[0] / t) if base else 0:4.2f}  [{name}]", flush=True)
@@ -97,7 +98,7 @@ def correctness(dev):
     cl = lambda t: t.contiguous(memory_format=torch.channels_last)
     ok = True
     for (B, Cin, hw, Cout, k, c2) in [(2, 320, 64, 320, 3, 0), (1, 640, 32, 640, 3, 0), (1, 64, 40, 96, 3, 0), (2, 320, 32, 320, 1, 0), (1, 640, 32, 320, 3, 320),
-                                      (3, 128, 24, 200, 3, 0)]:
+                                      (3, 128, 24, 200, 3, 0), (16, 320, 64, 320, 3, 0), (9, 64, 64, 160, 3, 0), (5, 128, 96, 96, 1, 64)]:
         x = cl(torch.randn(B, Cin, hw, hw, generator=gen, device=dev).half())
         x2 = cl(torch.randn(B, c2, hw, hw, generator=gen, device=dev).half()) if c2 else None
         w = cl((torch.randn(Cout, Cin + c2, k, k, generator=gen, device=dev) * (k * k * (Cin + c2)) ** -0.5).half())
@@ -111,7 +112,7 @@ def correctness(dev):
                 if "pp" not in L.last_kernel():
                     continue
                 ok &= check(f"conv B{B} {Cin}+{c2}->{Cout} @{hw} k{k} v{v} s{s}", y, want)
-    for (M, N, K) in [(8192, 320, 320), (4096, 960, 320), (1000, 640, 2560), (256, 1280, 1280), (333, 200, 128)]:
+    for (M, N, K) in [(8192, 320, 320), (4096, 960, 320), (1000, 640, 2560), (256, 1280, 1280), (333, 200, 128), (65536, 320, 320), (40000, 408, 128)]:
         x = torch.randn(M, K, generator=gen, device=dev).half()
         w = (torch.randn(N, K, generator=gen, device=dev) * K ** -0.5).half()
         b = torch.randn(N, generator=gen, device=dev).half()
@@ -123,13 +124,13 @@ def correctness(dev):
                 if "pp" not in L.last_kernel():
                     continue
                 ok &= check(f"linear {M}x{N}x{K} v{v} s{s}", y, want)
-    for (M, N, K) in [(2048, 1280, 320), (700, 2560, 640), (256, 128, 64)]:
+    for (M, N, K) in [(2048, 1280, 320), (700, 2560, 640), (256, 128, 64), (8192, 2560, 640), (33000, 200, 128)]:
         x = torch.randn(M, K, generator=gen, device=dev).half()
         w = (torch.randn(2 * N, K, generator=gen, device=dev) * K ** -0.5).half()
         b = torch.randn(2 * N, generator=gen, device=dev).half()
         h = x.float() @ w.float().t() + b.float()
         want = h[:, :N] * torch.nn.functional.gelu(h[:, N:])
-        for v in (53, 57):
+        for v in PP_GEGLU:
             y = F.linear(x, w, b, geglu=True, variant=v)
             if "pp" in L.last_kernel():
                 ok &= check(f"geglu {M}x{N}x{K} v{v}", y, want)
