@@ -191,11 +191,12 @@ def kernel_symbol(variant):
     of one tile shape share a symbol, so the split factor is dropped. A trailing "+staged" / "+gnstats" marks the
     instantiation with LDS-staged stores (last template argument)."""
     import re
-    mp = re.match(r"igemm_(conv|lin)_(f16|bf16)(_geglu)?\[256x(\d+),split=(\d+),pp(w?)(\d)\](\+staged|\+gnstats)?", variant)
+    mp = re.match(r"igemm_(conv|lin)_(f16|bf16)(_geglu)?\[256x(\d+),split=(\d+),pp([wl]?)(\d)\](\+staged|\+gnstats)?", variant)
     if mp:
-        # igemm_pp_kernel<T, BN, NS, KSP, PW, MODE, GEGLU, STAGED, EXP = 0> (csrc/igemm_pp.h): KSP = 2 with producer waves or the 256-wide tile
+        # igemm_pp_kernel<T, BN, NS, KSP, PW, MODE, GEGLU, STAGED, EXP = 0> (csrc/igemm_pp.h): "ppw" = four producer waves (KSP = 2), "ppl" =
+        # producers + lockstep consumers (KSP = 0), "pp" = the 8-wave ping-pong (KSP = 4; 2 for the 256-wide tile)
         bn, pw = int(mp.group(4)), 4 if mp.group(6) else 0
-        ksp = 2 if (pw or bn >= 256) else 4
+        ksp = 0 if mp.group(6) == "l" else 2 if (pw or bn >= 256) else 4
         t = "DF16_" if mp.group(2) == "f16" else "DF16b"
         staged = int(mp.group(8) is not None and int(mp.group(5)) == 1)
         return (f"_ZN5sfast15igemm_pp_kernelI{t}Li{bn}ELi{mp.group(7)}ELi{ksp}ELi{pw}ELi{1 if mp.group(1) == 'conv' else 0}ELb{int(mp.group(3) is not None)}"
