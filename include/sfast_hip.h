@@ -209,7 +209,11 @@ int sfast_hip_gemv_grouped(const void *x, const void *const *w, const void *cons
 /* diagnostic, host-only: the tile / split-K choice the MFMA path would make for an [M,N,K] problem.
  * out = {BM, BN (weight rows per tile), splits, k_tiles_per_split, variant id}; variant ids 1..5 are the
  * register-staged pipe, 11..18 the LDS-DMA ring (same tile shapes, ring depths 2..5), 21..23 the wave-specialised
- * LDS-DMA pipe (producer waves + consumer waves). */
+ * LDS-DMA pipe (producer waves + consumer waves), 31..34 the LDS-resident-patch conv pipe (probe build), 41..46 the packed-weight
+ * pipe (needs sfast_epilogue_ext.w_packed), 51..58 the 256-row tiles of pipe 5 (csrc/igemm_pp.h; K % 64 == 0 and M >= 256 only):
+ * 51 / 52 / 53 = 256 x 128 / 160 / 256 eight-wave ping-pong, 55 / 56 = 256 x 128 / 160 with four producer waves, 57 / 58 = the same with
+ * lockstep consumers (one barrier per K-tile; GEGLU: 53 and 57). Ids >= 16 are never chosen by the analytic model: they are measured
+ * candidates of the caller's autotuner (sfast/engine/autotune.py). */
 int sfast_hip_igemm_plan(int32_t M, int32_t N, int32_t K, int32_t geglu, int32_t variant, int32_t split_k,
                          int32_t out[5]);
 

@@ -7,8 +7,10 @@
 // BM * BN * 64 MACs: 128 x 128 needs 585 clocks of transfer for 512 clocks of MFMA issue, 256 x 160 needs 930 for 1280, 256 x 256
 // 1170 for 2048 -- only the 256-row tiles leave the matrix pipe something to hide the transfer behind. The schedule follows the
 // 8-phase template of the platform guide (cdna_hip_programming.md "The 256^2 8-phase template", T3+T4+T5): counted `s_waitcnt vmcnt`
-// (never 0 in the steady state), raw `s_barrier`, `s_setprio 1` around the MFMA clusters, LDS XOR swizzle with the inverse
-// permutation applied on the LDS-DMA SOURCE address.
+// (never 0 in the steady state), raw `s_barrier`, LDS XOR swizzle with the inverse
+// permutation applied on the LDS-DMA SOURCE address. The template's `s_setprio 1` around the
+// MFMA clusters is NOT in the product schedule: raising the priority of either part measured 0 - 1 % slower (EXP bit 3, below;
+// profiles/r06_pp_loop_probe_run8_timeline.log).
 //
 // Structure. BM = 256 pixels x BN weight rows per workgroup, 512 threads. Waves 0-3 are group 0, waves 4-7 group 1 (a workgroup's
 // waves go to the SIMDs cyclically, so waves w and w + 4 share one).
@@ -345,7 +347,8 @@ __device__ __forceinline__ void pp_producer(const IgemmArgs &a, char *smem, cons
 
 // ---- consumer wave of group G -------------------------------------------------------------------------------------------------------
 // EXP != 0: timing-only experiment instantiations (probe build, tools/pp_loop_probe.py; results are garbage): bit 0 no MFMAs, bit 1 no
-// fragment reads, bit 2 no LDS-DMA requests inside the loop, bit 3 (results CORRECT) s_setprio 1 around the MFMA part (measured 1 % slower than without: the partner wave's reads starve), bit 4 (CORRECT) timeline stamps.
+// fragment reads, bit 2 no LDS-DMA requests inside the loop, bit 3 (results CORRECT) s_setprio 1 over the MEMORY part (fragment reads + requests), back to 0 for the MFMA part -- measured 0 - 1 %
+// slower than no priority change, like the template's opposite arrangement before it --, bit 4 (CORRECT) timeline stamps.
 template <typename T, typename S, int KSP, int MODE, bool GEGLU, bool STAGED, int G, int EXP>
 __device__ __forceinline__ void pp_consumer(const IgemmArgs &a, char *smem, const BlockTile &bt, const int tid, const int wave) {
     using vec8 = typename Elem<T>::vec8;
