@@ -1090,7 +1090,7 @@ def main():
             out["weight_broadcast"] = {"bytes": bytes_bcast, "seconds": t_bcast, "gb_per_s": bytes_bcast / max(t_bcast, 1e-9) / 1e9}
         if not args.no_roofline and world == 1:
             rows = per_op_timing(loop)
-            roof, families, eager_total = roofline_from(rows, loop.plan, args.config if args.images == 1 else f"{args.config}_bs{args.images}")
+            roof, families, eager_total = roofline_from(rows, loop.plan, args.config if args.images == 1 else (f"bs{args.images}" if args.config == "sd15" else f"{args.config}_bs{args.images}"))  # (tools/gpu_pmc_bench.sh bs8 -> ..._bs8.json)
             out["roofline"] = roof
             out["kernel_families"] = families
             out["sum_of_kernel_ms_eager"] = eager_total * 1e3

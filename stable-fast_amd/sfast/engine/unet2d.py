@@ -303,6 +303,7 @@ def capture_plan_graph(plan, stream, pool=None, tail=None, calibrate=True):
     overlap returns; tools/replay_gap_probe.py, profiles/r02_replay_gap_probe.log)."""
     dev = plan.engine.device
     _trim_retired()
+    calibrate = calibrate and GRAPH_CALIBRATE
 
     def cap(forked):
         g = torch.cuda.CUDAGraph()
@@ -355,6 +356,9 @@ def capture_plan_graph(plan, stream, pool=None, tail=None, calibrate=True):
     return OwnedGraph(best[2], dev), best[1]
 
 
+# SFAST_GRAPH_CALIBRATE=0: keep the forked candidate without timing the two graph shapes against each other (52 extra replays of the step:
+# what made the counter passes over the SVD-XT step -- 930 launches each -- run into their timeouts, tools/gpu_pmc_bench.sh)
+GRAPH_CALIBRATE = os.environ.get("SFAST_GRAPH_CALIBRATE", "1") not in ("0", "false", "off", "")
 # A/B knobs of the round-5 crash hunt (tools/crash_repro.py): 1 = the round-4 behaviour
 FORK_EVENTS_LOCAL = os.environ.get("SFAST_FORK_EVENTS_LOCAL", "0") not in ("0", "false", "off", "")
 GRAPH_DESTROY_LOSER = os.environ.get("SFAST_GRAPH_DESTROY_LOSER", "0") not in ("0", "false", "off", "")
