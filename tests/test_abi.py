@@ -143,7 +143,13 @@ def test_bench_kernel_symbols_name_real_device_kernels(built_lib):
                 # pipe 4 (packed weights): every tile, linear and conv, staged and not, bf16
                 "igemm_lin_f16[64x160,split=1,pk4]@xcd1x8x1", "igemm_lin_f16[64x160,split=1,pk4]+gnstats@xcd1x4x2", "igemm_conv_f16[128x256,split=2,pk4]@xcd2x4x1",
                 "igemm_conv_f16[64x320,split=1,pk4]+gnstats", "igemm_lin_f16[128x160,split=1,pk4]", "igemm_conv_f16[64x256,split=6,pk4]",
-                "igemm_lin_bf16[128x128,split=1,pk4]+staged", "igemm_conv_bf16[128x128,split=12,pk4]@xcd4x1x2"]
+                "igemm_lin_bf16[128x128,split=1,pk4]+staged", "igemm_conv_bf16[128x128,split=12,pk4]@xcd4x1x2",
+                # pipe 5 (256-row tiles): ping-pong (pp), + producer waves (ppw), producers + lockstep consumers (ppl); GEGLU; bf16; split-K
+                "igemm_conv_f16[256x160,split=1,pp3]+staged@xcd1x8x1", "igemm_lin_f16[256x128,split=1,pp3]+staged", "igemm_conv_f16[256x256,split=1,pp2]+staged",
+                "igemm_lin_f16_geglu[256x256,split=1,pp2]@xcd1x4x2", "igemm_conv_f16[256x128,split=1,ppw3]+staged", "igemm_lin_f16[256x160,split=1,ppw3]+gnstats",
+                "igemm_conv_f16[256x160,split=1,ppl3]+gnstats@xcd1x8x1", "igemm_conv_f16[256x128,split=1,ppl3]+staged", "igemm_lin_f16[256x160,split=1,ppl3]+staged",
+                "igemm_lin_f16_geglu[256x128,split=1,ppl3]@xcd1x4x2", "igemm_conv_f16[256x160,split=3,ppl3]@xcd1x8x1", "igemm_conv_bf16[256x160,split=1,ppl3]+staged",
+                "igemm_lin_bf16_geglu[256x128,split=1,ppl3]"]
     for v in variants:
         sym = bench.kernel_symbol(v)
         assert sym.startswith("_ZN5sfast"), (v, sym)
