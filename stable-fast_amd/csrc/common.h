@@ -104,15 +104,19 @@ __device__ __forceinline__ float act_silu(float v) { return v * act_sigmoid(v); 
 // ~50-instruction two-branch polynomial. The GEGLU epilogue evaluates this 10M times per SD1.5 FF layer; with erff
 // it was VALU-bound for ~40 % of the kernel (per-workgroup phase trace, profiles/r01_igemm_phase_trace.log).
 // Negative arguments use erfc directly, so there is no 1 + erf(x) cancellation in the tail.
+// Round 6: the same formula with the constants folded (z = |v| / sqrt(2) never formed: 0.3275911 / sqrt(2) = 0.2316419, the 0.5 in the
+// coefficients, exp(-z^2) = exp2(-0.72134752 v^2)) and the sign select replaced by max(v, 0) - |v| h (v >= 0: v - v h, v < 0: v h):
+// 11 full-rate VALU operations + 2 transcendentals per value instead of 16 + 2 -- the GEGLU epilogue is ~2.5 us of VALU work per
+// tile round of the 256-row kernels (profiles/r06_pp_ksweep_run28.log: 5 us of fixed cost per round).
 __device__ __forceinline__ float act_gelu_erf(float v) {
-    const float z = fabsf(v) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float half_erfc = 0.5f * p * t * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);  // 0.5*erfc(|z|)
-    return v * (v >= 0.0f ? 1.0f - half_erfc : half_erfc);
+    const float a = fabsf(v);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, a, 1.0f));
+    float p = fmaf(0.5307027145f, t, -0.7265760135f);
+    p = fmaf(p, t, 0.7107068705f);
+    p = fmaf(p, t, -0.142248368f);
+    p = fmaf(p, t, 0.127414796f);
+    const float h = p * t * __builtin_amdgcn_exp2f(v * v * -0.72134752044448170368f);  // 0.5 * erfc(|v| / sqrt(2))
+    return fmaf(-a, h, fmaxf(v, 0.0f));
 }
 // tanh from one exp + one rcp; |x| < 0.1 uses the odd series (the rational form cancels there)
 __device__ __forceinline__ float act_tanh(float v) {
