@@ -41,7 +41,15 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=None,
+                    help="untimed steps before the timed ones. Default 150 (SVD-XT, 0.2 s per step: 20) = three 50-step images, the warm-up of the reference's own benchmark "
+                         "protocol (3 warm-up pipeline calls: SURVEY.md section 8d; /root/reference/src/sfast/cuda/graphs.py:87-92 warms a graph "
+                         "up with 3 calls too). With 20 (rounds 1 - 6) the SD1.5 line read 1.2 %% below its steady state (191.1 vs 193.4 it/s, "
+                         "twice each in one session; 200 / 1000 / 2000 timed steps behind 200 / 1000 warm-up steps all read 193.4 - 193.6): "
+                         "the chip needs about a second of sustained load to reach its steady clocks")
+    ap.add_argument("--preheat-seconds", type=float, default=None,
+                    help="sd15 / sdxl: replay the step untimed for this long before the warm-up steps (default 3.0; 0 = off): the chip takes "
+                         "seconds of sustained load to reach its steady clocks, reported as `preheat_seconds` in the line")
     ap.add_argument("--config", default="sd15", choices=["sd15", "sdxl", "vae", "svd"],
                     help="sd15 (the BASELINE metric) | sdxl | vae (SD VAE decode 64x64 latent -> 512x512, SURVEY 8f rank 1) | "
                          "svd (SVD-XT 576x1024, 25 frames, BASELINE configs[4])")
@@ -67,7 +75,12 @@ def parse():
     ap.add_argument("--bs64-sharded", action="store_true",
                     help="run the configs[3] leg (64 images split over the N ranks, 64 / N per GPU) for any N, not only N = 8")
     ap.add_argument("--dump-kernels", default=None, help="write the per-op timing table to this JSON file")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.preheat_seconds is None:
+        a.preheat_seconds = 3.0
+    if a.warmup is None:
+        a.warmup = 20 if a.config == "svd" else 150
+    return a
 
 
 def per_op_timing(loop, reps=2, burst=4):  # noqa: C901
@@ -516,7 +529,14 @@ def through_compile(args, cfg, params, dev, latents, ehs, engine_ms, added=None)
             "path": "module_from_params -> sfast.compilers.compile(enable_cuda_graph, trace_scheduler) -> pipeline-shaped CFG loop"}
 
 
-def _time_steps(step, steps, warmup, dev):
+def _time_steps(step, steps, warmup, dev, preheat=0.0):
+    if preheat > 0:   # sustained load first (see --preheat-seconds): a capture or a plan build in between lets the clocks fall back
+        t_end, k = time.perf_counter() + preheat, 0
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                step(k)
+                k += 1
+            torch.cuda.synchronize(dev)
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize(dev)
@@ -545,7 +565,7 @@ def step_variants(args, engine, cfg, hw, dev, latents, ehs, headline_ms):
         si["time_ids"].copy_(torch.tensor([1024., 1024, 0, 0, 1024, 1024], device=dev).repeat(2 * args.images))
     loop.set_inputs(latents, ehs)
     loop.capture(warmups=2)
-    ms = _time_steps(loop.step, steps, warm, dev) * 1e3
+    ms = _time_steps(loop.step, steps, warm, dev, preheat=args.preheat_seconds / 2) * 1e3
     out["text_kv_hoisted"] = {"value": 1e3 / ms, "unit": "it/s", "ms_per_step": ms, "kernel_launches_per_step": len(loop._step_ops) + 2,
                               "gain_vs_headline": headline_ms / ms,
                               "note": "cross-attention K/V projections of the text context run once per prompt (DenoiseLoop(hoist_text_kv=True)), not per step"}
@@ -571,19 +591,19 @@ def step_variants(args, engine, cfg, hw, dev, latents, ehs, headline_ms):
         torch.cuda.synchronize(dev)
         graph, _ = capture_plan_graph(plan, stream, tail=tail)
         with torch.cuda.stream(stream):
-            ms1 = _time_steps(lambda i: graph.replay(), steps, warm, dev) * 1e3
+            ms1 = _time_steps(lambda i: graph.replay(), steps, warm, dev, preheat=args.preheat_seconds / 2) * 1e3
         out["literal_b1"] = {"value": 1e3 / ms1, "unit": "it/s", "ms_per_step": ms1, "unet_batch": 1, "kernel_launches_per_step": len(plan.ops) + 1,
                              "note": "UNet forward at batch 1 (no classifier-free guidance) + DDIM update, one hipGraph -- SURVEY 8d config 2, B = 1"}
     return out
 
 
-def child_variant(extra, steps=200, warmup=20, timeout=150, env_extra=None):
+def child_variant(extra, steps=200, warmup=150, timeout=150, env_extra=None):
     """north_star asks for it/s on BOTH latent sizes and BASELINE configs[3] runs 8 images per GPU; the driver times `python bench.py`
     only. So the default SD1.5 run ends by timing (a) the 1x4x128x128-latent step (BASELINE configs[2]: SDXL 1024x1024 bs=1 fp16) and
     (b) the per-GPU shape of configs[3] (SD1.5, 8 images = UNet batch 16) -- CFG UNet + guidance + DDIM update as one hipGraph,
     packaged kernel choices -- each in a CHILD process of this same script (its own weights, plan and `roofline` block) and embeds the
     children's JSON lines. A failure is reported, never raised, and a hung child costs at most `timeout` seconds (240 s
-    before): the contract line must survive. The children time 200 steps behind 20 warm-up steps like the headline: with 20 / 5 (rounds
+    before): the contract line must survive. The children time 200 steps behind 150 warm-up steps like the headline: with 20 / 5 (rounds
     4 - 6) they read 3 - 5 % below the standalone runs of the same configurations (8 images: 51.2 vs 53.7 steps/s, SDXL 42.5 vs 43.8 it/s in
     one session, `--steps 20` / `60` / `200` twice each) -- the chip takes seconds of sustained load to reach its steady clocks."""
     import subprocess
@@ -600,7 +620,7 @@ def child_variant(extra, steps=200, warmup=20, timeout=150, env_extra=None):
         child = json.loads(line)
     except Exception as e:
         return {"error": f"{type(e).__name__}: {e}", "seconds": time.perf_counter() - t0}
-    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "gpu_ms_per_step_events", "outputs_finite",
+    keep = ("metric", "value", "unit", "steps", "warmup", "preheat_seconds", "ms_per_step", "dtype", "config", "gpu_ms_per_step_events", "outputs_finite",
             "kernel_launches_per_step", "packed_weight_launches", "roofline", "kernel_families", "sum_of_kernel_ms_eager")
     out = {k: child[k] for k in keep if k in child}
     out["wall_seconds_of_child_process"] = time.perf_counter() - t0
@@ -608,15 +628,15 @@ def child_variant(extra, steps=200, warmup=20, timeout=150, env_extra=None):
     return out
 
 
-def sdxl_variant(steps=200, warmup=20, timeout=150):
+def sdxl_variant(steps=200, warmup=150, timeout=150):
     return child_variant(["--config", "sdxl"], steps, warmup, timeout)
 
 
-def bs8_variant(steps=200, warmup=20, timeout=150):
+def bs8_variant(steps=200, warmup=150, timeout=150):
     return child_variant(["--config", "sd15", "--images", "8"], steps, warmup, timeout)
 
 
-def batch_invariant_variant(bs8, steps=200, warmup=20, timeout=150):
+def batch_invariant_variant(bs8, steps=200, warmup=150, timeout=150):
     """the cost of SFAST_BATCH_INVARIANT=1 (every kernel choice and statistics partition follows the per-sample
     problem at the reference batch 2, so a sample's latents are bit-equal at any batch: tests/test_unet_gpu.py
     test_batch_invariant_mode_is_bit_exact_across_batch_sizes) where it costs most -- 8 images per GPU (UNet batch 16), whose
@@ -1048,6 +1068,16 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # Pre-heat: the chip reaches its steady clocks only after seconds of sustained load (8 images per GPU: 54.1 steps/s behind 20 warm-up
+    # steps, 58.2 behind 150, 58.7 - 58.8 behind 500, timed over 200 or 1000 steps alike; SDXL 43.8 / 45.8 / 46.0 -- one session,
+    # profiles/r06_warmup_ramp_run43.log). The step is replayed untimed for --preheat-seconds before the W warm-up steps of the contract.
+    if args.preheat_seconds > 0:
+        t_end, k = time.perf_counter() + args.preheat_seconds, 0
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                loop.step(k)
+                k += 1
+            torch.cuda.synchronize()
     for i in range(args.warmup):
         loop.step(i)
     sync_all()
@@ -1073,6 +1103,7 @@ def main():
             "metric": (f"UNet iters/sec SD1.5 512x512 bs={args.images} fp16" if args.config == "sd15"
                        else f"UNet iters/sec SDXL 1024x1024 bs={args.images} fp16"),
             "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "preheat_seconds": args.preheat_seconds,
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_image_50_steps_unet_and_scheduler": elapsed / args.steps * 1e3 * 50 / max(1, args.images), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": ("synthetic latents / text embeddings, weights from " + args.weights) if args.weights else "synthetic",

@@ -170,7 +170,12 @@ def test_bench_contract_defaults_and_self_launch(monkeypatch):
     import bench
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
-    assert (a.gpus, a.steps, a.warmup, a.config, a.images) == (1, 200, 20, "sd15", 1)
+    assert (a.gpus, a.steps, a.warmup, a.config, a.images) == (1, 200, 150, "sd15", 1)   # warm-up: three 50-step images (the reference's protocol)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "svd"])
+    assert bench.parse().warmup == 20   # 0.2 s per step
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--warmup", "7"])
+    assert bench.parse().warmup == 7
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
     cmd = bench.torchrun_argv(4, ["--gpus", "4", "--steps", "7"], port=29511)
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"

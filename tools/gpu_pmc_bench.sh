@@ -10,6 +10,7 @@ CFG=${1:-sd15}
 STEPS=${2:-6}
 SUF=""; [ "$CFG" != "sd15" ] && SUF="_$CFG"
 BARGS="--config $CFG"; [ "$CFG" = "bs8" ] && BARGS="--config sd15 --images 8"
+BARGS="$BARGS --preheat-seconds 0"   # (bench.py replays the step for 3 s before its warm-up by default: thousands of dispatches under counters)
 # SVD-XT: 930 launches per step and two graph shapes calibrated with 26 replays each = 53 k dispatches per pass, ~15 ms each under counters
 [ "$CFG" = "svd" ] && export SFAST_GRAPH_CALIBRATE=0
 export BARGS
