@@ -1,4 +1,4 @@
-export SFAST_COMMIT=a10eeba
+export SFAST_COMMIT=db167da
 mkdir -p gpurun_out/r06f
 for cfg in sd15:6 bs8:4 sdxl:4 svd:2; do
   c=${cfg%%:*}; n=${cfg##*:}
