@@ -232,7 +232,10 @@ def test_engine_repacks_after_an_in_place_update():
     parameter dict (the tensors' own counters) -- and is a no-op otherwise; a forward after it equals a fresh engine's."""
     from oracle import unet_ref as U
     from sfast.engine import UNet2DEngine
+    from sfast.engine import unet2d as E
     from sfast.engine.unet_spec import random_params
+    if not E.PACKED_WEIGHTS:
+        pytest.skip("SFAST_PACKED_WEIGHTS=0: the engine keeps no packed copies")
     cfg = U.tiny_config()
     params = random_params(cfg, seed=3, dtype=torch.float16, device=DEV)
     eng = UNet2DEngine(cfg, params)
